@@ -1,0 +1,205 @@
+"""Generates the golden fixtures in this directory FROM THE REFERENCE.
+
+Run in the build container only (needs /root/reference); the outputs (small
+.npz / .json data files) are committed, the reference source never travels.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  enc_dec_n64.npz      reference Encoder / Decoder (imported from
+                       /root/reference/src/encoder.py, decoder.py) forward outputs and
+                       parameter / input gradients, train and eval mode, on
+                       deterministic inputs from gen.py.
+  common.json          reference greedy_get_subgraph / get_graph_mapping /
+                       heaviside latent_to_discrete / train_grbm / push_to_deque
+                       (imported from /root/reference/src/utils/*.py and
+                       src/model_wrapper.py with stub modules for the absent
+                       dwave / dimod / torchvision packages).
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import gen  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    """Empty stand-ins for packages absent from this image, so the reference's
+    own modules import.  They contain no behaviour."""
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    _stub("dwave")
+    _stub("dwave.system", DWaveSampler=_Dummy, FixedEmbeddingComposite=_Dummy)
+    _stub("dimod", Sampler=_Dummy, SampleSet=_Dummy, as_samples=lambda x: x)
+    _stub("dwave.plugins")
+    _stub("dwave.plugins.torch")
+    _stub("dwave.plugins.torch.models", DiscreteVariationalAutoencoder=_Dummy, GraphRestrictedBoltzmannMachine=_Dummy)
+    _stub("dwave.plugins.torch.nn")
+    _stub("dwave.plugins.torch.nn.functional", maximum_mean_discrepancy_loss=None)
+    _stub("dwave.plugins.torch.nn.modules")
+    _stub("dwave.plugins.torch.nn.modules.kernels", GaussianKernel=_Dummy)
+    _stub("torchvision")
+    _stub("torchvision.datasets", MNIST=_Dummy)
+    _stub("torchvision.transforms", Compose=_Dummy, Resize=_Dummy, ToTensor=_Dummy)
+    _stub("torchvision.utils", make_grid=None)
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    enc = importlib.import_module("src.encoder")
+    dec = importlib.import_module("src.decoder")
+    return enc.Encoder, dec.Decoder
+
+
+def to_t(d):
+    return {k: torch.from_numpy(np.array(v)) for k, v in d.items()}
+
+
+def enc_dec_fixture(n=64, B=4, R=2):
+    Encoder, Decoder = import_reference()
+    out = {"n": n, "B": B, "R": R}
+    # ---------------- encoder ----------------
+    pe = gen.make_params(n, "encoder", seed=101)
+    x = torch.from_numpy(gen.make_images(B, seed=202))
+    gl = torch.from_numpy(np.random.default_rng(303).standard_normal((B, n)).astype(np.float32))
+    for mode in ("train", "eval"):
+        enc = Encoder(n)
+        enc.load_state_dict(to_t(pe))
+        enc.train(mode == "train")
+        logits = enc(x)
+        out[f"enc_{mode}_logits"] = logits.detach().numpy()
+        if mode == "train":
+            (logits * gl).sum().backward()
+            sd = enc.state_dict()
+            for name, prm in enc.named_parameters():
+                g = prm.grad.numpy()
+                out[f"enc_grad_sub/{name}"] = gen.subsample(g)
+                out[f"enc_grad_norm/{name}"] = np.asarray([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+            for name in sd:
+                if "running" in name or "num_batches" in name:
+                    out[f"enc_after/{name}"] = sd[name].numpy()
+    # ---------------- decoder ----------------
+    pd = gen.make_params(n, "decoder", seed=404)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, seed=505)).requires_grad_(True)
+    masks = gen.make_masks(B * R, seed=606)
+    go = torch.from_numpy(np.random.default_rng(707).standard_normal((B, R, 1, 32, 32)).astype(np.float32))
+    for mode in ("train", "eval"):
+        dec = Decoder(n)
+        dec.load_state_dict(to_t(pd))
+        dec.train(mode == "train")
+        handles = []
+        if mode == "train":
+            # Inject the Dropout2d keep-masks (the reference draws them from torch's RNG):
+            # replace each Dropout2d's output by input * mask / 0.8, which is what
+            # Dropout2d computes for that mask.
+            k = 0
+            for mod in dec.convtrans:
+                if isinstance(mod, torch.nn.Dropout2d):
+                    m = torch.from_numpy(masks[k])[:, :, None, None] / 0.8
+
+                    def hook(module, inp, outp, m=m):
+                        return inp[0] * m
+
+                    handles.append(mod.register_forward_hook(hook))
+                    k += 1
+        if spins.grad is not None:
+            spins.grad = None
+        y = dec(spins)
+        out[f"dec_{mode}_out"] = y.detach().numpy()
+        if mode == "train":
+            (y * go).sum().backward()
+            out["dec_grad_spins"] = spins.grad.numpy().copy()
+            sd = dec.state_dict()
+            for name, prm in dec.named_parameters():
+                g = prm.grad.numpy()
+                out[f"dec_grad_sub/{name}"] = gen.subsample(g)
+                out[f"dec_grad_norm/{name}"] = np.asarray([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+            for name in sd:
+                if "running" in name or "num_batches" in name:
+                    out[f"dec_after/{name}"] = sd[name].numpy()
+        for h in handles:
+            h.remove()
+    # sanity: Dropout2d really is a per-(sample, channel) mask scaled by 1/0.8
+    torch.manual_seed(1)
+    d = torch.nn.Dropout2d(0.2)
+    t = d(torch.ones(16, 8, 3, 3))
+    assert set(t.unique().tolist()) <= {0.0, 1.25} and bool((t.amax((2, 3)) == t.amin((2, 3))).all())
+    np.savez_compressed(os.path.join(HERE, f"enc_dec_n{n}.npz"), **out)
+    print("wrote enc_dec fixture", {k: getattr(v, "shape", v) for k, v in list(out.items())[:6]})
+
+
+def common_fixture():
+    install_stubs()
+    sys.path.insert(0, REF)
+    common = importlib.import_module("src.utils.common")
+    pqs = importlib.import_module("src.utils.persistent_qpu_sampler")
+    spec = importlib.util.spec_from_file_location("image_generation_amd_graphs", os.path.join(ROOT, "image-generation_amd", "graphs.py"))
+    graphs = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = graphs
+    spec.loader.exec_module(graphs)
+    out = {}
+    # greedy_get_subgraph on the build's own topology generators
+    sub = {}
+    for fam, g in (("pegasus16", graphs.pegasus_graph(16)), ("zephyr12", graphs.zephyr_graph(12))):
+        for n in (64, 128):
+            for seed in (775321899904, 7):
+                sg = common.greedy_get_subgraph(n_nodes=n, random_seed=seed, graph=g)
+                mg, mapping = common.get_graph_mapping(sg)
+                sub[f"{fam}/{n}/{seed}"] = {
+                    "nodes": [int(v) for v in sg.nodes()],
+                    "mapped_edges": [[int(a), int(b)] for a, b in mg.edges()],
+                }
+    out["greedy_get_subgraph"] = sub
+    # heaviside latent_to_discrete
+    l2d = common.get_latent_to_discrete("heaviside")
+    logits = torch.tensor([[0.3, -0.2, 0.0, 1e-9, -5.0, 2.5]], requires_grad=True)
+    o = l2d(logits, 3)
+    o.sum().backward()
+    out["heaviside"] = {"logits": logits.detach().tolist(), "out": o.detach().tolist(), "grad": logits.grad.tolist(), "shape": list(o.shape)}
+    # train_grbm schedule (src/model_wrapper.py:59-67) -- needs demo_configs + plotly (present) + stubs
+    try:
+        mw = importlib.import_module("src.model_wrapper")
+        out["train_grbm"] = [[s, e, bool(mw.train_grbm(s, e))] for e in (0, 5, 6, 7) for s in (0, 1, 9, 10, 20, 25)]
+    except Exception as ex:  # pragma: no cover
+        print("model_wrapper import failed:", ex)
+    # push_to_deque
+    cases = []
+    for dq_n, x_n, size in ((0, 3, 4), (2, 3, 4), (4, 3, 4), (4, 6, 4), (3, 2, None)):
+        dq = torch.arange(dq_n * 2, dtype=torch.float32).reshape(dq_n, 2)
+        x = 100 + torch.arange(x_n * 2, dtype=torch.float32).reshape(x_n, 2)
+        try:
+            r = pqs.push_to_deque(dq, x, size)
+            cases.append({"dq": dq.tolist(), "x": x.tolist(), "size": size, "out": r.tolist()})
+        except Exception as ex:
+            cases.append({"dq": dq.tolist(), "x": x.tolist(), "size": size, "error": type(ex).__name__})
+    out["push_to_deque"] = cases
+    with open(os.path.join(HERE, "common.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote common.json", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    enc_dec_fixture()
+    common_fixture()

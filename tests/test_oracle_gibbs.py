@@ -1,0 +1,112 @@
+"""Pins the block-Gibbs definition (oracle/gibbs.py, oracle/gibbs_ref.c) on CPU."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import cref, gibbs, philox
+from image_generation_amd import graphs
+
+KATS = [  # Random123 known-answer vectors for philox4x32-10
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", KATS)
+def test_philox_kat(ctr, key, want):
+    got_py = [int(x) for x in philox.philox4x32_10(*ctr, *key)]
+    got_c = [int(x) for x in cref.philox(ctr, key)]
+    assert got_py == want
+    assert got_c == want
+
+
+def test_spec_exp_numpy_equals_c_and_is_accurate():
+    zs = np.concatenate([np.linspace(-87, 87, 20001), np.random.default_rng(0).normal(0, 3, 5000)]).astype(np.float32)
+    a = gibbs.spec_exp(zs)
+    b = np.array([cref.spec_exp(z) for z in zs], dtype=np.float32)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rel = np.abs(a.astype(np.float64) / np.exp(zs.astype(np.float64)) - 1)
+    assert rel.max() < 5e-7
+
+
+def _random_model(n, ei, ej, rng, hscale=0.05, jscale=5.0):
+    h = (hscale * rng.uniform(-1, 1, n)).astype(np.float32)
+    J = (jscale * rng.uniform(-1, 1, len(ei))).astype(np.float32)
+    return h, J
+
+
+@pytest.mark.parametrize("fam,n", [("pegasus", 64), ("zephyr", 128)])
+def test_numpy_equals_c_bit_exact(fam, n):
+    g = graphs.pegasus_graph(16) if fam == "pegasus" else graphs.zephyr_graph(12)
+    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(n, 775321899904, g))
+    _, ei, ej = graphs.edges_of(mg)
+    plan = graphs.build_plan(n, ei, ej)
+    rng = np.random.default_rng(5)
+    h, J = _random_model(n, ei, ej, rng)
+    hs, Js = gibbs.scaled_fields(h, J, 0.05, (-4, 4), (-1, 1))
+    chain_ids = np.arange(7, dtype=np.uint32) + 1000
+    s0 = gibbs.init_state(chain_ids, n, seed=775321899904)
+    assert np.array_equal(s0, cref.init_state(chain_ids, n, 775321899904))
+    a = gibbs.gibbs_sweeps(s0.copy(), chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 3, 6)
+    b = cref.gibbs_sweeps(s0.copy(), chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 3, 6)
+    assert np.array_equal(a, b)
+    assert set(np.unique(a).tolist()) <= {-1, 1}
+    # splitting the sweeps over two calls (persistent chains) gives the same stream
+    c = cref.gibbs_sweeps(s0.copy(), chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 3, 2)
+    c = cref.gibbs_sweeps(c, chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 5, 4)
+    assert np.array_equal(b, c)
+
+
+def test_colouring_is_proper_and_plan_consistent():
+    g = graphs.zephyr_graph(12)
+    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(128, 1, g))
+    _, ei, ej = graphs.edges_of(mg)
+    plan = graphs.build_plan(128, ei, ej)
+    colour = np.empty(128, dtype=int)
+    for k in range(plan.n_colours):
+        colour[plan.order[plan.class_ptr[k] : plan.class_ptr[k + 1]]] = k
+    assert np.all(colour[ei] != colour[ej])
+    assert sorted(plan.order.tolist()) == list(range(128))
+    ap, ai, ae = gibbs.build_csr(128, ei, ej)
+    assert np.array_equal(ap, plan.adj_ptr) and np.array_equal(ai, plan.adj_idx) and np.array_equal(ae, plan.adj_eid)
+
+
+def test_exact_boltzmann_statistics_small_graph():
+    """Chi-square of sampled state frequencies against exact enumeration (n = 8)."""
+    n = 8
+    edges = [(0, 1), (1, 2), (2, 3), (3, 0), (0, 2), (4, 5), (5, 6), (6, 7), (7, 4), (3, 4), (1, 6)]
+    ei = np.array([min(a, b) for a, b in edges]); ej = np.array([max(a, b) for a, b in edges])
+    plan = graphs.build_plan(n, ei, ej)
+    rng = np.random.default_rng(11)
+    h = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    J = rng.uniform(-0.7, 0.7, len(edges)).astype(np.float32)
+    beta = 1.0
+    C = 20000
+    chain_ids = np.arange(C, dtype=np.uint32)
+    s = cref.init_state(chain_ids, n, 42)
+    s = cref.gibbs_sweeps(s, chain_ids, h, J, beta, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 42, 0, 30)
+    states = np.array(list(itertools.product([-1, 1], repeat=n)), dtype=np.int8)
+    E = gibbs.energy(states, h, J, ei, ej)
+    p = np.exp(-beta * E); p /= p.sum()
+    code = ((s > 0).astype(np.int64) * (1 << np.arange(n - 1, -1, -1))).sum(1)
+    counts = np.bincount(code, minlength=2**n)
+    chi2 = ((counts - C * p) ** 2 / (C * p)).sum()
+    # dof = 255; mean 255, sd ~22.6 -> 5 sigma
+    assert chi2 < 255 + 5 * 22.6, chi2
+
+
+def test_zero_coupling_gives_independent_spins():
+    n = 16
+    ei = np.arange(0, n - 1); ej = np.arange(1, n)
+    plan = graphs.build_plan(n, ei, ej)
+    h = np.linspace(-1, 1, n).astype(np.float32)
+    J = np.zeros(n - 1, dtype=np.float32)
+    C = 40000
+    ids = np.arange(C, dtype=np.uint32)
+    s = cref.init_state(ids, n, 9)
+    s = cref.gibbs_sweeps(s, ids, h, J, 1.5, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 9, 0, 1)
+    want = 1.0 / (1.0 + np.exp(2 * 1.5 * h.astype(np.float64)))
+    got = (s > 0).mean(0)
+    assert np.max(np.abs(got - want)) < 5 * 0.5 / np.sqrt(C)

@@ -1,0 +1,126 @@
+"""Pins the CPU oracle against the fixtures generated from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen
+from oracle import nets, plugin
+from image_generation_amd import graphs
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "enc_dec_n64.npz")))
+
+
+@pytest.fixture(scope="module")
+def common(golden_dir):
+    with open(os.path.join(golden_dir, "common.json")) as f:
+        return json.load(f)
+
+
+def _t(d, grad=False):
+    out = {}
+    for k, v in d.items():
+        t = torch.from_numpy(np.array(v))
+        if grad and t.dtype == torch.float32 and "running" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def test_encoder_oracle_matches_reference(fx):
+    n, B = int(fx["n"]), int(fx["B"])
+    x = torch.from_numpy(gen.make_images(B, seed=202))
+    gl = torch.from_numpy(np.random.default_rng(303).standard_normal((B, n)).astype(np.float32))
+    p = _t(gen.make_params(n, "encoder", 101), grad=True)
+    logits = nets.encoder_forward(p, x, training=True)
+    np.testing.assert_allclose(logits.detach().numpy(), fx["enc_train_logits"], rtol=1e-5, atol=1e-6)
+    (logits * gl).sum().backward()
+    for name in nets.param_names(n, "encoder"):
+        g = p[name].grad.numpy()
+        np.testing.assert_allclose(gen.subsample(g), fx[f"enc_grad_sub/{name}"], rtol=1e-4, atol=1e-5)
+        s, l2 = fx[f"enc_grad_norm/{name}"]
+        # conv biases feeding a BatchNorm have an exactly-zero true gradient: what is left is rounding noise
+        assert abs(np.sqrt((g.astype(np.float64) ** 2).sum()) - l2) <= 1e-4 * l2 + 3e-4
+    for k in fx:
+        if k.startswith("enc_after/"):
+            np.testing.assert_allclose(p[k[len("enc_after/"):]].detach().numpy(), fx[k], rtol=1e-5, atol=1e-6)
+    pe = _t(gen.make_params(n, "encoder", 101))
+    np.testing.assert_allclose(nets.encoder_forward(pe, x, training=False).numpy(), fx["enc_eval_logits"], rtol=1e-5, atol=1e-6)
+
+
+def test_decoder_oracle_matches_reference(fx):
+    n, B, R = int(fx["n"]), int(fx["B"]), int(fx["R"])
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 505)).requires_grad_(True)
+    masks = [torch.from_numpy(m) for m in gen.make_masks(B * R, 606)]
+    go = torch.from_numpy(np.random.default_rng(707).standard_normal((B, R, 1, 32, 32)).astype(np.float32))
+    p = _t(gen.make_params(n, "decoder", 404), grad=True)
+    y = nets.decoder_forward(p, spins, training=True, dropout_masks=masks)
+    np.testing.assert_allclose(y.detach().numpy(), fx["dec_train_out"], rtol=1e-5, atol=1e-5)
+    (y * go).sum().backward()
+    np.testing.assert_allclose(spins.grad.numpy(), fx["dec_grad_spins"], rtol=1e-4, atol=1e-5)
+    for name in nets.param_names(n, "decoder"):
+        g = p[name].grad.numpy()
+        np.testing.assert_allclose(gen.subsample(g), fx[f"dec_grad_sub/{name}"], rtol=1e-4, atol=2e-5)
+    for k in fx:
+        if k.startswith("dec_after/"):
+            np.testing.assert_allclose(p[k[len("dec_after/"):]].detach().numpy(), fx[k], rtol=1e-5, atol=1e-6)
+    pe = _t(gen.make_params(n, "decoder", 404))
+    np.testing.assert_allclose(
+        nets.decoder_forward(pe, spins.detach(), training=False).numpy(), fx["dec_eval_out"], rtol=1e-5, atol=1e-5
+    )
+
+
+def test_greedy_get_subgraph_matches_reference(common):
+    gens = {"pegasus16": graphs.pegasus_graph(16), "zephyr12": graphs.zephyr_graph(12)}
+    for key, want in common["greedy_get_subgraph"].items():
+        fam, n, seed = key.split("/")
+        sg = graphs.greedy_get_subgraph(int(n), int(seed), gens[fam])
+        assert [int(v) for v in sg.nodes()] == want["nodes"], key
+        mg, _ = graphs.get_graph_mapping(sg)
+        assert [[int(a), int(b)] for a, b in mg.edges()] == want["mapped_edges"], key
+
+
+def test_heaviside_matches_reference(common):
+    hv = common["heaviside"]
+    logits = torch.tensor(hv["logits"], requires_grad=True)
+    o = plugin.heaviside_latent_to_discrete(logits, 3)
+    assert list(o.shape) == hv["shape"]
+    assert o.detach().tolist() == hv["out"]
+    o.sum().backward()
+    assert logits.grad.tolist() == hv["grad"]
+
+
+def test_gumbel_oracle_equals_torch_gumbel_softmax():
+    """The restated default latent_to_discrete reproduces F.gumbel_softmax draw for draw."""
+    torch.manual_seed(3)
+    logits = torch.randn(5, 32)
+    R = 4
+    two = torch.stack([logits, torch.zeros_like(logits)], -1).unsqueeze(1).repeat(1, R, 1, 1)
+    torch.manual_seed(77)
+    want = torch.nn.functional.gumbel_softmax(two, tau=1 / 7, hard=True)[..., 0] * 2 - 1
+    torch.manual_seed(77)
+    g = -torch.empty_like(two).exponential_().log()
+    got = plugin.gumbel_latent_to_discrete(logits, R, gumbels=g)
+    assert torch.equal(got, want)
+
+
+def test_mmd_properties():
+    torch.manual_seed(0)
+    x = torch.sign(torch.randn(96, 32)); y = torch.sign(torch.randn(64, 32))
+    v = plugin.mmd_loss(x, y)
+    assert abs(float(v)) < 0.05  # same distribution -> ~0
+    assert float(plugin.mmd_loss(x, -torch.ones(64, 32))) > 0.5
+    # matches a naive cdist formulation
+    xy = torch.cat([x, y])
+    D = torch.cdist(xy, xy)
+    bw = D.sum() / (160 * 160 - 160)
+    K = sum(torch.exp(-D / (bw * 2.0 ** (k - 3))) for k in range(7))
+    kxx, kyy, kxy = K[:96, :96], K[96:, 96:], K[:96, 96:]
+    want = (kxx.sum() - kxx.trace()) / (96 * 95) + (kyy.sum() - kyy.trace()) / (64 * 63) - 2 * kxy.mean()
+    assert abs(float(v - want)) < 1e-5
