@@ -1,0 +1,199 @@
+"""ctypes binding of the C ABI in include/dvg.h (libdvg.so).
+
+This is the stub a maintainer of the reference would add:
+plain pointers and sizes, torch only supplies device memory and the stream.
+There is no fallback: if the library is missing or a call fails, an exception
+is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvg.so")
+
+_lib = None
+
+
+class DvgError(RuntimeError):
+    pass
+
+
+class MmdCfg(ctypes.Structure):
+    _fields_ = [
+        ("n_kernels", c_int32),
+        ("factor", c_float),
+        ("bandwidth", c_float),
+        ("squared", c_int32),
+        ("reduce_mean", c_int32),
+        ("biased", c_int32),
+    ]
+
+
+class EncoderParams(ctypes.Structure):
+    _fields_ = [
+        ("conv_w", c_void_p * 4),
+        ("conv_b", c_void_p * 4),
+        ("bn_g", c_void_p * 4),
+        ("bn_b", c_void_p * 4),
+        ("bn_rm", c_void_p * 4),
+        ("bn_rv", c_void_p * 4),
+        ("bn_nbt", c_void_p * 4),
+        ("proj_w", c_void_p),
+        ("proj_b", c_void_p),
+    ]
+
+
+class EncoderGrads(ctypes.Structure):
+    _fields_ = [
+        ("conv_w", c_void_p * 4),
+        ("conv_b", c_void_p * 4),
+        ("bn_g", c_void_p * 4),
+        ("bn_b", c_void_p * 4),
+        ("proj_w", c_void_p),
+        ("proj_b", c_void_p),
+    ]
+
+
+class DecoderParams(ctypes.Structure):
+    _fields_ = [
+        ("lin_w", c_void_p),
+        ("lin_b", c_void_p),
+        ("conv_w", c_void_p * 5),
+        ("conv_b", c_void_p * 5),
+        ("bn_g", c_void_p * 4),
+        ("bn_b", c_void_p * 4),
+        ("bn_rm", c_void_p * 4),
+        ("bn_rv", c_void_p * 4),
+        ("bn_nbt", c_void_p * 4),
+    ]
+
+
+class DecoderGrads(ctypes.Structure):
+    _fields_ = [
+        ("lin_w", c_void_p),
+        ("lin_b", c_void_p),
+        ("conv_w", c_void_p * 5),
+        ("conv_b", c_void_p * 5),
+        ("bn_g", c_void_p * 4),
+        ("bn_b", c_void_p * 4),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/dvg.h declares
+_I32P = POINTER(c_int32)
+SIGNATURES = {
+    "dvg_version": (c_int, []),
+    "dvg_last_error": (c_char_p, []),
+    "dvg_graph_create": (c_int, [c_int, c_int, _I32P, _I32P, _I32P, _I32P, c_int, _I32P, _I32P, _I32P, POINTER(c_void_p)]),
+    "dvg_graph_destroy": (c_int, [c_void_p]),
+    "dvg_gibbs_sample": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_int,
+         c_uint32, c_uint64, c_uint32, c_int, c_int, c_void_p, c_void_p],
+    ),
+    "dvg_grbm_energy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dvg_grbm_suffstats_workspace_bytes": (c_size_t, [c_void_p]),
+    "dvg_grbm_suffstats": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
+    ),
+    "dvg_gumbel_fwd": (
+        c_int,
+        [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p],
+    ),
+    "dvg_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "dvg_heaviside_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "dvg_mmd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "dvg_mmd_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_int, POINTER(MmdCfg), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "dvg_encoder_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "dvg_encoder_fwd": (
+        c_int,
+        [POINTER(EncoderParams), c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "dvg_encoder_bwd": (
+        c_int,
+        [POINTER(EncoderParams), c_int, c_void_p, c_int64, c_void_p, POINTER(EncoderGrads), c_void_p, c_size_t, c_void_p],
+    ),
+    "dvg_decoder_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "dvg_decoder_fwd": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_int, POINTER(c_void_p), c_uint64, c_uint64, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
+    "dvg_decoder_bwd": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p,
+         c_size_t, c_void_p],
+    ),
+    "dvg_mse_workspace_bytes": (c_size_t, []),
+    "dvg_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dvg_adam_step": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
+         c_float, c_void_p],
+    ),
+    "dvg_prof_enable": (c_int, [c_int]),
+    "dvg_prof_reset": (c_int, []),
+    "dvg_prof_num_kernels": (c_int, []),
+    "dvg_prof_kernel_name": (c_char_p, [c_int]),
+    "dvg_prof_query": (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libdvg.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library.  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DvgError(
+                f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()). "
+                "The HIP library is required; there is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().dvg_last_error().decode("utf-8", "replace")
+        raise DvgError(f"{what or 'libdvg call'} failed with code {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t, name: str):
+    if not t.is_cuda:
+        raise DvgError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise DvgError(f"{name} must be contiguous")
+    return t

@@ -1,0 +1,103 @@
+// Shared plumbing for libdvg.so: error reporting, launch + optional event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dvg.h"
+
+namespace dvg {
+
+void set_error(const char* fmt, ...);
+
+#define DVG_CHECK_HIP(expr)                                                            \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      dvg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                     __LINE__);                                                        \
+      return DVG_E_HIP;                                                                \
+    }                                                                                  \
+  } while (0)
+
+#define DVG_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      dvg::set_error(__VA_ARGS__);        \
+      return DVG_E_INVALID;               \
+    }                                     \
+  } while (0)
+
+#define DVG_TRY(expr)          \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != DVG_OK) return _rc; \
+  } while (0)
+
+// ---- kernel ids for the profiler (names in prof.cpp must stay in sync) ----
+enum KernelId : int {
+  K_GIBBS = 0,
+  K_GRBM_ENERGY,
+  K_GRBM_SUFFSTATS,
+  K_GUMBEL_FWD,
+  K_GUMBEL_BWD,
+  K_MMD_PREP,
+  K_MMD_DISTSUM,
+  K_MMD_MAIN,
+  K_MMD_FINAL,
+  K_CONV_IGEMM_FWD,
+  K_CONV_IGEMM_DGRAD,
+  K_CONV_WGRAD,
+  K_WGRAD_REDUCE,
+  K_WEIGHT_PACK,
+  K_BN_FINALIZE,
+  K_ENC_CONV0_FWD,
+  K_ENC_CONV0_WGRAD,
+  K_ENC_BN_POOL_FWD,
+  K_ENC_BN_POOL_BWD_REDUCE,
+  K_ENC_BN_POOL_BWD_APPLY,
+  K_ENC_PROJ_FWD,
+  K_ENC_PROJ_BWD,
+  K_DEC_LINEAR,
+  K_DEC_BN_ACT_FWD,
+  K_DEC_BN_ACT_BWD_REDUCE,
+  K_DEC_BN_ACT_BWD_APPLY,
+  K_DEC_CONV3_FWD,
+  K_DEC_CONV3_BWD,
+  K_DEC_FINAL_FWD,
+  K_DEC_FINAL_BWD,
+  K_MSE,
+  K_ADAM,
+  K_MISC,
+  K_COUNT
+};
+
+// Profiler hooks (prof.cpp).  begin/end record a hipEvent pair on `s` when enabled.
+bool prof_on();
+void prof_begin(int id, hipStream_t s);
+void prof_end(int id, hipStream_t s);
+
+struct ProfScope {
+  int id; hipStream_t s; bool on;
+  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(prof_on()) { if (on) prof_begin(id, s); }
+  ~ProfScope() { if (on) prof_end(id, s); }
+};
+
+// Launch helper: kernel<<<grid, block, shmem, stream>>>(args...) wrapped in a profiler scope,
+// returning DVG_E_HIP from the enclosing function on a launch error.
+#define DVG_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                         \
+  do {                                                                                  \
+    dvg::ProfScope _ps((id), (stream));                                                 \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
+    hipError_t _le = hipGetLastError();                                                 \
+    if (_le != hipSuccess) {                                                            \
+      dvg::set_error("launch of %s failed: %s (%s:%d)", #kernel, hipGetErrorString(_le), \
+                     __FILE__, __LINE__);                                               \
+      return DVG_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace dvg

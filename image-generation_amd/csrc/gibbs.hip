@@ -1,0 +1,171 @@
+// Many-chain graph-coloured block-Gibbs sampler for the GRBM prior (stands in for
+// the QPU draw of /root/reference/src/model_wrapper.py:309-316).  Bit-exact
+// against oracle/gibbs.py ("DVG block-Gibbs v1").
+//
+// Mapping: a workgroup stages the graph once into LDS (h, CSR neighbours with
+// their couplings; coalesced HBM reads of the J/h tensors) and each group of LPC
+// lanes of a wavefront owns one chain whose +-1 state lives in LDS for all sweeps.
+// Within a colour class spins are conditionally independent, so the lanes update
+// them simultaneously; classes are separated by a wavefront-level fence only (no
+// workgroup barrier: chains never interact).
+#include "common.h"
+#include "graph.h"
+#include "philox.h"
+
+namespace dvg {
+
+struct GibbsArgs {
+  const int32_t *order, *class_ptr, *adj_ptr, *adj_idx, *adj_eid;
+  const float *linear, *quadratic;
+  int n, n_adj, n_colours;
+  float prefactor, h_lo, h_hi, j_lo, j_hi, two_beta;
+  int8_t* state;
+  float* samples_out;
+  int n_chains;
+  uint32_t chain_id0, k0, k1, sweep0;
+  int n_sweeps, init;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// LPC = lanes per chain (16, 32 or 64); WAVES waves per workgroup.
+template <int LPC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n = a.n, n_adj = a.n_adj;
+  // LDS carve-up (all 4-byte aligned first, then 2-byte, then bytes)
+  float* s_hs = reinterpret_cast<float*>(smem);                    // [n]
+  float* s_adjJ = s_hs + n;                                        // [n_adj]
+  int32_t* s_cls = reinterpret_cast<int32_t*>(s_adjJ + n_adj);     // [n_colours + 1]
+  uint16_t* s_adjptr = reinterpret_cast<uint16_t*>(s_cls + a.n_colours + 1);  // [n + 1] (+pad)
+  uint16_t* s_order = s_adjptr + ((n + 2) & ~1);                   // [n] (+pad)
+  uint16_t* s_adjidx = s_order + ((n + 1) & ~1);                   // [n_adj] (+pad)
+  int8_t* s_state = reinterpret_cast<int8_t*>(s_adjidx + ((n_adj + 1) & ~1));
+  const int n_pad = (n + 15) & ~15;
+
+  const int tid = threadIdx.x;
+  constexpr int NT = WAVES * 64;
+  for (int i = tid; i < n; i += NT) {
+    s_hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
+    s_order[i] = (uint16_t)a.order[i];
+  }
+  for (int i = tid; i <= n; i += NT) s_adjptr[i] = (uint16_t)a.adj_ptr[i];
+  for (int q = tid; q < n_adj; q += NT) {
+    s_adjJ[q] = clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[q]]), a.j_lo, a.j_hi);
+    s_adjidx[q] = (uint16_t)a.adj_idx[q];
+  }
+  for (int i = tid; i <= a.n_colours; i += NT) s_cls[i] = a.class_ptr[i];
+  __syncthreads();
+
+  constexpr int CPW = 64 / LPC;  // chains per wave
+  const int wave = tid >> 6, lane = tid & 63;
+  const int sub = lane / LPC, l = lane % LPC;
+  const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
+  const bool valid = chain < a.n_chains;
+  int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
+  const uint32_t cid = a.chain_id0 + (uint32_t)chain;
+
+  if (valid) {
+    if (a.init) {
+      for (int i = l; i < n; i += LPC) {
+        u32x4 r = philox4x32_10((uint32_t)i, cid, 0u, STREAM_INIT, a.k0, a.k1);
+        st[i] = (r.x >> 31) ? 1 : -1;
+      }
+    } else {
+      const int8_t* src = a.state + (size_t)chain * n;
+      for (int i = l; i < n; i += LPC) st[i] = src[i];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  if (valid) {
+    for (uint32_t t = a.sweep0; t < a.sweep0 + (uint32_t)a.n_sweeps; ++t) {
+      const uint32_t tq = t >> 2, tw = t & 3u;
+      for (int k = 0; k < a.n_colours; ++k) {
+        const int lo = s_cls[k], hi = s_cls[k + 1];
+        for (int p = lo + l; p < hi; p += LPC) {
+          const int i = s_order[p];
+          float f = s_hs[i];
+          const int q1 = s_adjptr[i + 1];
+          for (int q = s_adjptr[i]; q < q1; ++q) {
+            const float w = s_adjJ[q];
+            f = __fadd_rn(f, st[s_adjidx[q]] > 0 ? w : -w);
+          }
+          float z = clampf(__fmul_rn(a.two_beta, f), -87.0f, 87.0f);
+          const float tt = spec_exp(z);
+          const u32x4 r = philox4x32_10((uint32_t)i, cid, tq, STREAM_GIBBS, a.k0, a.k1);
+          const float u = u32_to_unit(pick(r, tw));
+          const float b = __fmul_rn(u, __fadd_rn(1.0f, tt));
+          st[i] = (b < 1.0f) ? 1 : -1;
+        }
+        // the next class reads what this one wrote (same wave): order LDS traffic
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    int8_t* dst = a.state + (size_t)chain * n;
+    for (int i = l; i < n; i += LPC) {
+      const int8_t v = st[i];
+      dst[i] = v;
+      if (a.samples_out) a.samples_out[(size_t)chain * n + i] = (float)v;
+    }
+  }
+}
+
+static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_block) {
+  size_t b = 0;
+  b += sizeof(float) * (size_t)(n + n_adj);
+  b += sizeof(int32_t) * (size_t)(n_colours + 1);
+  b += sizeof(uint16_t) * (size_t)(((n + 2) & ~1) + ((n + 1) & ~1) + ((n_adj + 1) & ~1));
+  b += (size_t)chains_per_block * ((n + 15) & ~15);
+  return b;
+}
+
+template <int LPC, int WAVES>
+static int launch_gibbs(const GibbsArgs& a, hipStream_t s) {
+  constexpr int CPB = WAVES * (64 / LPC);
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_adj, a.n_colours, CPB);
+  if (lds > 160 * 1024) {
+    set_error("gibbs: graph (n=%d, 2|E|=%d) needs %zu B of LDS > 160 KiB", a.n, a.n_adj, lds);
+    return DVG_E_UNSUPPORTED;
+  }
+  auto kern = gibbs_kernel<LPC, WAVES>;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)ceil_div(a.n_chains, CPB);
+  DVG_LAUNCH(K_GIBBS, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  return DVG_OK;
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const float* quadratic,
+                                float prefactor, float h_lo, float h_hi, float j_lo, float j_hi,
+                                float beta, int8_t* state, int n_chains, uint32_t chain_id0,
+                                uint64_t seed, uint32_t sweep0, int n_sweeps, int init,
+                                float* samples_out, dvg_stream_t stream) {
+  DVG_REQUIRE(g && linear && quadratic && state, "gibbs: null argument");
+  DVG_REQUIRE(n_chains > 0 && n_sweeps >= 0, "gibbs: n_chains=%d n_sweeps=%d", n_chains, n_sweeps);
+  DVG_REQUIRE(g->n <= 65535 && g->n_adj <= 65535, "gibbs: graph too large (n=%d, 2|E|=%d)", g->n, g->n_adj);
+  GibbsArgs a;
+  a.order = g->order; a.class_ptr = g->class_ptr; a.adj_ptr = g->adj_ptr;
+  a.adj_idx = g->adj_idx; a.adj_eid = g->adj_eid;
+  a.linear = linear; a.quadratic = quadratic;
+  a.n = g->n; a.n_adj = g->n_adj; a.n_colours = g->n_colours;
+  a.prefactor = prefactor; a.h_lo = h_lo; a.h_hi = h_hi; a.j_lo = j_lo; a.j_hi = j_hi;
+  a.two_beta = 2.0f * beta;
+  a.state = state; a.samples_out = samples_out; a.n_chains = n_chains;
+  a.chain_id0 = chain_id0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
+  a.sweep0 = sweep0; a.n_sweeps = n_sweeps; a.init = init;
+  hipStream_t s = (hipStream_t)stream;
+  // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
+  const int mc = g->max_class;
+  const bool big = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 4) > 72 * 1024;
+  if (mc <= 16) return launch_gibbs<16, 4>(a, s);
+  if (mc <= 32) return launch_gibbs<32, 4>(a, s);
+  if (big) return launch_gibbs<64, 2>(a, s);
+  return launch_gibbs<64, 4>(a, s);
+}

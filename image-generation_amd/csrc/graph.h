@@ -1,0 +1,15 @@
+// Device-side view of the GRBM graph held by a dvg_graph handle.
+#pragma once
+#include <stdint.h>
+
+struct dvg_graph {
+  int n, n_edges, n_colours, max_class, max_degree, n_adj;
+  int device;
+  // device arrays (owned)
+  int32_t *edge_i, *edge_j;      // [n_edges]
+  int32_t *order;                // [n] spins in colour-class order
+  int32_t *class_ptr;            // [n_colours + 1]
+  int32_t *adj_ptr;              // [n + 1]
+  int32_t *adj_idx, *adj_eid;    // [2 n_edges]
+  int32_t h_class_ptr[65];       // host copy (n_colours <= 64)
+};

@@ -1,0 +1,176 @@
+// Small fused kernels: latent->discrete (Gumbel-softmax / heaviside), MSE(+grad), Adam.
+#include "common.h"
+#include "philox.h"
+
+namespace dvg {
+
+// ---------------------------------------------------------------- Gumbel-softmax, 2 classes
+// Plugin default latent_to_discrete (call site /root/reference/src/model_wrapper.py:184-188, :297).
+__global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, int64_t B, int n, int R,
+                                                         float tau, const float* __restrict__ gumbels,
+                                                         uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi,
+                                                         float* __restrict__ spins, float* __restrict__ dspin) {
+  const int64_t total = B * R * (int64_t)n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e % n);
+    const int64_t b = e / ((int64_t)n * R);
+    const float l = logits[b * n + i];
+    float g0, g1;
+    if (gumbels) {
+      g0 = gumbels[2 * e];
+      g1 = gumbels[2 * e + 1];
+    } else {
+      const u32x4 r = philox4x32_10((uint32_t)e, off_lo, off_hi ^ (uint32_t)(e >> 32), STREAM_GUMBEL, k0, k1);
+      const float u0 = __fmul_rn(__uint2float_rn(r.x >> 8) + 0.5f, 5.9604644775390625e-08f);
+      const float u1 = __fmul_rn(__uint2float_rn(r.y >> 8) + 0.5f, 5.9604644775390625e-08f);
+      g0 = -logf(-logf(u0));
+      g1 = -logf(-logf(u1));
+    }
+    const float y0 = __fdiv_rn(__fadd_rn(l, g0), tau);
+    const float y1 = __fdiv_rn(g1, tau);
+    const float m = fmaxf(y0, y1);
+    const float e0 = expf(y0 - m), e1 = expf(y1 - m);
+    const float p0 = e0 / (e0 + e1);
+    spins[e] = (y0 >= y1) ? 1.0f : -1.0f;  // argmax, ties -> class 0 (+1)
+    dspin[e] = 2.0f * p0 * (1.0f - p0) / tau;
+  }
+}
+
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ dspin,
+                                                         int64_t B, int n, int R, float* __restrict__ gl) {
+  const int64_t total = B * (int64_t)n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e % n);
+    const int64_t b = e / n;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const int64_t k = (b * R + r) * n + i;
+      acc += gs[k] * dspin[k];
+    }
+    gl[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void heaviside_kernel(const float* __restrict__ l, int64_t numel, float* __restrict__ s) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += (int64_t)gridDim.x * 256)
+    s[e] = l[e] > 0.f ? 1.0f : -1.0f;  // H(0) = 0 -> -1 (/root/reference/src/utils/common.py:164-171)
+}
+
+// ---------------------------------------------------------------- MSE + gradient
+constexpr int MSE_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ recon, const float* __restrict__ img,
+                                                          int64_t B, int R, float gscale, double* __restrict__ partial,
+                                                          float* __restrict__ grad) {
+  const int64_t total4 = B * R * 256;  // float4 units (1024 pixels per image)
+  const float4* r4 = reinterpret_cast<const float4*>(recon);
+  const float4* i4 = reinterpret_cast<const float4*>(img);
+  float4* g4 = reinterpret_cast<float4*>(grad);
+  double acc = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / ((int64_t)R * 256);
+    const int px = (int)(e % 256);
+    const float4 a = r4[e], t = i4[b * 256 + px];
+    const float d0 = a.x - t.x, d1 = a.y - t.y, d2 = a.z - t.z, d3 = a.w - t.w;
+    acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+    if (grad) g4[e] = make_float4(gscale * d0, gscale * d1, gscale * d2, gscale * d3);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void mse_final_kernel(const double* __restrict__ partial, int nb, double inv_numel,
+                                                       float* __restrict__ loss) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nb; ++k) s += partial[k];
+    *loss = (float)(s * inv_numel);
+  }
+}
+
+// ---------------------------------------------------------------- Adam (coupled L2), flat buffers
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t numel,
+                                                   float step_size, float b1, float b2, float eps, float wd,
+                                                   float bc2_sqrt, float gscale) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += (int64_t)gridDim.x * 256) {
+    const float pe = p[e];
+    float ge = g[e] * gscale;
+    if (wd != 0.f) ge = ge + wd * pe;          // grad = grad.add(param, alpha=weight_decay)
+    const float me = m[e] + (1.0f - b1) * (ge - m[e]);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float ve = b2 * v[e] + (1.0f - b2) * ge * ge;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    m[e] = me;
+    v[e] = ve;
+    const float denom = sqrtf(ve) / bc2_sqrt + eps;
+    p[e] = pe - step_size * (me / denom);
+  }
+}
+
+static inline unsigned grid_for(int64_t n) {
+  int64_t b = ceil_div(n, 256);
+  return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, float tau, const float* gumbels,
+                              uint64_t seed, uint64_t offset, float* spins, float* dspin, dvg_stream_t stream) {
+  DVG_REQUIRE(logits && spins && dspin, "gumbel_fwd: null argument");
+  DVG_REQUIRE(B > 0 && n > 0 && R > 0 && tau > 0.f, "gumbel_fwd: B=%lld n=%d R=%d tau=%g", (long long)B, n, R, tau);
+  DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_kernel, dim3(grid_for(B * R * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
+             logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
+             (uint32_t)(offset >> 32), spins, dspin);
+  return DVG_OK;
+}
+
+extern "C" int dvg_gumbel_bwd(const float* grad_spins, const float* dspin, int64_t B, int n, int R,
+                              float* grad_logits, dvg_stream_t stream) {
+  DVG_REQUIRE(grad_spins && dspin && grad_logits, "gumbel_bwd: null argument");
+  DVG_REQUIRE(B > 0 && n > 0 && R > 0, "gumbel_bwd: bad shape");
+  DVG_LAUNCH(K_GUMBEL_BWD, gumbel_bwd_kernel, dim3(grid_for(B * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
+             grad_spins, dspin, B, n, R, grad_logits);
+  return DVG_OK;
+}
+
+extern "C" int dvg_heaviside_fwd(const float* logits, int64_t numel, float* spins, dvg_stream_t stream) {
+  DVG_REQUIRE(logits && spins && numel > 0, "heaviside_fwd: bad argument");
+  DVG_LAUNCH(K_GUMBEL_FWD, heaviside_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, logits, numel,
+             spins);
+  return DVG_OK;
+}
+
+extern "C" size_t dvg_mse_workspace_bytes(void) { return sizeof(double) * MSE_BLOCKS; }
+
+extern "C" int dvg_mse_fwd_bwd(const float* recon, const float* images, int64_t B, int R, float grad_scale,
+                               float* loss_out, float* grad_recon, void* ws, size_t ws_bytes, dvg_stream_t stream) {
+  DVG_REQUIRE(recon && images && loss_out && ws, "mse: null argument");
+  DVG_REQUIRE(B > 0 && R > 0, "mse: B=%lld R=%d", (long long)B, R);
+  if (ws_bytes < dvg_mse_workspace_bytes()) { set_error("mse: workspace too small"); return DVG_E_WORKSPACE; }
+  const double numel = (double)B * R * 1024.0;
+  const float gs = (float)(2.0 * (double)grad_scale / numel);
+  hipStream_t s = (hipStream_t)stream;
+  DVG_LAUNCH(K_MSE, mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, s, recon, images, B, R, gs, (double*)ws,
+             grad_recon);
+  DVG_LAUNCH(K_MSE, mse_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, MSE_BLOCKS, 1.0 / numel, loss_out);
+  return DVG_OK;
+}
+
+extern "C" int dvg_adam_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                             dvg_stream_t stream) {
+  DVG_REQUIRE(p && g && m && v, "adam: null argument");
+  DVG_REQUIRE(numel > 0 && step >= 1, "adam: numel=%lld step=%lld", (long long)numel, (long long)step);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  DVG_LAUNCH(K_ADAM, adam_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, numel,
+             (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2), grad_scale);
+  return DVG_OK;
+}

@@ -1,0 +1,89 @@
+// Error string + optional per-kernel HIP-event profiler of libdvg.so.
+#include "common.h"
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace dvg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static const char* kNames[K_COUNT] = {
+    "gibbs_sweeps", "grbm_energy", "grbm_suffstats", "gumbel_fwd", "gumbel_bwd", "mmd_prep",
+    "mmd_distsum", "mmd_main", "mmd_final", "conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad",
+    "wgrad_reduce", "weight_pack", "bn_finalize", "enc_conv0_fwd", "enc_conv0_wgrad",
+    "enc_bn_pool_fwd", "enc_bn_pool_bwd_reduce", "enc_bn_pool_bwd_apply", "enc_proj_fwd",
+    "enc_proj_bwd", "dec_linear", "dec_bn_act_fwd", "dec_bn_act_bwd_reduce",
+    "dec_bn_act_bwd_apply", "dec_conv3_fwd", "dec_conv3_bwd", "dec_final_fwd", "dec_final_bwd",
+    "mse", "adam", "misc"};
+
+struct EvPair { hipEvent_t a, b; };
+static bool g_on = false;
+static std::mutex g_mu;
+static std::vector<EvPair> g_pairs[K_COUNT];
+static std::vector<EvPair> g_free;
+static double g_ms[K_COUNT];
+static int64_t g_n[K_COUNT];
+static thread_local EvPair g_open[K_COUNT];
+
+bool prof_on() { return g_on; }
+
+void prof_begin(int id, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  EvPair p;
+  if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+  else { hipEventCreate(&p.a); hipEventCreate(&p.b); }
+  hipEventRecord(p.a, s);
+  g_open[id] = p;
+}
+
+void prof_end(int id, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEventRecord(g_open[id].b, s);
+  g_pairs[id].push_back(g_open[id]);
+}
+
+static void drain(int id) {
+  for (auto& p : g_pairs[id]) {
+    hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[id] += ms; g_n[id] += 1; }
+    g_free.push_back(p);
+  }
+  g_pairs[id].clear();
+}
+
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" {
+
+int dvg_version(void) { return 100; /* 0.1.0 */ }
+const char* dvg_last_error(void) { return g_err; }
+
+int dvg_prof_enable(int on) { g_on = on != 0; return DVG_OK; }
+int dvg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_n[i] = 0; }
+  return DVG_OK;
+}
+int dvg_prof_num_kernels(void) { return K_COUNT; }
+const char* dvg_prof_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : ""; }
+int dvg_prof_query(int id, double* total_ms, int64_t* launches) {
+  if (id < 0 || id >= K_COUNT) { set_error("bad kernel id %d", id); return DVG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g_mu);
+  drain(id);
+  if (total_ms) *total_ms = g_ms[id];
+  if (launches) *launches = g_n[id];
+  return DVG_OK;
+}
+
+}  // extern "C"

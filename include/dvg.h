@@ -1,0 +1,225 @@
+/* dvg.h — C ABI of libdvg.so: the MI355X (gfx950) DVAE + GRBM training path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python
+ * over PyTorch and the un-vendored `dwave-pytorch-plugin`; each entry point
+ * below replaces the arithmetic behind one reference call site (cited per
+ * function).  The reference-side binding is a ctypes stub, shown in
+ * INTEGRATION.md and implemented in image-generation_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `float*`/`int8_t*`/... argument not
+ *     marked [host] is a DEVICE pointer owned by the caller (torch owns memory);
+ *   - every function enqueues its work on `stream` (a hipStream_t passed as
+ *     void*) and returns without synchronising; no hidden allocation except
+ *     inside dvg_graph_create;
+ *   - return value: 0 (DVG_OK) or a negative DVG_E_* code; the message is
+ *     available from dvg_last_error() (thread-local); nothing throws or exits;
+ *   - no global mutable state besides the optional profiler; HIP is initialised
+ *     lazily by the first call in each process (the Dash app runs training in a
+ *     spawned worker: /root/reference/app.py:37-43).
+ */
+#ifndef DVG_H
+#define DVG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVG_OK 0
+#define DVG_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
+#define DVG_E_HIP (-2)         /* a HIP runtime call failed */
+#define DVG_E_WORKSPACE (-3)   /* caller workspace too small */
+#define DVG_E_UNSUPPORTED (-4) /* valid request this build cannot serve */
+
+typedef void *dvg_stream_t; /* hipStream_t */
+
+int dvg_version(void);
+const char *dvg_last_error(void);
+
+/* ------------------------------------------------------------------ graph
+ * The GRBM graph as the sampler and the energy kernels need it.  Built on the
+ * host by image-generation_amd/graphs.py::build_plan from what the reference
+ * derives at /root/reference/src/utils/common.py:123-126 and hands to
+ * GraphRestrictedBoltzmannMachine(nodes, edges)
+ * (/root/reference/src/model_wrapper.py:202-206).  All arrays [host], int32.
+ * The handle owns small device copies (the only allocation in this library).
+ */
+typedef struct dvg_graph dvg_graph_t;
+int dvg_graph_create(int n, int n_edges, const int32_t *edge_i, const int32_t *edge_j,
+                     const int32_t *order, const int32_t *class_ptr, int n_colours,
+                     const int32_t *adj_ptr, const int32_t *adj_idx, const int32_t *adj_eid,
+                     dvg_graph_t **out);
+int dvg_graph_destroy(dvg_graph_t *g);
+
+/* ------------------------------------------------------------------ sampler
+ * Replaces the QPU draw `sampler.sample_ising(h, J, num_reads=...)` issued by
+ * GraphRestrictedBoltzmannMachine.sample (/root/reference/src/model_wrapper.py:309-316,
+ * :369-376; /root/reference/src/utils/persistent_qpu_sampler.py:71-78) with
+ * `n_sweeps` sweeps of the graph-coloured block-Gibbs sampler defined in
+ * oracle/gibbs.py, on `n_chains` chains with global ids chain_id0 ... .
+ *   linear (n), quadratic (n_edges): raw GRBM parameters; the kernel applies
+ *     hs = clamp(prefactor*h, h_lo, h_hi), Js = clamp(prefactor*J, j_lo, j_hi)
+ *     (the plugin's to_ising) and samples p(s) ~ exp(-beta (hs.s + s.Js.s)).
+ *   state (n_chains, n) int8 +-1: in/out (persistent chains).  init != 0 draws
+ *     the start state from the INIT stream first.
+ *   samples_out (n_chains, n) float32 +-1, or NULL.
+ *   sweep0: global index of the first sweep (keeps the random stream moving).
+ */
+int dvg_gibbs_sample(const dvg_graph_t *g, const float *linear, const float *quadratic,
+                     float prefactor, float h_lo, float h_hi, float j_lo, float j_hi, float beta,
+                     int8_t *state, int n_chains, uint32_t chain_id0, uint64_t seed,
+                     uint32_t sweep0, int n_sweeps, int init, float *samples_out,
+                     dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ GRBM
+ * Energy  E(x) = x.h + sum_e J_e x_i x_j  per row: the plugin's
+ * GraphRestrictedBoltzmannMachine.__call__ as used by nll_loss
+ * (/root/reference/src/losses.py:61).  x (rows, n) float32.
+ */
+int dvg_grbm_energy(const dvg_graph_t *g, const float *x, int64_t rows, const float *linear,
+                    const float *quadratic, float *energy_out, dvg_stream_t stream);
+/* Backward of the energy = weighted sufficient statistics:
+ *   acc_linear[i]    (+)= scale * sum_r w_r x_ri ;
+ *   acc_quadratic[e] (+)= scale * sum_r w_r x_ri x_rj      (w_r = 1 when row_weight is NULL).
+ * accumulate == 0 overwrites.  With w = 1, scale = 1/rows this is the data (or, negated, the
+ * model) half of the quasi-NLL gradient of /root/reference/src/losses.py:61.  Deterministic
+ * (fixed-order two-stage reduction in double).  ws: dvg_grbm_suffstats_workspace_bytes(g). */
+size_t dvg_grbm_suffstats_workspace_bytes(const dvg_graph_t *g);
+int dvg_grbm_suffstats(const dvg_graph_t *g, const float *x, int64_t rows, const float *row_weight,
+                       float scale, float *acc_linear, float *acc_quadratic, int accumulate,
+                       void *ws, size_t ws_bytes, dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ latent -> discrete
+ * Default latent_to_discrete of DiscreteVariationalAutoencoder
+ * (/root/reference/src/model_wrapper.py:184-188 passes None -> plugin default):
+ * Gumbel-softmax over logits [l, 0], temperature tau, hard, R replicas, mapped
+ * to spins +-1 with the straight-through gradient.
+ *   logits (B, n); gumbels (B, R, n, 2) Gumbel(0,1) noise or NULL (then drawn
+ *   on device from Philox stream GUMBEL with (seed, offset));
+ *   spins (B, R, n) out; dspin (B, R, n) out: d spin / d logit, kept for bwd.
+ */
+int dvg_gumbel_fwd(const float *logits, int64_t B, int n, int R, float tau, const float *gumbels,
+                   uint64_t seed, uint64_t offset, float *spins, float *dspin,
+                   dvg_stream_t stream);
+/* grad_logits (B, n) = sum_r grad_spins[b,r,:] * dspin[b,r,:] */
+int dvg_gumbel_bwd(const float *grad_spins, const float *dspin, int64_t B, int n, int R,
+                   float *grad_logits, dvg_stream_t stream);
+/* "heaviside" mode (/root/reference/src/utils/common.py:160-173): spins (B,1,n) = 2*H(l)-1 with
+ * H(0)=0; the backward is the identity and needs no kernel. */
+int dvg_heaviside_fwd(const float *logits, int64_t numel, float *spins, dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ MMD
+ * GaussianKernel(n_kernels) + maximum_mean_discrepancy_loss(x, y, kernel)
+ * (/root/reference/src/model_wrapper.py:273, :320).  One fused pass computes the
+ * loss and d loss / d x (y carries no gradient in the reference: it is drawn
+ * under torch.no_grad(), model_wrapper.py:308).  Never materialises the
+ * (nx+ny)^2 kernel matrix.
+ */
+typedef struct {
+  int32_t n_kernels;   /* 7 in the reference */
+  float factor;        /* bandwidth multiplier base, 2.0 */
+  float bandwidth;     /* > 0: fixed base bandwidth; <= 0: data-driven sum(D)/(N^2-N) */
+  int32_t squared;     /* 0: Euclidean distance (default), 1: squared distance */
+  int32_t reduce_mean; /* 0: kernels summed (default), 1: averaged */
+  int32_t biased;      /* 0: unbiased estimator (default), 1: biased (plain means) */
+} dvg_mmd_cfg_t;
+size_t dvg_mmd_workspace_bytes(int64_t nx, int64_t ny, int dim);
+int dvg_mmd_fwd_bwd(const float *x, int64_t nx, const float *y, int64_t ny, int dim,
+                    const dvg_mmd_cfg_t *cfg, float *loss_out /* device scalar */,
+                    float *grad_x /* (nx, dim) or NULL */, void *ws, size_t ws_bytes,
+                    dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ encoder
+ * Encoder.forward / backward (/root/reference/src/encoder.py:18-49): 4 x
+ * [conv3x3 -> BatchNorm2d -> MaxPool2d(2) -> LeakyReLU] (no LeakyReLU after the
+ * last) with channels [1,32,64,128,n], then Linear(4,1) per channel.
+ * Parameter tensors are in the checkpoint layout (conv weight (Cout,Cin,3,3)).
+ * images (B,1,32,32) -> logits (B,n).  `ws` carries the saved activations from
+ * fwd to bwd (size from dvg_encoder_workspace_bytes) and must stay untouched in
+ * between.  training != 0: batch statistics, running stats updated in place
+ * (momentum 0.1, unbiased variance), num_batches_tracked += 1.
+ */
+typedef struct {
+  const float *conv_w[4], *conv_b[4]; /* Conv2d weight / bias */
+  const float *bn_g[4], *bn_b[4];     /* BatchNorm2d weight / bias */
+  float *bn_rm[4], *bn_rv[4];         /* running_mean / running_var (updated when training) */
+  int64_t *bn_nbt[4];                 /* num_batches_tracked (may be NULL) */
+  const float *proj_w, *proj_b;       /* Linear(4,1) */
+} dvg_encoder_params_t;
+typedef struct {
+  float *conv_w[4], *conv_b[4], *bn_g[4], *bn_b[4], *proj_w, *proj_b;
+} dvg_encoder_grads_t;
+size_t dvg_encoder_workspace_bytes(int64_t B, int n_latents);
+int dvg_encoder_fwd(const dvg_encoder_params_t *p, int n_latents, const float *images, int64_t B,
+                    int training, float *logits, void *ws, size_t ws_bytes, dvg_stream_t stream);
+int dvg_encoder_bwd(const dvg_encoder_params_t *p, int n_latents, const float *images, int64_t B,
+                    const float *grad_logits, const dvg_encoder_grads_t *grads, void *ws,
+                    size_t ws_bytes, dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ decoder
+ * Decoder.forward / backward (/root/reference/src/decoder.py:18-62):
+ * Linear(n,4n) -> (n,2,2) -> 4 x [ConvTranspose2d 3x3 -> BatchNorm2d ->
+ * Dropout2d(0.2) -> Upsample x2 -> LeakyReLU] with channels [n,128,64,32,1] ->
+ * ConvTranspose2d(1,1).  spins (N = B*R, n) -> out (N,1,32,32).
+ * ConvTranspose weights in checkpoint layout (Cin,Cout,3,3).
+ * dropout_keep[l]: (N, C_l) float {0,1} keep-masks, or NULL to draw them on
+ * device (Philox stream DROPOUT, (seed, offset)); ignored unless training.
+ */
+typedef struct {
+  const float *lin_w, *lin_b;         /* increase_latent_dim (4n,n), (4n) */
+  const float *conv_w[5], *conv_b[5]; /* convtrans.{0,5,10,15,20} */
+  const float *bn_g[4], *bn_b[4];
+  float *bn_rm[4], *bn_rv[4];
+  int64_t *bn_nbt[4];
+} dvg_decoder_params_t;
+typedef struct {
+  float *lin_w, *lin_b, *conv_w[5], *conv_b[5], *bn_g[4], *bn_b[4];
+} dvg_decoder_grads_t;
+size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents);
+int dvg_decoder_fwd(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                    int training, const float *const dropout_keep[4], uint64_t seed,
+                    uint64_t offset, float *out, void *ws, size_t ws_bytes, dvg_stream_t stream);
+int dvg_decoder_bwd(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                    const float *grad_out, const dvg_decoder_grads_t *grads,
+                    float *grad_spins /* (N,n) or NULL */, void *ws, size_t ws_bytes,
+                    dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ MSE
+ * torch.nn.functional.mse_loss(reconstructed, images.unsqueeze(1).repeat(1,R,...))
+ * (/root/reference/src/model_wrapper.py:302-305), fused with its gradient:
+ * loss_out = mean((recon - image)^2); grad_recon = grad_scale * 2 (recon - image) / numel.
+ * recon (B,R,1024), images (B,1024).
+ */
+size_t dvg_mse_workspace_bytes(void);
+int dvg_mse_fwd_bwd(const float *recon, const float *images, int64_t B, int R, float grad_scale,
+                    float *loss_out, float *grad_recon /* or NULL */, void *ws, size_t ws_bytes,
+                    dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ Adam
+ * torch.optim.Adam with coupled L2 weight decay, as configured at
+ * /root/reference/src/model_wrapper.py:208-217, on one flat parameter buffer.
+ * g <- grad_scale*g + wd*p;  m,v updated; p -= lr/(1-b1^t) * m / (sqrt(v/(1-b2^t)) + eps).
+ */
+int dvg_adam_step(float *p, const float *g, float *m, float *v, int64_t numel, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  float grad_scale, dvg_stream_t stream);
+
+/* ------------------------------------------------------------------ profiler
+ * Optional per-kernel HIP-event timing inside the library (used by bench.py for
+ * the `roofline` object).  Off by default; enabling it adds event records on
+ * the caller's stream around every kernel launch.
+ */
+int dvg_prof_enable(int on);
+int dvg_prof_reset(void);
+int dvg_prof_num_kernels(void);
+const char *dvg_prof_kernel_name(int id);
+/* synchronises the recorded events; returns total milliseconds and launch count */
+int dvg_prof_query(int id, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVG_H */
