@@ -4,8 +4,6 @@
 using namespace dvg;
 #define NOT_YET(name) do { set_error(name ": not implemented in this build"); return DVG_E_UNSUPPORTED; } while (0)
 extern "C" {
-size_t dvg_mmd_workspace_bytes(int64_t, int64_t, int) { return 0; }
-int dvg_mmd_fwd_bwd(const float*, int64_t, const float*, int64_t, int, const dvg_mmd_cfg_t*, float*, float*, void*, size_t, dvg_stream_t) { NOT_YET("dvg_mmd_fwd_bwd"); }
 size_t dvg_encoder_workspace_bytes(int64_t, int) { return 0; }
 int dvg_encoder_fwd(const dvg_encoder_params_t*, int, const float*, int64_t, int, float*, void*, size_t, dvg_stream_t) { NOT_YET("dvg_encoder_fwd"); }
 int dvg_encoder_bwd(const dvg_encoder_params_t*, int, const float*, int64_t, const float*, const dvg_encoder_grads_t*, void*, size_t, dvg_stream_t) { NOT_YET("dvg_encoder_bwd"); }

@@ -1,0 +1,130 @@
+"""GPU parity of the fused MMD / Gumbel / MSE / Adam kernels against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from image_generation_amd import _lib, functional as F
+from oracle import plugin
+
+pytestmark = pytest.mark.gpu
+
+
+def _spins(rng, rows, d, p=0.5):
+    return torch.from_numpy(np.where(rng.random((rows, d)) < p, -1.0, 1.0).astype(np.float32))
+
+
+def _ref_mmd(x, y, dtype=torch.float64, **kw):
+    xr = x.detach().to(dtype).requires_grad_(True)
+    loss = plugin.mmd_loss(xr, y.to(dtype), **kw)
+    loss.backward()
+    return loss.detach(), xr.grad
+
+
+@pytest.mark.parametrize("nx,ny,d", [(96, 64, 32), (512, 256, 64), (2048, 256, 128), (300, 77, 256), (160, 130, 512),
+                                      (40, 33, 1024), (200, 100, 192)])
+def test_mmd_default_matches_oracle(nx, ny, d):
+    rng = np.random.default_rng(nx + d)
+    x = _spins(rng, nx, d, 0.35)
+    x[: nx // 4] = x[0]  # duplicated rows: zero distances off the diagonal (replicas of one image)
+    y = _spins(rng, ny, d, 0.6)
+    want, gwant = _ref_mmd(x, y)
+    w32, g32 = _ref_mmd(x, y, dtype=torch.float32)
+    xg = x.cuda().requires_grad_(True)
+    loss = F.mmd_loss(xg, y.cuda())
+    loss.backward()
+    # within 1e-5 relative of the exact (float64) value -- and no worse than the fp32 CPU path
+    err = abs(float(loss.detach()) - float(want))
+    assert err <= max(1e-5 * abs(float(want)), 2e-7, 2 * abs(float(w32) - float(want))), (float(loss.detach()), float(want))
+    g = xg.grad.cpu().double()
+    scale = gwant.abs().max()
+    assert (g - gwant).abs().max() <= 2e-5 * scale + 1e-9
+
+
+@pytest.mark.parametrize("kw", [dict(squared=True), dict(biased=True), dict(reduce="mean"), dict(bandwidth=3.5),
+                                dict(n_kernels=3, factor=3.0)])
+def test_mmd_switches(kw):
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.standard_normal((150, 64)).astype(np.float32))  # general floats
+    y = torch.from_numpy((rng.standard_normal((90, 64)) + 0.3).astype(np.float32))
+    want, gwant = _ref_mmd(x, y, **kw)
+    k2 = dict(kw)
+    if "reduce" in k2:
+        k2["reduce_mean"] = k2.pop("reduce") == "mean"
+    xg = x.cuda().requires_grad_(True)
+    loss = F.mmd_loss(xg, y.cuda(), **k2)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want)) <= 2e-5 * abs(float(want)) + 1e-6
+    assert (xg.grad.cpu().double() - gwant).abs().max() <= 5e-5 * gwant.abs().max() + 1e-9
+
+
+def test_gumbel_injected_noise_bit_exact_spins_and_grad():
+    torch.manual_seed(0)
+    B, R, n = 16, 8, 128
+    logits = torch.randn(B, n) * 2
+    g = -torch.empty(B, R, n, 2).exponential_().log()
+    lr = logits.clone().requires_grad_(True)
+    want = plugin.gumbel_latent_to_discrete(lr, R, gumbels=g)
+    go = torch.randn(B, R, n)
+    (want * go).sum().backward()
+    lg = logits.cuda().requires_grad_(True)
+    got = F.gumbel_latent_to_discrete(lg, R, gumbels=g.cuda())
+    (got * go.cuda()).sum().backward()
+    assert torch.equal(got.cpu(), torch.sign(want.detach()))  # exactly +-1
+    assert int((got.cpu() != want.detach().round()).sum()) == 0
+    # saturated entries p(1-p) ~ 1e-7 carry only rounding noise: compare against the gradient's scale
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-4, atol=2e-6 * float(lr.grad.abs().max()))
+
+
+def test_gumbel_device_rng_statistics():
+    B, R, n = 64, 8, 256
+    logits = torch.linspace(-1, 1, n).repeat(B, 1).cuda()
+    s = F.gumbel_latent_to_discrete(logits, R, seed=123, offset=5)
+    p = (s > 0).float().mean((0, 1)).cpu().numpy()
+    want = torch.sigmoid(torch.linspace(-1, 1, n)).numpy()  # P(l + g0 > g1) = sigmoid(l)
+    assert np.abs(p - want).max() < 5 * 0.5 / np.sqrt(B * R)
+    s2 = F.gumbel_latent_to_discrete(logits, R, seed=123, offset=6)
+    assert not torch.equal(s, s2)
+    assert torch.equal(s, F.gumbel_latent_to_discrete(logits, R, seed=123, offset=5))
+
+
+def test_heaviside():
+    l = torch.tensor([[0.3, -0.2, 0.0, 1e-9, -5.0, 2.5]], device="cuda", requires_grad=True)
+    o = F.heaviside_latent_to_discrete(l, 1)
+    assert o.shape == (1, 1, 6) and o.flatten().tolist() == [1.0, -1.0, -1.0, 1.0, -1.0, 1.0]
+    o.sum().backward()
+    assert l.grad.flatten().tolist() == [1.0] * 6
+
+
+def test_mse_and_grad():
+    torch.manual_seed(1)
+    B, R = 5, 3
+    recon = torch.randn(B, R, 1, 32, 32, requires_grad=True)
+    img = (torch.rand(B, 1, 32, 32) < 0.13).float()
+    want = torch.nn.functional.mse_loss(recon, img.unsqueeze(1).repeat(1, R, 1, 1, 1))
+    want.backward()
+    rg = recon.detach().cuda().requires_grad_(True)
+    got = F.replicated_mse_loss(rg, img.cuda())
+    (got * 1.5).backward()
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    np.testing.assert_allclose(rg.grad.cpu().numpy(), 1.5 * recon.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_adam_matches_torch():
+    torch.manual_seed(2)
+    n = 10007
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-4, weight_decay=0.01)
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    L = _lib.lib()
+    for step in range(1, 6):
+        g = torch.randn(n)
+        ref.grad = g.clone()
+        lr = 1e-4 * 0.9**step
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        gd = g.cuda()
+        _lib.check(L.dvg_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, 0.9, 0.999, 1e-8,
+                                   0.01, step, 1.0, _lib.stream_ptr()))
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)
