@@ -1,0 +1,89 @@
+// Internal interfaces of the convolution machinery (not part of the C ABI).
+//
+// Activation layout inside the library: NHWC float32 with the pixels of each image
+// in Morton (Z-curve) order.  Morton order makes every 2x2 window contiguous at
+// every resolution: MaxPool2d(2) reads rows 4q..4q+3, nearest Upsample(x2) is
+// `index >> 2`, and the 2x2-sum that is the adjoint of the upsample falls on four
+// consecutive rows of an MFMA accumulator (one lane's registers).
+#pragma once
+#include "common.h"
+
+namespace dvg {
+
+__host__ __device__ __forceinline__ uint32_t compact1by1(uint32_t v) {
+  v &= 0x55555555u;
+  v = (v | (v >> 1)) & 0x33333333u;
+  v = (v | (v >> 2)) & 0x0f0f0f0fu;
+  v = (v | (v >> 4)) & 0x00ff00ffu;
+  return v;
+}
+__host__ __device__ __forceinline__ uint32_t part1by1(uint32_t v) {
+  v &= 0xffu;
+  v = (v | (v << 4)) & 0x0f0fu;
+  v = (v | (v << 2)) & 0x3333u;
+  v = (v | (v << 1)) & 0x5555u;
+  return v;
+}
+__host__ __device__ __forceinline__ uint32_t morton(uint32_t y, uint32_t x) { return part1by1(x) | (part1by1(y) << 1); }
+__host__ __device__ __forceinline__ uint32_t morton_y(uint32_t p) { return compact1by1(p >> 1); }
+__host__ __device__ __forceinline__ uint32_t morton_x(uint32_t p) { return compact1by1(p); }
+
+// How a packed GEMM weight Wp[tap][a][b] (a: reduction channel, b: output channel) maps to the
+// checkpoint (torch) layout.
+enum WeightMode : int {
+  WM_CONV_FWD = 0,    // Conv2d weight (Cout,Cin,3,3): a = ci, b = co
+  WM_CONV_DGRAD,      // a = co, b = ci, taps flipped
+  WM_CONVT_FWD,       // ConvTranspose2d weight (Cin,Cout,3,3): a = ci, b = co, taps flipped
+  WM_CONVT_DGRAD,     // a = co, b = ci
+  WM_LIN_FWD,         // Linear (4n, n): a = ci, b = p*n + c  <->  row c*4 + p   (NHWC output)
+  WM_LIN_DGRAD        // a = p*n + c, b = ci
+};
+
+struct WeightMap {
+  int mode, Ca, Cb, ntaps;
+};
+
+__host__ __device__ __forceinline__ int64_t torch_weight_offset(const WeightMap& w, int tap, int a, int b) {
+  switch (w.mode) {
+    case WM_CONV_FWD: return ((int64_t)b * w.Ca + a) * 9 + tap;
+    case WM_CONV_DGRAD: return ((int64_t)a * w.Cb + b) * 9 + (8 - tap);
+    case WM_CONVT_FWD: return ((int64_t)a * w.Cb + b) * 9 + (8 - tap);
+    case WM_CONVT_DGRAD: return ((int64_t)b * w.Ca + a) * 9 + tap;
+    case WM_LIN_FWD: { const int c = b % w.Ca, p = b / w.Ca; return (int64_t)(c * 4 + p) * w.Ca + a; }
+    default: { const int c = a % w.Cb, p = a / w.Cb; return (int64_t)(c * 4 + p) * w.Cb + b; }
+  }
+}
+
+// Implicit-GEMM 3x3 (or 1-tap) convolution:  out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] Wp[tap][ci][co] (+ bias)
+struct ConvArgs {
+  const float* in;    // [(images * HW_in), Cin]; HW_in = HW/4 when `ups` (nearest-upsampled on the fly)
+  const float* wp;    // [ntaps][Cin][Cout]
+  const float* bias;  // [Cout] or null
+  float* out;         // [M, Cout], or [M/4, Cout] when `poolsum`
+  float* stats;       // [m_blocks][Cout][2] per-block (sum, sum of squares) of the output, or null
+  int64_t M;          // images * HW (output-resolution pixels)
+  int Cin, Cout;
+  int L;              // log2(H) = log2(W) at the output resolution (0 for the 1-tap linear layer)
+  int ntaps;          // 9 or 1
+  int ups;            // input is stored at half resolution
+  int poolsum;        // sum each 2x2 output quad (adjoint of the upsample) before storing
+};
+int launch_conv_igemm(const ConvArgs& a, int kernel_id, hipStream_t s);
+int conv_stats_blocks(int64_t M, int Cout);  // number of m_blocks launch_conv_igemm will use (for `stats`)
+
+// Weight-gradient GEMM:  dWp[tap][a][b] = sum_m in[nbr(m,tap)][a] * dy[m][b], split over `ksplit` slabs.
+struct WgradArgs {
+  const float* in;   // as ConvArgs.in
+  const float* dy;   // [M, Cout]
+  float* slabs;      // [ksplit][ntaps][Cin][Cout]
+  int64_t M;
+  int Cin, Cout, L, ntaps, ups, ksplit;
+};
+int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps);
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
+// sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
+int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);
+// Wp[tap][a][b] <- checkpoint-layout weight
+int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s);
+
+}  // namespace dvg

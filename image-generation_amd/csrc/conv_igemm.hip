@@ -1,0 +1,335 @@
+// Implicit-GEMM 3x3 convolution on the f32 MFMA (v_mfma_f32_32x32x2_f32: exact fmaf chain),
+// used for every GEMM-shaped layer of the encoder / decoder, forward, data-gradient and
+// weight-gradient (/root/reference/src/encoder.py:28-30, /root/reference/src/decoder.py:28, :34-38).
+//
+// Forward / dgrad kernel: block tile BM pixels x BN output channels, K = 9*Cin walked in
+// 32-channel chunks per tap; A (im2col rows, gathered with the Morton neighbour map, optional
+// on-the-fly nearest upsample) and B (packed weights) staged through LDS, register prefetch of
+// the next chunk under the MFMA loop.  Epilogues: +bias, per-channel (sum, sum^2) partials for
+// BatchNorm, or the 2x2 quad-sum that is the adjoint of Upsample(x2).
+// Wgrad kernel: dW[tap] = X_tap^T dY, split-K over pixels into slabs, reduced in fixed order.
+#include "conv.h"
+
+namespace dvg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int crow16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int AP = 33, BP = BN + 4;
+  constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per chunk
+  constexpr int RB = (8 * BN + NT - 1) / NT;  // float4 loads of B per thread per chunk
+  __shared__ float As[BM * AP];
+  __shared__ __align__(16) float Bs[32 * BP];
+  __shared__ float red[WM * BN * 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, hh = lane >> 5, c = lane & 31;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int L = a.L, H = 1 << L, logHW = 2 * L;
+  const int64_t HWin = a.ups ? ((int64_t)1 << logHW) >> 2 : ((int64_t)1 << logHW);
+
+  // per-thread A rows
+  int ay[RA], ax[RA];
+  int64_t abase[RA];
+  bool aok[RA];
+  const int ac4 = tid & 7;
+#pragma unroll
+  for (int q = 0; q < RA; ++q) {
+    const int row = (tid + NT * q) >> 3;
+    const int64_t m = m0 + row;
+    aok[q] = m < a.M;
+    const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
+    ay[q] = (int)morton_y(p);
+    ax[q] = (int)morton_x(p);
+    abase[q] = (m >> logHW) * HWin;
+  }
+  const int nci = a.Cin >> 5, niter = a.ntaps * nci;
+  float4 areg[RA], breg[RB];
+  auto load = [&](int it) {
+    const int tap = it / nci, cc = it - tap * nci;
+    const int dy = a.ntaps == 9 ? tap / 3 - 1 : 0, dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+      const int yy = ay[q] + dy, xx = ax[q] + dx;
+      const bool ok = aok[q] && yy >= 0 && yy < H && xx >= 0 && xx < H;
+      uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
+      if (a.ups) src >>= 2;
+      const float* ptr = a.in + (abase[q] + src) * a.Cin + cc * 32 + ac4 * 4;
+      areg[q] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int idx = tid + NT * q;
+      const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+      if (krow < 32)
+        breg[q] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Cin + cc * 32 + krow) * a.Cout + n0 + c4 * 4);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
+
+  load(0);
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+      const int row = (tid + NT * q) >> 3;
+      float* p = As + row * AP + ac4 * 4;
+      p[0] = areg[q].x; p[1] = areg[q].y; p[2] = areg[q].z; p[3] = areg[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int idx = tid + NT * q;
+      const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+      if (krow < 32) *reinterpret_cast<float4*>(Bs + krow * BP + c4 * 4) = breg[q];
+    }
+    __syncthreads();
+    if (it + 1 < niter) load(it + 1);
+    const float* ap = As + (wm * TM * 32 + c) * AP + hh;
+    const float* bp = Bs + hh * BP + wn * TN * 32 + c;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = ap[i * 32 * AP + 2 * s];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = bp[2 * s * BP + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---------------- epilogue
+  if (a.poolsum) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + c;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+          const int64_t m = m0 + wm * TM * 32 + i * 32 + 8 * g + 4 * hh;
+          if (m < a.M) a.out[(m >> 2) * a.Cout + col] = v;
+        }
+      }
+    return;
+  }
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + c;
+      const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
+        if (m < a.M) {
+          const float v = acc[i][j][r] + bias;
+          a.out[m * a.Cout + col] = v;
+          s1[j] += v;
+          s2[j] = fmaf(v, v, s2[j]);
+        }
+      }
+    }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+      s2[j] += __shfl_xor(s2[j], 32, 64);
+      if (hh == 0) {
+        red[(wm * BN + wn * TN * 32 + j * 32 + c) * 2] = s1[j];
+        red[(wm * BN + wn * TN * 32 + j * 32 + c) * 2 + 1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)blockIdx.x * a.Cout + n0 + tid) * 2;
+      dst[0] = t1; dst[1] = t2;
+    }
+  }
+}
+
+static int igemm_cfg(int64_t M, int Cout) {
+  if (Cout % 64 == 0) return (ceil_div(M, 128) * (Cout / 64) >= 512) ? 0 : 1;
+  return 2;
+}
+
+int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_cfg(M, Cout) == 1 ? 64 : 128); }
+
+int launch_conv_igemm(const ConvArgs& a, int kernel_id, hipStream_t s) {
+  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 1)) {
+    set_error("conv_igemm: unsupported shape Cin=%d Cout=%d M=%lld ntaps=%d", a.Cin, a.Cout, (long long)a.M, a.ntaps);
+    return DVG_E_INVALID;
+  }
+  switch (igemm_cfg(a.M, a.Cout)) {
+    case 0:
+      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64), dim3(256), 0, s, a);
+      break;
+    case 1:
+      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64), dim3(256), 0, s, a);
+      break;
+    default:
+      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32), dim3(256), 0, s, a);
+      break;
+  }
+  return DVG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+template <int WA, int WB>
+__global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = WA * WB * 64, BA = 32 * WA, BB = 32 * WB;
+  constexpr int XP = BA + 4, YP = BB + 4;
+  constexpr int RX = 8 * BA / NT, RY = 8 * BB / NT;
+  __shared__ __align__(16) float Xs[32 * XP];
+  __shared__ __align__(16) float Ys[32 * YP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave / WB, wb = wave % WB, hh = lane >> 5, c = lane & 31;
+  const int tiles_b = a.Cout / BB;
+  const int a0 = (blockIdx.x / tiles_b) * BA, b0 = (blockIdx.x % tiles_b) * BB;
+  const int tap = blockIdx.y, z = blockIdx.z;
+  const int L = a.L, H = 1 << L, logHW = 2 * L;
+  const int64_t HWin = a.ups ? ((int64_t)1 << logHW) >> 2 : ((int64_t)1 << logHW);
+  const int dy = a.ntaps == 9 ? tap / 3 - 1 : 0, dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
+  int64_t per = (a.M + a.ksplit - 1) / a.ksplit;
+  per = (per + 31) & ~(int64_t)31;
+  const int64_t mbeg = (int64_t)z * per;
+  const int64_t mend = mbeg + per < a.M ? mbeg + per : a.M;
+
+  float4 xreg[RX], yreg[RY];
+  auto load = [&](int64_t m1) {
+#pragma unroll
+    for (int q = 0; q < RX; ++q) {
+      const int idx = tid + NT * q;
+      const int px = idx / (BA / 4), c4 = idx % (BA / 4);
+      const int64_t m = m1 + px;
+      const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
+      const int yy = (int)morton_y(p) + dy, xx = (int)morton_x(p) + dx;
+      const bool ok = m < mend && yy >= 0 && yy < H && xx >= 0 && xx < H;
+      uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
+      if (a.ups) src >>= 2;
+      const float* ptr = a.in + ((m >> logHW) * HWin + src) * a.Cin + a0 + c4 * 4;
+      xreg[q] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < RY; ++q) {
+      const int idx = tid + NT * q;
+      const int px = idx / (BB / 4), c4 = idx % (BB / 4);
+      const int64_t m = m1 + px;
+      yreg[q] = m < mend ? *reinterpret_cast<const float4*>(a.dy + m * a.Cout + b0 + c4 * 4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16 acc = {0};
+  if (mbeg < mend) load(mbeg);
+  for (int64_t m1 = mbeg; m1 < mend; m1 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RX; ++q) {
+      const int idx = tid + NT * q;
+      *reinterpret_cast<float4*>(Xs + (idx / (BA / 4)) * XP + (idx % (BA / 4)) * 4) = xreg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < RY; ++q) {
+      const int idx = tid + NT * q;
+      *reinterpret_cast<float4*>(Ys + (idx / (BB / 4)) * YP + (idx % (BB / 4)) * 4) = yreg[q];
+    }
+    __syncthreads();
+    if (m1 + 32 < mend) load(m1 + 32);
+    const float* xp = Xs + hh * XP + wa * 32 + c;
+    const float* yp = Ys + hh * YP + wb * 32 + c;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[2 * s * XP], yp[2 * s * YP], acc, 0, 0, 0);
+  }
+  float* dst = a.slabs + (((size_t)z * a.ntaps + tap) * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[r];
+}
+
+int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
+  const int ba = (Cin % 64 == 0) ? 64 : 32, bb = (Cout % 64 == 0) ? 64 : 32;
+  const int64_t tiles = (int64_t)(Cin / ba) * (Cout / bb) * ntaps;
+  int64_t k = ceil_div(1536, tiles);
+  const int64_t kmax = ceil_div(M, 256);
+  if (k > kmax) k = kmax;
+  if (k > 128) k = 128;
+  if (k < 1) k = 1;
+  return (int)k;
+}
+
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.ksplit < 1) {
+    set_error("conv_wgrad: unsupported shape Cin=%d Cout=%d M=%lld", a.Cin, a.Cout, (long long)a.M);
+    return DVG_E_INVALID;
+  }
+  const bool a64 = a.Cin % 64 == 0, b64 = a.Cout % 64 == 0;
+  const int ba = a64 ? 64 : 32, bb = b64 ? 64 : 32;
+  const dim3 grid((unsigned)((a.Cin / ba) * (a.Cout / bb)), (unsigned)a.ntaps, (unsigned)a.ksplit);
+  if (a64 && b64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
+  else if (a64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<2, 1>), grid, dim3(128), 0, s, a);
+  else if (b64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<1, 2>), grid, dim3(128), 0, s, a);
+  else DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<1, 1>), grid, dim3(64), 0, s, a);
+  return DVG_OK;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, WeightMap map,
+                                                           float* __restrict__ grad_w) {
+  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += slabs[(size_t)k * total + e];
+    const int b = (int)(e % map.Cb);
+    const int a = (int)((e / map.Cb) % map.Ca);
+    const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
+    grad_w[torch_weight_offset(map, tap, a, b)] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ wp) {
+  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e % map.Cb);
+    const int a = (int)((e / map.Cb) % map.Ca);
+    const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
+    wp[e] = w[torch_weight_offset(map, tap, a, b)];
+  }
+}
+
+static unsigned ew_grid(int64_t n) {
+  const int64_t b = ceil_div(n, 256);
+  return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s) {
+  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_kernel, dim3(ew_grid(total)), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+  return DVG_OK;
+}
+
+int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s) {
+  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w, map, wp);
+  return DVG_OK;
+}
+
+}  // namespace dvg

@@ -1,0 +1,223 @@
+// dvg_decoder_fwd / dvg_decoder_bwd: Decoder.forward of /root/reference/src/decoder.py:54-62 and its backward.
+//   Linear(n,4n) as a 1-tap MFMA GEMM writing NHWC (N,2x2,n) directly;
+//   layers 0-2 (n->128 @2x2, 128->64 @4x4, 64->32 @8x8): MFMA implicit GEMM with the x2 nearest upsample of the
+//   previous stage fused into the gather (never materialised); layer 3 (32->1 @16x16) and the final 1->1 @32x32
+//   ConvTranspose: VALU kernels.  Each of layers 0-3 is followed by BN(batch stats) -> Dropout2d -> LeakyReLU.
+//   Backward data-gradients of the upsample-fused layers sum each 2x2 quad in the MFMA epilogue.
+#include "conv.h"
+#include "kernels.h"
+
+using namespace dvg;
+
+namespace {
+
+struct DecPlan {
+  int64_t N;
+  int n;
+  int ch[5];
+  int64_t M[4];
+  int L[4];
+  int nblk[4];
+  size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
+  size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
+  size_t dXbuf, dYbuf, slabs, partA, partB, partW;
+  int ksplit_lin, ksplit[3];
+  size_t total_floats;
+};
+
+size_t bump(size_t& o, size_t count) {
+  const size_t r = o;
+  o += (count + 63) & ~(size_t)63;
+  return r;
+}
+
+DecPlan dec_plan(int64_t N, int n) {
+  DecPlan p;
+  p.N = N; p.n = n;
+  const int ch[5] = {n, 128, 64, 32, 1};
+  for (int i = 0; i < 5; ++i) p.ch[i] = ch[i];
+  size_t o = 0;
+  p.X0 = bump(o, (size_t)N * 4 * n);
+  p.wp_lin = bump(o, (size_t)n * 4 * n);
+  p.wpd_lin = bump(o, (size_t)n * 4 * n);
+  p.bias_lin = bump(o, (size_t)4 * n);
+  p.ksplit_lin = wgrad_ksplit(N, n, 4 * n, 1);
+  size_t max_slab = (size_t)p.ksplit_lin * n * 4 * n;
+  size_t max_dx = (size_t)N * 4 * n, max_dy = 0;
+  int cmax = 4 * n;
+  for (int l = 0; l < 4; ++l) {
+    p.L[l] = l + 1;
+    p.M[l] = N * ((int64_t)4 << (2 * l));
+    const int C = ch[l + 1];
+    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : conv_stats_blocks(p.M[l], C);
+    p.Y[l] = bump(o, (size_t)p.M[l] * C);
+    p.Xs[l] = bump(o, (size_t)p.M[l] * C);
+    p.mean[l] = bump(o, C);
+    p.invstd[l] = bump(o, C);
+    p.stats[l] = bump(o, (size_t)p.nblk[l] * C * 2);
+    p.mask[l] = bump(o, (size_t)N * C);
+    if (l < 3) {
+      p.wp[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.wpd[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
+      const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
+      if (slab > max_slab) max_slab = slab;
+    }
+    const size_t act = (size_t)p.M[l] * C;
+    if (act > max_dy) max_dy = act;
+    if (act > max_dx) max_dx = act;  // dXs[l] has the shape of Xs[l]
+  }
+  p.dXbuf = bump(o, max_dx);
+  p.dYbuf = bump(o, max_dy);
+  p.slabs = bump(o, max_slab);
+  p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
+  p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
+  p.partW = bump(o, (size_t)EW_BLOCKS * 288);
+  p.total_floats = o;
+  return p;
+}
+
+int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws, size_t ws_bytes, const DecPlan& pl) {
+  DVG_REQUIRE(p && ws, "decoder: null params/workspace");
+  DVG_REQUIRE(n >= 32 && n % 32 == 0 && n <= 4096, "decoder: n_latents=%d must be a multiple of 32", n);
+  DVG_REQUIRE(N >= 1 && N <= (1 << 22), "decoder: batch*replicas %lld out of range", (long long)N);
+  DVG_REQUIRE(p->lin_w && p->lin_b, "decoder: null linear parameter");
+  for (int l = 0; l < 5; ++l) DVG_REQUIRE(p->conv_w[l] && p->conv_b[l], "decoder: null conv parameter %d", l);
+  for (int l = 0; l < 4; ++l)
+    DVG_REQUIRE(p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l], "decoder: null BN parameter %d", l);
+  if (ws_bytes < pl.total_floats * sizeof(float)) {
+    set_error("decoder: workspace %zu < %zu bytes", ws_bytes, pl.total_floats * sizeof(float));
+    return DVG_E_WORKSPACE;
+  }
+  return DVG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents) {
+  if (N < 1 || n_latents < 32 || n_latents % 32) return 0;
+  return dec_plan(N, n_latents).total_floats * sizeof(float);
+}
+
+extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
+                               const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
+                               size_t ws_bytes, dvg_stream_t stream) {
+  const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)ws;
+
+  // Linear(n, 4n) -> X0 (N, 2x2 Morton, n)
+  DVG_TRY(launch_weight_pack(p->lin_w, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, W + pl.wp_lin, s));
+  DVG_TRY(launch_permute_vec(p->lin_b, 4 * n, n, 4, W + pl.bias_lin, s));  // bias'[p*n + c] = b[c*4 + p]
+  {
+    ConvArgs a;
+    a.in = spins; a.wp = W + pl.wp_lin; a.bias = W + pl.bias_lin; a.out = W + pl.X0; a.stats = nullptr;
+    a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+    DVG_TRY(launch_conv_igemm(a, K_DEC_LINEAR, s));
+  }
+  const float* x = W + pl.X0;
+  for (int l = 0; l < 4; ++l) {
+    const int Cin = pl.ch[l], C = pl.ch[l + 1];
+    if (l < 3) {
+      DVG_TRY(launch_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, W + pl.wp[l], s));
+      ConvArgs a;
+      a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
+      a.stats = training ? W + pl.stats[l] : nullptr;
+      a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = l > 0; a.poolsum = 0;
+      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_FWD, s));
+    } else {
+      DVG_TRY(launch_dec_conv3_fwd(x, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
+    }
+    DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
+                               p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
+    const float* mask = nullptr;
+    if (training) {
+      float* mdst = W + pl.mask[l];
+      if (dropout_keep && dropout_keep[l])
+        DVG_CHECK_HIP(hipMemcpyAsync(mdst, dropout_keep[l], sizeof(float) * (size_t)N * C, hipMemcpyDeviceToDevice, s));
+      else
+        DVG_TRY(launch_dropout_mask(N, C, seed, offset, l, mdst, s));
+      mask = mdst;
+    }
+    DVG_TRY(launch_dec_bn_act_fwd(W + pl.Y[l], pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                  p->bn_b[l], mask, W + pl.Xs[l], s));
+    x = W + pl.Xs[l];
+  }
+  DVG_TRY(launch_dec_final_fwd(x, N, p->conv_w[4], p->conv_b[4], out, s));
+  return DVG_OK;
+}
+
+extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
+                               const float* grad_out, const dvg_decoder_grads_t* g, float* grad_spins, void* ws,
+                               size_t ws_bytes, dvg_stream_t stream) {
+  const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  DVG_REQUIRE(spins && grad_out && g, "decoder_bwd: null argument");
+  DVG_REQUIRE(g->lin_w && g->lin_b, "decoder_bwd: null linear gradient buffer");
+  for (int l = 0; l < 5; ++l) DVG_REQUIRE(g->conv_w[l] && g->conv_b[l], "decoder_bwd: null conv gradient buffer %d", l);
+  for (int l = 0; l < 4; ++l) DVG_REQUIRE(g->bn_g[l] && g->bn_b[l], "decoder_bwd: null BN gradient buffer %d", l);
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)ws;
+  float* dX = W + pl.dXbuf;
+  float* dY = W + pl.dYbuf;
+  float* partA = W + pl.partA;
+  float* partB = W + pl.partB;
+  float* partW = W + pl.partW;
+
+  // final ConvTranspose2d(1,1): weight/bias gradient, then gradient wrt Xs[3] (16x16, quad-summed)
+  DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, partW, s));
+  DVG_TRY(launch_colsum(partW, EW_BLOCKS, 10, 9, 1.0f, g->conv_w[4], 0, 0, s));
+  DVG_TRY(launch_colsum(partW + 9, EW_BLOCKS, 10, 1, 1.0f, g->conv_b[4], 0, 0, s));
+  DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
+
+  for (int l = 3; l >= 0; --l) {
+    const int Cin = pl.ch[l], C = pl.ch[l + 1];
+    const float* Y = W + pl.Y[l];
+    const float* Xs = W + pl.Xs[l];
+    const float* mask = W + pl.mask[l];  // backward only exists for a training-mode forward
+    DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
+                                         partA, s));
+    DVG_TRY(launch_colsum(partA, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_b[l], 0, 0, s));
+    DVG_TRY(launch_colsum(partA + C, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_g[l], 0, 0, s));
+    DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                        mask, dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
+    DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
+    const float* xin = l == 0 ? W + pl.X0 : W + pl.Xs[l - 1];
+    if (l == 3) {
+      DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s));
+      DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s));  // [tap][ci] -> [ci][tap]
+      DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
+      continue;
+    }
+    WgradArgs wa;
+    wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
+    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
+    DVG_TRY(launch_conv_wgrad(wa, s));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s));
+    DVG_TRY(launch_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_DGRAD, C, Cin, 9}, W + pl.wpd[l], s));
+    ConvArgs a;
+    a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
+    a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
+    DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+  }
+  // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
+  {
+    WgradArgs wa;
+    wa.in = spins; wa.dy = dX; wa.slabs = W + pl.slabs;
+    wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;
+    DVG_TRY(launch_conv_wgrad(wa, s));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, g->lin_w, s));
+    DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, partB, s));
+    DVG_TRY(launch_colsum(partB, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s));  // j' = p*n+c -> c*4+p
+    if (grad_spins) {
+      DVG_TRY(launch_weight_pack(p->lin_w, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}, W + pl.wpd_lin, s));
+      ConvArgs a;
+      a.in = dX; a.wp = W + pl.wpd_lin; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
+      a.M = N; a.Cin = 4 * n; a.Cout = n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+    }
+  }
+  return DVG_OK;
+}

@@ -1,0 +1,359 @@
+// BatchNorm (batch statistics) fused with the layer's pointwise tail, forward and backward.
+//   encoder stage (/root/reference/src/encoder.py:32-36): BN -> MaxPool2d(2,2) -> LeakyReLU
+//   decoder stage (/root/reference/src/decoder.py:41-46): BN -> Dropout2d(0.2) -> [Upsample x2] -> LeakyReLU
+// (LeakyReLU commutes with the nearest upsample, which is fused into the consuming convolution.)
+// Reductions are two-stage and deterministic: fixed grid of EW_BLOCKS blocks writes per-block
+// partials, a finalize kernel sums them in order in double.
+#include "kernels.h"
+#include "philox.h"
+
+namespace dvg {
+
+// channel-lane mapping of the reducing kernels: C is 1 or a multiple of 32
+struct ChanMap {
+  int CW, RL, cl, rl;
+  __device__ ChanMap(int C) {
+    CW = C >= 32 ? 32 : C;
+    RL = 256 / CW;
+    cl = threadIdx.x % CW;
+    rl = threadIdx.x / CW;
+  }
+};
+
+template <int K>
+__device__ __forceinline__ void block_reduce_store(float (&acc)[K], const ChanMap& cm, float* red, float* dst_base,
+                                                   int C, int c0) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[k * 256 + threadIdx.x] = acc[k];
+  __syncthreads();
+  if (cm.rl == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t = 0.f;
+      for (int j = 0; j < cm.RL; ++j) t += red[k * 256 + j * cm.CW + cm.cl];
+      dst_base[((size_t)blockIdx.x * K + k) * C + c0 + cm.cl] = t;  // planar [block][k][C]
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- generic column sums of partials
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int G, int stride, int count,
+                                                     float scale, float* __restrict__ out, int permA, int permB) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= count) return;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += (double)part[(size_t)g * stride + w];
+  const int o = permA > 0 ? (w % permA) * permB + w / permA : w;
+  out[o] = (float)(s * (double)scale);
+}
+
+int launch_colsum(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB,
+                  hipStream_t s) {
+  DVG_LAUNCH(K_MISC, colsum_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, part, G, stride, count, scale,
+             out, permA, permB);
+  return DVG_OK;
+}
+
+// part[block][c] = sum over the block's rows of mat[row][c]   (cols is a multiple of 32)
+__global__ __launch_bounds__(256) void rowsum_partial_kernel(const float* __restrict__ mat, int64_t rows, int cols,
+                                                             float* __restrict__ part) {
+  __shared__ float red[256];
+  const ChanMap cm(cols);
+  for (int c0 = 0; c0 < cols; c0 += cm.CW) {
+    float acc[1] = {0.f};
+    for (int64_t r = (int64_t)blockIdx.x * cm.RL + cm.rl; r < rows; r += (int64_t)gridDim.x * cm.RL)
+      acc[0] += mat[r * cols + c0 + cm.cl];
+    block_reduce_store<1>(acc, cm, red, part, cols, c0);
+  }
+}
+
+int launch_rowsum_partial(const float* mat, int64_t rows, int cols, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, rowsum_partial_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, mat, rows, cols, part);
+  return DVG_OK;
+}
+
+// out[w] = in[(w % A) * B + w / A]
+__global__ __launch_bounds__(256) void permute_vec_kernel(const float* __restrict__ in, int count, int A, int B,
+                                                          float* __restrict__ out) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w < count) out[w] = in[(w % A) * B + w / A];
+}
+
+int launch_permute_vec(const float* in, int count, int A, int B, float* out, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, permute_vec_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, in, count, A, B, out);
+  return DVG_OK;
+}
+
+// ---------------------------------------------------------------- BN statistics
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
+                                                          int training, float* __restrict__ mean,
+                                                          float* __restrict__ invstd, float* __restrict__ rm,
+                                                          float* __restrict__ rv, int64_t* __restrict__ nbt) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= C) return;
+  if (!training) {
+    mean[c] = rm[c];
+    invstd[c] = 1.0f / sqrtf(rv[c] + BN_EPS);
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += (double)part[((size_t)k * C + c) * 2];
+    s2 += (double)part[((size_t)k * C + c) * 2 + 1];
+  }
+  const double mu = s1 / M;
+  double var = s2 / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  if (rm) {  // torch: running = (1 - momentum) * running + momentum * batch, unbiased variance
+    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+    rm[c] = (float)((1.0 - (double)BN_MOMENTUM) * (double)rm[c] + (double)BN_MOMENTUM * mu);
+    rv[c] = (float)((1.0 - (double)BN_MOMENTUM) * (double)rv[c] + (double)BN_MOMENTUM * unbiased);
+  }
+}
+
+int launch_bn_finalize(const float* stats_part, int nblk, int C, int64_t M, int training, float* mean, float* invstd,
+                       float* running_mean, float* running_var, int64_t* nbt, hipStream_t s) {
+  DVG_LAUNCH(K_BN_FINALIZE, bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, s, stats_part, nblk, C,
+             (double)M, training, mean, invstd, running_mean, running_var, nbt);
+  return DVG_OK;
+}
+
+// ---------------------------------------------------------------- encoder: BN -> maxpool -> lrelu
+// Y: [4Q][C] (Morton: rows 4q..4q+3 are one 2x2 window, in scan order), out: [Q][C]
+__global__ __launch_bounds__(256) void enc_bn_pool_fwd_kernel(const float* __restrict__ Y, int64_t Q, int C,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int lrelu,
+                                                              float* __restrict__ out) {
+  const int64_t total = Q * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t q = e / C;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float* y = Y + (q * 4) * C + c;
+    float best = fmaf((y[0] - mu) * is, g, b);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+      const float z = fmaf((y[(size_t)s * C] - mu) * is, g, b);
+      best = z > best ? z : best;  // strict: the first maximum wins, as in torch's max_pool2d
+    }
+    out[e] = (lrelu && best < 0.f) ? best * LRELU_SLOPE : best;
+  }
+}
+
+int launch_enc_bn_pool_fwd(const float* Y, int64_t Q, int C, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, int lrelu, float* out, hipStream_t s) {
+  const int64_t b = ceil_div(Q * C, 256);
+  DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_bn_pool_fwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, Y, Q, C,
+             mean, invstd, gamma, beta, lrelu, out);
+  return DVG_OK;
+}
+
+// recompute the window: returns argmax index, its zhat, and the LeakyReLU slope at the pooled value
+__device__ __forceinline__ int enc_window(const float* y, int C, float mu, float is, float g, float b, int lrelu,
+                                          float (&zh)[4], float& slope) {
+  int arg = 0;
+  float best = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    zh[s] = (y[(size_t)s * C] - mu) * is;
+    const float z = fmaf(zh[s], g, b);
+    if (s == 0 || z > best) { best = z; arg = s; }
+  }
+  slope = (lrelu && !(best > 0.f)) ? LRELU_SLOPE : 1.0f;
+  return arg;
+}
+
+__global__ __launch_bounds__(256) void enc_bn_pool_bwd_reduce_kernel(const float* __restrict__ Y, int64_t Q, int C,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, int lrelu,
+                                                                     const float* __restrict__ dOut,
+                                                                     float* __restrict__ part) {
+  __shared__ float red[2 * 256];
+  const ChanMap cm(C);
+  for (int c0 = 0; c0 < C; c0 += cm.CW) {
+    const int c = c0 + cm.cl;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    float acc[2] = {0.f, 0.f};
+    for (int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl; q < Q; q += (int64_t)gridDim.x * cm.RL) {
+      float zh[4], slope;
+      const int arg = enc_window(Y + (q * 4) * C + c, C, mu, is, g, b, lrelu, zh, slope);
+      const float dz = dOut[q * C + c] * slope;
+      acc[0] += dz;
+      acc[1] = fmaf(dz, zh[arg], acc[1]);
+    }
+    block_reduce_store<2>(acc, cm, red, part, C, c0);
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_bn_pool_bwd_apply_kernel(const float* __restrict__ Y, int64_t Q, int C,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int lrelu,
+                                                                    const float* __restrict__ dOut,
+                                                                    const float* __restrict__ sum_dz,
+                                                                    const float* __restrict__ sum_dzzh, float inv_m,
+                                                                    float* __restrict__ dY, float* __restrict__ part_db) {
+  __shared__ float red[256];
+  const ChanMap cm(C);
+  for (int c0 = 0; c0 < C; c0 += cm.CW) {
+    const int c = c0 + cm.cl;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], b = beta[c];
+    const float m1 = sum_dz[c] * inv_m, m2 = sum_dzzh[c] * inv_m, gi = g * is;
+    float acc[1] = {0.f};
+    for (int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl; q < Q; q += (int64_t)gridDim.x * cm.RL) {
+      float zh[4], slope;
+      const int arg = enc_window(Y + (q * 4) * C + c, C, mu, is, g, b, lrelu, zh, slope);
+      const float dz = dOut[q * C + c] * slope;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float v = gi * (((s == arg) ? dz : 0.f) - m1 - zh[s] * m2);
+        dY[(q * 4 + s) * C + c] = v;
+        acc[0] += v;
+      }
+    }
+    block_reduce_store<1>(acc, cm, red, part_db, C, c0);
+  }
+}
+
+int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int lrelu, const float* dOut, float* part,
+                                  hipStream_t s) {
+  DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_bn_pool_bwd_reduce_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
+             invstd, gamma, beta, lrelu, dOut, part);
+  return DVG_OK;
+}
+
+int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int lrelu, const float* dOut, const float* sum_dz,
+                                 const float* sum_dzzh, float* dY, float* part_db, hipStream_t s) {
+  DVG_LAUNCH(K_ENC_BN_POOL_BWD_APPLY, enc_bn_pool_bwd_apply_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
+             invstd, gamma, beta, lrelu, dOut, sum_dz, sum_dzzh, (float)(1.0 / (4.0 * (double)Q)), dY, part_db);
+  return DVG_OK;
+}
+
+// ---------------------------------------------------------------- decoder: BN -> dropout2d -> lrelu
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t N, int C, uint32_t k0, uint32_t k1, uint32_t off_lo,
+                                                           uint32_t off_hi, uint32_t layer, float* __restrict__ mask) {
+  const int64_t total = N * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const u32x4 r = philox4x32_10((uint32_t)e, off_lo ^ (layer << 28), off_hi ^ (uint32_t)(e >> 32), STREAM_DROPOUT, k0, k1);
+    mask[e] = u32_to_unit(r.x) < DROPOUT_KEEP ? 1.0f : 0.0f;
+  }
+}
+
+int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, int layer, float* mask, hipStream_t s) {
+  const int64_t b = ceil_div(N * C, 256);
+  DVG_LAUNCH(K_MISC, dropout_mask_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, s, N, C, (uint32_t)seed,
+             (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)layer, mask);
+  return DVG_OK;
+}
+
+__global__ __launch_bounds__(256) void dec_bn_act_fwd_kernel(const float* __restrict__ Y, int64_t M, int C, int logHW,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mask, float* __restrict__ X) {
+  const int64_t total = M * C;
+  const float keep_scale = 1.0f / DROPOUT_KEEP;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const int64_t m = e / C;
+    float z = fmaf((Y[e] - mean[c]) * invstd[c], gamma[c], beta[c]);
+    if (mask) z *= mask[(m >> logHW) * C + c] * keep_scale;
+    X[e] = z < 0.f ? z * LRELU_SLOPE : z;
+  }
+}
+
+int launch_dec_bn_act_fwd(const float* Y, int64_t M, int C, int logHW, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const float* mask, float* X, hipStream_t s) {
+  const int64_t b = ceil_div(M * C, 256);
+  DVG_LAUNCH(K_DEC_BN_ACT_FWD, dec_bn_act_fwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, Y, M, C,
+             logHW, mean, invstd, gamma, beta, mask, X);
+  return DVG_OK;
+}
+
+__device__ __forceinline__ float dec_dz(float dx, float x, float mk) {
+  return dx * ((x > 0.f) ? 1.0f : LRELU_SLOPE) * mk;
+}
+
+__global__ __launch_bounds__(256) void dec_bn_act_bwd_reduce_kernel(const float* __restrict__ Y,
+                                                                    const float* __restrict__ X, int64_t M, int C,
+                                                                    int logHW, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ mask,
+                                                                    const float* __restrict__ dX,
+                                                                    float* __restrict__ part) {
+  __shared__ float red[2 * 256];
+  const ChanMap cm(C);
+  const float keep_scale = 1.0f / DROPOUT_KEEP;
+  for (int c0 = 0; c0 < C; c0 += cm.CW) {
+    const int c = c0 + cm.cl;
+    const float mu = mean[c], is = invstd[c];
+    float acc[2] = {0.f, 0.f};
+    for (int64_t m = (int64_t)blockIdx.x * cm.RL + cm.rl; m < M; m += (int64_t)gridDim.x * cm.RL) {
+      const int64_t e = m * C + c;
+      const float mk = mask ? mask[(m >> logHW) * C + c] * keep_scale : 1.0f;
+      const float dz = dec_dz(dX[e], X[e], mk);
+      acc[0] += dz;
+      acc[1] = fmaf(dz, (Y[e] - mu) * is, acc[1]);
+    }
+    block_reduce_store<2>(acc, cm, red, part, C, c0);
+  }
+}
+
+__global__ __launch_bounds__(256) void dec_bn_act_bwd_apply_kernel(const float* __restrict__ Y,
+                                                                   const float* __restrict__ X, int64_t M, int C,
+                                                                   int logHW, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mask,
+                                                                   const float* __restrict__ dX,
+                                                                   const float* __restrict__ sum_dz,
+                                                                   const float* __restrict__ sum_dzzh, float inv_m,
+                                                                   float* __restrict__ dY, float* __restrict__ part_db) {
+  __shared__ float red[256];
+  const ChanMap cm(C);
+  const float keep_scale = 1.0f / DROPOUT_KEEP;
+  for (int c0 = 0; c0 < C; c0 += cm.CW) {
+    const int c = c0 + cm.cl;
+    const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
+    const float m1 = sum_dz[c] * inv_m, m2 = sum_dzzh[c] * inv_m;
+    float acc[1] = {0.f};
+    for (int64_t m = (int64_t)blockIdx.x * cm.RL + cm.rl; m < M; m += (int64_t)gridDim.x * cm.RL) {
+      const int64_t e = m * C + c;
+      const float mk = mask ? mask[(m >> logHW) * C + c] * keep_scale : 1.0f;
+      const float dz = dec_dz(dX[e], X[e], mk);
+      const float v = gi * (dz - m1 - (Y[e] - mu) * is * m2);
+      dY[e] = v;
+      acc[0] += v;
+    }
+    block_reduce_store<1>(acc, cm, red, part_db, C, c0);
+  }
+}
+
+int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
+                                 const float* invstd, const float* mask, const float* dX, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_BN_ACT_BWD_REDUCE, dec_bn_act_bwd_reduce_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
+             mean, invstd, mask, dX, part);
+  return DVG_OK;
+}
+
+int launch_dec_bn_act_bwd_apply(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
+                                const float* invstd, const float* gamma, const float* mask, const float* dX,
+                                const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_bn_act_bwd_apply_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
+             mean, invstd, gamma, mask, dX, sum_dz, sum_dzzh, (float)(1.0 / (double)M), dY, part_db);
+  return DVG_OK;
+}
+
+}  // namespace dvg

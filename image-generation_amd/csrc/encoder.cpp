@@ -1,0 +1,184 @@
+// dvg_encoder_fwd / dvg_encoder_bwd: Encoder.forward of /root/reference/src/encoder.py:44-49 and its
+// backward, as a fixed sequence of kernels on the caller's stream.
+//   layer 0 (1->32 @32x32): VALU conv;  layers 1-3 (32->64 @16, 64->128 @8, 128->n @4): MFMA implicit GEMM
+//   each followed by BN(batch stats) -> MaxPool2d(2) -> LeakyReLU (none after the last); then Linear(4,1).
+#include "conv.h"
+#include "kernels.h"
+
+using namespace dvg;
+
+namespace {
+
+struct EncPlan {
+  int64_t B;
+  int n;
+  int ch[5];
+  int64_t M[4], Q[4];
+  int L[4];
+  int nblk[4];
+  // offsets in floats
+  size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
+  size_t dXbuf, dYbuf, slabs, partA, partB, part320;
+  int ksplit[4];
+  size_t total_floats;
+};
+
+size_t bump(size_t& o, size_t count) {
+  const size_t r = o;
+  o += (count + 63) & ~(size_t)63;  // 256-byte granules
+  return r;
+}
+
+EncPlan enc_plan(int64_t B, int n) {
+  EncPlan p;
+  p.B = B; p.n = n;
+  const int ch[5] = {1, 32, 64, 128, n};
+  for (int i = 0; i < 5; ++i) p.ch[i] = ch[i];
+  size_t o = 0;
+  size_t max_dx = 0, max_dy = 0, max_slab = 0;
+  int cmax = 0;
+  for (int l = 0; l < 4; ++l) {
+    p.L[l] = 5 - l;
+    p.M[l] = B * (1024 >> (2 * l));
+    p.Q[l] = p.M[l] / 4;
+    const int C = ch[l + 1];
+    if (C > cmax) cmax = C;
+    p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : conv_stats_blocks(p.M[l], C);
+    p.Y[l] = bump(o, (size_t)p.M[l] * C);
+    p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
+    p.mean[l] = bump(o, C);
+    p.invstd[l] = bump(o, C);
+    p.stats[l] = bump(o, (size_t)p.nblk[l] * C * 2);
+    p.wp[l] = p.wpd[l] = 0;
+    p.ksplit[l] = 0;
+    if (l > 0) {
+      p.wp[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.wpd[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
+      const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
+      if (slab > max_slab) max_slab = slab;
+      const size_t dx = (size_t)p.M[l] * ch[l];  // gradient wrt the layer's input (same resolution)
+      if (dx > max_dx) max_dx = dx;
+    }
+    const size_t dy = (size_t)p.M[l] * C;
+    if (dy > max_dy) max_dy = dy;
+  }
+  const size_t dp = (size_t)p.Q[3] * n;  // gradient wrt the pooled map feeding the projection
+  if (dp > max_dx) max_dx = dp;
+  p.dXbuf = bump(o, max_dx);
+  p.dYbuf = bump(o, max_dy);
+  p.slabs = bump(o, max_slab);
+  p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
+  p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
+  p.part320 = bump(o, (size_t)EW_BLOCKS * 320);
+  p.total_floats = o;
+  return p;
+}
+
+int check_common(const dvg_encoder_params_t* p, int n, int64_t B, const void* ws, size_t ws_bytes, const EncPlan& pl) {
+  DVG_REQUIRE(p && ws, "encoder: null params/workspace");
+  DVG_REQUIRE(n >= 32 && n % 32 == 0 && n <= 4096, "encoder: n_latents=%d must be a multiple of 32", n);
+  DVG_REQUIRE(B >= 1 && B <= (1 << 20), "encoder: batch %lld out of range", (long long)B);
+  for (int l = 0; l < 4; ++l)
+    DVG_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
+                "encoder: null parameter in layer %d", l);
+  DVG_REQUIRE(p->proj_w && p->proj_b, "encoder: null projection parameter");
+  if (ws_bytes < pl.total_floats * sizeof(float)) {
+    set_error("encoder: workspace %zu < %zu bytes", ws_bytes, pl.total_floats * sizeof(float));
+    return DVG_E_WORKSPACE;
+  }
+  return DVG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dvg_encoder_workspace_bytes(int64_t B, int n_latents) {
+  if (B < 1 || n_latents < 32 || n_latents % 32) return 0;
+  return enc_plan(B, n_latents).total_floats * sizeof(float);
+}
+
+extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float* images, int64_t B, int training,
+                               float* logits, void* ws, size_t ws_bytes, dvg_stream_t stream) {
+  const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
+  DVG_REQUIRE(images && logits, "encoder_fwd: null images/logits");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)ws;
+  const float* x = images;
+  for (int l = 0; l < 4; ++l) {
+    const int Cin = pl.ch[l], C = pl.ch[l + 1];
+    if (l == 0) {
+      DVG_TRY(launch_enc_conv0_fwd(images, B, p->conv_w[0], p->conv_b[0], W + pl.Y[0], W + pl.stats[0], s));
+    } else {
+      const WeightMap map{WM_CONV_FWD, Cin, C, 9};
+      DVG_TRY(launch_weight_pack(p->conv_w[l], map, W + pl.wp[l], s));
+      ConvArgs a;
+      a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
+      a.stats = training ? W + pl.stats[l] : nullptr;
+      a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
+      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_FWD, s));
+    }
+    DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
+                               p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
+    DVG_TRY(launch_enc_bn_pool_fwd(W + pl.Y[l], pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l],
+                                   l < 3, W + pl.Xp[l], s));
+    x = W + pl.Xp[l];
+  }
+  DVG_TRY(launch_enc_proj_fwd(W + pl.Xp[3], B, n, p->proj_w, p->proj_b, logits, s));
+  return DVG_OK;
+}
+
+extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float* images, int64_t B,
+                               const float* grad_logits, const dvg_encoder_grads_t* g, void* ws, size_t ws_bytes,
+                               dvg_stream_t stream) {
+  const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
+  DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
+  for (int l = 0; l < 4; ++l)
+    DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);
+  DVG_REQUIRE(g->proj_w && g->proj_b, "encoder_bwd: null projection gradient buffer");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)ws;
+  float* dX = W + pl.dXbuf;
+  float* dY = W + pl.dYbuf;
+  float* partA = W + pl.partA;
+  float* partB = W + pl.partB;
+
+  // projection: dP (B,4,n), d proj_w (4), d proj_b (1)
+  DVG_TRY(launch_enc_proj_bwd(W + pl.Xp[3], B, n, p->proj_w, grad_logits, dX, partA, s));
+  DVG_TRY(launch_colsum(partA, EW_BLOCKS, 5, 4, 1.0f, g->proj_w, 0, 0, s));
+  DVG_TRY(launch_colsum(partA + 4, EW_BLOCKS, 5, 1, 1.0f, g->proj_b, 0, 0, s));
+
+  for (int l = 3; l >= 0; --l) {
+    const int Cin = pl.ch[l], C = pl.ch[l + 1];
+    const float* Y = W + pl.Y[l];
+    // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
+    DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
+                                          dX, partA, s));
+    DVG_TRY(launch_colsum(partA, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_b[l], 0, 0, s));
+    DVG_TRY(launch_colsum(partA + C, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_g[l], 0, 0, s));
+    DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
+                                         dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
+    if (l == 0) {
+      DVG_TRY(launch_enc_conv0_wgrad(images, B, dY, W + pl.part320, s));
+      DVG_TRY(launch_colsum(W + pl.part320, EW_BLOCKS, 320, 288, 1.0f, g->conv_w[0], 0, 0, s));
+      DVG_TRY(launch_colsum(W + pl.part320 + 288, EW_BLOCKS, 320, 32, 1.0f, g->conv_b[0], 0, 0, s));
+      break;
+    }
+    DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
+    // weight gradient
+    WgradArgs wa;
+    wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
+    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
+    DVG_TRY(launch_conv_wgrad(wa, s));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s));
+    // data gradient -> dX (gradient wrt this layer's input = previous stage's output)
+    const WeightMap dmap{WM_CONV_DGRAD, C, Cin, 9};
+    DVG_TRY(launch_weight_pack(p->conv_w[l], dmap, W + pl.wpd[l], s));
+    ConvArgs a;
+    a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
+    a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
+    DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+  }
+  return DVG_OK;
+}

@@ -1,0 +1,72 @@
+// Internal launch interfaces of the elementwise / special-case kernels (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+namespace dvg {
+
+constexpr int EW_BLOCKS = 512;       // fixed grid of the reducing elementwise kernels (partials per block)
+constexpr float BN_EPS = 1e-5f;      // torch.nn.BatchNorm2d defaults (/root/reference/src/encoder.py:32)
+constexpr float BN_MOMENTUM = 0.1f;
+constexpr float LRELU_SLOPE = 0.01f;  // torch.nn.LeakyReLU() default (/root/reference/src/encoder.py:36)
+constexpr float DROPOUT_KEEP = 0.8f;  // Dropout2d(0.2) (/root/reference/src/decoder.py:42)
+
+// out[perm(w)] = scale * sum_g part[g*stride + w], w < count, accumulated in double in fixed order.
+// permA > 0: perm(w) = (w % permA) * permB + w / permA, else identity.
+int launch_colsum(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB,
+                  hipStream_t s);
+
+// part[EW_BLOCKS][cols] column sums of a (rows, cols) matrix; out[w] = in[(w % A) * B + w / A]
+int launch_rowsum_partial(const float* mat, int64_t rows, int cols, float* part, hipStream_t s);
+int launch_permute_vec(const float* in, int count, int A, int B, float* out, hipStream_t s);
+
+// BatchNorm statistics from per-block (sum, sum^2) partials; updates running stats when training.
+int launch_bn_finalize(const float* stats_part, int nblk, int C, int64_t M, int training, float* mean, float* invstd,
+                       float* running_mean, float* running_var, int64_t* nbt, hipStream_t s);
+
+// ---- encoder stage: BN -> MaxPool2d(2) -> (LeakyReLU)
+int launch_enc_bn_pool_fwd(const float* Y, int64_t Q, int C, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, int lrelu, float* out, hipStream_t s);
+// part [EW_BLOCKS][2][C]: per-block (sum dz, sum dz*zhat)
+int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int lrelu, const float* dOut, float* part,
+                                  hipStream_t s);
+int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int lrelu, const float* dOut, const float* sum_dz,
+                                 const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);
+
+// ---- decoder stage: BN -> Dropout2d mask -> LeakyReLU (the x2 upsample is fused into the consumer)
+int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, int layer, float* mask, hipStream_t s);
+int launch_dec_bn_act_fwd(const float* Y, int64_t M, int C, int logHW, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, const float* mask, float* X, hipStream_t s);
+int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
+                                 const float* invstd, const float* mask, const float* dX, float* part, hipStream_t s);
+int launch_dec_bn_act_bwd_apply(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
+                                const float* invstd, const float* gamma, const float* mask, const float* dX,
+                                const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);
+
+// ---- special-case layers
+// encoder conv0 (1 -> 32 channels, 32x32): images row-major in, Morton NHWC out (+ BN partials [blocks][32][2])
+int enc_conv0_blocks(int64_t B);
+int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const float* b, float* Y, float* stats_part,
+                         hipStream_t s);
+// part: [EW_BLOCKS][320]: 288 weight-gradient entries in checkpoint order, then 32 bias-gradient entries
+int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s);
+// Linear(4,1) over the 2x2 pooled map: P (B,4,n) -> logits (B,n)
+int launch_enc_proj_fwd(const float* P, int64_t B, int n, const float* w, const float* b, float* logits, hipStream_t s);
+// dP (B,4,n); part [EW_BLOCKS][5]: d w[0..3], d b
+int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const float* dlogits, float* dP, float* part,
+                        hipStream_t s);
+// decoder conv3 (32 -> 1 channel, 16x16, input upsampled from 8x8)
+int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
+                         hipStream_t s);
+int dec_conv3_blocks(int64_t N);
+int launch_dec_conv3_dgrad(const float* dY, int64_t N, const float* w, float* dX, hipStream_t s);
+// part [EW_BLOCKS][288] indexed tap*32 + ci (tap = kh*3+kw of the checkpoint weight)
+int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* part, hipStream_t s);
+// decoder final ConvTranspose2d(1,1) at 32x32 from the upsampled 16x16 map; row-major output
+int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s);
+int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s);
+// part [EW_BLOCKS][10]: d w[0..8], d b
+int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s);
+
+}  // namespace dvg

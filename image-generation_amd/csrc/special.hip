@@ -1,0 +1,396 @@
+// Layers whose GEMM shape is degenerate (1 input or 1 output channel, or a 4-element dot):
+// direct VALU kernels.  encoder conv0 1->32 (/root/reference/src/encoder.py:28-30 with
+// channels[0]=1), encoder Linear(4,1) (:41), decoder ConvTranspose 32->1 and 1->1
+// (/root/reference/src/decoder.py:34-38 last iteration, :49-51).
+#include "kernels.h"
+#include "conv.h"
+
+namespace dvg {
+
+// ------------------------------------------------------------------------------ encoder conv0
+// images (B,32,32) row-major {0,1}; W (32,1,3,3); Y [B*1024 (Morton)][32]
+__global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restrict__ img, int64_t B,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, float* __restrict__ stats_part) {
+  __shared__ float ws[32 * 9 + 32];
+  __shared__ float tile[256 * 33];
+  __shared__ float red[2 * 8 * 32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += 256) ws[i] = w[i];
+  if (tid < 32) ws[288 + tid] = bias[tid];
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * 256 + tid;  // B*1024 is a multiple of 256
+  const int64_t b = m >> 10;
+  const uint32_t p = (uint32_t)(m & 1023);
+  const int y = (int)morton_y(p), x = (int)morton_x(p);
+  float in[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    in[t] = (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) ? img[b * 1024 + yy * 32 + xx] : 0.f;
+  }
+#pragma unroll 4
+  for (int co = 0; co < 32; ++co) {
+    float v = ws[288 + co];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v = fmaf(in[t], ws[co * 9 + t], v);
+    tile[tid * 33 + co] = v;
+  }
+  __syncthreads();
+  // coalesced store + per-channel partial sums: thread (co = tid&31, part = tid>>5) walks 32 pixels
+  const int co = tid & 31, part = tid >> 5;
+  float s1 = 0.f, s2 = 0.f;
+  float* dst = Y + ((int64_t)blockIdx.x * 256) * 32;
+  for (int k = 0; k < 32; ++k) {
+    const int px = part * 32 + k;
+    const float v = tile[px * 33 + co];
+    dst[px * 32 + co] = v;
+    s1 += v;
+    s2 = fmaf(v, v, s2);
+  }
+  red[part * 32 + co] = s1;
+  red[256 + part * 32 + co] = s2;
+  __syncthreads();
+  if (tid < 32) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < 8; ++k) { t1 += red[k * 32 + tid]; t2 += red[256 + k * 32 + tid]; }
+    stats_part[((size_t)blockIdx.x * 32 + tid) * 2] = t1;
+    stats_part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] = t2;
+  }
+}
+
+int enc_conv0_blocks(int64_t B) { return (int)(B * 4); }
+
+int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const float* b, float* Y, float* stats_part,
+                         hipStream_t s) {
+  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_conv0_fwd_kernel, dim3((unsigned)(B * 4)), dim3(256), 0, s, images, B, w, b, Y,
+             stats_part);
+  return DVG_OK;
+}
+
+// dW[co][t] = sum_m dY[m][co] * in_t[m];  db[co] = sum_m dY[m][co];  part [EW_BLOCKS][320]
+__global__ __launch_bounds__(256) void enc_conv0_wgrad_kernel(const float* __restrict__ img, int64_t B,
+                                                              const float* __restrict__ dY, float* __restrict__ part) {
+  __shared__ float dys[256 * 33];
+  __shared__ float ins[10 * 256];
+  const int tid = threadIdx.x;
+  float acc0 = 0.f, acc1 = 0.f;  // work items w = tid and tid + 256 (< 320)
+  const int w0 = tid, w1 = tid + 256;
+  const int co0 = w0 < 288 ? w0 / 9 : w0 - 288, t0 = w0 < 288 ? w0 % 9 : 9;
+  const int co1 = w1 < 288 ? w1 / 9 : w1 - 288, t1 = w1 < 288 ? w1 % 9 : 9;
+  const int64_t nchunk = B * 4;
+  for (int64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const int64_t m = ch * 256 + tid;
+    const int64_t b = m >> 10;
+    const uint32_t p = (uint32_t)(m & 1023);
+    const int y = (int)morton_y(p), x = (int)morton_x(p);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      ins[t * 256 + tid] = (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) ? img[b * 1024 + yy * 32 + xx] : 0.f;
+    }
+    ins[9 * 256 + tid] = 1.0f;
+    // dY tile: 256 px x 32 ch, coalesced
+    const float* src = dY + ch * 256 * 32;
+    for (int k = 0; k < 32; ++k) {
+      const int e = k * 256 + tid;
+      dys[(e >> 5) * 33 + (e & 31)] = src[e];
+    }
+    __syncthreads();
+    for (int px = 0; px < 256; ++px) {
+      acc0 = fmaf(dys[px * 33 + co0], ins[t0 * 256 + px], acc0);
+      if (w1 < 320) acc1 = fmaf(dys[px * 33 + co1], ins[t1 * 256 + px], acc1);
+    }
+  }
+  part[(size_t)blockIdx.x * 320 + w0] = acc0;
+  if (w1 < 320) part[(size_t)blockIdx.x * 320 + w1] = acc1;
+}
+
+int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_conv0_wgrad_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, images, B, dY, part);
+  return DVG_OK;
+}
+
+// ------------------------------------------------------------------------------ encoder projection
+__global__ __launch_bounds__(256) void enc_proj_fwd_kernel(const float* __restrict__ P, int64_t B, int n,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ logits) {
+  const int64_t total = B * n;
+  const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], bb = b[0];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % n);
+    const float* p = P + (e / n) * 4 * n + c;
+    // flatten order of the (2,2) map is h*2+w == Morton index of a 2x2 image
+    logits[e] = fmaf(p[3 * (size_t)n], w3, fmaf(p[2 * (size_t)n], w2, fmaf(p[n], w1, p[0] * w0))) + bb;
+  }
+}
+
+int launch_enc_proj_fwd(const float* P, int64_t B, int n, const float* w, const float* b, float* logits, hipStream_t s) {
+  const int64_t g = ceil_div(B * n, 256);
+  DVG_LAUNCH(K_ENC_PROJ_FWD, enc_proj_fwd_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, P, B, n, w, b,
+             logits);
+  return DVG_OK;
+}
+
+__global__ __launch_bounds__(256) void enc_proj_bwd_kernel(const float* __restrict__ P, int64_t B, int n,
+                                                           const float* __restrict__ w, const float* __restrict__ dl,
+                                                           float* __restrict__ dP, float* __restrict__ part) {
+  __shared__ float red[5 * 256];
+  const int64_t total = B * n;
+  const float wv[4] = {w[0], w[1], w[2], w[3]};
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % n);
+    const int64_t base = (e / n) * 4 * n + c;
+    const float g = dl[e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k] = fmaf(g, P[base + (size_t)k * n], acc[k]);
+      dP[base + (size_t)k * n] = g * wv[k];
+    }
+    acc[4] += g;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k * 256 + threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+    for (int j = 0; j < 256; ++j) t += red[threadIdx.x * 256 + j];
+    part[(size_t)blockIdx.x * 5 + threadIdx.x] = t;
+  }
+}
+
+int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const float* dlogits, float* dP, float* part,
+                        hipStream_t s) {
+  DVG_LAUNCH(K_ENC_PROJ_BWD, enc_proj_bwd_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, P, B, n, w, dlogits, dP, part);
+  return DVG_OK;
+}
+
+// ------------------------------------------------------------------------------ decoder conv3 (32 -> 1)
+// X [N*64 (8x8 Morton)][32], upsampled x2 on the fly; Wt (32,1,3,3); Y [N*256 (16x16 Morton)]
+// ConvTranspose (stride 1, pad 1):  out(y,x) = sum_{ci,kh,kw} in(y+1-kh, x+1-kw) Wt[ci][0][kh][kw]
+__global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restrict__ X, int64_t N,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, float* __restrict__ stats_part) {
+  __shared__ __align__(16) float ws[9 * 32];  // [tap = kh*3+kw][ci]
+  __shared__ float red[2 * 256];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += 256) ws[(i % 9) * 32 + i / 9] = w[i];  // w[ci*9 + tap]
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * 256 + tid;  // N*256 pixels: one image per block
+  const int64_t img = m >> 8;
+  const uint32_t p = (uint32_t)(m & 255);
+  const int y = (int)morton_y(p), x = (int)morton_x(p);
+  float acc = bias[0];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int yy = y + 1 - kh, xx = x + 1 - kw;
+      if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16) {
+        const float4* row = reinterpret_cast<const float4*>(X + (img * 64 + (morton((uint32_t)yy, (uint32_t)xx) >> 2)) * 32);
+        const float4* wr = reinterpret_cast<const float4*>(ws + (kh * 3 + kw) * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 a = row[k], b = wr[k];
+          acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+      }
+    }
+  Y[m] = acc;
+  red[tid] = acc;
+  red[256 + tid] = acc * acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { red[tid] += red[tid + s]; red[256 + tid] += red[256 + tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { stats_part[(size_t)blockIdx.x * 2] = red[0]; stats_part[(size_t)blockIdx.x * 2 + 1] = red[256]; }
+}
+
+int dec_conv3_blocks(int64_t N) { return (int)N; }
+
+int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
+                         hipStream_t s) {
+  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel, dim3((unsigned)N), dim3(256), 0, s, X, N, w, b, Y, stats_part);
+  return DVG_OK;
+}
+
+// dX_small[q][ci] = sum over the 4 up-pixels (y,x) of quad q and taps: dY(y+kh-1, x+kw-1) Wt[ci][kh][kw]
+// thread = (small pixel, group of 8 channels)
+__global__ __launch_bounds__(256) void dec_conv3_dgrad_kernel(const float* __restrict__ dY, int64_t N,
+                                                              const float* __restrict__ w, float* __restrict__ dX) {
+  __shared__ float ws[9 * 32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += 256) ws[(i % 9) * 32 + i / 9] = w[i];
+  __syncthreads();
+  const int64_t total = N * 64 * 4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < total; e += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(e & 3);
+    const int64_t q = e >> 2;  // global small pixel
+    const int64_t img = q >> 6;
+    const uint32_t ps = (uint32_t)(q & 63);
+    const int ys = (int)morton_y(ps), xs = (int)morton_x(ps);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const int y = 2 * ys + sy, x = 2 * xs + sx;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int yy = y + kh - 1, xx = x + kw - 1;
+            if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16) {
+              const float g = dY[img * 256 + morton((uint32_t)yy, (uint32_t)xx)];
+              const float* wr = ws + (kh * 3 + kw) * 32 + cg * 8;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc[k] = fmaf(g, wr[k], acc[k]);
+            }
+          }
+      }
+    float4* dst = reinterpret_cast<float4*>(dX + q * 32 + cg * 8);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+int launch_dec_conv3_dgrad(const float* dY, int64_t N, const float* w, float* dX, hipStream_t s) {
+  const int64_t g = ceil_div(N * 256, 256);
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_dgrad_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, dY, N, w, dX);
+  return DVG_OK;
+}
+
+// dWt[ci][kh][kw] = sum_{img,y,x} dY(y,x) * Xup(y+1-kh, x+1-kw)[ci]; part[blk][tap*32 + ci]
+// block = 288 threads (tap, ci); one image (256 output pixels) per iteration
+__global__ __launch_bounds__(288) void dec_conv3_wgrad_kernel(const float* __restrict__ X, int64_t N,
+                                                              const float* __restrict__ dY, float* __restrict__ part) {
+  __shared__ float dys[256];
+  const int tid = threadIdx.x;
+  const int tap = tid >> 5, ci = tid & 31;
+  const int kh = tap / 3, kw = tap % 3;
+  float acc = 0.f;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();
+    if (tid < 256) dys[tid] = dY[img * 256 + tid];
+    __syncthreads();
+    const float* xb = X + img * 64 * 32 + ci;
+    for (int p = 0; p < 256; ++p) {
+      const int yy = (int)morton_y((uint32_t)p) + 1 - kh, xx = (int)morton_x((uint32_t)p) + 1 - kw;
+      if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16)
+        acc = fmaf(dys[p], xb[(size_t)(morton((uint32_t)yy, (uint32_t)xx) >> 2) * 32], acc);
+    }
+  }
+  part[(size_t)blockIdx.x * 288 + tid] = acc;
+}
+
+int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_wgrad_kernel, dim3(EW_BLOCKS), dim3(288), 0, s, X, N, dY, part);
+  return DVG_OK;
+}
+
+// ------------------------------------------------------------------------------ decoder final conv (1 -> 1)
+// X [N*256 (16x16 Morton)] upsampled to 32x32; out (N,32,32) row-major
+__global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restrict__ X, int64_t N,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out) {
+  const int64_t total = N * 1024;
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = w[t];
+  const float bb = bias[0];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t img = e >> 10;
+    const int y = (int)((e >> 5) & 31), x = (int)(e & 31);
+    float acc = bb;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + 1 - kh, xx = x + 1 - kw;
+        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32)
+          acc = fmaf(X[img * 256 + morton((uint32_t)(yy >> 1), (uint32_t)(xx >> 1))], wv[kh * 3 + kw], acc);
+      }
+    out[e] = acc;
+  }
+}
+
+int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s) {
+  const int64_t g = ceil_div(N * 1024, 256);
+  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, X, N, w, b, out);
+  return DVG_OK;
+}
+
+// dX[q] = sum over the quad's 4 pixels and taps of dOut(y+kh-1, x+kw-1) w[kh][kw]
+__global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __restrict__ dOut, int64_t N,
+                                                              const float* __restrict__ w, float* __restrict__ dX) {
+  const int64_t total = N * 256;
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = w[t];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t img = e >> 8;
+    const uint32_t ps = (uint32_t)(e & 255);
+    const int ys = (int)morton_y(ps), xs = (int)morton_x(ps);
+    float acc = 0.f;
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int yy = 2 * ys + sy + kh - 1, xx = 2 * xs + sx + kw - 1;
+            if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) acc = fmaf(dOut[img * 1024 + yy * 32 + xx], wv[kh * 3 + kw], acc);
+          }
+    dX[e] = acc;
+  }
+}
+
+int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s) {
+  const int64_t g = ceil_div(N * 256, 256);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, dOut, N, w, dX);
+  return DVG_OK;
+}
+
+// dw[kh][kw] = sum dOut(y,x) Xup(y+1-kh, x+1-kw); db = sum dOut;  part [EW_BLOCKS][10]
+__global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __restrict__ X, int64_t N,
+                                                              const float* __restrict__ dOut, float* __restrict__ part) {
+  __shared__ float red[10 * 256];
+  const int64_t total = N * 1024;
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t img = e >> 10;
+    const int y = (int)((e >> 5) & 31), x = (int)(e & 31);
+    const float g = dOut[e];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int yy = y + 1 - kh, xx = x + 1 - kw;
+        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32)
+          acc[kh * 3 + kw] = fmaf(g, X[img * 256 + morton((uint32_t)(yy >> 1), (uint32_t)(xx >> 1))], acc[kh * 3 + kw]);
+      }
+    acc[9] += g;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) red[k * 256 + threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 10) {
+    float t = 0.f;
+    for (int j = 0; j < 256; ++j) t += red[threadIdx.x * 256 + j];
+    part[(size_t)blockIdx.x * 10 + threadIdx.x] = t;
+  }
+}
+
+int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, X, N, dOut, part);
+  return DVG_OK;
+}
+
+}  // namespace dvg
