@@ -1,0 +1,309 @@
+"""MI355X-native ``ModelWrapper``: same entry points as /root/reference/src/model_wrapper.py
+(``setup``, ``train_init``, ``step``, ``save``, ``load``, the YAML-backed attributes), with
+every piece of arithmetic in libdvg.so and the QPU replaced by the on-GPU block-Gibbs sampler.
+
+Reference quirks that are reproduced on purpose: the learning-rate
+schedule is applied *after* the step (:347-351), the GRBM trains only for ``epoch < 6`` on
+every 10th step (:59-67) with a second, independent sampler draw (:332-342), and the
+checkpoint holds only the two ``state_dict``s (:148-162).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import functional as F
+from .losses import nll_loss
+from .modules import Decoder, Encoder
+from .optim import FlatAdam
+from .persistent_sampler import PersistentQPUSampleHelper
+from .plugin import DiscreteVariationalAutoencoder, GaussianKernel, GraphRestrictedBoltzmannMachine, maximum_mean_discrepancy_loss
+from .sampler import get_sampler_and_sampler_kwargs
+
+_DEFAULT_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "training_parameters.yaml")
+
+
+def train_dvae(opt_step: int, epoch: int) -> bool:
+    return True  # /root/reference/src/model_wrapper.py:48-56
+
+
+def train_grbm(opt_step: int, epoch: int) -> bool:
+    return epoch < 6 and opt_step % 10 == 0  # /root/reference/src/model_wrapper.py:59-67
+
+
+def get_latent_to_discrete(mode):
+    """/root/reference/src/utils/common.py:143-175."""
+    if mode is None:
+        return None
+    if mode != "heaviside":
+        raise ValueError("Invalid Mode: Mode is not heaviside.")
+    return F.heaviside_latent_to_discrete
+
+
+class TrainingError(Exception):
+    """Error when training the model."""
+
+
+class ModelWrapper:
+    """Container for the discrete VAE with a GRBM prior.
+
+    Args:
+        qpu: solver name; selects the topology of the local sampler (graphs.LOCAL_SOLVERS).
+        n_latents: number of latent spins (= GRBM nodes); a multiple of 32.
+        training_parameter_file: YAML with the reference's keys (+ the GIBBS_* keys).
+        dist: optional ``parallel.DataParallel`` context (one process per GPU).
+    """
+
+    def __init__(self, qpu: str, n_latents: Optional[int] = None, training_parameter_file: Optional[str] = None,
+                 dist=None) -> None:
+        self.qpu = qpu
+        self.n_latents = n_latents
+        self._dvae = None
+        self._grbm = None
+        self._device = None
+        self.sampler = None
+        self.sampler_kwargs = None
+        self._dvae_optimizer = None
+        self._grbm_optimizer = None
+        self._dataloader = None
+        self.losses = {"mse_losses": [], "dvae_losses": []}
+        self.dist = dist
+        self.noise_hook: Optional[Callable[[int], dict]] = None  # parity tests inject Gumbel noise / dropout masks
+        self.sync_losses = True   # False: keep loss tensors on device (no .item() host syncs in the step)
+        self.last = {}            # device scalars of the last step: mse, mmd, nll
+        with open(training_parameter_file or _DEFAULT_YAML, "r") as f:
+            self._params = yaml.safe_load(f)
+
+    def __getattr__(self, name: str):
+        params = self.__dict__.get("_params")
+        if params is not None and name in params:
+            return params[name]
+        raise AttributeError(name)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, file_path) -> None:
+        """Two ``state_dict`` files, as /root/reference/src/model_wrapper.py:148-162."""
+        file_path = Path(file_path)
+        file_path.mkdir(exist_ok=True, parents=True)
+        torch.save({k: v.detach().cpu().clone() for k, v in self._dvae.state_dict().items()}, file_path / "dvae.pth")
+        torch.save({k: v.detach().cpu().clone() for k, v in self._grbm.state_dict().items()}, file_path / "grbm.pth")
+
+    def load(self, file_path) -> None:
+        file_path = Path(file_path)
+        self.setup()
+        grbm_sd = torch.load(file_path / "grbm.pth", weights_only=True)
+        if grbm_sd["_edge_idx_i"].numel() != self._grbm._edge_idx_i.numel() or not (
+            torch.equal(grbm_sd["_edge_idx_i"].cpu(), self._grbm._edge_idx_i.cpu())
+            and torch.equal(grbm_sd["_edge_idx_j"].cpu(), self._grbm._edge_idx_j.cpu())
+        ):
+            # the checkpoint was trained on another (real-QPU) sub-graph: rebuild GRBM + sampler on ITS edges
+            self._rebuild_on_edges(grbm_sd["_edge_idx_i"].cpu().numpy(), grbm_sd["_edge_idx_j"].cpu().numpy())
+        self._dvae.load_state_dict(torch.load(file_path / "dvae.pth", weights_only=True))
+        self._grbm.load_state_dict(grbm_sd)
+
+    def _rebuild_on_edges(self, ei, ej):
+        from .graphs import build_plan
+        from .sampler import GibbsSampler
+
+        n = self.n_latents
+        plan = build_plan(n, ei, ej)
+        old = self.sampler
+        self.sampler = GibbsSampler(plan, list(range(n)), beta=old.beta, sweeps=old.sweeps, seed=old.seed,
+                                    persistent=old.persistent, device=self._device, chain_offset=old.chain_offset,
+                                    h_range=tuple(old.properties["h_range"]), j_range=tuple(old.properties["j_range"]))
+        grbm = GraphRestrictedBoltzmannMachine(list(range(n)), list(zip(ei.tolist(), ej.tolist())))
+        self._grbm = grbm.to(self._device)
+        self._make_optimizers()
+
+    # ------------------------------------------------------------------ construction
+    def setup(self) -> None:
+        """Build DVAE, sampler, GRBM and the two optimizers (/root/reference/src/model_wrapper.py:177-217)."""
+        self._device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if self.LATENT_TO_DISCRETE in ["heaviside"] and self.N_REPLICAS != 1:
+            raise ValueError("heaviside latent-to-discrete can only be used with n_replicas=1")
+        dvae = DiscreteVariationalAutoencoder(
+            encoder=Encoder(n_latents=self.n_latents),
+            decoder=Decoder(n_latents=self.n_latents),
+            latent_to_discrete=get_latent_to_discrete(self.LATENT_TO_DISCRETE),
+        )
+        self._dvae = dvae.to(self._device)
+        rank = self.dist.rank if self.dist is not None else 0
+        num_reads = self.local_num_reads()
+        self.sampler, self.sampler_kwargs, graph, self.linear_range, self.quadratic_range = get_sampler_and_sampler_kwargs(
+            num_reads=num_reads,
+            annealing_time=self.ANNEALING_TIME,
+            n_latents=self.n_latents,
+            random_seed=self.RANDOM_SEED,
+            qpu=self.qpu,
+            sweeps=int(self._params.get("GIBBS_SWEEPS", 50)),
+            beta=self._params.get("GIBBS_BETA"),
+            prefactor=self.PREFACTOR,
+            persistent=bool(self._params.get("GIBBS_PERSISTENT", True)),
+            device=self._device,
+            chain_offset=rank * num_reads,  # chains are globally numbered: G GPUs sample G*num_reads distinct chains
+        )
+        grbm = GraphRestrictedBoltzmannMachine(graph.nodes, graph.edges)
+        self._grbm = grbm.to(self._device)
+        self._dvae.gumbel_seed = int(self.RANDOM_SEED) + 7919 * rank
+        self._dvae.decoder.dropout_seed = int(self.RANDOM_SEED) + 104729 * rank
+        self._make_optimizers()
+
+    def local_num_reads(self) -> int:
+        """Chains per rank.  Data parallelism is weak-scaled: every rank keeps the full per-GPU
+        workload (its own mini-batch AND its own NUM_READS chains, globally numbered by rank)."""
+        return int(self.NUM_READS)
+
+    def _make_optimizers(self):
+        cls = FlatAdam if self._device.type == "cuda" else _DeferredAdam
+        self._dvae_optimizer = cls(self._dvae.parameters(), lr=self.AUTOENCODER_INITIAL_LR,
+                                   weight_decay=self.AUTOENCODER_WEIGHT_DECAY)
+        self._grbm_optimizer = cls(self._grbm.parameters(), lr=self.BM_INITIAL_LR, weight_decay=self.BM_WEIGHT_DECAY)
+
+    def set_dataloader(self, dataloader) -> None:
+        """Any iterable of ``(images (B,1,32,32) in {0,1}, labels)`` with ``len()``."""
+        self._dataloader = dataloader
+
+    def _load_dataset(self, batch_size: int, dataset_size: Optional[int] = None) -> None:
+        from .data import get_dataloader
+
+        self._dataloader = get_dataloader(self.IMAGE_SIZE, batch_size, dataset_size, seed=self.RANDOM_SEED)
+
+    def train_init(self, n_epochs: int) -> None:
+        """/root/reference/src/model_wrapper.py:229-277."""
+        self.losses["mse_losses"].clear()
+        self.losses["dvae_losses"].clear()
+        torch.manual_seed(self.RANDOM_SEED)
+        self._tpar = {}
+        self._tpar["persistent_qpu_sample_helper"] = PersistentQPUSampleHelper(
+            max_deque_size=self.MAX_DEQUE_SIZE, iterations_before_resampling=self.ITERATIONS_BEFORE_RESAMPLING
+        )
+        if self._dvae is None or self._grbm is None:
+            self.setup()
+        if self._dataloader is None:
+            self._load_dataset(batch_size=self.BATCH_SIZE, dataset_size=self.DATASET_SIZE)
+        total_opt_steps = n_epochs * len(self._dataloader)
+        self._tpar["dvae_lr_schedule"] = np.geomspace(self.AUTOENCODER_INITIAL_LR, self.AUTOENCODER_FINAL_LR,
+                                                      total_opt_steps + 1)
+        self._tpar["grbm_lr_schedule"] = np.geomspace(self.BM_INITIAL_LR, self.BM_FINAL_LR, total_opt_steps + 1)
+        self._tpar["opt_step"] = 0
+        self._tpar["kernel"] = GaussianKernel(n_kernels=7).to(self._device)
+        self._tpar["sample_set"] = None
+        self._tpar["init_done"] = True
+
+    # ------------------------------------------------------------------ the hot path
+    def step(self, batch, epoch: int) -> torch.Tensor:
+        """One training step; same order of operations as /root/reference/src/model_wrapper.py:279-353."""
+        if not self._tpar.get("init_done", True):
+            raise TrainingError("Initialization required before training.")
+        images, _ = batch
+        images = images.to(self._device)
+        self._dvae.train()
+        self._grbm.train()
+        opt_step = self._tpar["opt_step"]
+        if self.noise_hook is not None:
+            noise = self.noise_hook(opt_step)
+            if noise.get("gumbels") is not None:
+                self._dvae.inject_gumbels(noise["gumbels"].to(self._device))
+            if noise.get("dropout_masks") is not None:
+                self._dvae.decoder.inject_dropout_masks([m.to(self._device) for m in noise["dropout_masks"]])
+
+        _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)
+
+        if train_dvae(opt_step, epoch):
+            self._dvae_optimizer.zero_grad()
+            mse_loss = F.replicated_mse_loss(reconstructed_images, images)
+            self._log("mse_losses", mse_loss)
+            with torch.no_grad():
+                samples = self._grbm.sample(
+                    sampler=self.sampler,
+                    prefactor=self.PREFACTOR,
+                    linear_range=self.linear_range,
+                    quadratic_range=self.quadratic_range,
+                    device=spins.device,
+                    sample_params=self.sampler_kwargs,
+                )
+            spins = spins.reshape(-1, spins.shape[-1])
+            _mmd_loss = maximum_mean_discrepancy_loss(x=spins, y=samples, kernel=self._tpar["kernel"])
+            dvae_loss = mse_loss + _mmd_loss
+            self._log("dvae_losses", dvae_loss)
+            dvae_loss.backward()
+            self._reduce_and_step(self._dvae_optimizer)
+            self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
+
+        if train_grbm(opt_step, epoch):
+            self._grbm_optimizer.zero_grad()
+            grbm_loss, self._tpar["sample_set"] = nll_loss(
+                spins=spins.detach(),
+                grbm=self._grbm,
+                sampler=self.sampler,
+                sampler_kwargs=self.sampler_kwargs,
+                linear_range=self.linear_range,
+                quadratic_range=self.quadratic_range,
+                prefactor=self.PREFACTOR,
+                persistent_qpu_sample_helper=self._tpar["persistent_qpu_sample_helper"],
+                sample_set=self._tpar["sample_set"],
+            )
+            grbm_loss.backward()
+            self._reduce_and_step(self._grbm_optimizer)
+            self.last.update(nll=grbm_loss.detach())
+
+        for param_group in self._dvae_optimizer.param_groups:
+            param_group["lr"] = self._tpar["dvae_lr_schedule"][opt_step]
+        for param_group in self._grbm_optimizer.param_groups:
+            param_group["lr"] = self._tpar["grbm_lr_schedule"][opt_step]
+        self._tpar["opt_step"] += 1
+        return mse_loss
+
+    def _log(self, key: str, value: torch.Tensor):
+        self.losses[key].append(value.item() if self.sync_losses else value.detach())
+
+    def _reduce_and_step(self, opt):
+        if self.dist is not None and self.dist.world_size > 1:
+            flat = opt.gather_grads()
+            self.dist.all_reduce_mean(flat)  # ONE collective over the flat gradient buffer
+            opt.step(gathered=True)
+        else:
+            opt.step()
+
+    # ------------------------------------------------------------------ generation (tensor-returning core)
+    @torch.no_grad()
+    def generate_images(self, sharpen: bool = False, lower: float = 0.35, upper: float = 0.65) -> torch.Tensor:
+        """Sampler -> decoder -> clip, the compute of /root/reference/src/model_wrapper.py:355-385
+        (plotting left to the caller).  Returns (NUM_READS, 1, 32, 32) on the device."""
+        self._dvae.eval()
+        self._grbm.eval()
+        samples = self._grbm.sample(self.sampler, prefactor=self.PREFACTOR, device=self._device,
+                                    linear_range=self.linear_range, quadratic_range=self.quadratic_range,
+                                    sample_params=self.sampler_kwargs)
+        images = self._dvae.decoder(samples.unsqueeze(1)).squeeze(1).clip(0.0, 1.0)
+        if sharpen:
+            over = (images > upper).to(images.dtype)   # heaviside(x, 0): strict
+            under = (images > lower).to(images.dtype)
+            images = (over + (1 - over) * images) * under
+        return images
+
+
+class _DeferredAdam:
+    """Placeholder used when no GPU is present (CPU-side construction / checkpoint tests): it keeps
+    the optimizer surface (``param_groups``, ``zero_grad``) and refuses to step: no CPU fallback."""
+
+    def __init__(self, params, lr, weight_decay=0.0):
+        self.params = list(params)
+        self.param_groups = [dict(params=self.params, lr=lr, weight_decay=weight_decay)]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, *a, **k):
+        from ._lib import DvgError
+
+        raise DvgError("optimizer step needs the HIP library and a GPU; there is no CPU fallback")
+
+    def gather_grads(self):
+        return self.step()

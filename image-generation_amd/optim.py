@@ -1,0 +1,81 @@
+"""Fused Adam over one flat parameter buffer (``dvg_adam_step``).
+
+Counterpart of the two ``torch.optim.Adam(..., weight_decay=...)`` instances the reference
+builds at /root/reference/src/model_wrapper.py:208-217 (coupled L2 weight decay, betas
+(0.9, 0.999), eps 1e-8).  All parameters of the optimizer are re-homed as views into one
+contiguous float32 buffer, so a step is a single kernel launch and -- on several GPUs -- the
+gradient exchange is a single all-reduce of ``flat_grad``.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import _lib
+
+
+class FlatAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam got an empty parameter list")
+        dev = self.params[0].device
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatAdam needs float32 parameters on one device")
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off: off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off: off + n].view(p.shape)  # parameters become views of the flat buffer
+                self.offsets.append(off)
+                off += n
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> torch.Tensor:
+        """Pack the per-tensor gradients into ``flat_grad`` (missing gradients count as zero)."""
+        views = []
+        for p, off in zip(self.params, self.offsets):
+            views.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=self.flat.device))
+        torch.cat(views, out=self.flat_grad)
+        return self.flat_grad
+
+    def step(self, grad_scale: float = 1.0, gathered: bool = False):
+        if not self.flat.is_cuda:
+            raise _lib.DvgError("FlatAdam.step needs CUDA tensors; there is no CPU fallback")
+        if not gathered:
+            self.gather_grads()
+        g = self.param_groups[0]
+        self.step_count += 1
+        with torch.cuda.device(self.flat.device):
+            _lib.check(
+                _lib.lib().dvg_adam_step(self.flat.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), self.numel, float(g["lr"]), float(g["betas"][0]),
+                                         float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                         self.step_count, float(grad_scale), _lib.stream_ptr(self.flat.device)),
+                "dvg_adam_step",
+            )
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    lr=self.param_groups[0]["lr"])
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0]["lr"] = sd["lr"]

@@ -199,7 +199,114 @@ def common_fixture():
     print("wrote common.json", {k: len(v) for k, v in out.items()})
 
 
+def step_fixture(n=64, steps=12):
+    """Drives the reference's VERBATIM ModelWrapper.train_init / .step
+    (/root/reference/src/model_wrapper.py:229-353) over the oracle restatement of the absent
+    plugin classes and the oracle Gibbs sampler, recording every random draw it consumes."""
+    import yaml
+    from oracle import plugin as oplugin
+    from oracle.sampler import OracleGibbsSampler
+
+    install_stubs()
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("image_generation_amd_graphs", os.path.join(ROOT, "image-generation_amd", "graphs.py"))
+    graphs = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = graphs
+    spec.loader.exec_module(graphs)
+
+    rec = {"gumbels": [], "masks": []}
+
+    def capturing_l2d(logits, n_samples, gumbels=None, tau=oplugin.GUMBEL_TAU):
+        two_shape = (logits.shape[0], n_samples, logits.shape[1], 2)
+        g = -torch.empty(two_shape).exponential_().log()  # the draw F.gumbel_softmax makes
+        rec["gumbels"].append(g.numpy().copy())
+        return _orig_l2d(logits, n_samples, gumbels=g, tau=tau)
+
+    _orig_l2d = oplugin.gumbel_latent_to_discrete
+    oplugin.gumbel_latent_to_discrete = capturing_l2d
+    sys.modules["dwave.plugins.torch.models"].DiscreteVariationalAutoencoder = oplugin.DiscreteVariationalAutoencoder
+    sys.modules["dwave.plugins.torch.models"].GraphRestrictedBoltzmannMachine = oplugin.GraphRestrictedBoltzmannMachine
+    sys.modules["dwave.plugins.torch.nn.functional"].maximum_mean_discrepancy_loss = oplugin.maximum_mean_discrepancy_loss
+    sys.modules["dwave.plugins.torch.nn.modules.kernels"].GaussianKernel = oplugin.GaussianKernel
+    for m in [k for k in sys.modules if k.startswith("src")]:
+        del sys.modules[m]
+    mw = importlib.import_module("src.model_wrapper")
+
+    params_file = os.path.join(HERE, "step_params.yaml")
+    cfg = yaml.safe_load(open(params_file))
+
+    def fake_sampler_factory(num_reads, annealing_time, n_latents, random_seed, qpu):
+        make, h_range, j_range = graphs.LOCAL_SOLVERS[qpu]
+        sub = graphs.greedy_get_subgraph(n_latents, random_seed, make())
+        mapped, _ = graphs.get_graph_mapping(sub)
+        nodes, ei, ej = graphs.edges_of(mapped)
+        plan = graphs.build_plan(len(nodes), ei, ej)
+        sampler = OracleGibbsSampler(plan, beta=1.0 / cfg["PREFACTOR"], sweeps=cfg["GIBBS_SWEEPS"], seed=random_seed,
+                                     persistent=cfg["GIBBS_PERSISTENT"])
+        kwargs = dict(num_reads=num_reads, answer_mode="raw", auto_scale=False, annealing_time=annealing_time, label="x")
+        return sampler, kwargs, mapped, tuple(h_range), tuple(j_range)
+
+    mw.get_sampler_and_sampler_kwargs = fake_sampler_factory
+
+    class CapturingDecoder(mw.Decoder):
+        def __init__(self, n_latents):
+            super().__init__(n_latents)
+            for mod in self.convtrans:
+                if isinstance(mod, torch.nn.Dropout2d):
+                    mod.register_forward_hook(self._hook)
+
+        @staticmethod
+        def _hook(module, inp, outp):
+            if module.training:
+                kept = (outp.abs().sum((2, 3)) > 0) | (inp[0].abs().sum((2, 3)) == 0)
+                rec["masks"].append(kept.float().numpy().copy())
+
+    mw.Decoder = CapturingDecoder
+    nlls = []
+    _orig_nll = mw.nll_loss
+
+    def capturing_nll(*a, **k):
+        out = _orig_nll(*a, **k)
+        nlls.append(float(out[0]))
+        return out
+
+    mw.nll_loss = capturing_nll
+
+    B = cfg["BATCH_SIZE"]
+    images = torch.from_numpy(gen.make_images(B * steps, seed=909)).reshape(steps, B, 1, 32, 32)
+    batches = [(images[k], torch.zeros(B, dtype=torch.int64)) for k in range(steps)]
+    model = mw.ModelWrapper(qpu="Advantage_system4", n_latents=n, training_parameter_file=params_file)
+    model._dataloader = batches
+    model.train_init(n_epochs=1)
+    out = {"n": n, "steps": steps}
+    for name, t in list(model._dvae.state_dict().items()) + list(model._grbm.state_dict().items()):
+        if t.dtype == torch.float32:
+            out[f"init_norm/{name}"] = np.asarray([float(t.double().sum()), float(t.double().norm())])
+    mses = []
+    for k, batch in enumerate(batches):
+        mses.append(float(model.step(batch, epoch=0)))
+    out["mse"] = np.asarray(model.losses["mse_losses"])
+    out["dvae"] = np.asarray(model.losses["dvae_losses"])
+    out["nll"] = np.asarray(nlls)
+    assert np.allclose(mses, out["mse"])
+    out["gumbels"] = np.stack(rec["gumbels"]).astype(np.float32)
+    for l in range(4):
+        out[f"masks{l}"] = np.stack(rec["masks"][l::4]).astype(np.uint8)
+    for name, t in list(model._dvae.state_dict().items()) + list(model._grbm.state_dict().items()):
+        if t.dtype == torch.float32:
+            out[f"final_norm/{name}"] = np.asarray([float(t.double().sum()), float(t.double().norm())])
+    out["final_lr"] = np.asarray([model._dvae_optimizer.param_groups[0]["lr"], model._grbm_optimizer.param_groups[0]["lr"]])
+    out["sampler_calls"] = model.sampler.calls
+    np.savez_compressed(os.path.join(HERE, "step_n64.npz"), **out)
+    print("wrote step fixture: mse", out["mse"][:3], "dvae", out["dvae"][:3], "nll", out["nll"], "calls", model.sampler.calls)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    enc_dec_fixture()
-    common_fixture()
+    which = sys.argv[1:] or ["enc_dec", "common", "step"]
+    if "enc_dec" in which:
+        enc_dec_fixture()
+    if "common" in which:
+        common_fixture()
+    if "step" in which:
+        step_fixture()
