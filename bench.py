@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DVAE + GRBM train-step images/s on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full `ModelWrapper.step` (/root/reference/src/model_wrapper.py:279-353) on one
+synthetic batch resident in HBM: encoder fwd+bwd, Gumbel discretisation, R decoder replicas fwd+bwd,
+MSE, one block-Gibbs draw, fused MMD fwd+bwd, Adam; the GRBM quasi-NLL branch (second draw, energy,
+sufficient statistics, Adam) runs at its natural duty of every 10th step.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case
+    "c1": dict(B=64, n=64, R=8, C=256, sweeps=1, qpu="Advantage_system4", persistent=False,
+               desc="MNIST-shaped 32x32 synthetic, B=64, 64-spin Pegasus sub-graph GRBM, R=8, 256 reads, 1 Gibbs sweep"),
+    # configs[1]: the configuration the metric is quoted on (fits one GPU) -> the bench workload
+    "c2": dict(B=256, n=128, R=8, C=256, sweeps=50, qpu="Advantage_system4", persistent=True,
+               desc="MNIST-shaped 32x32 synthetic, B=256, 128-spin Pegasus sub-graph GRBM, R=8, 256 reads, 50-sweep PCD Gibbs"),
+    "c3": dict(B=4096, n=512, R=8, C=256, sweeps=200, qpu="Advantage2_system1", persistent=True,
+               desc="MNIST-shaped 32x32 synthetic, B=4096, 512-spin Zephyr sub-graph GRBM, R=8, 256 reads, 200-sweep PCD Gibbs"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def write_yaml(cfg, path):
+    base = yaml.safe_load(open(os.path.join(ROOT, "image-generation_amd", "training_parameters.yaml")))
+    base.update(BATCH_SIZE=cfg["B"], N_REPLICAS=cfg["R"], NUM_READS=cfg["C"], GIBBS_SWEEPS=cfg["sweeps"],
+                GIBBS_PERSISTENT=cfg["persistent"])
+    with open(path, "w") as f:
+        yaml.safe_dump(base, f)
+
+
+def conv_flops(cfg):
+    """Algorithmic FLOPs per step of the MFMA GEMM kernels, by profiler kernel id (SURVEY.md §8d formulas)."""
+    B, n, R = cfg["B"], cfg["n"], cfg["R"]
+    N = B * R
+    enc = [(B * 256, 32, 64), (B * 64, 64, 128), (B * 16, 128, n)]          # (pixels, Cin, Cout), 9 taps
+    dec = [(N * 4, n, 128), (N * 16, 128, 64), (N * 64, 64, 32)]
+    igemm = sum(2 * m * 9 * ci * co for m, ci, co in enc + dec)
+    lin = 2 * N * n * 4 * n
+    return {"conv_igemm_fwd": igemm, "dec_linear": lin, "conv_igemm_dgrad": igemm + lin, "conv_wgrad": igemm + lin}
+
+
+def mmd_flops(cfg):
+    nx, ny, d = cfg["B"] * cfg["R"], cfg["C"], cfg["n"]
+    N = nx + ny
+    return 2 * N * N * d + 2 * nx * N * d  # Gram + gradient GEMM
+
+
+def net_flops_per_image(n, R):
+    f_enc = 18 * (32 * 1024 + 32 * 64 * 256 + 64 * 128 * 64 + 128 * n * 16) + 8 * n
+    f_dec = 8 * n * n + 18 * (n * 128 * 4 + 128 * 64 * 16 + 64 * 32 * 64 + 32 * 256 + 1024)
+    return 3 * (f_enc + R * f_dec)
+
+
+def cpu_baseline(cfg, seconds=20.0):
+    """The CPU oracle (a port: stock PyTorch CPU ops + the C Gibbs restatement) on this box's host cores."""
+    from image_generation_amd import graphs
+    from oracle.step import OracleTrainer
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    make, h_range, j_range = graphs.LOCAL_SOLVERS[cfg["qpu"]]
+    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(cfg["n"], 775321899904, make()))
+    _, ei, ej = graphs.edges_of(mg)
+    plan = graphs.build_plan(cfg["n"], ei, ej)
+    tr = OracleTrainer(plan, cfg["n"], cfg["R"], cfg["C"], cfg["sweeps"], 0.05, seed=1, h_range=h_range, j_range=j_range)
+    g = torch.Generator().manual_seed(3)
+    batch = lambda: (torch.rand((cfg["B"], 1, 32, 32), generator=g) < 0.13).float()  # noqa: E731
+    t0 = time.perf_counter()
+    tr.step(batch(), force_grbm=False)  # warm-up
+    first = time.perf_counter() - t0
+    steps = max(2, min(20, int(seconds / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        tr.step(batch())  # GRBM branch at its natural duty (step 10k)
+    dt = time.perf_counter() - t0
+    return {"value": cfg["B"] * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps of the same workload (B={cfg['B']}) on the CPU oracle after 1 warm-up step; "
+                      f"{dt / steps * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default="", help="write the per-kernel HIP-event breakdown (JSON) to this path")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    from image_generation_amd import _lib
+    from image_generation_amd.data import synthetic_images
+    from image_generation_amd.model_wrapper import ModelWrapper
+    from image_generation_amd.parallel import DataParallel
+
+    dp = DataParallel()
+    if dp.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world_size}: launch with torch.distributed.run")
+    dev = torch.device("cuda", dp.local_rank)
+    torch.cuda.set_device(dev)
+
+    tmp = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False)
+    tmp.close()
+    write_yaml(cfg, tmp.name)
+    model = ModelWrapper(cfg["qpu"], n_latents=cfg["n"], training_parameter_file=tmp.name,
+                         dist=dp if dp.world_size > 1 else None)
+    # synthetic batches resident in HBM (a pool, so no step re-reads the batch it just saw)
+    pool = 16
+    imgs = synthetic_images(pool * cfg["B"], seed=775321899904 + dp.rank, device=dev).reshape(pool, cfg["B"], 1, 32, 32)
+    labels = torch.zeros(cfg["B"], dtype=torch.int64, device=dev)
+    batches = [(imgs[k], labels) for k in range(pool)]
+    model.set_dataloader(batches * ((args.steps + args.warmup) // pool + 1))
+    model.train_init(n_epochs=1)
+    model.sync_losses = False  # no .item() host syncs inside the step
+
+    L = _lib.lib()
+    step_idx = 0
+    for _ in range(args.warmup):
+        model.step(batches[step_idx % pool], epoch=0)
+        step_idx += 1
+    torch.cuda.synchronize()
+    # per-kernel HIP-event timing of the MFMA GEMM kernels + MMD over the timed region (events are
+    # recorded on the stream the kernels run on: torch's current stream)
+    names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
+    profiled = {"conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad", "dec_linear", "mmd_main"}
+    mask = sum(1 << i for i, nm in enumerate(names) if nm in profiled) if not args.breakdown else (1 << len(names)) - 1
+    L.dvg_prof_reset()
+    L.dvg_prof_enable(mask)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.step(batches[step_idx % pool], epoch=0)
+        step_idx += 1
+    torch.cuda.synchronize()
+    dp.barrier()
+    elapsed = time.perf_counter() - t0
+    L.dvg_prof_enable(0)
+    elapsed = dp.max_over_ranks(elapsed)
+
+    import ctypes
+
+    per_kernel = {}
+    for i, nm in enumerate(names):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        L.dvg_prof_query(i, ctypes.byref(ms), ctypes.byref(cnt))
+        if cnt.value:
+            per_kernel[nm] = {"total_ms": ms.value, "launches": cnt.value}
+    if dp.rank == 0:
+        flops = dict(conv_flops(cfg), mmd_main=mmd_flops(cfg))
+        cands = {k: v for k, v in per_kernel.items() if k in flops}
+        dom = max(cands, key=lambda k: cands[k]["total_ms"])
+        ach = flops[dom] * args.steps / (cands[dom]["total_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_us": cands[dom]["total_ms"] * 1e3 / cands[dom]["launches"],
+                    "launches": cands[dom]["launches"],
+                    "all_mfma_kernels": {k: {"tflops": flops[k] * args.steps / (v["total_ms"] * 1e-3) / 1e12,
+                                              "ms_per_step": v["total_ms"] / args.steps} for k, v in cands.items()}}
+        ips = args.gpus * cfg["B"] * args.steps / elapsed
+        out = {
+            "metric": "dvae_grbm_train_step_images_per_s", "value": ips, "unit": "images/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}", "global_batch": cfg["B"] * args.gpus,
+                       "n_latents": cfg["n"], "n_replicas": cfg["R"], "num_reads_per_gpu": cfg["C"],
+                       "gibbs_sweeps": cfg["sweeps"], "parallelism": f"dp{args.gpus}",
+                       "net_gflop_per_step": net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9},
+            "roofline": roofline,
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        if args.breakdown:
+            with open(args.breakdown, "w") as f:
+                json.dump({"ms_per_step": elapsed / args.steps * 1e3, "kernels": per_kernel}, f, indent=1)
+        print(json.dumps(out), flush=True)
+    dp.shutdown()
+    os.unlink(tmp.name)
+
+
+if __name__ == "__main__":
+    main()

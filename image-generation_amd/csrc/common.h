@@ -73,13 +73,13 @@ enum KernelId : int {
 };
 
 // Profiler hooks (prof.cpp).  begin/end record a hipEvent pair on `s` when enabled.
-bool prof_on();
+bool prof_on(int id);
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 
 struct ProfScope {
   int id; hipStream_t s; bool on;
-  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(prof_on()) { if (on) prof_begin(id, s); }
+  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(prof_on(id_)) { if (on) prof_begin(id, s); }
   ~ProfScope() { if (on) prof_end(id, s); }
 };
 

@@ -25,7 +25,7 @@ static const char* kNames[K_COUNT] = {
     "mse", "adam", "misc"};
 
 struct EvPair { hipEvent_t a, b; };
-static bool g_on = false;
+static uint64_t g_mask = 0;
 static std::mutex g_mu;
 static std::vector<EvPair> g_pairs[K_COUNT];
 static std::vector<EvPair> g_free;
@@ -33,7 +33,7 @@ static double g_ms[K_COUNT];
 static int64_t g_n[K_COUNT];
 static thread_local EvPair g_open[K_COUNT];
 
-bool prof_on() { return g_on; }
+bool prof_on(int id) { return (g_mask >> id) & 1ull; }
 
 void prof_begin(int id, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -69,7 +69,7 @@ extern "C" {
 int dvg_version(void) { return 100; /* 0.1.0 */ }
 const char* dvg_last_error(void) { return g_err; }
 
-int dvg_prof_enable(int on) { g_on = on != 0; return DVG_OK; }
+int dvg_prof_enable(uint64_t kernel_mask) { g_mask = kernel_mask; return DVG_OK; }
 int dvg_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_n[i] = 0; }

@@ -209,10 +209,11 @@ int dvg_adam_step(float *p, const float *g, float *m, float *v, int64_t numel, f
 
 /* ------------------------------------------------------------------ profiler
  * Optional per-kernel HIP-event timing inside the library (used by bench.py for
- * the `roofline` object).  Off by default; enabling it adds event records on
- * the caller's stream around every kernel launch.
+ * the `roofline` object).  Off by default.  `kernel_mask` bit i enables kernel id i
+ * (ids/names: dvg_prof_num_kernels / dvg_prof_kernel_name); an enabled kernel gets
+ * one event pair recorded on the caller's stream around each of its launches.
  */
-int dvg_prof_enable(int on);
+int dvg_prof_enable(uint64_t kernel_mask);
 int dvg_prof_reset(void);
 int dvg_prof_num_kernels(void);
 const char *dvg_prof_kernel_name(int id);
