@@ -144,6 +144,7 @@ SIGNATURES = {
     "dvg_prof_num_kernels": (c_int, []),
     "dvg_prof_kernel_name": (c_char_p, [c_int]),
     "dvg_prof_query": (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
+    "dvg_prof_query_work": (c_int, [c_int, POINTER(c_double)]),
 }
 
 
@@ -165,6 +166,10 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()). "
                 "The HIP library is required; there is no CPU fallback."
             )
+        # torch bundles its own libamdhip64; import it FIRST so libdvg.so binds to the same HIP runtime
+        # (two runtimes in one process do not share devices, streams or allocations)
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

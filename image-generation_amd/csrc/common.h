@@ -45,9 +45,13 @@ enum KernelId : int {
   K_MMD_DISTSUM,
   K_MMD_MAIN,
   K_MMD_FINAL,
-  K_CONV_IGEMM_FWD,
-  K_CONV_IGEMM_DGRAD,
-  K_CONV_WGRAD,
+  K_IGEMM_128x64,   // conv_igemm_kernel<128,64,2,2>
+  K_IGEMM_64x64,    // conv_igemm_kernel<64,64,2,2>
+  K_IGEMM_128x32,   // conv_igemm_kernel<128,32,4,1>
+  K_WGRAD_2x2,      // conv_wgrad_kernel<2,2>
+  K_WGRAD_2x1,
+  K_WGRAD_1x2,
+  K_WGRAD_1x1,
   K_WGRAD_REDUCE,
   K_WEIGHT_PACK,
   K_BN_FINALIZE,
@@ -58,7 +62,6 @@ enum KernelId : int {
   K_ENC_BN_POOL_BWD_APPLY,
   K_ENC_PROJ_FWD,
   K_ENC_PROJ_BWD,
-  K_DEC_LINEAR,
   K_DEC_BN_ACT_FWD,
   K_DEC_BN_ACT_BWD_REDUCE,
   K_DEC_BN_ACT_BWD_APPLY,
@@ -75,19 +78,25 @@ enum KernelId : int {
 // Profiler hooks (prof.cpp).  begin/end record a hipEvent pair on `s` when enabled.
 bool prof_on(int id);
 void prof_begin(int id, hipStream_t s);
-void prof_end(int id, hipStream_t s);
+void prof_end(int id, hipStream_t s, double work);
 
+// `work`: algorithmic work of the launch (FLOPs for the GEMM kernels), summed per kernel id
 struct ProfScope {
-  int id; hipStream_t s; bool on;
-  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(prof_on(id_)) { if (on) prof_begin(id, s); }
-  ~ProfScope() { if (on) prof_end(id, s); }
+  int id; hipStream_t s; bool on; double work;
+  ProfScope(int id_, hipStream_t s_, double work_ = 0.0) : id(id_), s(s_), on(prof_on(id_)), work(work_) {
+    if (on) prof_begin(id, s);
+  }
+  ~ProfScope() { if (on) prof_end(id, s, work); }
 };
 
 // Launch helper: kernel<<<grid, block, shmem, stream>>>(args...) wrapped in a profiler scope,
 // returning DVG_E_HIP from the enclosing function on a launch error.
-#define DVG_LAUNCH(id, kernel, grid, block, shmem, stream, ...)                         \
+#define DVG_LAUNCH(id, kernel, grid, block, shmem, stream, ...) \
+  DVG_LAUNCH_WORK(id, 0.0, kernel, grid, block, shmem, stream, __VA_ARGS__)
+
+#define DVG_LAUNCH_WORK(id, work, kernel, grid, block, shmem, stream, ...)              \
   do {                                                                                  \
-    dvg::ProfScope _ps((id), (stream));                                                 \
+    dvg::ProfScope _ps((id), (stream), (work));                                         \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
     hipError_t _le = hipGetLastError();                                                 \
     if (_le != hipSuccess) {                                                            \

@@ -68,7 +68,7 @@ struct ConvArgs {
   int ups;            // input is stored at half resolution
   int poolsum;        // sum each 2x2 output quad (adjoint of the upsample) before storing
 };
-int launch_conv_igemm(const ConvArgs& a, int kernel_id, hipStream_t s);
+int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);  // number of m_blocks launch_conv_igemm will use (for `stats`)
 
 // Weight-gradient GEMM:  dWp[tap][a][b] = sum_m in[nbr(m,tap)][a] * dy[m][b], split over `ksplit` slabs.

@@ -176,20 +176,21 @@ static int igemm_cfg(int64_t M, int Cout) {
 
 int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_cfg(M, Cout) == 1 ? 64 : 128); }
 
-int launch_conv_igemm(const ConvArgs& a, int kernel_id, hipStream_t s) {
+int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
   if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 1)) {
     set_error("conv_igemm: unsupported shape Cin=%d Cout=%d M=%lld ntaps=%d", a.Cin, a.Cout, (long long)a.M, a.ntaps);
     return DVG_E_INVALID;
   }
+  const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;  // algorithmic
   switch (igemm_cfg(a.M, a.Cout)) {
     case 0:
-      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64), dim3(256), 0, s, a);
       break;
     case 1:
-      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64), dim3(256), 0, s, a);
       break;
     default:
-      DVG_LAUNCH(kernel_id, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32), dim3(256), 0, s, a);
       break;
   }
   return DVG_OK;
@@ -285,10 +286,11 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   const bool a64 = a.Cin % 64 == 0, b64 = a.Cout % 64 == 0;
   const int ba = a64 ? 64 : 32, bb = b64 ? 64 : 32;
   const dim3 grid((unsigned)((a.Cin / ba) * (a.Cout / bb)), (unsigned)a.ntaps, (unsigned)a.ksplit);
-  if (a64 && b64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
-  else if (a64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<2, 1>), grid, dim3(128), 0, s, a);
-  else if (b64) DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<1, 2>), grid, dim3(128), 0, s, a);
-  else DVG_LAUNCH(K_CONV_WGRAD, (conv_wgrad_kernel<1, 1>), grid, dim3(64), 0, s, a);
+  const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;
+  if (a64 && b64) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, s, a);
+  else if (a64) DVG_LAUNCH_WORK(K_WGRAD_2x1, flops, (conv_wgrad_kernel<2, 1>), grid, dim3(128), 0, s, a);
+  else if (b64) DVG_LAUNCH_WORK(K_WGRAD_1x2, flops, (conv_wgrad_kernel<1, 2>), grid, dim3(128), 0, s, a);
+  else DVG_LAUNCH_WORK(K_WGRAD_1x1, flops, (conv_wgrad_kernel<1, 1>), grid, dim3(64), 0, s, a);
   return DVG_OK;
 }
 

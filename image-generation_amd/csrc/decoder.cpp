@@ -115,7 +115,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = spins; a.wp = W + pl.wp_lin; a.bias = W + pl.bias_lin; a.out = W + pl.X0; a.stats = nullptr;
     a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
-    DVG_TRY(launch_conv_igemm(a, K_DEC_LINEAR, s));
+    DVG_TRY(launch_conv_igemm(a, s));
   }
   const float* x = W + pl.X0;
   for (int l = 0; l < 4; ++l) {
@@ -126,7 +126,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = l > 0; a.poolsum = 0;
-      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_FWD, s));
+      DVG_TRY(launch_conv_igemm(a, s));
     } else {
       DVG_TRY(launch_dec_conv3_fwd(x, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
     }
@@ -200,7 +200,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
-    DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+    DVG_TRY(launch_conv_igemm(a, s));
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
   {
@@ -216,7 +216,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       ConvArgs a;
       a.in = dX; a.wp = W + pl.wpd_lin; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
       a.M = N; a.Cin = 4 * n; a.Cout = n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
-      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+      DVG_TRY(launch_conv_igemm(a, s));
     }
   }
   return DVG_OK;

@@ -38,19 +38,31 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[K], const ChanMa
 }
 
 // ---------------------------------------------------------------- generic column sums of partials
+// one wavefront per output element: lanes stride over the G partials, fixed-shape shuffle tree in
+// double -> deterministic and ~G/64 dependent adds deep instead of G
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int G, int stride, int count,
                                                      float scale, float* __restrict__ out, int permA, int permB) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (w >= count) return;
   double s = 0.0;
-  for (int g = 0; g < G; ++g) s += (double)part[(size_t)g * stride + w];
-  const int o = permA > 0 ? (w % permA) * permB + w / permA : w;
-  out[o] = (float)(s * (double)scale);
+  for (int g = lane; g < G; g += 64) s += (double)part[(size_t)g * stride + w];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int o = permA > 0 ? (w % permA) * permB + w / permA : w;
+    out[o] = (float)(s * (double)scale);
+  }
 }
 
 int launch_colsum(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB,
                   hipStream_t s) {
-  DVG_LAUNCH(K_MISC, colsum_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, s, part, G, stride, count, scale,
+  DVG_LAUNCH(K_MISC, colsum_kernel, dim3((unsigned)ceil_div(count, 4)), dim3(256), 0, s, part, G, stride, count, scale,
              out, permA, permB);
   return DVG_OK;
 }
@@ -90,19 +102,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           int training, float* __restrict__ mean,
                                                           float* __restrict__ invstd, float* __restrict__ rm,
                                                           float* __restrict__ rv, int64_t* __restrict__ nbt) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && training && nbt) *nbt += 1;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per channel
+  const int lane = threadIdx.x & 63;
+  if (c == 0 && lane == 0 && training && nbt) *nbt += 1;
   if (c >= C) return;
   if (!training) {
-    mean[c] = rm[c];
-    invstd[c] = 1.0f / sqrtf(rv[c] + BN_EPS);
+    if (lane == 0) {
+      mean[c] = rm[c];
+      invstd[c] = 1.0f / sqrtf(rv[c] + BN_EPS);
+    }
     return;
   }
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = lane; k < nblk; k += 64) {
     s1 += (double)part[((size_t)k * C + c) * 2];
     s2 += (double)part[((size_t)k * C + c) * 2 + 1];
   }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane != 0) return;
   const double mu = s1 / M;
   double var = s2 / M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 int launch_bn_finalize(const float* stats_part, int nblk, int C, int64_t M, int training, float* mean, float* invstd,
                        float* running_mean, float* running_var, int64_t* nbt, hipStream_t s) {
-  DVG_LAUNCH(K_BN_FINALIZE, bn_finalize_kernel, dim3((unsigned)ceil_div(C, 256)), dim3(256), 0, s, stats_part, nblk, C,
+  DVG_LAUNCH(K_BN_FINALIZE, bn_finalize_kernel, dim3((unsigned)ceil_div(C, 4)), dim3(256), 0, s, stats_part, nblk, C,
              (double)M, training, mean, invstd, running_mean, running_var, nbt);
   return DVG_OK;
 }

@@ -116,7 +116,7 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
-      DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_FWD, s));
+      DVG_TRY(launch_conv_igemm(a, s));
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
                                p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
@@ -178,7 +178,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
-    DVG_TRY(launch_conv_igemm(a, K_CONV_IGEMM_DGRAD, s));
+    DVG_TRY(launch_conv_igemm(a, s));
   }
   return DVG_OK;
 }

@@ -150,19 +150,21 @@ __global__ __launch_bounds__(256) void mmd_distsum_kernel(MmdArgs a) {
   if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
-// coef layout in workspace: [0..7] c_k, [8] bandwidth
+__device__ __forceinline__ double mmd_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// coef layout in workspace: [0..7] c_k, [8] bandwidth.  One wavefront; fixed reduction shape.
 __global__ __launch_bounds__(64) void mmd_bandwidth_kernel(const double* __restrict__ part, int nparts, double n_total,
                                                            float fixed_bw, float factor, int n_kernels,
                                                            float* __restrict__ coef) {
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += 64) s += part[k];
+  s = mmd_wave_sum(s);
   if (threadIdx.x != 0) return;
-  double bw;
-  if (fixed_bw > 0.f) {
-    bw = fixed_bw;
-  } else {
-    double s = 0.0;
-    for (int k = 0; k < nparts; ++k) s += part[k];
-    bw = s / (n_total * n_total - n_total);
-  }
+  const double bw = fixed_bw > 0.f ? (double)fixed_bw : s / (n_total * n_total - n_total);
   const float bwf = (float)bw;
   coef[8] = bwf;
   for (int k = 0; k < 8; ++k) {
@@ -317,13 +319,16 @@ __global__ __launch_bounds__(256) void mmd_final_kernel(const double* __restrict
                                                         int64_t ny, int biased, float* __restrict__ loss_out,
                                                         const float* __restrict__ grad_part, int S, int64_t numel,
                                                         float* __restrict__ grad_x) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
     double sxx = 0, sxy = 0, syy = 0;
-    for (int k = 0; k < nparts; ++k) { sxx += loss_part[3 * k]; sxy += loss_part[3 * k + 1]; syy += loss_part[3 * k + 2]; }
-    const double dnx = (double)nx, dny = (double)ny;
-    const double xx = sxx / (biased ? dnx * dnx : dnx * (dnx - 1.0));
-    const double yy = syy / (biased ? dny * dny : dny * (dny - 1.0));
-    *loss_out = (float)(xx + yy - 2.0 * sxy / (dnx * dny));
+    for (int k = threadIdx.x; k < nparts; k += 64) { sxx += loss_part[3 * k]; sxy += loss_part[3 * k + 1]; syy += loss_part[3 * k + 2]; }
+    sxx = mmd_wave_sum(sxx); sxy = mmd_wave_sum(sxy); syy = mmd_wave_sum(syy);
+    if (threadIdx.x == 0) {
+      const double dnx = (double)nx, dny = (double)ny;
+      const double xx = sxx / (biased ? dnx * dnx : dnx * (dnx - 1.0));
+      const double yy = syy / (biased ? dny * dny : dny * (dny - 1.0));
+      *loss_out = (float)(xx + yy - 2.0 * sxy / (dnx * dny));
+    }
   }
   if (grad_x && S > 1) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += (int64_t)gridDim.x * 256) {
@@ -376,7 +381,9 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   auto kern = mmd_main_kernel<NFB>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DVG_LAUNCH(K_MMD_MAIN, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)p.zslices), dim3(256), lds, s, a);
+  const double N = (double)(a.nx + a.ny);
+  const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;  // Gram + gradient GEMM
+  DVG_LAUNCH_WORK(K_MMD_MAIN, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)p.zslices), dim3(256), lds, s, a);
   return DVG_OK;
 }
 

@@ -17,10 +17,12 @@ void set_error(const char* fmt, ...) {
 
 static const char* kNames[K_COUNT] = {
     "gibbs_sweeps", "grbm_energy", "grbm_suffstats", "gumbel_fwd", "gumbel_bwd", "mmd_prep",
-    "mmd_distsum", "mmd_main", "mmd_final", "conv_igemm_fwd", "conv_igemm_dgrad", "conv_wgrad",
+    "mmd_distsum", "mmd_main", "mmd_final", "conv_igemm_kernel<128,64,2,2>", "conv_igemm_kernel<64,64,2,2>",
+    "conv_igemm_kernel<128,32,4,1>", "conv_wgrad_kernel<2,2>", "conv_wgrad_kernel<2,1>", "conv_wgrad_kernel<1,2>",
+    "conv_wgrad_kernel<1,1>",
     "wgrad_reduce", "weight_pack", "bn_finalize", "enc_conv0_fwd", "enc_conv0_wgrad",
     "enc_bn_pool_fwd", "enc_bn_pool_bwd_reduce", "enc_bn_pool_bwd_apply", "enc_proj_fwd",
-    "enc_proj_bwd", "dec_linear", "dec_bn_act_fwd", "dec_bn_act_bwd_reduce",
+    "enc_proj_bwd", "dec_bn_act_fwd", "dec_bn_act_bwd_reduce",
     "dec_bn_act_bwd_apply", "dec_conv3_fwd", "dec_conv3_bwd", "dec_final_fwd", "dec_final_bwd",
     "mse", "adam", "misc"};
 
@@ -31,6 +33,7 @@ static std::vector<EvPair> g_pairs[K_COUNT];
 static std::vector<EvPair> g_free;
 static double g_ms[K_COUNT];
 static int64_t g_n[K_COUNT];
+static double g_work[K_COUNT];
 static thread_local EvPair g_open[K_COUNT];
 
 bool prof_on(int id) { return (g_mask >> id) & 1ull; }
@@ -44,8 +47,9 @@ void prof_begin(int id, hipStream_t s) {
   g_open[id] = p;
 }
 
-void prof_end(int id, hipStream_t s) {
+void prof_end(int id, hipStream_t s, double work) {
   std::lock_guard<std::mutex> lk(g_mu);
+  g_work[id] += work;
   hipEventRecord(g_open[id].b, s);
   g_pairs[id].push_back(g_open[id]);
 }
@@ -72,7 +76,7 @@ const char* dvg_last_error(void) { return g_err; }
 int dvg_prof_enable(uint64_t kernel_mask) { g_mask = kernel_mask; return DVG_OK; }
 int dvg_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_n[i] = 0; }
+  for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_n[i] = 0; g_work[i] = 0; }
   return DVG_OK;
 }
 int dvg_prof_num_kernels(void) { return K_COUNT; }
@@ -83,6 +87,12 @@ int dvg_prof_query(int id, double* total_ms, int64_t* launches) {
   drain(id);
   if (total_ms) *total_ms = g_ms[id];
   if (launches) *launches = g_n[id];
+  return DVG_OK;
+}
+int dvg_prof_query_work(int id, double* work) {
+  if (id < 0 || id >= K_COUNT || !work) { set_error("bad kernel id %d", id); return DVG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g_mu);
+  *work = g_work[id];
   return DVG_OK;
 }
 

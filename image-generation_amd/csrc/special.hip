@@ -265,23 +265,38 @@ int launch_dec_conv3_dgrad(const float* dY, int64_t N, const float* w, float* dX
 
 // dWt[ci][kh][kw] = sum_{img,y,x} dY(y,x) * Xup(y+1-kh, x+1-kw)[ci]; part[blk][tap*32 + ci]
 // block = 288 threads (tap, ci); one image (256 output pixels) per iteration
+// Per image: first fold the output gradient onto the 8x8 input grid,
+//   G[q][tap] = sum of dY over the (<= 4) output pixels whose tap reads input pixel q,
+// then dW[tap][ci] += sum_q G[q][tap] * X[q][ci]  (64 coalesced row reads instead of 256 gathers).
 __global__ __launch_bounds__(288) void dec_conv3_wgrad_kernel(const float* __restrict__ X, int64_t N,
                                                               const float* __restrict__ dY, float* __restrict__ part) {
   __shared__ float dys[256];
+  __shared__ float G[64 * 9];
   const int tid = threadIdx.x;
   const int tap = tid >> 5, ci = tid & 31;
-  const int kh = tap / 3, kw = tap % 3;
   float acc = 0.f;
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();
     if (tid < 256) dys[tid] = dY[img * 256 + tid];
     __syncthreads();
-    const float* xb = X + img * 64 * 32 + ci;
-    for (int p = 0; p < 256; ++p) {
-      const int yy = (int)morton_y((uint32_t)p) + 1 - kh, xx = (int)morton_x((uint32_t)p) + 1 - kw;
-      if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16)
-        acc = fmaf(dys[p], xb[(size_t)(morton((uint32_t)yy, (uint32_t)xx) >> 2) * 32], acc);
+    for (int e = tid; e < 576; e += 288) {
+      const int q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
+      const int ys = (int)morton_y((uint32_t)q), xs = (int)morton_x((uint32_t)q);
+      float g = 0.f;
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          // output pixel (y,x) reads input (y+1-kh, x+1-kw); that lands in quad q for these (y,x):
+          const int y = 2 * ys + sy - 1 + kh, x = 2 * xs + sx - 1 + kw;
+          if (y >= 0 && y < 16 && x >= 0 && x < 16) g += dys[morton((uint32_t)y, (uint32_t)x)];
+        }
+      G[e] = g;
     }
+    __syncthreads();
+    const float* xb = X + img * 64 * 32 + ci;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) acc = fmaf(G[q * 9 + tap], xb[q * 32], acc);
   }
   part[(size_t)blockIdx.x * 288 + tid] = acc;
 }

@@ -219,6 +219,8 @@ int dvg_prof_num_kernels(void);
 const char *dvg_prof_kernel_name(int id);
 /* synchronises the recorded events; returns total milliseconds and launch count */
 int dvg_prof_query(int id, double *total_ms, int64_t *launches);
+/* algorithmic work (FLOPs for the GEMM-shaped kernels, 0 otherwise) summed over the timed launches */
+int dvg_prof_query_work(int id, double *work);
 
 #ifdef __cplusplus
 }
