@@ -13,20 +13,37 @@
 namespace dvg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // register-resident (a float4 array can end up in scratch)
 
 __device__ __forceinline__ int crow16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// Diagnostic build only (-DDVG_STAMP): per-phase cycle sums of the main loop, written to ConvArgs.stats
+// (which the diagnostic harness points at a debug buffer: 8 uint64 per block).  Never in the product build.
+#ifdef DVG_STAMP
+#define STAMP(var)                                                                 \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int AP = 33, BP = BN + 4;
-  constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per chunk
-  constexpr int RB = (8 * BN + NT - 1) / NT;  // float4 loads of B per thread per chunk
+  constexpr int BK = 64;                 // K per iteration: two 32-channel chunks (possibly of different taps)
+  constexpr int AP = BK + 1, BP = BN + 4;
+  constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per 32-chunk
+  constexpr int RB = 8 * BN / NT;        // float4 loads of B per thread per 32-chunk
+  static_assert(RB * NT == 8 * BN && RA * NT == 8 * BM, "tile loaders must divide evenly");
   __shared__ float As[BM * AP];
-  __shared__ __align__(16) float Bs[32 * BP];
+  __shared__ __align__(16) float Bs[BK * BP];
   __shared__ float red[WM * BN * 2];
+  __shared__ int nbr[BM * 9];            // source row of every (tile row, tap), -1 = zero padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, hh = lane >> 5, c = lane & 31;
@@ -35,82 +52,139 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   const int L = a.L, H = 1 << L, logHW = 2 * L;
   const int64_t HWin = a.ups ? ((int64_t)1 << logHW) >> 2 : ((int64_t)1 << logHW);
 
-  // per-thread A rows
-  int ay[RA], ax[RA];
-  int64_t abase[RA];
-  bool aok[RA];
-  const int ac4 = tid & 7;
-#pragma unroll
-  for (int q = 0; q < RA; ++q) {
-    const int row = (tid + NT * q) >> 3;
+  // neighbour table: the Morton decode / re-encode happens once per (row, tap), not once per K-chunk
+  for (int e = tid; e < BM * a.ntaps; e += NT) {
+    const int row = e / a.ntaps, tap = e - row * a.ntaps;
     const int64_t m = m0 + row;
-    aok[q] = m < a.M;
     const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
-    ay[q] = (int)morton_y(p);
-    ax[q] = (int)morton_x(p);
-    abase[q] = (m >> logHW) * HWin;
-  }
-  const int nci = a.Cin >> 5, niter = a.ntaps * nci;
-  float4 areg[RA], breg[RB];
-  auto load = [&](int it) {
-    const int tap = it / nci, cc = it - tap * nci;
     const int dy = a.ntaps == 9 ? tap / 3 - 1 : 0, dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
-#pragma unroll
-    for (int q = 0; q < RA; ++q) {
-      const int yy = ay[q] + dy, xx = ax[q] + dx;
-      const bool ok = aok[q] && yy >= 0 && yy < H && xx >= 0 && xx < H;
-      uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
-      if (a.ups) src >>= 2;
-      const float* ptr = a.in + (abase[q] + src) * a.Cin + cc * 32 + ac4 * 4;
-      areg[q] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const int idx = tid + NT * q;
-      const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-      if (krow < 32)
-        breg[q] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Cin + cc * 32 + krow) * a.Cout + n0 + c4 * 4);
-    }
-  };
+    const int yy = (int)morton_y(p) + dy, xx = (int)morton_x(p) + dx;
+    const bool ok = m < a.M && yy >= 0 && yy < H && xx >= 0 && xx < H;
+    uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
+    if (a.ups) src >>= 2;
+    nbr[row * 9 + tap] = ok ? (int)((m >> logHW) * HWin + src) : -1;
+  }
+  __syncthreads();
 
+  const int ac4 = tid & 7;
+  const char* in_bytes = reinterpret_cast<const char*>(a.in);
+  const char* wp_bytes = reinterpret_cast<const char*>(a.wp);
+  const uint32_t row_bytes = (uint32_t)a.Cin * 4u, wrow_bytes = (uint32_t)a.Cout * 4u;
+  const int nci = a.Cin >> 5, nchunk = a.ntaps * nci, niter = (nchunk + 1) >> 1;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
 
-  load(0);
-  for (int it = 0; it < niter; ++it) {
+  // Software pipeline with ONE load site: iteration `it` issues the global loads of K-chunks 2it, 2it+1, runs the
+  // MFMAs of the previous pair out of LDS while they fly, then (barrier) parks the new pair in LDS.
+#ifdef DVG_STAMP
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, ph[5] = {0, 0, 0, 0, 0};
+#endif
+  for (int it = 0; it <= niter; ++it) {
+    f32x4 areg[2][RA], breg[2][RB];
+    STAMP(t0);
+    float amask[2][RA];
+    if (it < niter) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kc = 2 * it + h;
+        const bool live = kc < nchunk;
+        const int tap = live ? kc / nci : 0, cc = live ? kc - tap * nci : 0;
+        // 32-bit byte offsets from the (wave-uniform) tensor bases: every tensor here is < 4 GiB, and the loads
+        // become `global_load_dwordx4 v, voff, s[base]` instead of 64-bit pointer arithmetic per lane
+        const uint32_t a_col = (uint32_t)(cc * 128 + ac4 * 16);
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+          const int src = nbr[((tid >> 3) + (NT >> 3) * q) * 9 + tap];
+          const bool ok = live && src >= 0;
+          // Branch-free zero padding: always load (from a valid address); the 0/1 mask is applied when the
+          // registers are parked in LDS, AFTER the MFMA loop.  (A select lets the compiler sink the load into a
+          // divergent branch and wait for it there; a multiply right here would need the data immediately.
+          // Either way the prefetch would be serialised -- both seen in the ISA.)
+          const uint32_t off = ok ? (uint32_t)src * row_bytes + a_col : 0u;
+          areg[h][q] = *reinterpret_cast<const f32x4*>(in_bytes + off);
+          amask[h][q] = ok ? 1.0f : 0.0f;
+        }
+        const uint32_t b_row0 = (uint32_t)(tap * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int idx = tid + NT * q;
+          const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+          breg[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u));
+        }
+      }
+    }
+    STAMP(t1);
+    if (it > 0) {
+      const float* ap = As + (wm * TM * 32 + c) * AP + hh;
+      const float* bp = Bs + hh * BP + wn * TN * 32 + c;
+      // operand reads run one k-step ahead of the MFMAs (register double buffer): the LDS latency of step s+1
+      // hides behind the matrix pipe working on step s instead of being waited for in front of every MFMA
+      float av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = ap[i * 32 * AP];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[0][j] = bp[j * 32];
+#pragma unroll
+      for (int s = 0; s < BK / 2; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[nxt][i] = ap[i * 32 * AP + 2 * (s + 1)];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bv[nxt][j] = bp[2 * (s + 1) * BP + j * 32];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        // pin the interleave: [LDS reads of step s+1] then [MFMAs of step s]  (hipcc otherwise re-serialises
+        // read -> wait -> MFMA; mask 0x100 = DS read, 0x008 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+    }
+    STAMP(t2);
     __syncthreads();
+    STAMP(t3);
+    if (it < niter) {
 #pragma unroll
-    for (int q = 0; q < RA; ++q) {
-      const int row = (tid + NT * q) >> 3;
-      float* p = As + row * AP + ac4 * 4;
-      p[0] = areg[q].x; p[1] = areg[q].y; p[2] = areg[q].z; p[3] = areg[q].w;
-    }
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const int idx = tid + NT * q;
-      const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-      if (krow < 32) *reinterpret_cast<float4*>(Bs + krow * BP + c4 * 4) = breg[q];
+        for (int q = 0; q < RA; ++q) {
+          const int row = (tid + NT * q) >> 3;
+          float* p = As + row * AP + h * 32 + ac4 * 4;
+          const float mk = amask[h][q];
+          p[0] = areg[h][q].x * mk; p[1] = areg[h][q].y * mk; p[2] = areg[h][q].z * mk; p[3] = areg[h][q].w * mk;
+        }
+        // the second half of an odd last pair multiplies A-zeros: its B rows only have to be finite (they are:
+        // a re-read of tap 0)
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int idx = tid + NT * q;
+          const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+          *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = breg[h][q];
+        }
+      }
     }
+    STAMP(t4);
     __syncthreads();
-    if (it + 1 < niter) load(it + 1);
-    const float* ap = As + (wm * TM * 32 + c) * AP + hh;
-    const float* bp = Bs + hh * BP + wn * TN * 32 + c;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = ap[i * 32 * AP + 2 * s];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = bp[2 * s * BP + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
+    STAMP(t5);
+#ifdef DVG_STAMP
+    ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3; ph[4] += t5 - t4;
+#endif
   }
+#ifdef DVG_STAMP
+  if (tid == 0 && a.stats) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.stats) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    for (int k = 0; k < 5; ++k) dbg[k] = ph[k];
+    dbg[5] = niter;
+  }
+  if (a.stats) return;
+#endif
 
   // ---------------- epilogue
   if (a.poolsum) {
@@ -181,6 +255,12 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     set_error("conv_igemm: unsupported shape Cin=%d Cout=%d M=%lld ntaps=%d", a.Cin, a.Cout, (long long)a.M, a.ntaps);
     return DVG_E_INVALID;
   }
+  // the kernel addresses its input and weights with 32-bit byte offsets
+  const double in_bytes = (double)(a.ups ? a.M / 4 : a.M) * a.Cin * 4.0;
+  if (in_bytes >= 4294967296.0 || a.M >= 2147483647LL) {
+    set_error("conv_igemm: input tensor of %.0f bytes exceeds the 4 GiB addressing range of this kernel", in_bytes);
+    return DVG_E_UNSUPPORTED;
+  }
   const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;  // algorithmic
   switch (igemm_cfg(a.M, a.Cout)) {
     case 0:
@@ -217,7 +297,8 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
   const int64_t mbeg = (int64_t)z * per;
   const int64_t mend = mbeg + per < a.M ? mbeg + per : a.M;
 
-  float4 xreg[RX], yreg[RY];
+  f32x4 xreg[RX], yreg[RY];
+  float xmask[RX], ymask[RY];
   auto load = [&](int64_t m1) {
 #pragma unroll
     for (int q = 0; q < RX; ++q) {
@@ -229,16 +310,18 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
       const bool ok = m < mend && yy >= 0 && yy < H && xx >= 0 && xx < H;
       uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
       if (a.ups) src >>= 2;
-      const float* ptr = a.in + ((m >> logHW) * HWin + src) * a.Cin + a0 + c4 * 4;
-      xreg[q] = ok ? *reinterpret_cast<const float4*>(ptr) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* ptr = a.in + (ok ? ((m >> logHW) * HWin + src) * a.Cin + a0 + c4 * 4 : 0);
+      xreg[q] = *reinterpret_cast<const f32x4*>(ptr);  // unconditional load; 0/1 mask applied at the LDS store
+      xmask[q] = ok ? 1.0f : 0.0f;
     }
 #pragma unroll
     for (int q = 0; q < RY; ++q) {
       const int idx = tid + NT * q;
       const int px = idx / (BB / 4), c4 = idx % (BB / 4);
       const int64_t m = m1 + px;
-      yreg[q] = m < mend ? *reinterpret_cast<const float4*>(a.dy + m * a.Cout + b0 + c4 * 4)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool oky = m < mend;
+      yreg[q] = *reinterpret_cast<const f32x4*>(a.dy + (oky ? m * a.Cout + b0 + c4 * 4 : 0));
+      ymask[q] = oky ? 1.0f : 0.0f;
     }
   };
   f32x16 acc = {0};
@@ -248,12 +331,12 @@ __global__ __launch_bounds__(WA* WB * 64) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < RX; ++q) {
       const int idx = tid + NT * q;
-      *reinterpret_cast<float4*>(Xs + (idx / (BA / 4)) * XP + (idx % (BA / 4)) * 4) = xreg[q];
+      *reinterpret_cast<f32x4*>(Xs + (idx / (BA / 4)) * XP + (idx % (BA / 4)) * 4) = xreg[q] * xmask[q];
     }
 #pragma unroll
     for (int q = 0; q < RY; ++q) {
       const int idx = tid + NT * q;
-      *reinterpret_cast<float4*>(Ys + (idx / (BB / 4)) * YP + (idx % (BB / 4)) * 4) = yreg[q];
+      *reinterpret_cast<f32x4*>(Ys + (idx / (BB / 4)) * YP + (idx % (BB / 4)) * 4) = yreg[q] * ymask[q];
     }
     __syncthreads();
     if (m1 + 32 < mend) load(m1 + 32);

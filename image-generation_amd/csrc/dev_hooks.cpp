@@ -1,0 +1,33 @@
+// Development hooks (include/dvg_dev.h): direct launches of the MFMA GEMM kernels for unit tests / micro-benchmarks.
+#include "conv.h"
+#include "../../include/dvg_dev.h"
+using namespace dvg;
+
+extern "C" int dvg_dev_conv_igemm(const float* in, const float* w, int mode, float* wp, const float* bias, float* out,
+                                  float* stats, int64_t M, int Cin, int Cout, int L, int ntaps, int ups, int poolsum,
+                                  int repack, dvg_stream_t stream) {
+  DVG_REQUIRE(in && w && wp && out, "dev_conv_igemm: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (repack) DVG_TRY(launch_weight_pack(w, WeightMap{mode, Cin, Cout, ntaps}, wp, s));
+  ConvArgs a;
+  a.in = in; a.wp = wp; a.bias = bias; a.out = out; a.stats = stats;
+  a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.ntaps = ntaps; a.ups = ups; a.poolsum = poolsum;
+  return launch_conv_igemm(a, s);
+}
+
+extern "C" int dvg_dev_conv_stats_blocks(int64_t M, int Cout) { return conv_stats_blocks(M, Cout); }
+
+extern "C" size_t dvg_dev_wgrad_slab_floats(int64_t M, int Cin, int Cout, int ntaps) {
+  return (size_t)wgrad_ksplit(M, Cin, Cout, ntaps) * ntaps * Cin * Cout;
+}
+
+extern "C" int dvg_dev_conv_wgrad(const float* in, const float* dy, float* slabs, float* grad_w, int mode, int64_t M,
+                                  int Cin, int Cout, int L, int ntaps, int ups, dvg_stream_t stream) {
+  DVG_REQUIRE(in && dy && slabs && grad_w, "dev_conv_wgrad: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs wa;
+  wa.in = in; wa.dy = dy; wa.slabs = slabs; wa.M = M; wa.Cin = Cin; wa.Cout = Cout; wa.L = L; wa.ntaps = ntaps;
+  wa.ups = ups; wa.ksplit = wgrad_ksplit(M, Cin, Cout, ntaps);
+  DVG_TRY(launch_conv_wgrad(wa, s));
+  return launch_wgrad_reduce(slabs, wa.ksplit, WeightMap{mode, Cin, Cout, ntaps}, grad_w, s);
+}

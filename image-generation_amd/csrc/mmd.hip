@@ -16,6 +16,7 @@
 namespace dvg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MmdArgs {
   const float* x; const float* y;
@@ -45,20 +46,24 @@ __device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ src_i, int
   const int hh = lane >> 5, c = lane & 31;
   f32x16 acc = {0};
   const int nchunk = d / 32;
-  float4 zreg[4], xreg;
+  f32x4 zreg[4], xreg;
+  float zmask[4], xmask;
   auto load_chunk = [&](int ch) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       const int row = idx >> 3, c4 = idx & 7;
       const int64_t gr = base_j + row;
-      zreg[q] = gr < cnt_j ? *reinterpret_cast<const float4*>(src_j + gr * d + ch * 32 + c4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool okz = gr < cnt_j;
+      // unconditional load; the 0/1 mask is applied when parking the registers in LDS (see conv_igemm.hip)
+      zreg[q] = *reinterpret_cast<const f32x4*>(src_j + (okz ? gr * d + ch * 32 + c4 * 4 : 0));
+      zmask[q] = okz ? 1.0f : 0.0f;
     }
     const int row = tid >> 3, c4 = tid & 7;
     const int64_t gr = base_i + row;
-    xreg = gr < cnt_i ? *reinterpret_cast<const float4*>(src_i + gr * d + ch * 32 + c4 * 4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okx = gr < cnt_i;
+    xreg = *reinterpret_cast<const f32x4*>(src_i + (okx ? gr * d + ch * 32 + c4 * 4 : 0));
+    xmask = okx ? 1.0f : 0.0f;
   };
   load_chunk(0);
   for (int ch = 0; ch < nchunk; ++ch) {
@@ -68,12 +73,12 @@ __device__ __forceinline__ f32x16 gram_tile(const float* __restrict__ src_i, int
       const int idx = tid + 256 * q;
       const int row = idx >> 3, c4 = idx & 7;
       float* p = Zs + row * MMD_PITCH + c4 * 4;
-      p[0] = zreg[q].x; p[1] = zreg[q].y; p[2] = zreg[q].z; p[3] = zreg[q].w;
+      p[0] = zreg[q].x * zmask[q]; p[1] = zreg[q].y * zmask[q]; p[2] = zreg[q].z * zmask[q]; p[3] = zreg[q].w * zmask[q];
     }
     {
       const int row = tid >> 3, c4 = tid & 7;
       float* p = Xs + row * MMD_PITCH + c4 * 4;
-      p[0] = xreg.x; p[1] = xreg.y; p[2] = xreg.z; p[3] = xreg.w;
+      p[0] = xreg.x * xmask; p[1] = xreg.y * xmask; p[2] = xreg.z * xmask; p[3] = xreg.w * xmask;
     }
     __syncthreads();
     if (ch + 1 < nchunk) load_chunk(ch + 1);
@@ -266,12 +271,12 @@ __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gj = base_j + wave * 32 + crow(r, hh);
-        const float* zrow = src_j + gj * a.d;
         const bool vj = gj < cnt_j;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
           const int ff = f + fb * 32;
-          const float av = (vj && ff < a.d) ? zrow[ff] : 0.f;
+          const bool oka = vj && ff < a.d;
+          const float av = src_j[oka ? gj * a.d + ff : 0] * (oka ? 1.0f : 0.0f);
           G[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w[r], G[fb], 0, 0, 0);
         }
       }

@@ -1,0 +1,76 @@
+"""Development access to the two MFMA GEMM kernels (include/dvg_dev.h) + layout helpers.
+Used by kernel-level tests and micro-benchmarks; not part of the product surface."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_SIGS = {
+    "dvg_dev_conv_igemm": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
+                           [ctypes.c_int64] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    "dvg_dev_conv_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
+    "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dvg_dev_conv_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                           [ctypes.c_void_p]),
+}
+_bound = False
+
+
+def lib():
+    global _bound
+    L = _lib.lib()
+    if not _bound:
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _bound = True
+    return L
+
+
+def morton_perm(side: int) -> torch.Tensor:
+    """perm[m] = row-major index (y*side + x) of the pixel stored at Morton position m."""
+    def compact(v):
+        v &= 0x55555555
+        v = (v | (v >> 1)) & 0x33333333
+        v = (v | (v >> 2)) & 0x0F0F0F0F
+        v = (v | (v >> 4)) & 0x00FF00FF
+        return v
+    m = np.arange(side * side)
+    return torch.from_numpy((compact(m >> 1) * side + compact(m)).astype(np.int64))
+
+
+def nchw_to_morton(x: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) -> (N*H*W, C) NHWC with Morton-ordered pixels."""
+    N, C, H, W = x.shape
+    perm = morton_perm(H).to(x.device)
+    return x.permute(0, 2, 3, 1).reshape(N, H * W, C)[:, perm, :].reshape(N * H * W, C).contiguous()
+
+
+def morton_to_nchw(t: torch.Tensor, N: int, C: int, side: int) -> torch.Tensor:
+    perm = morton_perm(side).to(t.device)
+    out = torch.empty((N, side * side, C), dtype=t.dtype, device=t.device)
+    out[:, perm, :] = t.reshape(N, side * side, C)
+    return out.reshape(N, side, side, C).permute(0, 3, 1, 2).contiguous()
+
+
+def conv_igemm(x_m, w, mode, M, Cin, Cout, L, ntaps=9, ups=0, poolsum=0, bias=None, stats=False, wp=None, repack=True):
+    Lb = lib()
+    dev = x_m.device
+    wp = wp if wp is not None else torch.empty(ntaps * Cin * Cout, device=dev)
+    out = torch.empty(((M // 4) if poolsum else M, Cout), device=dev)
+    st = torch.empty((Lb.dvg_dev_conv_stats_blocks(M, Cout), Cout, 2), device=dev) if stats else None
+    _lib.check(Lb.dvg_dev_conv_igemm(x_m.data_ptr(), w.data_ptr(), mode, wp.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                     _lib.ptr(st), M, Cin, Cout, L, ntaps, ups, poolsum, int(repack), _lib.stream_ptr(dev)))
+    return (out, st) if stats else out
+
+
+def conv_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ntaps=9, ups=0):
+    Lb = lib()
+    dev = x_m.device
+    slabs = torch.empty(Lb.dvg_dev_wgrad_slab_floats(M, Cin, Cout, ntaps), device=dev)
+    gw = torch.empty(w_shape, device=dev)
+    _lib.check(Lb.dvg_dev_conv_wgrad(x_m.data_ptr(), dy.data_ptr(), slabs.data_ptr(), gw.data_ptr(), mode, M, Cin, Cout, L,
+                                     ntaps, ups, _lib.stream_ptr(dev)))
+    return gw

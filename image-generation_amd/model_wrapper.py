@@ -75,6 +75,8 @@ class ModelWrapper:
         self.dist = dist
         self.noise_hook: Optional[Callable[[int], dict]] = None  # parity tests inject Gumbel noise / dropout masks
         self.sync_losses = True   # False: keep loss tensors on device (no .item() host syncs in the step)
+        self.overlap_sampler = True  # run the step's sampler draw on a side stream under the forward pass
+        self._side_stream = None
         self.last = {}            # device scalars of the last step: mse, mmd, nll
         with open(training_parameter_file or _DEFAULT_YAML, "r") as f:
             self._params = yaml.safe_load(f)
@@ -212,21 +214,29 @@ class ModelWrapper:
             if noise.get("dropout_masks") is not None:
                 self._dvae.decoder.inject_dropout_masks([m.to(self._device) for m in noise["dropout_masks"]])
 
+        # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
+        # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
+        # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
+        samples = self._draw_overlapped() if (self.overlap_sampler and train_dvae(opt_step, epoch)) else None
+
         _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)
 
         if train_dvae(opt_step, epoch):
             self._dvae_optimizer.zero_grad()
             mse_loss = F.replicated_mse_loss(reconstructed_images, images)
             self._log("mse_losses", mse_loss)
-            with torch.no_grad():
-                samples = self._grbm.sample(
-                    sampler=self.sampler,
-                    prefactor=self.PREFACTOR,
-                    linear_range=self.linear_range,
-                    quadratic_range=self.quadratic_range,
-                    device=spins.device,
-                    sample_params=self.sampler_kwargs,
-                )
+            if samples is None:
+                with torch.no_grad():
+                    samples = self._grbm.sample(
+                        sampler=self.sampler,
+                        prefactor=self.PREFACTOR,
+                        linear_range=self.linear_range,
+                        quadratic_range=self.quadratic_range,
+                        device=spins.device,
+                        sample_params=self.sampler_kwargs,
+                    )
+            else:
+                torch.cuda.current_stream(self._device).wait_stream(self._side_stream)
             spins = spins.reshape(-1, spins.shape[-1])
             _mmd_loss = maximum_mean_discrepancy_loss(x=spins, y=samples, kernel=self._tpar["kernel"])
             dvae_loss = mse_loss + _mmd_loss
@@ -258,6 +268,20 @@ class ModelWrapper:
             param_group["lr"] = self._tpar["grbm_lr_schedule"][opt_step]
         self._tpar["opt_step"] += 1
         return mse_loss
+
+    def _draw_overlapped(self):
+        if self._device.type != "cuda":
+            return None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self._device)
+        main = torch.cuda.current_stream(self._device)
+        self._side_stream.wait_stream(main)  # the previous step's GRBM update must have landed
+        with torch.cuda.stream(self._side_stream), torch.no_grad():
+            samples = self._grbm.sample(sampler=self.sampler, prefactor=self.PREFACTOR, linear_range=self.linear_range,
+                                        quadratic_range=self.quadratic_range, device=self._device,
+                                        sample_params=self.sampler_kwargs)
+        samples.record_stream(main)
+        return samples
 
     def _log(self, key: str, value: torch.Tensor):
         self.losses[key].append(value.item() if self.sync_losses else value.detach())

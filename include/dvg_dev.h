@@ -1,0 +1,26 @@
+/* dvg_dev.h — development hooks of libdvg.so: direct access to the two MFMA GEMM kernels, used by
+ * the kernel-level unit tests and micro-benchmarks (tests/test_gpu_kernels.py, scratch/).  NOT part of
+ * the drop-in boundary (include/dvg.h); signatures may change between rounds.
+ * Tensors are in the library's internal layout: NHWC float32, pixels of each image in Morton order. */
+#ifndef DVG_DEV_H
+#define DVG_DEV_H
+#include "dvg.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* mode: 0 Conv2d fwd, 1 Conv2d dgrad, 2 ConvTranspose2d fwd, 3 ConvTranspose2d dgrad, 4 Linear fwd, 5 Linear dgrad
+ * (csrc/conv.h WeightMode).  w: checkpoint-layout weight; wp: scratch for the packed copy (ntaps*Cin*Cout floats).
+ * out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] * Wp[tap][ci][co] (+bias); stats: [blocks][Cout][2] or NULL. */
+int dvg_dev_conv_igemm(const float *in, const float *w, int mode, float *wp, const float *bias, float *out,
+                       float *stats, int64_t M, int Cin, int Cout, int L, int ntaps, int ups, int poolsum,
+                       int repack, dvg_stream_t stream);
+int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
+/* grad_w (checkpoint layout, `mode` = the layer's FORWARD mode) = sum_m in[nbr(m,tap)] (x) dy[m]; slabs: scratch of
+ * dvg_dev_wgrad_slab_floats() floats. */
+size_t dvg_dev_wgrad_slab_floats(int64_t M, int Cin, int Cout, int ntaps);
+int dvg_dev_conv_wgrad(const float *in, const float *dy, float *slabs, float *grad_w, int mode, int64_t M, int Cin,
+                       int Cout, int L, int ntaps, int ups, dvg_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

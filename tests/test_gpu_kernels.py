@@ -1,0 +1,73 @@
+"""Kernel-level parity of the MFMA implicit-GEMM conv / wgrad kernels (through include/dvg_dev.h)
+against torch's CPU convolutions, for every weight mode, with and without the fused upsample / quad-sum."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from image_generation_amd import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4)])
+def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side):
+    torch.manual_seed(N)
+    x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    L, M = side.bit_length() - 1, N * side * side
+    xm = dev.nchw_to_morton(x.detach()).cuda()
+    out, st = dev.conv_igemm(xm, w.detach().cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+    assert _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side), y.detach()) < 2e-6
+    s = st.sum(0).cpu()
+    assert _rel(s[:, 0], y.detach().sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y.detach() ** 2).sum((0, 2, 3))) < 1e-5
+    gym = dev.nchw_to_morton(gy).cuda()
+    dx = dev.conv_igemm(gym, w.detach().cuda(), 1, M, Cout, Cin, L)
+    assert _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side), x.grad) < 2e-6
+    gw = dev.conv_wgrad(xm, gym, 0, w.shape, M, Cin, Cout, L)
+    assert _rel(gw.cpu(), w.grad) < 3e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(4, 128, 64, 4), (3, 64, 32, 8), (2, 96, 128, 2)])
+def test_convtranspose_with_fused_upsample(N, Cin, Cout, side):
+    """side = OUTPUT resolution; the input lives at side/2 and is nearest-upsampled inside the gather;
+    the data-gradient sums each 2x2 quad in the epilogue."""
+    torch.manual_seed(side)
+    xs = torch.randn(N, Cin, side // 2, side // 2, requires_grad=True)
+    w = (torch.randn(Cin, Cout, 3, 3) / (3 * Cin**0.5)).requires_grad_(True)
+    b = torch.randn(Cout)
+    y = F.conv_transpose2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    L, M = side.bit_length() - 1, N * side * side
+    xm = dev.nchw_to_morton(xs.detach()).cuda()
+    out = dev.conv_igemm(xm, w.detach().cuda(), 2, M, Cin, Cout, L, ups=1, bias=b.cuda())
+    assert _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side), y.detach()) < 2e-6
+    gym = dev.nchw_to_morton(gy).cuda()
+    dx = dev.conv_igemm(gym, w.detach().cuda(), 3, M, Cout, Cin, L, poolsum=1)
+    assert _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side // 2), xs.grad) < 3e-6
+    gw = dev.conv_wgrad(xm, gym, 2, w.shape, M, Cin, Cout, L, ups=1)
+    assert _rel(gw.cpu(), w.grad) < 3e-6
+
+
+def test_linear_as_one_tap_gemm():
+    torch.manual_seed(0)
+    N, n = 37, 64
+    x = torch.randn(N, n, requires_grad=True); w = (torch.randn(4 * n, n) / n**0.5).requires_grad_(True)
+    y = F.linear(x, w)  # (N, 4n), column c*4+p
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    out = dev.conv_igemm(x.detach().cuda(), w.detach().cuda(), 4, N, n, 4 * n, 0, ntaps=1)  # column p*n + c
+    want = y.detach().reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n)
+    assert _rel(out.cpu(), want) < 2e-6
+    gyp = gy.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n).contiguous().cuda()
+    dx = dev.conv_igemm(gyp, w.detach().cuda(), 5, N, 4 * n, n, 0, ntaps=1)
+    assert _rel(dx.cpu(), x.grad) < 2e-6
+    gw = dev.conv_wgrad(x.detach().cuda(), gyp, 4, w.shape, N, n, 4 * n, 0, ntaps=1)
+    assert _rel(gw.cpu(), w.grad) < 3e-6
