@@ -85,5 +85,9 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);
 // Wp[tap][a][b] <- checkpoint-layout weight
 int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s);
+// several packs in ONE launch (forward and data-gradient packs of a whole network)
+struct PackJob { const float* w; float* wp; WeightMap map; };
+constexpr int MAX_PACK_JOBS = 8;
+int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);
 
 }  // namespace dvg

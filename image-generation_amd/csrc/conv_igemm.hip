@@ -400,6 +400,36 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restric
   }
 }
 
+struct PackJobs { PackJob job[MAX_PACK_JOBS]; };
+
+__global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
+  const PackJob& j = jobs.job[blockIdx.y];
+  const WeightMap map = j.map;
+  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e % map.Cb);
+    const int a = (int)((e / map.Cb) % map.Ca);
+    const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
+    j.wp[e] = j.w[torch_weight_offset(map, tap, a, b)];
+  }
+}
+
+int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s) {
+  if (njobs < 1 || njobs > MAX_PACK_JOBS) { set_error("weight_pack_multi: %d jobs", njobs); return DVG_E_INVALID; }
+  PackJobs pj;
+  int64_t biggest = 0;
+  for (int k = 0; k < njobs; ++k) {
+    pj.job[k] = jobs[k];
+    const int64_t t = (int64_t)jobs[k].map.ntaps * jobs[k].map.Ca * jobs[k].map.Cb;
+    if (t > biggest) biggest = t;
+  }
+  int64_t gx = ceil_div(biggest, 256 * 4);
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_multi_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, s, pj);
+  return DVG_OK;
+}
+
 static unsigned ew_grid(int64_t n) {
   const int64_t b = ceil_div(n, 256);
   return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));

@@ -109,7 +109,16 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
   float* W = (float*)ws;
 
   // Linear(n, 4n) -> X0 (N, 2x2 Morton, n)
-  DVG_TRY(launch_weight_pack(p->lin_w, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, W + pl.wp_lin, s));
+  {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
+    PackJob jobs[8];
+    jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}};
+    jobs[1] = PackJob{p->lin_w, W + pl.wpd_lin, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}};
+    for (int l = 0; l < 3; ++l) {
+      jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}};
+      jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}};
+    }
+    DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
+  }
   DVG_TRY(launch_permute_vec(p->lin_b, 4 * n, n, 4, W + pl.bias_lin, s));  // bias'[p*n + c] = b[c*4 + p]
   {
     ConvArgs a;
@@ -121,7 +130,6 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     if (l < 3) {
-      DVG_TRY(launch_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, W + pl.wp[l], s));
       ConvArgs a;
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
@@ -168,8 +176,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
 
   // final ConvTranspose2d(1,1): weight/bias gradient, then gradient wrt Xs[3] (16x16, quad-summed)
   DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, partW, s));
-  DVG_TRY(launch_colsum(partW, EW_BLOCKS, 10, 9, 1.0f, g->conv_w[4], 0, 0, s));
-  DVG_TRY(launch_colsum(partW + 9, EW_BLOCKS, 10, 1, 1.0f, g->conv_b[4], 0, 0, s));
+  DVG_TRY(launch_colsum2(partW, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4], s));
   DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
 
   for (int l = 3; l >= 0; --l) {
@@ -179,8 +186,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     const float* mask = W + pl.mask[l];  // backward only exists for a training-mode forward
     DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
                                          partA, s));
-    DVG_TRY(launch_colsum(partA, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_b[l], 0, 0, s));
-    DVG_TRY(launch_colsum(partA + C, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_g[l], 0, 0, s));
+    DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
     DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                         mask, dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
@@ -196,7 +202,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
     DVG_TRY(launch_conv_wgrad(wa, s));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s));
-    DVG_TRY(launch_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_DGRAD, C, Cin, 9}, W + pl.wpd[l], s));
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
@@ -212,7 +217,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, partB, s));
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s));  // j' = p*n+c -> c*4+p
     if (grad_spins) {
-      DVG_TRY(launch_weight_pack(p->lin_w, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}, W + pl.wpd_lin, s));
       ConvArgs a;
       a.in = dX; a.wp = W + pl.wpd_lin; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
       a.M = N; a.Cin = 4 * n; a.Cout = n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;

@@ -67,6 +67,27 @@ int launch_colsum(const float* part, int G, int stride, int count, float scale, 
   return DVG_OK;
 }
 
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ part, int G, int stride, int count_a,
+                                                      float* __restrict__ out_a, int count_b, float* __restrict__ out_b) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= count_a + count_b) return;
+  double s = 0.0;
+  for (int g = lane; g < G; g += 64) s += (double)part[(size_t)g * stride + w];
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (w < count_a) out_a[w] = (float)s;
+    else out_b[w - count_a] = (float)s;
+  }
+}
+
+int launch_colsum2(const float* part, int G, int stride, int count_a, float* out_a, int count_b, float* out_b,
+                   hipStream_t s) {
+  DVG_LAUNCH(K_MISC, colsum2_kernel, dim3((unsigned)ceil_div(count_a + count_b, 4)), dim3(256), 0, s, part, G, stride,
+             count_a, out_a, count_b, out_b);
+  return DVG_OK;
+}
+
 // part[block][c] = sum over the block's rows of mat[row][c]   (cols is a multiple of 32)
 __global__ __launch_bounds__(256) void rowsum_partial_kernel(const float* __restrict__ mat, int64_t rows, int cols,
                                                              float* __restrict__ part) {

@@ -105,13 +105,19 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
   const float* x = images;
+  {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
+    PackJob jobs[6];
+    for (int l = 1; l < 4; ++l) {
+      jobs[2 * (l - 1)] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}};
+      jobs[2 * (l - 1) + 1] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9}};
+    }
+    DVG_TRY(launch_weight_pack_multi(jobs, 6, s));
+  }
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     if (l == 0) {
       DVG_TRY(launch_enc_conv0_fwd(images, B, p->conv_w[0], p->conv_b[0], W + pl.Y[0], W + pl.stats[0], s));
     } else {
-      const WeightMap map{WM_CONV_FWD, Cin, C, 9};
-      DVG_TRY(launch_weight_pack(p->conv_w[l], map, W + pl.wp[l], s));
       ConvArgs a;
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
@@ -146,8 +152,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
 
   // projection: dP (B,4,n), d proj_w (4), d proj_b (1)
   DVG_TRY(launch_enc_proj_bwd(W + pl.Xp[3], B, n, p->proj_w, grad_logits, dX, partA, s));
-  DVG_TRY(launch_colsum(partA, EW_BLOCKS, 5, 4, 1.0f, g->proj_w, 0, 0, s));
-  DVG_TRY(launch_colsum(partA + 4, EW_BLOCKS, 5, 1, 1.0f, g->proj_b, 0, 0, s));
+  DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b, s));
 
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
@@ -155,14 +160,12 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
     DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                           dX, partA, s));
-    DVG_TRY(launch_colsum(partA, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_b[l], 0, 0, s));
-    DVG_TRY(launch_colsum(partA + C, EW_BLOCKS, 2 * C, C, 1.0f, g->bn_g[l], 0, 0, s));
+    DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
     DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                          dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
     if (l == 0) {
       DVG_TRY(launch_enc_conv0_wgrad(images, B, dY, W + pl.part320, s));
-      DVG_TRY(launch_colsum(W + pl.part320, EW_BLOCKS, 320, 288, 1.0f, g->conv_w[0], 0, 0, s));
-      DVG_TRY(launch_colsum(W + pl.part320 + 288, EW_BLOCKS, 320, 32, 1.0f, g->conv_b[0], 0, 0, s));
+      DVG_TRY(launch_colsum2(W + pl.part320, EW_BLOCKS, 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
       break;
     }
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
@@ -173,8 +176,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     DVG_TRY(launch_conv_wgrad(wa, s));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s));
     // data gradient -> dX (gradient wrt this layer's input = previous stage's output)
-    const WeightMap dmap{WM_CONV_DGRAD, C, Cin, 9};
-    DVG_TRY(launch_weight_pack(p->conv_w[l], dmap, W + pl.wpd[l], s));
+    // (the data-gradient weight layout was packed by the forward call: same weights)
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;

@@ -15,6 +15,10 @@ constexpr float DROPOUT_KEEP = 0.8f;  // Dropout2d(0.2) (/root/reference/src/dec
 int launch_colsum(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB,
                   hipStream_t s);
 
+// two destinations in one launch: out_a[w] for w < count_a, out_b[w - count_a] for the next count_b columns
+int launch_colsum2(const float* part, int G, int stride, int count_a, float* out_a, int count_b, float* out_b,
+                   hipStream_t s);
+
 // part[EW_BLOCKS][cols] column sums of a (rows, cols) matrix; out[w] = in[(w % A) * B + w / A]
 int launch_rowsum_partial(const float* mat, int64_t rows, int cols, float* part, hipStream_t s);
 int launch_permute_vec(const float* in, int count, int A, int B, float* out, hipStream_t s);

@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
 
 __global__ __launch_bounds__(64) void mse_final_kernel(const double* __restrict__ partial, int nb, double inv_numel,
                                                        float* __restrict__ loss) {
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int k = 0; k < nb; ++k) s += partial[k];
-    *loss = (float)(s * inv_numel);
-  }
+  double s = 0.0;
+  for (int k = threadIdx.x; k < nb; k += 64) s += partial[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) *loss = (float)(s * inv_numel);
 }
 
 // ---------------------------------------------------------------- Adam (coupled L2), flat buffers
