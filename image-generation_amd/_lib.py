@@ -93,7 +93,7 @@ SIGNATURES = {
     "dvg_gibbs_sample": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_int,
-         c_uint32, c_uint64, c_uint32, c_int, c_int, c_void_p, c_void_p],
+         c_uint32, c_uint64, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p],
     ),
     "dvg_grbm_energy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvg_grbm_suffstats_workspace_bytes": (c_size_t, [c_void_p]),
@@ -103,7 +103,7 @@ SIGNATURES = {
     ),
     "dvg_gumbel_fwd": (
         c_int,
-        [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p],
+        [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "dvg_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvg_heaviside_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
@@ -125,7 +125,7 @@ SIGNATURES = {
     "dvg_decoder_fwd": (
         c_int,
         [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_int, POINTER(c_void_p), c_uint64, c_uint64, c_void_p,
-         c_void_p, c_size_t, c_void_p],
+         c_void_p, c_size_t, c_void_p, c_void_p],
     ),
     "dvg_decoder_bwd": (
         c_int,
@@ -137,7 +137,7 @@ SIGNATURES = {
     "dvg_adam_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
-         c_float, c_void_p],
+         c_float, c_void_p, c_int, c_void_p],
     ),
     "dvg_prof_enable": (c_int, [c_uint64]),
     "dvg_prof_reset": (c_int, []),
@@ -177,6 +177,36 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+# Device address of the active dvg_step_state_t, or None.  Set by model_wrapper while a training step is being
+# captured into / replayed from a hipGraph: the wrappers then hand it to the kernels that take per-step scalars.
+DYN = None
+
+
+class StepState:
+    """Host mirror + device copy of ``dvg_step_state_t`` (include/dvg.h)."""
+
+    FORMAT = "<IIQQ2f2f"  # sweep0, reserved, gumbel_offset, dropout_offset, adam_step_size[2], adam_bc2_sqrt[2]
+
+    def __init__(self, device):
+        import struct
+
+        import torch
+
+        self._struct = struct.Struct(self.FORMAT)
+        self.host = torch.zeros(self._struct.size, dtype=torch.uint8).pin_memory()
+        self.dev = torch.zeros(self._struct.size, dtype=torch.uint8, device=device)
+
+    @property
+    def ptr(self) -> int:
+        return self.dev.data_ptr()
+
+    def write(self, sweep0, gumbel_offset, dropout_offset, step_size, bc2_sqrt):
+        raw = self._struct.pack(int(sweep0) & 0xFFFFFFFF, 0, int(gumbel_offset), int(dropout_offset), float(step_size[0]),
+                                float(step_size[1]), float(bc2_sqrt[0]), float(bc2_sqrt[1]))
+        self.host.numpy()[:] = memoryview(raw)
+        self.dev.copy_(self.host, non_blocking=True)
 
 
 def check(rc: int, what: str = "") -> None:

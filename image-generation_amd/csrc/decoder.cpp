@@ -101,7 +101,7 @@ extern "C" size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents) {
 
 extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
                                const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
-                               size_t ws_bytes, dvg_stream_t stream) {
+                               size_t ws_bytes, const dvg_step_state_t* dyn, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
@@ -146,7 +146,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       if (dropout_keep && dropout_keep[l])
         DVG_CHECK_HIP(hipMemcpyAsync(mdst, dropout_keep[l], sizeof(float) * (size_t)N * C, hipMemcpyDeviceToDevice, s));
       else
-        DVG_TRY(launch_dropout_mask(N, C, seed, offset, l, mdst, s));
+        DVG_TRY(launch_dropout_mask(N, C, seed, offset, dyn ? &dyn->dropout_offset : nullptr, l, mdst, s));
       mask = mdst;
     }
     DVG_TRY(launch_dec_bn_act_fwd(W + pl.Y[l], pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],

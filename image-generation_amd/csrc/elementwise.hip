@@ -281,7 +281,9 @@ int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* 
 
 // ---------------------------------------------------------------- decoder: BN -> dropout2d -> lrelu
 __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t N, int C, uint32_t k0, uint32_t k1, uint32_t off_lo,
-                                                           uint32_t off_hi, uint32_t layer, float* __restrict__ mask) {
+                                                           uint32_t off_hi, uint32_t layer, const uint64_t* __restrict__ off_dev,
+                                                           float* __restrict__ mask) {
+  if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
   const int64_t total = N * C;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const u32x4 r = philox4x32_10((uint32_t)e, off_lo ^ (layer << 28), off_hi ^ (uint32_t)(e >> 32), STREAM_DROPOUT, k0, k1);
@@ -289,10 +291,11 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t N, int C, uin
   }
 }
 
-int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, int layer, float* mask, hipStream_t s) {
+int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int layer,
+                        float* mask, hipStream_t s) {
   const int64_t b = ceil_div(N * C, 256);
   DVG_LAUNCH(K_MISC, dropout_mask_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, s, N, C, (uint32_t)seed,
-             (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)layer, mask);
+             (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)layer, offset_dev, mask);
   return DVG_OK;
 }
 

@@ -23,6 +23,7 @@ struct GibbsArgs {
   float* samples_out;
   int n_chains;
   uint32_t chain_id0, k0, k1, sweep0;
+  const uint32_t* sweep0_dev;  // non-null: read the first-sweep index from device memory (graph replay)
   int n_sweeps, init;
 };
 
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   __builtin_amdgcn_wave_barrier();
 
   if (valid) {
-    for (uint32_t t = a.sweep0; t < a.sweep0 + (uint32_t)a.n_sweeps; ++t) {
+    const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
+    for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
       const uint32_t tq = t >> 2, tw = t & 3u;
       for (int k = 0; k < a.n_colours; ++k) {
         const int lo = s_cls[k], hi = s_cls[k + 1];
@@ -146,7 +148,7 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
                                 float prefactor, float h_lo, float h_hi, float j_lo, float j_hi,
                                 float beta, int8_t* state, int n_chains, uint32_t chain_id0,
                                 uint64_t seed, uint32_t sweep0, int n_sweeps, int init,
-                                float* samples_out, dvg_stream_t stream) {
+                                float* samples_out, const dvg_step_state_t* dyn, dvg_stream_t stream) {
   DVG_REQUIRE(g && linear && quadratic && state, "gibbs: null argument");
   DVG_REQUIRE(n_chains > 0 && n_sweeps >= 0, "gibbs: n_chains=%d n_sweeps=%d", n_chains, n_sweeps);
   DVG_REQUIRE(g->n <= 65535 && g->n_adj <= 65535, "gibbs: graph too large (n=%d, 2|E|=%d)", g->n, g->n_adj);
@@ -160,6 +162,7 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   a.state = state; a.samples_out = samples_out; a.n_chains = n_chains;
   a.chain_id0 = chain_id0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
   a.sweep0 = sweep0; a.n_sweeps = n_sweeps; a.init = init;
+  a.sweep0_dev = dyn ? &dyn->sweep0 : nullptr;
   hipStream_t s = (hipStream_t)stream;
   // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
   const int mc = g->max_class;

@@ -9,7 +9,9 @@ namespace dvg {
 __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, int64_t B, int n, int R,
                                                          float tau, const float* __restrict__ gumbels,
                                                          uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi,
+                                                         const uint64_t* __restrict__ off_dev,
                                                          float* __restrict__ spins, float* __restrict__ dspin) {
+  if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
   const int64_t total = B * R * (int64_t)n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e % n);
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(64) void mse_final_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t numel,
                                                    float step_size, float b1, float b2, float eps, float wd,
-                                                   float bc2_sqrt, float gscale) {
+                                                   float bc2_sqrt, float gscale, const float* __restrict__ dyn_step,
+                                                   const float* __restrict__ dyn_bc2) {
+  if (dyn_step) { step_size = *dyn_step; bc2_sqrt = *dyn_bc2; }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < numel; e += (int64_t)gridDim.x * 256) {
     const float pe = p[e];
     float ge = g[e] * gscale;
@@ -122,12 +126,13 @@ static inline unsigned grid_for(int64_t n) {
 using namespace dvg;
 
 extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, float tau, const float* gumbels,
-                              uint64_t seed, uint64_t offset, float* spins, float* dspin, dvg_stream_t stream) {
+                              uint64_t seed, uint64_t offset, float* spins, float* dspin, const dvg_step_state_t* dyn,
+                              dvg_stream_t stream) {
   DVG_REQUIRE(logits && spins && dspin, "gumbel_fwd: null argument");
   DVG_REQUIRE(B > 0 && n > 0 && R > 0 && tau > 0.f, "gumbel_fwd: B=%lld n=%d R=%d tau=%g", (long long)B, n, R, tau);
   DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_kernel, dim3(grid_for(B * R * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
              logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
-             (uint32_t)(offset >> 32), spins, dspin);
+             (uint32_t)(offset >> 32), dyn ? &dyn->gumbel_offset : nullptr, spins, dspin);
   return DVG_OK;
 }
 
@@ -165,12 +170,14 @@ extern "C" int dvg_mse_fwd_bwd(const float* recon, const float* images, int64_t 
 
 extern "C" int dvg_adam_step(float* p, const float* g, float* m, float* v, int64_t numel, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                             dvg_stream_t stream) {
+                             const dvg_step_state_t* dyn, int dyn_slot, dvg_stream_t stream) {
+  DVG_REQUIRE(dyn_slot == 0 || dyn_slot == 1, "adam: dyn_slot=%d", dyn_slot);
   DVG_REQUIRE(p && g && m && v, "adam: null argument");
   DVG_REQUIRE(numel > 0 && step >= 1, "adam: numel=%lld step=%lld", (long long)numel, (long long)step);
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   DVG_LAUNCH(K_ADAM, adam_kernel, dim3(grid_for(numel)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, numel,
-             (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2), grad_scale);
+             (float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2), grad_scale,
+             dyn ? &dyn->adam_step_size[dyn_slot] : nullptr, dyn ? &dyn->adam_bc2_sqrt[dyn_slot] : nullptr);
   return DVG_OK;
 }

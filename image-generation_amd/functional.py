@@ -76,7 +76,8 @@ class _Gumbel(torch.autograd.Function):
                 raise ValueError(f"gumbels must have shape {(B, R, n, 2)}, got {tuple(gb.shape)}")
         with torch.cuda.device(lg.device):
             check(L.dvg_gumbel_fwd(lg.data_ptr(), B, n, R, float(tau), _lib.ptr(gb), int(seed) & (2**64 - 1),
-                                   int(offset) & (2**64 - 1), spins.data_ptr(), dspin.data_ptr(), stream_ptr(lg.device)),
+                                   int(offset) & (2**64 - 1), spins.data_ptr(), dspin.data_ptr(), _lib.DYN,
+                                   stream_ptr(lg.device)),
                   "dvg_gumbel_fwd")
         ctx.save_for_backward(dspin)
         ctx.shape = (B, n, R)

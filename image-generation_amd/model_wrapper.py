@@ -77,6 +77,15 @@ class ModelWrapper:
         self.sync_losses = True   # False: keep loss tensors on device (no .item() host syncs in the step)
         self.overlap_sampler = True  # run the step's sampler draw on a side stream under the forward pass
         self._side_stream = None
+        # use_graph: replay the autoencoder half of the step from a captured hipGraph (needs sync_losses = False);
+        # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
+        self.use_graph = False
+        self._graph = None
+        self._graph_out = None
+        self._graph_failed = False
+        self._static_images = None
+        self._dyn = None
+        self._eager_steps = 0
         self.last = {}            # device scalars of the last step: mse, mmd, nll
         with open(training_parameter_file or _DEFAULT_YAML, "r") as f:
             self._params = yaml.safe_load(f)
@@ -214,36 +223,14 @@ class ModelWrapper:
             if noise.get("dropout_masks") is not None:
                 self._dvae.decoder.inject_dropout_masks([m.to(self._device) for m in noise["dropout_masks"]])
 
-        # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
-        # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
-        # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
-        samples = self._draw_overlapped() if (self.overlap_sampler and train_dvae(opt_step, epoch)) else None
-
-        _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)
-
-        if train_dvae(opt_step, epoch):
-            self._dvae_optimizer.zero_grad()
-            mse_loss = F.replicated_mse_loss(reconstructed_images, images)
+        if self._graph_eligible(opt_step, epoch, images):
+            mse_loss = self._step_graphed(images)
+        else:
+            mse_loss, dvae_loss, _mmd_loss, spins = self._dvae_half(images)
             self._log("mse_losses", mse_loss)
-            if samples is None:
-                with torch.no_grad():
-                    samples = self._grbm.sample(
-                        sampler=self.sampler,
-                        prefactor=self.PREFACTOR,
-                        linear_range=self.linear_range,
-                        quadratic_range=self.quadratic_range,
-                        device=spins.device,
-                        sample_params=self.sampler_kwargs,
-                    )
-            else:
-                torch.cuda.current_stream(self._device).wait_stream(self._side_stream)
-            spins = spins.reshape(-1, spins.shape[-1])
-            _mmd_loss = maximum_mean_discrepancy_loss(x=spins, y=samples, kernel=self._tpar["kernel"])
-            dvae_loss = mse_loss + _mmd_loss
             self._log("dvae_losses", dvae_loss)
-            dvae_loss.backward()
-            self._reduce_and_step(self._dvae_optimizer)
             self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
+            self._eager_steps += 1
 
         if train_grbm(opt_step, epoch):
             self._grbm_optimizer.zero_grad()
@@ -268,6 +255,101 @@ class ModelWrapper:
             param_group["lr"] = self._tpar["grbm_lr_schedule"][opt_step]
         self._tpar["opt_step"] += 1
         return mse_loss
+
+    def _dvae_half(self, images):
+        """Forward, MSE + MMD, backward and Adam for the autoencoder (/root/reference/src/model_wrapper.py:297-327)."""
+        # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
+        # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
+        # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
+        samples = self._draw_overlapped() if self.overlap_sampler else None
+        _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)
+        self._dvae_optimizer.zero_grad()
+        mse_loss = F.replicated_mse_loss(reconstructed_images, images)
+        if samples is None:
+            with torch.no_grad():
+                samples = self._grbm.sample(
+                    sampler=self.sampler,
+                    prefactor=self.PREFACTOR,
+                    linear_range=self.linear_range,
+                    quadratic_range=self.quadratic_range,
+                    device=spins.device,
+                    sample_params=self.sampler_kwargs,
+                )
+        else:
+            torch.cuda.current_stream(self._device).wait_stream(self._side_stream)
+        spins = spins.reshape(-1, spins.shape[-1])
+        _mmd_loss = maximum_mean_discrepancy_loss(x=spins, y=samples, kernel=self._tpar["kernel"])
+        dvae_loss = mse_loss + _mmd_loss
+        dvae_loss.backward()
+        self._reduce_and_step(self._dvae_optimizer)
+        return mse_loss, dvae_loss, _mmd_loss, spins
+
+    # ------------------------------------------------------------------ hipGraph replay of the autoencoder half
+    def _graph_eligible(self, opt_step, epoch, images) -> bool:
+        """The captured graph covers the steps without a GRBM update (9 of 10 in the first 6 epochs, all afterwards);
+        GRBM steps, noise-injected (parity) steps and multi-GPU runs take the eager path."""
+        return (self.use_graph and self._device.type == "cuda" and self.noise_hook is None and not self._graph_failed
+                and not train_grbm(opt_step, epoch) and (self.dist is None or self.dist.world_size == 1)
+                and self._eager_steps >= 3 and not self.sync_losses
+                and (self._static_images is None or images.shape == self._static_images.shape))
+
+    def _host_counters(self):
+        d, s = self._dvae, self.sampler
+        return (s.sweep_count, s.calls, d._gumbel_calls, d.decoder._dropout_calls, self._dvae_optimizer.step_count)
+
+    def _set_host_counters(self, c):
+        d, s = self._dvae, self.sampler
+        s.sweep_count, s.calls, d._gumbel_calls, d.decoder._dropout_calls, self._dvae_optimizer.step_count = c
+
+    def _write_dyn(self):
+        """Per-step scalars of the NEXT autoencoder half, as the kernels would receive them by value."""
+        c = self._host_counters()
+        step_size, bc2 = self._dvae_optimizer.hyper(c[4] + 1)
+        self._dyn.write(sweep0=c[0], gumbel_offset=c[2], dropout_offset=c[3], step_size=(step_size, 0.0), bc2_sqrt=(bc2, 1.0))
+
+    def _capture(self, images):
+        from . import _lib
+
+        self._dyn = _lib.StepState(self._device)
+        self._static_images = torch.empty_like(images)
+        self._static_images.copy_(images)
+        saved = self._host_counters()
+        self._write_dyn()
+        torch.cuda.synchronize(self._device)
+        graph = torch.cuda.CUDAGraph()
+        _lib.DYN = self._dyn.ptr
+        try:
+            with torch.cuda.graph(graph):
+                mse, dvae, mmd, _ = self._dvae_half(self._static_images)
+        finally:
+            _lib.DYN = None
+            self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
+        self._graph, self._graph_out = graph, (mse, dvae, mmd)
+
+    def _step_graphed(self, images):
+        if self._graph is None:
+            try:
+                self._capture(images)
+            except Exception as exc:  # capture is an optimisation: fall back to eager, loudly, once
+                import warnings
+
+                self._graph_failed = True
+                warnings.warn(f"hipGraph capture of the training step failed ({exc!r}); continuing eagerly")
+                mse_loss, dvae_loss, _mmd_loss, _ = self._dvae_half(images)
+                self._log("mse_losses", mse_loss)
+                self._log("dvae_losses", dvae_loss)
+                self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
+                return mse_loss
+        self._static_images.copy_(images)
+        self._write_dyn()
+        self._graph.replay()
+        c = self._host_counters()
+        self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
+        mse, dvae, mmd = self._graph_out
+        self.losses["mse_losses"].append(mse)   # static tensors: valid until the next replay (sync_losses is off)
+        self.losses["dvae_losses"].append(dvae)
+        self.last.update(mse=mse, mmd=mmd)
+        return mse
 
     def _draw_overlapped(self):
         if self._device.type != "cuda":

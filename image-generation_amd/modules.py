@@ -154,7 +154,7 @@ class _DecoderFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(L.dvg_decoder_fwd(ctypes.byref(st), n, x.data_ptr(), N, int(training),
                                     mask_arr if keep else None, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
-                                    out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(x.device)), "dvg_decoder_fwd")
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.DYN, stream_ptr(x.device)), "dvg_decoder_fwd")
         ctx.module, ctx.training, ctx.shape = module, training, (B, R, n)
         ctx.need_input_grad = spins.requires_grad
         ctx.save_for_backward(x, ws, *params)

@@ -41,6 +41,7 @@ class FlatAdam:
                 self.offsets.append(off)
                 off += n
         self.step_count = 0
+        self.dyn_slot = 0  # which adam_* slot of dvg_step_state_t this optimizer reads under graph replay
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -66,9 +67,22 @@ class FlatAdam:
                 _lib.lib().dvg_adam_step(self.flat.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                          self.exp_avg_sq.data_ptr(), self.numel, float(g["lr"]), float(g["betas"][0]),
                                          float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                         self.step_count, float(grad_scale), _lib.stream_ptr(self.flat.device)),
+                                         self.step_count, float(grad_scale), _lib.DYN, int(self.dyn_slot),
+                                         _lib.stream_ptr(self.flat.device)),
                 "dvg_adam_step",
             )
+
+    def hyper(self, step_count=None):
+        """(lr / (1 - beta1^t), sqrt(1 - beta2^t)) for step t, rounded exactly as dvg_adam_step derives them from its
+        float32 by-value arguments (so a graph replay reading them from device memory is bit-identical to eager)."""
+        import numpy as np
+
+        g = self.param_groups[0]
+        t = self.step_count if step_count is None else step_count
+        lr32, b1, b2 = float(np.float32(g["lr"])), float(np.float32(g["betas"][0])), float(np.float32(g["betas"][1]))
+        step_size = np.float32(lr32 / (1.0 - b1 ** t))
+        bc2_sqrt = np.float32((1.0 - b2 ** t) ** 0.5)
+        return float(step_size), float(bc2_sqrt)
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

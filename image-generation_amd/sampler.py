@@ -148,7 +148,7 @@ class GibbsSampler:
                 L.dvg_gibbs_sample(self.graph.ptr, lin.data_ptr(), quad.data_ptr(), float(prefactor), float(hl),
                                    float(hh), float(jl), float(jh), self.beta, self._state.data_ptr(), num_reads,
                                    self.chain_offset & 0xFFFFFFFF, self.seed, self.sweep_count & 0xFFFFFFFF,
-                                   self.sweeps, init, out.data_ptr(), _lib.stream_ptr(lin.device)),
+                                   self.sweeps, init, out.data_ptr(), _lib.DYN, _lib.stream_ptr(lin.device)),
                 "dvg_gibbs_sample",
             )
         self.sweep_count += self.sweeps

@@ -39,6 +39,18 @@ typedef void *dvg_stream_t; /* hipStream_t */
 int dvg_version(void);
 const char *dvg_last_error(void);
 
+/* Device-resident per-step values, for steps replayed from a captured hipGraph.  A function handed a
+ * non-NULL `dyn` (DEVICE pointer) reads these fields at run time instead of its by-value arguments of the
+ * same meaning; the host rewrites the struct (one small async copy) before each replay.  NULL = by-value. */
+typedef struct {
+  uint32_t sweep0;         /* dvg_gibbs_sample: global index of the first sweep */
+  uint32_t reserved;
+  uint64_t gumbel_offset;  /* dvg_gumbel_fwd: Philox offset */
+  uint64_t dropout_offset; /* dvg_decoder_fwd: Philox offset */
+  float adam_step_size[2]; /* dvg_adam_step (slot 0 / 1): lr / (1 - beta1^t) */
+  float adam_bc2_sqrt[2];  /*                              sqrt(1 - beta2^t) */
+} dvg_step_state_t;
+
 /* ------------------------------------------------------------------ graph
  * The GRBM graph as the sampler and the energy kernels need it.  Built on the
  * host by image-generation_amd/graphs.py::build_plan from what the reference
@@ -72,7 +84,7 @@ int dvg_gibbs_sample(const dvg_graph_t *g, const float *linear, const float *qua
                      float prefactor, float h_lo, float h_hi, float j_lo, float j_hi, float beta,
                      int8_t *state, int n_chains, uint32_t chain_id0, uint64_t seed,
                      uint32_t sweep0, int n_sweeps, int init, float *samples_out,
-                     dvg_stream_t stream);
+                     const dvg_step_state_t *dyn, dvg_stream_t stream);
 
 /* ------------------------------------------------------------------ GRBM
  * Energy  E(x) = x.h + sum_e J_e x_i x_j  per row: the plugin's
@@ -103,7 +115,7 @@ int dvg_grbm_suffstats(const dvg_graph_t *g, const float *x, int64_t rows, const
  */
 int dvg_gumbel_fwd(const float *logits, int64_t B, int n, int R, float tau, const float *gumbels,
                    uint64_t seed, uint64_t offset, float *spins, float *dspin,
-                   dvg_stream_t stream);
+                   const dvg_step_state_t *dyn, dvg_stream_t stream);
 /* grad_logits (B, n) = sum_r grad_spins[b,r,:] * dspin[b,r,:] */
 int dvg_gumbel_bwd(const float *grad_spins, const float *dspin, int64_t B, int n, int R,
                    float *grad_logits, dvg_stream_t stream);
@@ -181,7 +193,8 @@ typedef struct {
 size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents);
 int dvg_decoder_fwd(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
                     int training, const float *const dropout_keep[4], uint64_t seed,
-                    uint64_t offset, float *out, void *ws, size_t ws_bytes, dvg_stream_t stream);
+                    uint64_t offset, float *out, void *ws, size_t ws_bytes, const dvg_step_state_t *dyn,
+                    dvg_stream_t stream);
 int dvg_decoder_bwd(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
                     const float *grad_out, const dvg_decoder_grads_t *grads,
                     float *grad_spins /* (N,n) or NULL */, void *ws, size_t ws_bytes,
@@ -205,7 +218,7 @@ int dvg_mse_fwd_bwd(const float *recon, const float *images, int64_t B, int R, f
  */
 int dvg_adam_step(float *p, const float *g, float *m, float *v, int64_t numel, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                  float grad_scale, dvg_stream_t stream);
+                  float grad_scale, const dvg_step_state_t *dyn, int dyn_slot, dvg_stream_t stream);
 
 /* ------------------------------------------------------------------ profiler
  * Optional per-kernel HIP-event timing inside the library (used by bench.py for

@@ -38,9 +38,9 @@ def test_version_and_error_string():
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any device work (safe on a CPU-only box)."""
     L = _lib.lib()
-    rc = L.dvg_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None)
+    rc = L.dvg_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None, 0, None)
     assert rc == -1 and b"null" in L.dvg_last_error()
-    rc = L.dvg_gibbs_sample(None, None, None, 1.0, -1, 1, -1, 1, 1.0, None, 4, 0, 0, 0, 1, 1, None, None)
+    rc = L.dvg_gibbs_sample(None, None, None, 1.0, -1, 1, -1, 1, 1.0, None, 4, 0, 0, 0, 1, 1, None, None, None)
     assert rc == -1
 
 

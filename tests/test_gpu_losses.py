@@ -126,5 +126,5 @@ def test_adam_matches_torch():
         opt.step()
         gd = g.cuda()
         _lib.check(L.dvg_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, 0.9, 0.999, 1e-8,
-                                   0.01, step, 1.0, _lib.stream_ptr()))
+                                   0.01, step, 1.0, None, 0, _lib.stream_ptr()))
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-7)

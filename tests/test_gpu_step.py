@@ -76,3 +76,31 @@ def test_save_load_roundtrip_and_generate(tmp_path, golden_dir):
         assert torch.equal(a.cpu(), b.cpu()), k
     imgs = m2.generate_images()
     assert imgs.shape == (16, 1, 32, 32) and float(imgs.min()) >= 0.0 and float(imgs.max()) <= 1.0
+
+
+def test_graph_replay_is_bit_identical_to_eager(golden_dir):
+    """The hipGraph-replayed autoencoder half computes exactly what the eager step computes: same kernels, same
+    per-step scalars (read from the device-side dvg_step_state_t instead of by-value arguments)."""
+    def run(use_graph):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 16, seed=4)).reshape(16, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(16)])
+        m.train_init(1)
+        m.sync_losses = False
+        m.use_graph = use_graph
+        out = []
+        for k in range(16):
+            m.step((imgs[k], None), epoch=0)
+            out.append((float(m.last["mse"]), float(m.last["mmd"])))
+        torch.cuda.synchronize()
+        sd = {k: v.clone() for k, v in m._dvae.state_dict().items()}
+        return out, sd, m
+
+    eager, sd_e, _ = run(False)
+    graphed, sd_g, mg = run(True)
+    assert mg._graph is not None and not mg._graph_failed, "the step was not captured"
+    assert eager == graphed
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
