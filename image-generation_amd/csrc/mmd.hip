@@ -25,6 +25,7 @@ struct MmdArgs {
   const float* sq;      // [nx + ny] squared row norms
   const float* coef;    // [8]: c_k = -1/(bw * mult_k); coef[7+1]... see MmdCoef
   int n_kernels, squared, reduce_mean, biased;
+  int pow2;             // factor == 2: exp(c_k D) by repeated squaring
   double* loss_part;    // [nblocks][3]  (xx, xy, yy)
   float* grad_part;     // [S][nx][d] (or grad_x itself when S == 1)
   int S;                // column splits
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) ck[k] = a.coef[k];
   const float kscale = a.reduce_mean ? 1.0f / (float)a.n_kernels : 1.0f;
+  const int nk = a.n_kernels;
   const double dnx = (double)a.nx, dny = (double)a.ny;
   const float a_xx = (float)(2.0 / (a.biased ? dnx * dnx : dnx * (dnx - 1.0)));
   const float a_xy = (float)(-2.0 / (dnx * dny));
@@ -244,12 +246,26 @@ __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
         const float d2 = diag ? 0.f : fmaxf(sqi + sq_j[gj] - 2.0f * T[r], 0.f);
         const float D = a.squared ? d2 : sqrtf(d2);
         float ks = 0.f, kp = 0.f;
+        if (a.pow2) {
+          // bandwidth multipliers are powers of two: c_k = 2 c_{k+1}, so exp(c_k D) = exp(c_{k+1} D)^2.
+          // One exp for the widest kernel, the others by repeated squaring (VALU-bound phase: 7 exps -> 1).
+          float e = expf(ck[nk - 1] * D);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (k < a.n_kernels) {
-            const float e = expf(ck[k] * D);
-            ks += e;
-            kp = fmaf(ck[k], e, kp);
+          for (int k = 7; k >= 0; --k) {
+            if (k < nk) {
+              ks += e;
+              kp = fmaf(ck[k], e, kp);
+              e *= e;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < nk) {
+              const float e = expf(ck[k] * D);
+              ks += e;
+              kp = fmaf(ck[k], e, kp);
+            }
           }
         }
         if (a.biased || !diag) lsum += ks * kscale;
@@ -417,6 +433,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   a.sq = (float*)(w + p.off_sq);
   a.coef = (float*)(w + p.off_coef);
   a.n_kernels = cfg->n_kernels; a.squared = cfg->squared; a.reduce_mean = cfg->reduce_mean; a.biased = cfg->biased;
+  a.pow2 = cfg->factor == 2.0f;
   a.loss_part = (double*)(w + p.off_loss);
   a.grad_part = grad_x ? (p.S > 1 ? (float*)(w + p.off_grad) : grad_x) : nullptr;
   a.S = p.S;

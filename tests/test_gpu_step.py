@@ -104,3 +104,27 @@ def test_graph_replay_is_bit_identical_to_eager(golden_dir):
     assert eager == graphed
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+def test_training_driver_and_model_files(tmp_path, golden_dir):
+    """execute_training + create_model_files: the reference's loop and side-file formats; the loss goes down."""
+    import json
+
+    from image_generation_amd.data import TensorBatches, synthetic_images
+    from image_generation_amd.training import create_model_files, execute_training
+
+    m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+    imgs = torch.zeros(160, 1, 32, 32)
+    imgs[:, :, 8:24, 12:20] = 1.0  # a learnable constant pattern
+    m.set_dataloader(TensorBatches(imgs.cuda(), torch.zeros(160).cuda(), batch_size=8, seed=1))
+    m.train_init(n_epochs=2)
+    rep = execute_training(m, 2, details_path=str(tmp_path / "problem_details.json"), verbose=False)
+    assert len(rep) == 2 and rep[0]["Epoch"] == "1/2" and rep[1]["Batch Size"] == 8
+    assert len(m.losses["mse_losses"]) == 40 and m.losses["mse_losses"][-1] < 0.5 * m.losses["mse_losses"][0]
+    create_model_files(m, tmp_path / "run", n_epochs=2)
+    params = json.load(open(tmp_path / "run" / "parameters.json"))
+    assert set(params) == {"n_latents", "n_epochs", "prefactor", "qpu", "num_read", "loss_function", "image_size",
+                           "batch_size", "dateset_size", "random_seed"}
+    losses = json.load(open(tmp_path / "run" / "losses.json"))
+    assert len(losses["mse_losses"]) == 40 and len(losses["dvae_losses"]) == 40
+    assert (tmp_path / "run" / "dvae.pth").exists() and (tmp_path / "run" / "grbm.pth").exists()
