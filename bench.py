@@ -109,7 +109,7 @@ def main():
     tmp.close()
     write_yaml(cfg, tmp.name)
     model = ModelWrapper(cfg["qpu"], n_latents=cfg["n"], training_parameter_file=tmp.name,
-                         dist=dp if dp.world_size > 1 else None)
+                         dist=dp if (dp.world_size > 1 or dp.force) else None)
     # synthetic batches resident in HBM (a pool, so no step re-reads the batch it just saw)
     pool = 16
     imgs = synthetic_images(pool * cfg["B"], seed=775321899904 + dp.rank, device=dev).reshape(pool, cfg["B"], 1, 32, 32)
@@ -125,7 +125,7 @@ def main():
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm)) if not args.breakdown else (1 << len(names)) - 1
     # Steps without a GRBM update are replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); the GRBM steps (every 10th) run eagerly.  --eager disables the graph.
-    model.use_graph = not args.eager and dp.world_size == 1
+    model.use_graph = not args.eager and dp.world_size == 1 and not dp.force
     step_idx = 0
 
     def run(k):

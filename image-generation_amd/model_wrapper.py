@@ -369,7 +369,7 @@ class ModelWrapper:
         self.losses[key].append(value.item() if self.sync_losses else value.detach())
 
     def _reduce_and_step(self, opt):
-        if self.dist is not None and self.dist.world_size > 1:
+        if self.dist is not None and (self.dist.world_size > 1 or getattr(self.dist, "force", False)):
             flat = opt.gather_grads()
             self.dist.all_reduce_mean(flat)  # ONE collective over the flat gradient buffer
             opt.step(gathered=True)

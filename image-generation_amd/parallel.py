@@ -23,7 +23,8 @@ class DataParallel:
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.owns_group = False
-        if self.world_size > 1 and not dist.is_initialized():
+        self.force = os.environ.get("DVG_FORCE_DIST") == "1"  # exercise the collective path with a single rank
+        if (self.world_size > 1 or self.force) and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl":
@@ -35,7 +36,7 @@ class DataParallel:
 
     def all_reduce_mean(self, flat: torch.Tensor) -> torch.Tensor:
         """In-place mean over ranks of one flat buffer: the single collective of a step."""
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.mul_(1.0 / self.world_size)
         return flat
@@ -46,11 +47,11 @@ class DataParallel:
         return flat
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
