@@ -52,6 +52,20 @@ def net_flops_per_image(n, R):
     return 3 * (f_enc + R * f_dec)
 
 
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs of `bench.py --eager`; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).
+    PMC counters cannot be read from inside the process, so the number is the last committed measurement."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
+    if not os.path.exists(path):
+        return None, None
+    norm = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").split("(")[0]  # noqa: E731
+    for name, rec in json.load(open(path)).items():
+        if norm(name) == norm(kernel):
+            return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle (a port: stock PyTorch CPU ops + the C Gibbs restatement) on this box's host cores."""
     from image_generation_amd import graphs
@@ -191,6 +205,7 @@ def main():
                     "all_gemm_kernels": {k: {"tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12,
                                               "ms_per_step": v["total_ms"] / prof_steps,
                                               "avg_launch_us": v["total_ms"] * 1e3 / v["launches"]} for k, v in cands.items()}}
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, args.config)
         ips = args.gpus * cfg["B"] * args.steps / elapsed
         out = {
             "metric": "dvae_grbm_train_step_images_per_s", "value": ips, "unit": "images/s", "n_gpus": args.gpus,

@@ -67,9 +67,14 @@ struct ConvArgs {
   int ntaps;          // 9 or 1
   int ups;            // input is stored at half resolution
   int poolsum;        // sum each 2x2 output quad (adjoint of the upsample) before storing
+  float* splitk_ws;   // scratch of conv_splitk_floats() floats, or null: never split K
+  int ksplit;         // set by launch_conv_igemm
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
-int conv_stats_blocks(int64_t M, int Cout);  // number of m_blocks launch_conv_igemm will use (for `stats`)
+int conv_stats_blocks(int64_t M, int Cout);
+// K-split chosen for a launch (1 = none) and the scratch it needs (0 = none)
+int conv_igemm_ksplit(int64_t M, int Cin, int Cout, int ntaps);
+size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum);  // number of m_blocks launch_conv_igemm will use (for `stats`)
 
 // Weight-gradient GEMM:  dWp[tap][a][b] = sum_m in[nbr(m,tap)][a] * dy[m][b], split over `ksplit` slabs.
 struct WgradArgs {

@@ -82,11 +82,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #ifdef DVG_STAMP
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, ph[5] = {0, 0, 0, 0, 0};
 #endif
-  for (int it = 0; it <= niter; ++it) {
+  // split-K (small-M layers): grid.z slices the K iterations; each slice writes a raw partial slab
+  const int it_per = (niter + a.ksplit - 1) / a.ksplit;
+  const int it_beg = (int)blockIdx.z * it_per, it_end = it_beg + it_per < niter ? it_beg + it_per : niter;
+  for (int it = it_beg; it <= it_end; ++it) {
     f32x4 areg[2][RA], breg[2][RB];
     STAMP(t0);
     float amask[2][RA];
-    if (it < niter) {
+    if (it < it_end) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kc = 2 * it + h;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
       }
     }
     STAMP(t1);
-    if (it > 0) {
+    if (it > it_beg) {
       const float* ap = As + (wm * TM * 32 + c) * AP + hh;
       const float* bp = Bs + hh * BP + wn * TN * 32 + c;
       // operand reads run one k-step ahead of the MFMAs (register double buffer): the LDS latency of step s+1
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
     STAMP(t2);
     __syncthreads();
     STAMP(t3);
-    if (it < niter) {
+    if (it < it_end) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -187,6 +190,31 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #endif
 
   // ---------------- epilogue
+  if (a.ksplit > 1) {  // raw partial sums (quad-summed if asked); bias and BN partials happen in splitk_reduce_kernel
+    const int64_t rows_out = a.poolsum ? a.M >> 2 : a.M;
+    float* slab = a.splitk_ws + (size_t)blockIdx.z * rows_out * a.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + c;
+        if (a.poolsum) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
+            const int64_t m = m0 + wm * TM * 32 + i * 32 + 8 * g + 4 * hh;
+            if (m < a.M) slab[(m >> 2) * a.Cout + col] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
+            if (m < a.M) slab[m * a.Cout + col] = acc[i][j][r];
+          }
+        }
+      }
+    return;
+  }
   if (a.poolsum) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -243,6 +271,39 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+// Sums the split-K slabs in order, adds the bias, writes the output and (optionally) the per-row-block BatchNorm
+// partials in the layout of the unsplit kernel: stats[row_block][Cout][2], row blocks of `bm` OUTPUT pixels.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t rows, int C,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ stats, int bm) {
+  __shared__ float red[2 * 256];
+  // block = (row block of `bm` rows) x (32 channels); thread = (channel, one of 8 row lanes)
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * bm;
+  const int64_t r1 = r0 + bm < rows ? r0 + bm : rows;
+  const int c = blockIdx.y * 32 + cl;
+  const float b = bias ? bias[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += 8) {
+    float v = b;
+    for (int k = 0; k < ksplit; ++k) v += ws[((size_t)k * rows + r) * C + c];
+    out[r * C + c] = v;
+    s1 += v;
+    s2 = fmaf(v, v, s2);
+  }
+  if (stats) {
+    red[threadIdx.x] = s1;
+    red[256 + threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < 8; ++j) { t1 += red[j * 32 + cl]; t2 += red[256 + j * 32 + cl]; }
+      stats[((size_t)blockIdx.x * C + c) * 2] = t1;
+      stats[((size_t)blockIdx.x * C + c) * 2 + 1] = t2;
+    }
+  }
+}
+
 static int igemm_cfg(int64_t M, int Cout) {
   if (Cout % 64 == 0) return (ceil_div(M, 128) * (Cout / 64) >= 512) ? 0 : 1;
   return 2;
@@ -250,7 +311,24 @@ static int igemm_cfg(int64_t M, int Cout) {
 
 int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_cfg(M, Cout) == 1 ? 64 : 128); }
 
-int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+// K-split of the forward / data-gradient kernel: only for launches that would leave most CUs idle
+int conv_igemm_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
+  const int cfg = igemm_cfg(M, Cout);
+  const int64_t blocks = ceil_div(M, cfg == 1 ? 64 : 128) * (Cout / (cfg == 2 ? 32 : 64));
+  const int niter = (ntaps * (Cin / 32) + 1) / 2;
+  if (blocks >= 192 || niter < 6) return 1;  // measured: splitting a launch with >= 256 blocks loses to its reduce pass
+  int64_t k = ceil_div(512, blocks);
+  if (k > niter / 3) k = niter / 3;
+  return (int)(k < 1 ? 1 : k);
+}
+
+size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) {
+  const int k = conv_igemm_ksplit(M, Cin, Cout, ntaps);
+  return k > 1 ? (size_t)k * (size_t)(poolsum ? M / 4 : M) * Cout : 0;
+}
+
+int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
+  ConvArgs a = a_in;
   if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 1)) {
     set_error("conv_igemm: unsupported shape Cin=%d Cout=%d M=%lld ntaps=%d", a.Cin, a.Cout, (long long)a.M, a.ntaps);
     return DVG_E_INVALID;
@@ -262,16 +340,26 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     return DVG_E_UNSUPPORTED;
   }
   const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;  // algorithmic
-  switch (igemm_cfg(a.M, a.Cout)) {
+  a.ksplit = a.splitk_ws ? conv_igemm_ksplit(a.M, a.Cin, a.Cout, a.ntaps) : 1;
+  const unsigned kz = (unsigned)a.ksplit;
+  const int cfg = igemm_cfg(a.M, a.Cout);
+  switch (cfg) {
     case 0:
-      DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64, kz), dim3(256), 0, s, a);
       break;
     case 1:
-      DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64, kz), dim3(256), 0, s, a);
       break;
     default:
-      DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32, kz), dim3(256), 0, s, a);
       break;
+  }
+  if (a.ksplit > 1) {
+    // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks
+    const int64_t rows_out = a.poolsum ? a.M / 4 : a.M;
+    const int bm = (cfg == 1 ? 64 : 128) / (a.poolsum ? 4 : 1);
+    DVG_LAUNCH(K_MISC, splitk_reduce_kernel, dim3((unsigned)ceil_div(rows_out, bm), a.Cout / 32), dim3(256), 0, s, a.splitk_ws, a.ksplit,
+               rows_out, a.Cout, a.bias, a.out, a.poolsum ? nullptr : a.stats, bm);
   }
   return DVG_OK;
 }

@@ -20,7 +20,7 @@ struct DecPlan {
   int nblk[4];
   size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
-  size_t dXbuf, dYbuf, slabs, partA, partB, partW;
+  size_t dXbuf, dYbuf, slabs, partA, partB, partW, splitk;
   int ksplit_lin, ksplit[3];
   size_t total_floats;
 };
@@ -44,6 +44,8 @@ DecPlan dec_plan(int64_t N, int n) {
   p.ksplit_lin = wgrad_ksplit(N, n, 4 * n, 1);
   size_t max_slab = (size_t)p.ksplit_lin * n * 4 * n;
   size_t max_dx = (size_t)N * 4 * n, max_dy = 0;
+  size_t max_split = conv_splitk_floats(N, n, 4 * n, 1, 0);
+  { const size_t sd = conv_splitk_floats(N, 4 * n, n, 1, 0); if (sd > max_split) max_split = sd; }
   int cmax = 4 * n;
   for (int l = 0; l < 4; ++l) {
     p.L[l] = l + 1;
@@ -62,6 +64,9 @@ DecPlan dec_plan(int64_t N, int n) {
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
+      const size_t sk_f = conv_splitk_floats(p.M[l], ch[l], C, 9, 0), sk_d = conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
+      if (sk_f > max_split) max_split = sk_f;
+      if (sk_d > max_split) max_split = sk_d;
     }
     const size_t act = (size_t)p.M[l] * C;
     if (act > max_dy) max_dy = act;
@@ -73,6 +78,7 @@ DecPlan dec_plan(int64_t N, int n) {
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
   p.partW = bump(o, (size_t)EW_BLOCKS * 288);
+  p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
 }
@@ -124,6 +130,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = spins; a.wp = W + pl.wp_lin; a.bias = W + pl.bias_lin; a.out = W + pl.X0; a.stats = nullptr;
     a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+    a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
   }
   const float* x = W + pl.X0;
@@ -134,6 +141,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = l > 0; a.poolsum = 0;
+      a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     } else {
       DVG_TRY(launch_dec_conv3_fwd(x, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
@@ -205,6 +213,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
+    a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
@@ -220,6 +229,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       ConvArgs a;
       a.in = dX; a.wp = W + pl.wpd_lin; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
       a.M = N; a.Cin = 4 * n; a.Cout = n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+      a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     }
   }

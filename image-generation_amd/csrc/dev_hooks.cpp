@@ -5,14 +5,19 @@ using namespace dvg;
 
 extern "C" int dvg_dev_conv_igemm(const float* in, const float* w, int mode, float* wp, const float* bias, float* out,
                                   float* stats, int64_t M, int Cin, int Cout, int L, int ntaps, int ups, int poolsum,
-                                  int repack, dvg_stream_t stream) {
+                                  int repack, float* splitk_ws, dvg_stream_t stream) {
   DVG_REQUIRE(in && w && wp && out, "dev_conv_igemm: null argument");
   hipStream_t s = (hipStream_t)stream;
   if (repack) DVG_TRY(launch_weight_pack(w, WeightMap{mode, Cin, Cout, ntaps}, wp, s));
   ConvArgs a;
   a.in = in; a.wp = wp; a.bias = bias; a.out = out; a.stats = stats;
   a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.ntaps = ntaps; a.ups = ups; a.poolsum = poolsum;
+  a.splitk_ws = splitk_ws;
   return launch_conv_igemm(a, s);
+}
+
+extern "C" size_t dvg_dev_conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) {
+  return conv_splitk_floats(M, Cin, Cout, ntaps, poolsum);
 }
 
 extern "C" int dvg_dev_conv_stats_blocks(int64_t M, int Cout) { return conv_stats_blocks(M, Cout); }

@@ -18,7 +18,7 @@ struct EncPlan {
   int nblk[4];
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
-  size_t dXbuf, dYbuf, slabs, partA, partB, part320;
+  size_t dXbuf, dYbuf, slabs, partA, partB, part320, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -35,7 +35,7 @@ EncPlan enc_plan(int64_t B, int n) {
   const int ch[5] = {1, 32, 64, 128, n};
   for (int i = 0; i < 5; ++i) p.ch[i] = ch[i];
   size_t o = 0;
-  size_t max_dx = 0, max_dy = 0, max_slab = 0;
+  size_t max_dx = 0, max_dy = 0, max_slab = 0, max_split = 0;
   int cmax = 0;
   for (int l = 0; l < 4; ++l) {
     p.L[l] = 5 - l;
@@ -57,6 +57,9 @@ EncPlan enc_plan(int64_t B, int n) {
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
+      const size_t sk_f = conv_splitk_floats(p.M[l], ch[l], C, 9, 0), sk_d = conv_splitk_floats(p.M[l], C, ch[l], 9, 0);
+      if (sk_f > max_split) max_split = sk_f;
+      if (sk_d > max_split) max_split = sk_d;
       const size_t dx = (size_t)p.M[l] * ch[l];  // gradient wrt the layer's input (same resolution)
       if (dx > max_dx) max_dx = dx;
     }
@@ -71,6 +74,7 @@ EncPlan enc_plan(int64_t B, int n) {
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
   p.part320 = bump(o, (size_t)EW_BLOCKS * 320);
+  p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
 }
@@ -122,6 +126,7 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
+      a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
@@ -180,6 +185,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
+    a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
   }
   return DVG_OK;

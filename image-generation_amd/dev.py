@@ -9,7 +9,8 @@ from . import _lib
 
 _SIGS = {
     "dvg_dev_conv_igemm": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
-                           [ctypes.c_int64] + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+                           [ctypes.c_int64] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "dvg_dev_conv_splitk_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
     "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 5 +
@@ -55,14 +56,18 @@ def morton_to_nchw(t: torch.Tensor, N: int, C: int, side: int) -> torch.Tensor:
     return out.reshape(N, side, side, C).permute(0, 3, 1, 2).contiguous()
 
 
-def conv_igemm(x_m, w, mode, M, Cin, Cout, L, ntaps=9, ups=0, poolsum=0, bias=None, stats=False, wp=None, repack=True):
+def conv_igemm(x_m, w, mode, M, Cin, Cout, L, ntaps=9, ups=0, poolsum=0, bias=None, stats=False, wp=None, repack=True,
+               splitk=True):
     Lb = lib()
     dev = x_m.device
     wp = wp if wp is not None else torch.empty(ntaps * Cin * Cout, device=dev)
     out = torch.empty(((M // 4) if poolsum else M, Cout), device=dev)
     st = torch.empty((Lb.dvg_dev_conv_stats_blocks(M, Cout), Cout, 2), device=dev) if stats else None
+    nsk = Lb.dvg_dev_conv_splitk_floats(M, Cin, Cout, ntaps, poolsum) if splitk else 0
+    sk = torch.empty(nsk, device=dev) if nsk else None
     _lib.check(Lb.dvg_dev_conv_igemm(x_m.data_ptr(), w.data_ptr(), mode, wp.data_ptr(), _lib.ptr(bias), out.data_ptr(),
-                                     _lib.ptr(st), M, Cin, Cout, L, ntaps, ups, poolsum, int(repack), _lib.stream_ptr(dev)))
+                                     _lib.ptr(st), M, Cin, Cout, L, ntaps, ups, poolsum, int(repack), _lib.ptr(sk),
+                                     _lib.stream_ptr(dev)))
     return (out, st) if stats else out
 
 

@@ -13,7 +13,8 @@ extern "C" {
  * out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] * Wp[tap][ci][co] (+bias); stats: [blocks][Cout][2] or NULL. */
 int dvg_dev_conv_igemm(const float *in, const float *w, int mode, float *wp, const float *bias, float *out,
                        float *stats, int64_t M, int Cin, int Cout, int L, int ntaps, int ups, int poolsum,
-                       int repack, dvg_stream_t stream);
+                       int repack, float *splitk_ws, dvg_stream_t stream);
+size_t dvg_dev_conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum);
 int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
 /* grad_w (checkpoint layout, `mode` = the layer's FORWARD mode) = sum_m in[nbr(m,tap)] (x) dy[m]; slabs: scratch of
  * dvg_dev_wgrad_slab_floats() floats. */

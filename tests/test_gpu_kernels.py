@@ -13,7 +13,8 @@ def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4)])
+@pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4),
+                                             (256, 128, 128, 4), (64, 128, 128, 4)])  # the last two take the split-K path
 def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side):
     torch.manual_seed(N)
     x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
