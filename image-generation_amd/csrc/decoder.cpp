@@ -133,6 +133,20 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
   }
+  if (training) {  // Dropout2d keep-masks of all four stages: copied in (parity runs) or drawn on device, one launch
+    bool given = dropout_keep != nullptr;
+    for (int l = 0; l < 4 && given; ++l) given = dropout_keep[l] != nullptr;
+    if (given) {
+      for (int l = 0; l < 4; ++l)
+        DVG_CHECK_HIP(hipMemcpyAsync(W + pl.mask[l], dropout_keep[l], sizeof(float) * (size_t)N * pl.ch[l + 1],
+                                     hipMemcpyDeviceToDevice, s));
+    } else {
+      DVG_REQUIRE(dropout_keep == nullptr || (!dropout_keep[0] && !dropout_keep[1] && !dropout_keep[2] && !dropout_keep[3]),
+                  "decoder_fwd: give all four dropout masks or none");
+      float* masks[4] = {W + pl.mask[0], W + pl.mask[1], W + pl.mask[2], W + pl.mask[3]};
+      DVG_TRY(launch_dropout_masks(N, &pl.ch[1], masks, seed, offset, dyn ? &dyn->dropout_offset : nullptr, s));
+    }
+  }
   const float* x = W + pl.X0;
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
@@ -148,15 +162,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
                                p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
-    const float* mask = nullptr;
-    if (training) {
-      float* mdst = W + pl.mask[l];
-      if (dropout_keep && dropout_keep[l])
-        DVG_CHECK_HIP(hipMemcpyAsync(mdst, dropout_keep[l], sizeof(float) * (size_t)N * C, hipMemcpyDeviceToDevice, s));
-      else
-        DVG_TRY(launch_dropout_mask(N, C, seed, offset, dyn ? &dyn->dropout_offset : nullptr, l, mdst, s));
-      mask = mdst;
-    }
+    const float* mask = training ? W + pl.mask[l] : nullptr;
     DVG_TRY(launch_dec_bn_act_fwd(W + pl.Y[l], pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                   p->bn_b[l], mask, W + pl.Xs[l], s));
     x = W + pl.Xs[l];

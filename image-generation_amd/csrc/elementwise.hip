@@ -280,22 +280,29 @@ int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* 
 }
 
 // ---------------------------------------------------------------- decoder: BN -> dropout2d -> lrelu
-__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t N, int C, uint32_t k0, uint32_t k1, uint32_t off_lo,
-                                                           uint32_t off_hi, uint32_t layer, const uint64_t* __restrict__ off_dev,
-                                                           float* __restrict__ mask) {
+// all four Dropout2d keep-masks of a decoder forward in one launch (blockIdx.y = layer)
+struct DropoutJobs { float* mask[4]; int C[4]; };
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t N, DropoutJobs jobs, uint32_t k0, uint32_t k1,
+                                                           uint32_t off_lo, uint32_t off_hi,
+                                                           const uint64_t* __restrict__ off_dev) {
   if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
-  const int64_t total = N * C;
+  const uint32_t layer = blockIdx.y;
+  float* mask = jobs.mask[layer];
+  const int64_t total = N * jobs.C[layer];
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const u32x4 r = philox4x32_10((uint32_t)e, off_lo ^ (layer << 28), off_hi ^ (uint32_t)(e >> 32), STREAM_DROPOUT, k0, k1);
     mask[e] = u32_to_unit(r.x) < DROPOUT_KEEP ? 1.0f : 0.0f;
   }
 }
 
-int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int layer,
-                        float* mask, hipStream_t s) {
-  const int64_t b = ceil_div(N * C, 256);
-  DVG_LAUNCH(K_MISC, dropout_mask_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, s, N, C, (uint32_t)seed,
-             (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)layer, offset_dev, mask);
+int launch_dropout_masks(int64_t N, const int C[4], float* const mask[4], uint64_t seed, uint64_t offset,
+                         const uint64_t* offset_dev, hipStream_t s) {
+  DropoutJobs jobs;
+  int cmax = 1;
+  for (int l = 0; l < 4; ++l) { jobs.mask[l] = mask[l]; jobs.C[l] = C[l]; if (C[l] > cmax) cmax = C[l]; }
+  const int64_t b = ceil_div(N * cmax, 256);
+  DVG_LAUNCH(K_MISC, dropout_mask_kernel, dim3((unsigned)(b > 1024 ? 1024 : b), 4), dim3(256), 0, s, N, jobs, (uint32_t)seed,
+             (uint32_t)(seed >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), offset_dev);
   return DVG_OK;
 }
 

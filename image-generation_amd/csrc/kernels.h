@@ -39,8 +39,8 @@ int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* 
                                  const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);
 
 // ---- decoder stage: BN -> Dropout2d mask -> LeakyReLU (the x2 upsample is fused into the consumer)
-int launch_dropout_mask(int64_t N, int C, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int layer,
-                        float* mask, hipStream_t s);
+int launch_dropout_masks(int64_t N, const int C[4], float* const mask[4], uint64_t seed, uint64_t offset,
+                         const uint64_t* offset_dev, hipStream_t s);
 int launch_dec_bn_act_fwd(const float* Y, int64_t M, int C, int logHW, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const float* mask, float* X, hipStream_t s);
 int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,

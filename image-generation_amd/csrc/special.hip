@@ -69,42 +69,46 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
 }
 
 // dW[co][t] = sum_m dY[m][co] * in_t[m];  db[co] = sum_m dY[m][co];  part [EW_BLOCKS][320]
+// A (32 x K) x (K x 10) GEMM with K = B*1024 pixels: one f32 MFMA per two pixels.  The A operand (dY rows, 32
+// channels = 128 B) and the B operand (the 9 shifted input pixels + a column of ones for the bias, rest zero) go
+// straight from global memory to the MFMA: no LDS, no staging.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void enc_conv0_wgrad_kernel(const float* __restrict__ img, int64_t B,
                                                               const float* __restrict__ dY, float* __restrict__ part) {
-  __shared__ float dys[256 * 33];
-  __shared__ float ins[10 * 256];
-  const int tid = threadIdx.x;
-  float acc0 = 0.f, acc1 = 0.f;  // work items w = tid and tid + 256 (< 320)
-  const int w0 = tid, w1 = tid + 256;
-  const int co0 = w0 < 288 ? w0 / 9 : w0 - 288, t0 = w0 < 288 ? w0 % 9 : 9;
-  const int co1 = w1 < 288 ? w1 / 9 : w1 - 288, t1 = w1 < 288 ? w1 % 9 : 9;
-  const int64_t nchunk = B * 4;
-  for (int64_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-    const int64_t m = ch * 256 + tid;
-    const int64_t b = m >> 10;
-    const uint32_t p = (uint32_t)(m & 1023);
-    const int y = (int)morton_y(p), x = (int)morton_x(p);
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-      ins[t * 256 + tid] = (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) ? img[b * 1024 + yy * 32 + xx] : 0.f;
+  __shared__ float red[4 * 32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  const int64_t P = B * 1024;
+  int64_t per = (P + gridDim.x * 4 - 1) / (gridDim.x * 4);
+  per = (per + 1) & ~(int64_t)1;  // pixels per wave, even
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * per;
+  const int64_t p1 = p0 + per < P ? p0 + per : P;
+  const int dy = c < 9 ? c / 3 - 1 : 0, dx = c < 9 ? c % 3 - 1 : 0;
+  f32x16s acc = {0};
+  for (int64_t p = p0; p < p1; p += 2) {
+    const int64_t m = p + hh;
+    const bool live = m < p1;
+    const float av = live ? dY[m * 32 + c] : 0.f;  // A[co = c][k = hh]
+    float bv = 0.f;                                 // B[k = hh][col = c]
+    if (live && c < 10) {
+      if (c == 9) {
+        bv = 1.0f;
+      } else {
+        const uint32_t q = (uint32_t)(m & 1023);
+        const int yy = (int)morton_y(q) + dy, xx = (int)morton_x(q) + dx;
+        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) bv = img[(m >> 10) * 1024 + yy * 32 + xx];
+      }
     }
-    ins[9 * 256 + tid] = 1.0f;
-    // dY tile: 256 px x 32 ch, coalesced
-    const float* src = dY + ch * 256 * 32;
-    for (int k = 0; k < 32; ++k) {
-      const int e = k * 256 + tid;
-      dys[(e >> 5) * 33 + (e & 31)] = src[e];
-    }
-    __syncthreads();
-    for (int px = 0; px < 256; ++px) {
-      acc0 = fmaf(dys[px * 33 + co0], ins[t0 * 256 + px], acc0);
-      if (w1 < 320) acc1 = fmaf(dys[px * 33 + co1], ins[t1 * 256 + px], acc1);
-    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
   }
-  part[(size_t)blockIdx.x * 320 + w0] = acc0;
-  if (w1 < 320) part[(size_t)blockIdx.x * 320 + w1] = acc1;
+  // D[row = co][col = t]: lane holds column c, rows (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = acc[r];
+  __syncthreads();
+  for (int w = tid; w < 320; w += 256) {
+    const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
+    part[(size_t)blockIdx.x * 320 + w] =
+        (red[(0 * 32 + co) * 33 + t] + red[(1 * 32 + co) * 33 + t]) + (red[(2 * 32 + co) * 33 + t] + red[(3 * 32 + co) * 33 + t]);
+  }
 }
 
 int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s) {
