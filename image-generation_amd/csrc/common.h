@@ -44,6 +44,7 @@ enum KernelId : int {
   K_MMD_PREP,
   K_MMD_DISTSUM,
   K_MMD_MAIN,
+  K_MMD_PM1,
   K_MMD_FINAL,
   K_IGEMM_128x64,   // conv_igemm_kernel<128,64,2,2>
   K_IGEMM_64x64,    // conv_igemm_kernel<64,64,2,2>

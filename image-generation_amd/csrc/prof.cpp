@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 
 static const char* kNames[K_COUNT] = {
     "gibbs_sweeps", "grbm_energy", "grbm_suffstats", "gumbel_fwd", "gumbel_bwd", "mmd_prep",
-    "mmd_distsum", "mmd_main", "mmd_final", "conv_igemm_kernel<128,64,2,2>", "conv_igemm_kernel<64,64,2,2>",
+    "mmd_distsum", "mmd_main", "mmd_pm1", "mmd_final", "conv_igemm_kernel<128,64,2,2>", "conv_igemm_kernel<64,64,2,2>",
     "conv_igemm_kernel<128,32,4,1>", "conv_wgrad_kernel<2,2>", "conv_wgrad_kernel<2,1>", "conv_wgrad_kernel<1,2>",
     "conv_wgrad_kernel<1,1>",
     "wgrad_reduce", "weight_pack", "bn_finalize", "enc_conv0_fwd", "enc_conv0_wgrad",

@@ -57,6 +57,44 @@ def test_mmd_switches(kw):
     assert (xg.grad.cpu().double() - gwant).abs().max() <= 5e-5 * gwant.abs().max() + 1e-9
 
 
+@pytest.mark.parametrize("kw", [dict(squared=True), dict(biased=True), dict(reduce="mean"), dict(bandwidth=3.5),
+                                dict(n_kernels=3, factor=3.0)])
+def test_mmd_switches_spin_inputs(kw):
+    """Same switches on +-1 rows: the library takes its int8/bf16 spin path (table lookup per pair)."""
+    rng = np.random.default_rng(11)
+    x = _spins(rng, 200, 128, 0.4)
+    x[5] = x[9]
+    y = _spins(rng, 70, 128, 0.55)
+    want, gwant = _ref_mmd(x, y, **kw)
+    k2 = dict(kw)
+    if "reduce" in k2:
+        k2["reduce_mean"] = k2.pop("reduce") == "mean"
+    xg = x.cuda().requires_grad_(True)
+    loss = F.mmd_loss(xg, y.cuda(), **k2)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want)) <= 2e-5 * abs(float(want)) + 1e-6
+    assert (xg.grad.cpu().double() - gwant).abs().max() <= 2e-5 * gwant.abs().max() + 1e-9
+
+
+@pytest.mark.parametrize("nx,ny,d", [(300, 77, 256), (2048, 256, 128), (70, 40, 1024), (64, 64, 2048)])
+def test_mmd_spin_and_float_paths_agree(nx, ny, d):
+    """One entry nudged off +-1 by one ulp sends the call down the general f32 path; the two implementations must
+    agree to rounding (d = 2048 is beyond the spin path's LDS budget and always takes the f32 kernels)."""
+    rng = np.random.default_rng(d + nx)
+    x = _spins(rng, nx, d, 0.45)
+    y = _spins(rng, ny, d, 0.5)
+    xa = x.cuda().requires_grad_(True)
+    la = F.mmd_loss(xa, y.cuda())
+    la.backward()
+    y2 = y.clone()
+    y2[-1, -1] = torch.nextafter(y2[-1, -1], torch.tensor(0.0))
+    xb = x.cuda().requires_grad_(True)
+    lb = F.mmd_loss(xb, y2.cuda())
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)) + 1e-7
+    assert (xa.grad - xb.grad).abs().max().item() <= 2e-5 * xa.grad.abs().max().item() + 1e-10
+
+
 def test_gumbel_injected_noise_bit_exact_spins_and_grad():
     torch.manual_seed(0)
     B, R, n = 16, 8, 128
