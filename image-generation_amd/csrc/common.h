@@ -76,6 +76,16 @@ enum KernelId : int {
   K_COUNT
 };
 
+// Fork/join helpers (streams.cpp).  side_stream(s) is the library's side stream of the current device (or `s` itself
+// when DVG_NO_SIDE_STREAM is set); stream_order_after(w, p) makes everything enqueued on `w` from now on wait for what
+// has been enqueued on `p` so far (no-op when w == p).  Capture-safe.
+bool side_enabled();
+hipStream_t side_stream(hipStream_t fallback);
+int stream_order_after(hipStream_t waiter, hipStream_t producer);
+// The same in two halves: mark a point of `producer` now, make `waiter` wait for exactly that point later.
+int stream_mark(hipStream_t producer, hipEvent_t* mark);
+int stream_wait_mark(hipStream_t waiter, hipEvent_t mark);
+
 // Profiler hooks (prof.cpp).  begin/end record a hipEvent pair on `s` when enabled.
 bool prof_on(int id);
 void prof_begin(int id, hipStream_t s);

@@ -20,7 +20,7 @@ struct DecPlan {
   int nblk[4];
   size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
-  size_t dXbuf, dYbuf, slabs, partA, partB, partW, splitk;
+  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB, partW, splitk;
   int ksplit_lin, ksplit[3];
   size_t total_floats;
 };
@@ -74,6 +74,7 @@ DecPlan dec_plan(int64_t N, int n) {
   }
   p.dXbuf = bump(o, max_dx);
   p.dYbuf = bump(o, max_dy);
+  p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
@@ -181,9 +182,11 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
   for (int l = 0; l < 5; ++l) DVG_REQUIRE(g->conv_w[l] && g->conv_b[l], "decoder_bwd: null conv gradient buffer %d", l);
   for (int l = 0; l < 4; ++l) DVG_REQUIRE(g->bn_g[l] && g->bn_b[l], "decoder_bwd: null BN gradient buffer %d", l);
   hipStream_t s = (hipStream_t)stream;
+  hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
-  float* dY = W + pl.dYbuf;
+  float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
+  hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
   float* partB = W + pl.partB;
   float* partW = W + pl.partW;
@@ -198,37 +201,46 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     const float* Y = W + pl.Y[l];
     const float* Xs = W + pl.Xs[l];
     const float* mask = W + pl.mask[l];  // backward only exists for a training-mode forward
+    float* dY = dYpp[l & 1];
     DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
                                          partA, s));
     DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+    // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
+    if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                         mask, dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
+    // Fork: dY is ready.  The caller's-stream kernel is enqueued BEFORE the side-stream ones: when the call is being
+    // captured into a hipGraph, the first child captured after a fork inherits the parent's hardware queue, and a
+    // data-gradient chain that changes queue at every layer pays a cross-queue signal (~10-15 us) per hop.
+    hipEvent_t dy_ready = nullptr;
+    if (s2 != s) DVG_TRY(stream_mark(s, &dy_ready));
     const float* xin = l == 0 ? W + pl.X0 : W + pl.Xs[l - 1];
     if (l == 3) {
-      DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s));
-      DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s));  // [tap][ci] -> [ci][tap]
       DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
+      if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+      DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
+      DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
+      if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[3]));
       continue;
     }
-    WgradArgs wa;
-    wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
-    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
-    DVG_TRY(launch_conv_wgrad(wa, s));
-    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s));
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
+    if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+    WgradArgs wa;
+    wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
+    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
+    DVG_TRY(launch_conv_wgrad(wa, s2));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[l]));
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
   {
-    WgradArgs wa;
-    wa.in = spins; wa.dy = dX; wa.slabs = W + pl.slabs;
-    wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;
-    DVG_TRY(launch_conv_wgrad(wa, s));
-    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, g->lin_w, s));
+    hipEvent_t dx_ready = nullptr;  // dX is final
+    if (s2 != s) DVG_TRY(stream_mark(s, &dx_ready));
     DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, partB, s));
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s));  // j' = p*n+c -> c*4+p
     if (grad_spins) {
@@ -238,6 +250,13 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     }
+    if (s2 != s) DVG_TRY(stream_wait_mark(s2, dx_ready));
+    WgradArgs wa;
+    wa.in = spins; wa.dy = dX; wa.slabs = W + pl.slabs;
+    wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;
+    DVG_TRY(launch_conv_wgrad(wa, s2));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, g->lin_w, s2));
+    DVG_TRY(stream_order_after(s, s2));  // join
   }
   return DVG_OK;
 }

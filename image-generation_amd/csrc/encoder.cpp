@@ -18,7 +18,7 @@ struct EncPlan {
   int nblk[4];
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
-  size_t dXbuf, dYbuf, slabs, partA, partB, part320, splitk;
+  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB, part320, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -70,6 +70,7 @@ EncPlan enc_plan(int64_t B, int n) {
   if (dp > max_dx) max_dx = dp;
   p.dXbuf = bump(o, max_dx);
   p.dYbuf = bump(o, max_dy);
+  p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
@@ -149,9 +150,11 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);
   DVG_REQUIRE(g->proj_w && g->proj_b, "encoder_bwd: null projection gradient buffer");
   hipStream_t s = (hipStream_t)stream;
+  hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
-  float* dY = W + pl.dYbuf;
+  float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
+  hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
   float* partB = W + pl.partB;
 
@@ -162,10 +165,13 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     const float* Y = W + pl.Y[l];
+    float* dY = dYpp[l & 1];
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
     DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                           dX, partA, s));
     DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+    // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
+    if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                          dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
     if (l == 0) {
@@ -174,12 +180,9 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
       break;
     }
     DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
-    // weight gradient
-    WgradArgs wa;
-    wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
-    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
-    DVG_TRY(launch_conv_wgrad(wa, s));
-    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s));
+    // fork: dY is ready; the caller's-stream kernel goes first (see decoder.cpp: queue inheritance under capture)
+    hipEvent_t dy_ready = nullptr;
+    if (s2 != s) DVG_TRY(stream_mark(s, &dy_ready));
     // data gradient -> dX (gradient wrt this layer's input = previous stage's output)
     // (the data-gradient weight layout was packed by the forward call: same weights)
     ConvArgs a;
@@ -187,6 +190,15 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
+    if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+    // weight gradient
+    WgradArgs wa;
+    wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
+    wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
+    DVG_TRY(launch_conv_wgrad(wa, s2));
+    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[l]));
   }
+  DVG_TRY(stream_order_after(s, s2));  // join
   return DVG_OK;
 }

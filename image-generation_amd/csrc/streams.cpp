@@ -1,0 +1,76 @@
+// Library-owned side stream for fork/join concurrency inside one C-ABI call.
+//
+// The backward passes have two independent chains per layer: the data gradient (critical path: it feeds the next
+// layer's BN backward) and the weight gradient (only the optimizer reads it).  The weight-gradient chain is enqueued
+// on a side stream behind an event of the caller's stream and joined back before the call returns, so to the caller
+// the call is still "a sequence of work on `stream`".  The pattern is capture-safe: under hipStreamBeginCapture the
+// event wait pulls the side stream into the capture and the join closes the fork, so the captured graph simply gets
+// two parallel branches.  DVG_NO_SIDE_STREAM=1 keeps everything on the caller's stream (A/B measurements, debugging).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace dvg {
+
+namespace {
+constexpr int kMaxDevices = 16;
+constexpr int kEvents = 64;
+struct SideCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t ev[kEvents];
+  int next = 0;
+  bool ready = false;
+};
+SideCtx g_ctx[kMaxDevices];
+
+SideCtx* ctx() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  SideCtx& c = g_ctx[dev];
+  if (!c.ready) {
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < kEvents; ++i)
+      if (hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    c.ready = true;
+  }
+  return &c;
+}
+}  // namespace
+
+bool side_enabled() {
+  static const bool off = [] {
+    const char* e = std::getenv("DVG_NO_SIDE_STREAM");
+    return e && e[0] && e[0] != '0';
+  }();
+  return !off;
+}
+
+hipStream_t side_stream(hipStream_t fallback) {
+  if (!side_enabled()) return fallback;
+  SideCtx* c = ctx();
+  return c ? c->side : fallback;
+}
+
+int stream_mark(hipStream_t producer, hipEvent_t* mark) {
+  SideCtx* c = ctx();
+  DVG_REQUIRE(c, "side stream: no context for this device");
+  hipEvent_t e = c->ev[c->next];
+  c->next = (c->next + 1) % kEvents;
+  DVG_CHECK_HIP(hipEventRecord(e, producer));
+  *mark = e;
+  return DVG_OK;
+}
+
+int stream_wait_mark(hipStream_t waiter, hipEvent_t mark) {
+  DVG_CHECK_HIP(hipStreamWaitEvent(waiter, mark, 0));
+  return DVG_OK;
+}
+
+int stream_order_after(hipStream_t waiter, hipStream_t producer) {
+  if (waiter == producer) return DVG_OK;
+  hipEvent_t e;
+  DVG_TRY(stream_mark(producer, &e));
+  return stream_wait_mark(waiter, e);
+}
+
+}  // namespace dvg

@@ -76,6 +76,7 @@ class ModelWrapper:
         self.noise_hook: Optional[Callable[[int], dict]] = None  # parity tests inject Gumbel noise / dropout masks
         self.sync_losses = True   # False: keep loss tensors on device (no .item() host syncs in the step)
         self.overlap_sampler = True  # run the step's sampler draw on a side stream under the forward pass
+        self.overlap_mmd = True      # ... and the MMD behind it, under the decoder forward
         self._side_stream = None
         # use_graph: replay the autoencoder half of the step from a captured hipGraph (needs sync_losses = False);
         # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
@@ -262,6 +263,28 @@ class ModelWrapper:
         # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
         # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
         samples = self._draw_overlapped() if self.overlap_sampler else None
+        if samples is not None and self.overlap_mmd:
+            # The MMD needs only the spins and the draw, so it follows the draw on the side stream and runs under
+            # the decoder forward and the MSE; the streams join before the two losses are added.
+            main, side = torch.cuda.current_stream(self._device), self._side_stream
+            latents = self._dvae.encoder(images)
+            spins = self._dvae.latent_to_discrete(latents, self.N_REPLICAS)
+            spins_ready = torch.cuda.Event()
+            spins_ready.record(main)
+            # (the main-stream work is enqueued first: under hipGraph capture the first child captured after a fork
+            # keeps the parent's hardware queue, and the decoder chain is the critical path)
+            reconstructed_images = self._dvae.decoder(spins)
+            self._dvae_optimizer.zero_grad()
+            mse_loss = F.replicated_mse_loss(reconstructed_images, images)
+            side.wait_event(spins_ready)
+            with torch.cuda.stream(side):
+                flat = spins.reshape(-1, spins.shape[-1])
+                _mmd_loss = maximum_mean_discrepancy_loss(x=flat, y=samples, kernel=self._tpar["kernel"])
+            main.wait_stream(side)
+            dvae_loss = mse_loss + _mmd_loss
+            dvae_loss.backward()
+            self._reduce_and_step(self._dvae_optimizer)
+            return mse_loss, dvae_loss, _mmd_loss, flat
         _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)
         self._dvae_optimizer.zero_grad()
         mse_loss = F.replicated_mse_loss(reconstructed_images, images)
