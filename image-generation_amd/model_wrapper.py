@@ -225,7 +225,7 @@ class ModelWrapper:
                 self._dvae.decoder.inject_dropout_masks([m.to(self._device) for m in noise["dropout_masks"]])
 
         if self._graph_eligible(opt_step, epoch, images):
-            mse_loss = self._step_graphed(images)
+            mse_loss, spins = self._step_graphed(images)
         else:
             mse_loss, dvae_loss, _mmd_loss, spins = self._dvae_half(images)
             self._log("mse_losses", mse_loss)
@@ -309,10 +309,11 @@ class ModelWrapper:
 
     # ------------------------------------------------------------------ hipGraph replay of the autoencoder half
     def _graph_eligible(self, opt_step, epoch, images) -> bool:
-        """The captured graph covers the steps without a GRBM update (9 of 10 in the first 6 epochs, all afterwards);
-        GRBM steps, noise-injected (parity) steps and multi-GPU runs take the eager path."""
+        """The captured graph covers the autoencoder half of every step (on a GRBM step the quasi-NLL update runs
+        eagerly behind the replay, on the replay's static spins); noise-injected (parity) steps and multi-GPU runs
+        take the eager path."""
         return (self.use_graph and self._device.type == "cuda" and self.noise_hook is None and not self._graph_failed
-                and not train_grbm(opt_step, epoch) and (self.dist is None or self.dist.world_size == 1)
+                and (self.dist is None or self.dist.world_size == 1)
                 and self._eager_steps >= 3 and not self.sync_losses
                 and (self._static_images is None or images.shape == self._static_images.shape))
 
@@ -343,11 +344,11 @@ class ModelWrapper:
         _lib.DYN = self._dyn.ptr
         try:
             with torch.cuda.graph(graph):
-                mse, dvae, mmd, _ = self._dvae_half(self._static_images)
+                mse, dvae, mmd, spins = self._dvae_half(self._static_images)
         finally:
             _lib.DYN = None
             self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
-        self._graph, self._graph_out = graph, (mse, dvae, mmd)
+        self._graph, self._graph_out = graph, (mse, dvae, mmd, spins.detach())
 
     def _step_graphed(self, images):
         if self._graph is None:
@@ -358,21 +359,21 @@ class ModelWrapper:
 
                 self._graph_failed = True
                 warnings.warn(f"hipGraph capture of the training step failed ({exc!r}); continuing eagerly")
-                mse_loss, dvae_loss, _mmd_loss, _ = self._dvae_half(images)
+                mse_loss, dvae_loss, _mmd_loss, spins = self._dvae_half(images)
                 self._log("mse_losses", mse_loss)
                 self._log("dvae_losses", dvae_loss)
                 self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
-                return mse_loss
+                return mse_loss, spins
         self._static_images.copy_(images)
         self._write_dyn()
         self._graph.replay()
         c = self._host_counters()
         self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
-        mse, dvae, mmd = self._graph_out
+        mse, dvae, mmd, spins = self._graph_out
         self.losses["mse_losses"].append(mse)   # static tensors: valid until the next replay (sync_losses is off)
         self.losses["dvae_losses"].append(dvae)
         self.last.update(mse=mse, mmd=mmd)
-        return mse
+        return mse, spins
 
     def _draw_overlapped(self):
         if self._device.type != "cuda":

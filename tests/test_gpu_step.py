@@ -96,6 +96,7 @@ def test_graph_replay_is_bit_identical_to_eager(golden_dir):
             out.append((float(m.last["mse"]), float(m.last["mmd"])))
         torch.cuda.synchronize()
         sd = {k: v.clone() for k, v in m._dvae.state_dict().items()}
+        sd.update({"grbm." + k: v.clone() for k, v in m._grbm.state_dict().items()})  # steps 0 and 10 train the GRBM
         return out, sd, m
 
     eager, sd_e, _ = run(False)
