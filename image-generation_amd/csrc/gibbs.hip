@@ -8,6 +8,8 @@
 // Within a colour class spins are conditionally independent, so the lanes update
 // them simultaneously; classes are separated by a wavefront-level fence only (no
 // workgroup barrier: chains never interact).
+#include <cstdlib>
+
 #include "common.h"
 #include "graph.h"
 #include "philox.h"
@@ -25,6 +27,7 @@ struct GibbsArgs {
   uint32_t chain_id0, k0, k1, sweep0;
   const uint32_t* sweep0_dev;  // non-null: read the first-sweep index from device memory (graph replay)
   int n_sweeps, init;
+  int passes;  // fast kernel: ceil(max_class / lanes per chain)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -115,6 +118,134 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   }
 }
 
+// Fast path for graphs with at most GIBBS_MAXS (colour class, pass) slots per lane, a pass being LPC spins of a class
+// -- every graph the shipped solvers produce up to 512 spins.  Same arithmetic, same order, same random stream as
+// gibbs_kernel (bit-exact); what changes is the schedule:
+//   * a lane owns the same spin of every slot in every sweep, so its CSR range, local field offset and spin index
+//     are read from LDS once, before the sweep loop, and live in registers;
+//   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends,
+//     instead of being recomputed every sweep;
+//   * the neighbour loop issues its LDS reads eight at a time (indices and couplings, then the eight states) and only
+//     the adds stay sequential -- the rolled loop paid two dependent LDS latencies per neighbour.
+constexpr int GIBBS_MAXS = 12;
+template <int LPC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n = a.n, n_adj = a.n_adj;
+  float* s_hs = reinterpret_cast<float*>(smem);
+  float* s_adjJ = s_hs + n;
+  int32_t* s_cls = reinterpret_cast<int32_t*>(s_adjJ + n_adj);
+  uint16_t* s_adjptr = reinterpret_cast<uint16_t*>(s_cls + a.n_colours + 1);
+  uint16_t* s_order = s_adjptr + ((n + 2) & ~1);
+  uint16_t* s_adjidx = s_order + ((n + 1) & ~1);
+  int8_t* s_state = reinterpret_cast<int8_t*>(s_adjidx + ((n_adj + 1) & ~1));
+  const int n_pad = (n + 15) & ~15;
+
+  const int tid = threadIdx.x;
+  constexpr int NT = WAVES * 64;
+  for (int i = tid; i < n; i += NT) {
+    s_hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
+    s_order[i] = (uint16_t)a.order[i];
+  }
+  for (int i = tid; i <= n; i += NT) s_adjptr[i] = (uint16_t)a.adj_ptr[i];
+  for (int q = tid; q < n_adj; q += NT) {
+    s_adjJ[q] = clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[q]]), a.j_lo, a.j_hi);
+    s_adjidx[q] = (uint16_t)a.adj_idx[q];
+  }
+  for (int i = tid; i <= a.n_colours; i += NT) s_cls[i] = a.class_ptr[i];
+  __syncthreads();
+
+  constexpr int CPW = 64 / LPC;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int sub = lane / LPC, l = lane % LPC;
+  const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
+  const bool valid = chain < a.n_chains;
+  int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
+  const uint32_t cid = a.chain_id0 + (uint32_t)chain;
+
+  if (valid) {
+    if (a.init) {
+      for (int i = l; i < n; i += LPC) {
+        u32x4 r = philox4x32_10((uint32_t)i, cid, 0u, STREAM_INIT, a.k0, a.k1);
+        st[i] = (r.x >> 31) ? 1 : -1;
+      }
+    } else {
+      const int8_t* src = a.state + (size_t)chain * n;
+      for (int i = l; i < n; i += LPC) st[i] = src[i];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (!valid) return;
+
+  // this lane's spin in each (colour, pass) slot (-1: none), with its CSR range and clamped field offset
+  const int passes = a.passes, n_slots = a.n_colours * passes;
+  int sp[GIBBS_MAXS], q0[GIBBS_MAXS], q1[GIBBS_MAXS];
+  float hs[GIBBS_MAXS];
+#pragma unroll
+  for (int k = 0; k < GIBBS_MAXS; ++k) {
+    sp[k] = -1; q0[k] = 0; q1[k] = 0; hs[k] = 0.f;
+    if (k < n_slots) {
+      const int col = k / passes, pass = k - col * passes;
+      const int p = s_cls[col] + pass * LPC + l;
+      if (p < s_cls[col + 1]) {
+        const int i = s_order[p];
+        sp[k] = i; q0[k] = s_adjptr[i]; q1[k] = s_adjptr[i + 1]; hs[k] = s_hs[i];
+      }
+    }
+  }
+  u32x4 rr[GIBBS_MAXS];
+  const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
+  for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
+    const uint32_t tq = t >> 2, tw = t & 3u;
+    if (t == sweep0 || tw == 0u) {
+#pragma unroll
+      for (int k = 0; k < GIBBS_MAXS; ++k)
+        if (sp[k] >= 0) rr[k] = philox4x32_10((uint32_t)sp[k], cid, tq, STREAM_GIBBS, a.k0, a.k1);
+    }
+#pragma unroll
+    for (int k = 0; k < GIBBS_MAXS; ++k) {
+      if (k < n_slots) {
+        if (sp[k] >= 0) {
+          float f = hs[k];
+          const int qe = q1[k];
+          for (int q = q0[k]; q < qe; q += 8) {
+            int idx[8];
+            float w[8];
+            int8_t sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int qq = q + u < qe ? q + u : qe - 1;  // clamped: the batch is one straight line of LDS reads
+              idx[u] = s_adjidx[qq];
+              w[u] = s_adjJ[qq];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sv[u] = st[idx[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (q + u < qe) f = __fadd_rn(f, sv[u] > 0 ? w[u] : -w[u]);
+          }
+          const float z = clampf(__fmul_rn(a.two_beta, f), -87.0f, 87.0f);
+          const float tt = spec_exp(z);
+          const float u01 = u32_to_unit(pick(rr[k], tw));
+          const float b = __fmul_rn(u01, __fadd_rn(1.0f, tt));
+          st[sp[k]] = (b < 1.0f) ? 1 : -1;
+        }
+        // the next class reads what this one wrote (same wave): order LDS traffic.  (Passes of one class are
+        // independent of each other, so a fence between them is harmless.)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  int8_t* dst = a.state + (size_t)chain * n;
+  for (int i = l; i < n; i += LPC) {
+    const int8_t v = st[i];
+    dst[i] = v;
+    if (a.samples_out) a.samples_out[(size_t)chain * n + i] = (float)v;
+  }
+}
+
 static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_block) {
   size_t b = 0;
   b += sizeof(float) * (size_t)(n + n_adj);
@@ -125,14 +256,16 @@ static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_bl
 }
 
 template <int LPC, int WAVES>
-static int launch_gibbs(const GibbsArgs& a, hipStream_t s) {
+static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
+  a.passes = (max_class + LPC - 1) / LPC;
+  fast = fast && a.n_colours * a.passes <= GIBBS_MAXS;
   constexpr int CPB = WAVES * (64 / LPC);
   const size_t lds = gibbs_lds_bytes(a.n, a.n_adj, a.n_colours, CPB);
   if (lds > 160 * 1024) {
     set_error("gibbs: graph (n=%d, 2|E|=%d) needs %zu B of LDS > 160 KiB", a.n, a.n_adj, lds);
     return DVG_E_UNSUPPORTED;
   }
-  auto kern = gibbs_kernel<LPC, WAVES>;
+  auto kern = fast ? gibbs_fast_kernel<LPC, WAVES> : gibbs_kernel<LPC, WAVES>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)ceil_div(a.n_chains, CPB);
@@ -167,8 +300,11 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
   const int mc = g->max_class;
   const bool big = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 4) > 72 * 1024;
-  if (mc <= 16) return launch_gibbs<16, 4>(a, s);
-  if (mc <= 32) return launch_gibbs<32, 4>(a, s);
-  if (big) return launch_gibbs<64, 2>(a, s);
-  return launch_gibbs<64, 4>(a, s);
+  // (DVG_GIBBS_GENERIC=1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
+  static const bool force_generic = [] { const char* e = getenv("DVG_GIBBS_GENERIC"); return e && e[0] == '1'; }();
+  const bool fast = !force_generic;
+  if (mc <= 16) return launch_gibbs<16, 4>(a, s, fast, mc);
+  if (mc <= 32) return launch_gibbs<32, 4>(a, s, fast, mc);
+  if (big) return launch_gibbs<64, 2>(a, s, fast, mc);
+  return launch_gibbs<64, 4>(a, s, fast, mc);
 }

@@ -25,7 +25,8 @@ def _model(plan, rng):
 
 
 @pytest.mark.parametrize("fam,n,C,sweeps", [("pegasus", 64, 37, 3), ("zephyr", 128, 256, 5), ("pegasus", 256, 130, 4),
-                                             ("zephyr", 512, 64, 3), ("zephyr", 1024, 9, 2)])
+                                             ("zephyr", 512, 64, 3), ("zephyr", 1024, 9, 2), ("pegasus", 128, 256, 50),
+                                             ("zephyr", 512, 33, 13)])
 def test_gibbs_bit_exact(fam, n, C, sweeps):
     plan, nodes = _plan(fam, n)
     rng = np.random.default_rng(n)
