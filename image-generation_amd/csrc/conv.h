@@ -36,8 +36,16 @@ enum WeightMode : int {
   WM_CONVT_FWD,       // ConvTranspose2d weight (Cin,Cout,3,3): a = ci, b = co, taps flipped
   WM_CONVT_DGRAD,     // a = co, b = ci
   WM_LIN_FWD,         // Linear (4n, n): a = ci, b = p*n + c  <->  row c*4 + p   (NHWC output)
-  WM_LIN_DGRAD        // a = p*n + c, b = ci
+  WM_LIN_DGRAD,       // a = p*n + c, b = ci
+  // ConvTranspose2d behind a nearest Upsample(x2), folded (see ConvArgs.fold): 16 "taps" = 4 output parity classes
+  // x 2x2 source pixels; each packed entry is the SUM of the 1, 2 or 4 original taps that read that source pixel
+  WM_CONVT_FOLD_FWD,  // tap = cls*4 + t: a = ci, b = co
+  WM_CONVT_FOLD_DGRAD // tap = cls*4 + t: a = co, b = ci
 };
+
+// Folding a 3x3 kernel over a x2-upsampled input: output pixel (2i+pa, 2j+pb) reads source rows i-1+pa+dr, dr in
+// {0,1}; kernel row r (0..2, forward-GEMM tap order) lands on dr = fold_src(pa, r).
+__host__ __device__ __forceinline__ int fold_src(int parity, int r) { return parity == 0 ? (r >= 1) : (r >= 2); }
 
 struct WeightMap {
   int mode, Ca, Cb, ntaps;
@@ -54,6 +62,21 @@ __host__ __device__ __forceinline__ int64_t torch_weight_offset(const WeightMap&
   }
 }
 
+// Value of packed entry (tap, a, b): one checkpoint element, or for the folded layouts the sum (fixed order) of the
+// original taps that share a source pixel.
+__host__ __device__ __forceinline__ float packed_weight(const float* w, const WeightMap& m, int tap, int a, int b) {
+  if (m.mode != WM_CONVT_FOLD_FWD && m.mode != WM_CONVT_FOLD_DGRAD) return w[torch_weight_offset(m, tap, a, b)];
+  const int cls = tap >> 2, t = tap & 3, pa = cls >> 1, pb = cls & 1, dr = t >> 1, dc = t & 1;
+  const int ci = m.mode == WM_CONVT_FOLD_FWD ? a : b, co = m.mode == WM_CONVT_FOLD_FWD ? b : a;
+  const int Cout = m.mode == WM_CONVT_FOLD_FWD ? m.Cb : m.Ca;
+  float acc = 0.f;
+  for (int r = 0; r < 3; ++r)
+    for (int s = 0; s < 3; ++s)
+      if (fold_src(pa, r) == dr && fold_src(pb, s) == dc)
+        acc += w[((int64_t)ci * Cout + co) * 9 + (8 - (r * 3 + s))];  // ConvTranspose2d (Cin,Cout,3,3), taps flipped
+  return acc;
+}
+
 // Implicit-GEMM 3x3 (or 1-tap) convolution:  out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] Wp[tap][ci][co] (+ bias)
 struct ConvArgs {
   const float* in;    // [(images * HW_in), Cin]; HW_in = HW/4 when `ups` (nearest-upsampled on the fly)
@@ -67,11 +90,21 @@ struct ConvArgs {
   int ntaps;          // 9 or 1
   int ups;            // input is stored at half resolution
   int poolsum;        // sum each 2x2 output quad (adjoint of the upsample) before storing
+  // Folded upsample (x2 nearest) + 3x3: the 9 taps of an output pixel read only 2x2 distinct source pixels, so the
+  // layer is 4 GEMMs (one per output parity class) with 4 pre-summed taps each: 4/9 of the FLOPs.
+  //   fold = 1 (forward):  rows = SOURCE pixels (M = their count, L = log2 of the source side), ntaps = 4,
+  //            wp = [16][Cin][Cout] (WM_CONVT_FOLD_FWD); grid.x also spans the 4 classes; out row = 4*m + class.
+  //   fold = 2 (data gradient wrt the source map): rows = SOURCE pixels, ntaps = 16, `in` = dY at the output
+  //            resolution, wp = [16][Cout_fwd][Cin_fwd] (WM_CONVT_FOLD_DGRAD); out row = m.
+  int fold = 0;
   float* splitk_ws;   // scratch of conv_splitk_floats() floats, or null: never split K
   int ksplit;         // set by launch_conv_igemm
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);
+// fold = 1 launches: M source pixels; usable when conv_fold_ok (whole row blocks per class)
+bool conv_fold_ok(int64_t Msrc);
+int conv_stats_blocks_fold(int64_t Msrc, int Cout);
 // K-split chosen for a launch (1 = none) and the scratch it needs (0 = none)
 int conv_igemm_ksplit(int64_t M, int Cin, int Cout, int ntaps);
 size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum);  // number of m_blocks launch_conv_igemm will use (for `stats`)

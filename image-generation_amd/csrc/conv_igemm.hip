@@ -43,11 +43,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   __shared__ float As[BM * AP];
   __shared__ __align__(16) float Bs[BK * BP];
   __shared__ float red[WM * BN * 2];
-  __shared__ int nbr[BM * 9];            // source row of every (tile row, tap), -1 = zero padding
+  constexpr int NBS = 16;                // taps per row in the neighbour table (9, 4 or 16 used)
+  __shared__ int nbr[BM * NBS];          // source row of every (tile row, tap), -1 = zero padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, hh = lane >> 5, c = lane & 31;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  // fold = 1: grid.x = 4 output parity classes x row blocks of source pixels
+  const int mblocks = (int)((a.M + BM - 1) / BM);
+  const int cls = a.fold == 1 ? (int)blockIdx.x / mblocks : 0;
+  const int64_t m0 = (int64_t)(a.fold == 1 ? (int)blockIdx.x - cls * mblocks : (int)blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const int L = a.L, H = 1 << L, logHW = 2 * L;
   const int64_t HWin = a.ups ? ((int64_t)1 << logHW) >> 2 : ((int64_t)1 << logHW);
@@ -57,12 +61,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
     const int row = e / a.ntaps, tap = e - row * a.ntaps;
     const int64_t m = m0 + row;
     const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
-    const int dy = a.ntaps == 9 ? tap / 3 - 1 : 0, dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
+    int dy, dx, cq = 0;
+    if (a.fold == 1) {         // source pixel (i-1+pa+dr, j-1+pb+dc) of output class (pa, pb)
+      dy = (cls >> 1) - 1 + (tap >> 1); dx = (cls & 1) - 1 + (tap & 1);
+    } else if (a.fold == 2) {  // adjoint: the output pixel of class cq whose tap (dr, dc) read this source pixel
+      cq = tap >> 2;
+      dy = -((cq >> 1) - 1 + ((tap >> 1) & 1)); dx = -((cq & 1) - 1 + (tap & 1));
+    } else {
+      dy = a.ntaps == 9 ? tap / 3 - 1 : 0; dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
+    }
     const int yy = (int)morton_y(p) + dy, xx = (int)morton_x(p) + dx;
     const bool ok = m < a.M && yy >= 0 && yy < H && xx >= 0 && xx < H;
     uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
     if (a.ups) src >>= 2;
-    nbr[row * 9 + tap] = ok ? (int)((m >> logHW) * HWin + src) : -1;
+    const int64_t img = m >> logHW;
+    nbr[row * NBS + tap] = !ok ? -1 : a.fold == 2 ? (int)(img * (HWin << 2) + 4 * src + cq) : (int)(img * HWin + src);
   }
   __syncthreads();
 
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
         const uint32_t a_col = (uint32_t)(cc * 128 + ac4 * 16);
 #pragma unroll
         for (int q = 0; q < RA; ++q) {
-          const int src = nbr[((tid >> 3) + (NT >> 3) * q) * 9 + tap];
+          const int src = nbr[((tid >> 3) + (NT >> 3) * q) * NBS + tap];
           const bool ok = live && src >= 0;
           // Branch-free zero padding: always load (from a valid address); the 0/1 mask is applied when the
           // registers are parked in LDS, AFTER the MFMA loop.  (A select lets the compiler sink the load into a
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
           areg[h][q] = *reinterpret_cast<const f32x4*>(in_bytes + off);
           amask[h][q] = ok ? 1.0f : 0.0f;
         }
-        const uint32_t b_row0 = (uint32_t)(tap * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;
+        const uint32_t b_row0 = (uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           const int idx = tid + NT * q;
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
   // ---------------- epilogue
   if (a.ksplit > 1) {  // raw partial sums (quad-summed if asked); bias and BN partials happen in splitk_reduce_kernel
-    const int64_t rows_out = a.poolsum ? a.M >> 2 : a.M;
+    const int64_t rows_out = a.poolsum ? a.M >> 2 : (a.fold == 1 ? a.M << 2 : a.M);
     float* slab = a.splitk_ws + (size_t)blockIdx.z * rows_out * a.Cout;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
-            if (m < a.M) slab[m * a.Cout + col] = acc[i][j][r];
+            if (m < a.M) slab[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = acc[i][j][r];
           }
         }
       }
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
         const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
         if (m < a.M) {
           const float v = acc[i][j][r] + bias;
-          a.out[m * a.Cout + col] = v;
+          a.out[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = v;
           s1[j] += v;
           s2[j] = fmaf(v, v, s2[j]);
         }
@@ -311,7 +324,12 @@ static int igemm_cfg(int64_t M, int Cout) {
 
 int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_cfg(M, Cout) == 1 ? 64 : 128); }
 
+// fold = 1: tile config chosen on the OUTPUT pixel count (4 per source pixel); row blocks never straddle a class
+bool conv_fold_ok(int64_t Msrc) { return Msrc > 0 && Msrc % 128 == 0; }
+int conv_stats_blocks_fold(int64_t Msrc, int Cout) { return 4 * (int)ceil_div(Msrc, igemm_cfg(4 * Msrc, Cout) == 1 ? 64 : 128); }
+
 // K-split of the forward / data-gradient kernel: only for launches that would leave most CUs idle
+// (fold = 1 callers pass M = 4 * source pixels, ntaps = 4: same block count and K depth as the launch)
 int conv_igemm_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   const int cfg = igemm_cfg(M, Cout);
   const int64_t blocks = ceil_div(M, cfg == 1 ? 64 : 128) * (Cout / (cfg == 2 ? 32 : 64));
@@ -329,34 +347,42 @@ size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) 
 
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
-  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || (a.ntaps != 9 && a.ntaps != 1)) {
+  const bool taps_ok = a.fold == 1 ? a.ntaps == 4 : a.fold == 2 ? a.ntaps == 16 : (a.ntaps == 9 || a.ntaps == 1);
+  if (a.fold && (a.ups || a.poolsum || !conv_fold_ok(a.M))) {
+    set_error("conv_igemm: fold=%d needs ups=poolsum=0 and whole 128-row blocks (M=%lld)", a.fold, (long long)a.M);
+    return DVG_E_INVALID;
+  }
+  if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || !taps_ok) {
     set_error("conv_igemm: unsupported shape Cin=%d Cout=%d M=%lld ntaps=%d", a.Cin, a.Cout, (long long)a.M, a.ntaps);
     return DVG_E_INVALID;
   }
   // the kernel addresses its input and weights with 32-bit byte offsets
-  const double in_bytes = (double)(a.ups ? a.M / 4 : a.M) * a.Cin * 4.0;
+  const double in_bytes = (double)(a.ups ? a.M / 4 : (a.fold == 2 ? a.M * 4 : a.M)) * a.Cin * 4.0;
   if (in_bytes >= 4294967296.0 || a.M >= 2147483647LL) {
     set_error("conv_igemm: input tensor of %.0f bytes exceeds the 4 GiB addressing range of this kernel", in_bytes);
     return DVG_E_UNSUPPORTED;
   }
-  const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;  // algorithmic
-  a.ksplit = a.splitk_ws ? conv_igemm_ksplit(a.M, a.Cin, a.Cout, a.ntaps) : 1;
+  // FLOPs executed (the folded forms do 4/9 of the 9-tap count): what the roofline is priced on
+  const int64_t Mg = a.fold == 1 ? a.M * 4 : a.M;  // GEMM rows over all classes
+  const double flops = 2.0 * (double)Mg * a.Cin * a.Cout * a.ntaps;
+  a.ksplit = a.splitk_ws ? conv_igemm_ksplit(Mg, a.Cin, a.Cout, a.ntaps) : 1;
   const unsigned kz = (unsigned)a.ksplit;
-  const int cfg = igemm_cfg(a.M, a.Cout);
+  const int cfg = igemm_cfg(Mg, a.Cout);
+  const unsigned cm = a.fold == 1 ? 4u : 1u;
   switch (cfg) {
     case 0:
-      DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 64, kz), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), dim3(cm * (unsigned)ceil_div(a.M, 128), a.Cout / 64, kz), dim3(256), 0, s, a);
       break;
     case 1:
-      DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), dim3((unsigned)ceil_div(a.M, 64), a.Cout / 64, kz), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), dim3(cm * (unsigned)ceil_div(a.M, 64), a.Cout / 64, kz), dim3(256), 0, s, a);
       break;
     default:
-      DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), dim3((unsigned)ceil_div(a.M, 128), a.Cout / 32, kz), dim3(256), 0, s, a);
+      DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), dim3(cm * (unsigned)ceil_div(a.M, 128), a.Cout / 32, kz), dim3(256), 0, s, a);
       break;
   }
   if (a.ksplit > 1) {
     // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks
-    const int64_t rows_out = a.poolsum ? a.M / 4 : a.M;
+    const int64_t rows_out = a.poolsum ? a.M / 4 : Mg;
     const int bm = (cfg == 1 ? 64 : 128) / (a.poolsum ? 4 : 1);
     DVG_LAUNCH(K_MISC, splitk_reduce_kernel, dim3((unsigned)ceil_div(rows_out, bm), a.Cout / 32), dim3(256), 0, s, a.splitk_ws, a.ksplit,
                rows_out, a.Cout, a.bias, a.out, a.poolsum ? nullptr : a.stats, bm);
@@ -672,7 +698,7 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restric
     const int b = (int)(e % map.Cb);
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
-    wp[e] = w[torch_weight_offset(map, tap, a, b)];
+    wp[e] = packed_weight(w, map, tap, a, b);
   }
 }
 
@@ -686,7 +712,7 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
     const int b = (int)(e % map.Cb);
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
-    j.wp[e] = j.w[torch_weight_offset(map, tap, a, b)];
+    j.wp[e] = packed_weight(j.w, map, tap, a, b);
   }
 }
 

@@ -4,6 +4,8 @@
 //   previous stage fused into the gather (never materialised); layer 3 (32->1 @16x16) and the final 1->1 @32x32
 //   ConvTranspose: VALU kernels.  Each of layers 0-3 is followed by BN(batch stats) -> Dropout2d -> LeakyReLU.
 //   Backward data-gradients of the upsample-fused layers sum each 2x2 quad in the MFMA epilogue.
+#include <cstdlib>
+
 #include "conv.h"
 #include "kernels.h"
 
@@ -22,8 +24,15 @@ struct DecPlan {
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
   size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB, partW, splitk;
   int ksplit_lin, ksplit[3];
+  bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   size_t total_floats;
 };
+
+// DVG_NO_FOLD=1 keeps the upsample-fused 9-tap form everywhere (A/B runs)
+bool fold_enabled() {
+  static const bool off = [] { const char* e = getenv("DVG_NO_FOLD"); return e && e[0] == '1'; }();
+  return !off;
+}
 
 size_t bump(size_t& o, size_t count) {
   const size_t r = o;
@@ -51,7 +60,8 @@ DecPlan dec_plan(int64_t N, int n) {
     p.L[l] = l + 1;
     p.M[l] = N * ((int64_t)4 << (2 * l));
     const int C = ch[l + 1];
-    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : conv_stats_blocks(p.M[l], C);
+    p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
+    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xs[l] = bump(o, (size_t)p.M[l] * C);
     p.mean[l] = bump(o, C);
@@ -59,12 +69,13 @@ DecPlan dec_plan(int64_t N, int n) {
     p.stats[l] = bump(o, (size_t)p.nblk[l] * C * 2);
     p.mask[l] = bump(o, (size_t)N * C);
     if (l < 3) {
-      p.wp[l] = bump(o, (size_t)9 * ch[l] * C);
-      p.wpd[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.wp[l] = bump(o, (size_t)16 * ch[l] * C);   // 9 taps, or 16 folded (class, tap) pairs
+      p.wpd[l] = bump(o, (size_t)16 * ch[l] * C);
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
-      const size_t sk_f = conv_splitk_floats(p.M[l], ch[l], C, 9, 0), sk_d = conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
+      const size_t sk_f = p.fold[l] ? conv_splitk_floats(p.M[l], ch[l], C, 4, 0) : conv_splitk_floats(p.M[l], ch[l], C, 9, 0);
+      const size_t sk_d = p.fold[l] ? conv_splitk_floats(p.M[l] / 4, C, ch[l], 16, 0) : conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
       if (sk_f > max_split) max_split = sk_f;
       if (sk_d > max_split) max_split = sk_d;
     }
@@ -121,6 +132,11 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}};
     jobs[1] = PackJob{p->lin_w, W + pl.wpd_lin, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}};
     for (int l = 0; l < 3; ++l) {
+      if (pl.fold[l]) {
+        jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FOLD_FWD, pl.ch[l], pl.ch[l + 1], 16}};
+        jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_FOLD_DGRAD, pl.ch[l + 1], pl.ch[l], 16}};
+        continue;
+      }
       jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}};
       jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}};
     }
@@ -156,6 +172,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       a.in = x; a.wp = W + pl.wp[l]; a.bias = p->conv_b[l]; a.out = W + pl.Y[l];
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = l > 0; a.poolsum = 0;
+      if (pl.fold[l]) { a.M = pl.M[l] / 4; a.L = pl.L[l] - 1; a.ntaps = 4; a.ups = 0; a.fold = 1; }
       a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     } else {
@@ -227,6 +244,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     ConvArgs a;
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
+    if (pl.fold[l]) { a.M = pl.M[l] / 4; a.L = pl.L[l] - 1; a.ntaps = 16; a.poolsum = 0; a.fold = 2; }
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
