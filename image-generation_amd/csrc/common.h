@@ -53,6 +53,7 @@ enum KernelId : int {
   K_WGRAD_2x1,
   K_WGRAD_1x2,
   K_WGRAD_1x1,
+  K_WGRAD_FOLD,     // conv_wgrad_fold_kernel
   K_WGRAD_REDUCE,
   K_WEIGHT_PACK,
   K_BN_FINALIZE,

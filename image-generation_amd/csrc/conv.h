@@ -116,8 +116,14 @@ struct WgradArgs {
   float* slabs;      // [ksplit][ntaps][Cin][Cout]
   int64_t M;
   int Cin, Cout, L, ntaps, ups, ksplit;
+  // fold = 1: weight gradient of the folded Upsample(x2)+3x3 layer (ConvArgs.fold): `in` is the SOURCE map (M source
+  // pixels, side 2^L), `dy` has 4*M rows, ntaps = 16 and the slabs hold the 16 (class, tap) pairs; the reduce pass
+  // (launch_wgrad_reduce with fold = true) sums the 4 classes back onto the 9 checkpoint taps.
+  int fold = 0;
 };
 int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps);
+int wgrad_fold_ksplit(int64_t Msrc, int Cin, int Cout);
+int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);

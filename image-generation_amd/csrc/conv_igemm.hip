@@ -624,6 +624,156 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void conv_wgrad9_kernel(WgradArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, folded upsample
+// Weight gradient of Upsample(x2) + ConvTranspose 3x3 in the folded form (conv.h: ConvArgs.fold):
+//     dWf[cls][t][ci][co] = sum_q X[q + off(cls, t)][ci] * dY[4q + cls][co],   off = (pa-1+dr, pb-1+dc)
+// over SOURCE pixels q: 16 (class, tap) pairs x 1/4 of the pixels = 4/9 of the 9-tap FLOPs.  A chunk is 32 source
+// pixels: their haloed patch of X is staged once (as in conv_wgrad9_kernel) together with the 128 CONTIGUOUS dY rows
+// of their 4 output pixels each (Morton order).  One wave per parity class: it needs one dY row and 4 shifted X rows
+// per pixel pair, 4 accumulator tiles.
+__global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(WgradArgs a) {
+  constexpr int NT = 256, BA = 32, BB = 32, XP = BA + 4, YP = BB + 4, SMAX = 128;
+  __shared__ __align__(16) float Xs[SMAX * XP];
+  __shared__ __align__(16) float Ys[128 * YP];
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int cls = __builtin_amdgcn_readfirstlane(tid >> 6), pa = cls >> 1, pb = cls & 1;
+  const int tiles_b = a.Cout / BB;
+  const int a0 = (blockIdx.x / tiles_b) * BA, b0 = (blockIdx.x % tiles_b) * BB;
+  const int z = blockIdx.y;
+  const int L = a.L, H = 1 << L, logHW = 2 * L, HW = 1 << logHW;
+  const int ph = H < 4 ? H : 4, pw = H < 8 ? H : 8;
+  const int SW = pw + 2, SP = (ph + 2) * SW;
+  const int pix_per_img = HW < 32 ? HW : 32;
+  const int nimg = 32 / pix_per_img;
+  const int S = nimg * SP;
+  int64_t per = (a.M + a.ksplit - 1) / a.ksplit;
+  per = (per + 31) & ~(int64_t)31;
+  const int64_t mbeg = (int64_t)z * per;
+  const int64_t mend = mbeg + per < a.M ? mbeg + per : a.M;
+
+  int base_slot[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = 2 * s + hh;
+    const uint32_t p = (uint32_t)(k & (pix_per_img - 1));
+    base_slot[s] = (k / pix_per_img) * SP + ((int)morton_y(p) + 1) * SW + (int)morton_x(p) + 1;
+  }
+  int shift[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) shift[t] = ((pa - 1 + (t >> 1)) * SW + (pb - 1 + (t & 1))) * XP;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x16){0};
+
+  constexpr int RX = SMAX * (BA / 4) / NT;  // 4
+  constexpr int RY = 128 * (BB / 4) / NT;   // 4
+  const int nx = S * (BA / 4);
+  const int64_t nchunks = mbeg < mend ? (mend - mbeg + 31) / 32 : 0;
+  int q_il[RX], q_dy[RX], q_dx[RX];
+  uint32_t q_col[RX];
+  bool q_live[RX];
+#pragma unroll
+  for (int q = 0; q < RX; ++q) {
+    const int e = tid + NT * q;
+    const int slot = e / (BA / 4), c4 = e % (BA / 4);
+    const int il = slot / SP, r = slot - il * SP;
+    q_il[q] = il; q_dy[q] = r / SW - 1; q_dx[q] = r % SW - 1;
+    q_col[q] = (uint32_t)(a0 + c4 * 4);
+    q_live[q] = e < nx;
+  }
+  for (int64_t it = 0; it <= nchunks; ++it) {
+    f32x4 xreg[RX], yreg[RY];
+    float xmask[RX], ymask[RY];
+    if (it < nchunks) {
+      const int64_t m1 = mbeg + it * 32;
+      const int64_t img0 = m1 >> logHW;
+      const uint32_t p0 = (uint32_t)(m1 & (HW - 1));
+      const int y0 = (int)morton_y(p0), x0 = (int)morton_x(p0);
+#pragma unroll
+      for (int q = 0; q < RX; ++q) {
+        const int y = y0 + q_dy[q], x = x0 + q_dx[q];
+        const int64_t img = img0 + q_il[q];
+        const bool ok = q_live[q] && y >= 0 && y < H && x >= 0 && x < H && img * HW < a.M;
+        const uint32_t src = morton((uint32_t)y, (uint32_t)x);
+        xreg[q] = *reinterpret_cast<const f32x4*>(a.in + (ok ? (img * HW + src) * a.Cin + q_col[q] : 0));
+        xmask[q] = ok ? 1.0f : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < RY; ++q) {
+        const int e = tid + NT * q;
+        const int row = e / (BB / 4), c4 = e % (BB / 4);
+        const int64_t m = 4 * m1 + row;  // output pixel: 4 * source pixel + class
+        const bool ok = m < 4 * mend;
+        yreg[q] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? m * a.Cout + b0 + c4 * 4 : 0));
+        ymask[q] = ok ? 1.0f : 0.0f;
+      }
+    }
+    if (it > 0) {
+      const float* xp = Xs + c;
+      const float* yp = Ys + cls * YP + c;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float bv = yp[4 * (2 * s + hh) * YP];
+        const float* xr = xp + base_slot[s] * XP;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[shift[t]], bv, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (it < nchunks) {
+#pragma unroll
+      for (int q = 0; q < RX; ++q) {
+        const int e = tid + NT * q;
+        if (e < nx) *reinterpret_cast<f32x4*>(Xs + (e / (BA / 4)) * XP + (e % (BA / 4)) * 4) = xreg[q] * xmask[q];
+      }
+#pragma unroll
+      for (int q = 0; q < RY; ++q) {
+        const int e = tid + NT * q;
+        *reinterpret_cast<f32x4*>(Ys + (e / (BB / 4)) * YP + (e % (BB / 4)) * 4) = yreg[q] * ymask[q];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float* dst = a.slabs + (((size_t)z * 16 + cls * 4 + t) * a.Cin + a0) * a.Cout + b0 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[t][r];
+  }
+}
+
+int wgrad_fold_ksplit(int64_t Msrc, int Cin, int Cout) {
+  const int64_t tiles = (int64_t)(Cin / 32) * (Cout / 32);
+  int64_t k = 512 / tiles;  // two 4-wave blocks are resident per CU (4 accumulator tiles per wave)
+  const int64_t kmax = ceil_div(Msrc, 64);
+  if (k > kmax) k = kmax;
+  if (k > 256) k = 256;
+  return (int)(k < 1 ? 1 : k);
+}
+
+// Sums the slabs in order AND the 4 parity classes back onto the 9 taps; scatters into the ConvTranspose2d layout.
+__global__ __launch_bounds__(256) void wgrad_fold_reduce_kernel(const float* __restrict__ slabs, int ksplit, int Cin, int Cout,
+                                                                float* __restrict__ grad_w) {
+  const int64_t plane = (int64_t)Cin * Cout, total = 9 * plane;
+  const int sub = threadIdx.x & 7;
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += ((int64_t)gridDim.x * 256) >> 3) {
+    const int tap = (int)(e / plane);
+    const int64_t ab = e - (int64_t)tap * plane;  // ci * Cout + co
+    const int r = tap / 3, sx = tap % 3;
+    float s = 0.f;
+    for (int k = sub; k < ksplit; k += 8) {
+      const float* sl = slabs + (size_t)k * 16 * plane + ab;
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls)
+        s += sl[(size_t)(cls * 4 + fold_src(cls >> 1, r) * 2 + fold_src(cls & 1, sx)) * plane];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) grad_w[ab * 9 + (8 - tap)] = s;
+  }
+}
+
 int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   const int ba = (Cin % 64 == 0) ? 64 : 32, bb = (Cout % 64 == 0) ? 64 : 32;
   const int64_t tiles = (int64_t)(Cin / ba) * (Cout / bb);
@@ -652,6 +802,13 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.ksplit < 1) {
     set_error("conv_wgrad: unsupported shape Cin=%d Cout=%d M=%lld", a.Cin, a.Cout, (long long)a.M);
     return DVG_E_INVALID;
+  }
+  if (a.fold) {
+    if (a.ntaps != 16 || a.ups) { set_error("conv_wgrad: fold needs ntaps=16, ups=0"); return DVG_E_INVALID; }
+    const double fl = 2.0 * (double)a.M * a.Cin * a.Cout * 16;  // executed FLOPs (4/9 of the 9-tap form)
+    DVG_LAUNCH_WORK(K_WGRAD_FOLD, fl, conv_wgrad_fold_kernel, dim3((unsigned)((a.Cin / 32) * (a.Cout / 32)), (unsigned)a.ksplit),
+                    dim3(256), 0, s, a);
+    return DVG_OK;
   }
   const bool a64 = a.Cin % 64 == 0, b64 = a.Cout % 64 == 0;
   const int ba = a64 ? 64 : 32, bb = b64 ? 64 : 32;
@@ -740,6 +897,12 @@ static unsigned ew_grid(int64_t n) {
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_kernel, dim3(ew_grid(total * 8)), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+  return DVG_OK;
+}
+
+int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s) {
+  DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_fold_reduce_kernel, dim3(ew_grid((int64_t)9 * Cin * Cout * 8)), dim3(256), 0, s, slabs, ksplit,
+             Cin, Cout, grad_w);
   return DVG_OK;
 }
 

@@ -71,8 +71,8 @@ DecPlan dec_plan(int64_t N, int n) {
     if (l < 3) {
       p.wp[l] = bump(o, (size_t)16 * ch[l] * C);   // 9 taps, or 16 folded (class, tap) pairs
       p.wpd[l] = bump(o, (size_t)16 * ch[l] * C);
-      p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
-      const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
+      p.ksplit[l] = p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
+      const size_t slab = (size_t)p.ksplit[l] * (p.fold[l] ? 16 : 9) * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
       const size_t sk_f = p.fold[l] ? conv_splitk_floats(p.M[l], ch[l], C, 4, 0) : conv_splitk_floats(p.M[l], ch[l], C, 9, 0);
       const size_t sk_d = p.fold[l] ? conv_splitk_floats(p.M[l] / 4, C, ch[l], 16, 0) : conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
@@ -251,8 +251,14 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
-    DVG_TRY(launch_conv_wgrad(wa, s2));
-    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    if (pl.fold[l]) {
+      wa.M = pl.M[l] / 4; wa.L = pl.L[l] - 1; wa.ntaps = 16; wa.ups = 0; wa.fold = 1;
+      DVG_TRY(launch_conv_wgrad(wa, s2));
+      DVG_TRY(launch_wgrad_fold_reduce(W + pl.slabs, pl.ksplit[l], Cin, C, g->conv_w[l], s2));
+    } else {
+      DVG_TRY(launch_conv_wgrad(wa, s2));
+      DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    }
     if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[l]));
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
