@@ -37,6 +37,53 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[K], const ChanMa
   __syncthreads();
 }
 
+// ---------------------------------------------------------------- float4-of-channels variants (C % 32 == 0)
+// The BN tails are pure streaming passes; with one float per thread they were latency-bound (one 4-byte load per
+// tensor per iteration, ~1-1.7 TB/s on L2/MALL-resident tensors).  Here a thread owns 4 consecutive channels
+// (16-byte loads, a wave covers whole rows) and walks two rows per iteration.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct Chan4 {
+  int CQ, RL, cq, rl;  // channel quads per pass (<= 256), rows per pass, this thread's quad and row lane
+  __device__ Chan4(int C) {
+    CQ = (C >> 2) < 256 ? (C >> 2) : 256;
+    RL = 256 / CQ;
+    cq = threadIdx.x % CQ;
+    rl = threadIdx.x / CQ;
+  }
+};
+__device__ __forceinline__ f32x4v ld4(const float* p) { return *reinterpret_cast<const f32x4v*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4v v) { *reinterpret_cast<f32x4v*>(p) = v; }
+
+// red: [K][4][256]; partials land planar as [block][k][C] like block_reduce_store
+template <int K>
+__device__ __forceinline__ void block_reduce_store4(f32x4v (&acc)[K], const Chan4& cm, float* red, float* dst_base,
+                                                    int C, int c0) {
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(k * 4 + j) * 256 + threadIdx.x] = acc[k][j];
+  __syncthreads();
+  if (cm.rl == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      f32x4v t = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < cm.RL; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] += red[(k * 4 + j) * 256 + r * cm.CQ + cm.cq];
+      st4(dst_base + ((size_t)blockIdx.x * K + k) * C + c0 + 4 * cm.cq, t);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void enc_bn_pool_fwd_v4_kernel(const float* __restrict__ Y, int64_t Q, int C, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, int lrelu, float* __restrict__ out);
+__global__ void dec_bn_act_fwd_v4_kernel(const float* __restrict__ Y, int64_t M, int C, int logHW,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mask, float* __restrict__ X);
+
 // ---------------------------------------------------------------- generic column sums of partials
 // one wavefront per output element: lanes stride over the G partials, fixed-shape shuffle tree in
 // double -> deterministic and ~G/64 dependent adds deep instead of G
@@ -187,6 +234,12 @@ __global__ __launch_bounds__(256) void enc_bn_pool_fwd_kernel(const float* __res
 
 int launch_enc_bn_pool_fwd(const float* Y, int64_t Q, int C, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, int lrelu, float* out, hipStream_t s) {
+  if (C % 32 == 0) {
+    const int64_t b4 = ceil_div(Q * (C / 4), 256);
+    DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_bn_pool_fwd_v4_kernel, dim3((unsigned)(b4 > 2048 ? 2048 : b4)), dim3(256), 0, s, Y, Q,
+               C, mean, invstd, gamma, beta, lrelu, out);
+    return DVG_OK;
+  }
   const int64_t b = ceil_div(Q * C, 256);
   DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_bn_pool_fwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, Y, Q, C,
              mean, invstd, gamma, beta, lrelu, out);
@@ -263,9 +316,108 @@ __global__ __launch_bounds__(256) void enc_bn_pool_bwd_apply_kernel(const float*
   }
 }
 
+// ---- encoder stage, float4-of-channels variants
+__global__ __launch_bounds__(256) void enc_bn_pool_fwd_v4_kernel(const float* __restrict__ Y, int64_t Q, int C,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int lrelu,
+                                                                 float* __restrict__ out) {
+  const Chan4 cm(C);
+  for (int c0 = 0; c0 < C; c0 += 4 * cm.CQ) {
+    const int c = c0 + 4 * cm.cq;
+    const f32x4v mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    for (int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl; q < Q; q += (int64_t)gridDim.x * cm.RL) {
+      const float* y = Y + (q * 4) * C + c;
+      f32x4v w[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w[s] = ld4(y + (size_t)s * C);
+      f32x4v o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float best = fmaf((w[0][j] - mu[j]) * is[j], g[j], b[j]);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) {
+          const float z = fmaf((w[s][j] - mu[j]) * is[j], g[j], b[j]);
+          best = z > best ? z : best;  // strict: the first maximum wins, as in torch's max_pool2d
+        }
+        o[j] = (lrelu && best < 0.f) ? best * LRELU_SLOPE : best;
+      }
+      st4(out + q * C + c, o);
+    }
+  }
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void enc_bn_pool_bwd_v4_kernel(const float* __restrict__ Y, int64_t Q, int C,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int lrelu,
+                                                                 const float* __restrict__ dOut,
+                                                                 const float* __restrict__ sum_dz,
+                                                                 const float* __restrict__ sum_dzzh, float inv_m,
+                                                                 float* __restrict__ dY, float* __restrict__ part) {
+  __shared__ float red[2 * 4 * 256];
+  const Chan4 cm(C);
+  for (int c0 = 0; c0 < C; c0 += 4 * cm.CQ) {
+    const int c = c0 + 4 * cm.cq;
+    const f32x4v mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    f32x4v m1 = {0.f, 0.f, 0.f, 0.f}, m2 = m1;
+    if (APPLY) { m1 = ld4(sum_dz + c) * inv_m; m2 = ld4(sum_dzzh + c) * inv_m; }
+    f32x4v acc[APPLY ? 1 : 2];
+#pragma unroll
+    for (int k = 0; k < (APPLY ? 1 : 2); ++k) acc[k] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl; q < Q; q += (int64_t)gridDim.x * cm.RL) {
+      const float* y = Y + (q * 4) * C + c;
+      f32x4v w[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) w[s] = ld4(y + (size_t)s * C);
+      const f32x4v go = ld4(dOut + q * C + c);
+      f32x4v v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // recompute the window: argmax, its zhat, and the LeakyReLU slope at the pooled value
+        float zh[4], best = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          zh[s] = (w[s][j] - mu[j]) * is[j];
+          const float z = fmaf(zh[s], g[j], b[j]);
+          if (s == 0 || z > best) { best = z; arg = s; }
+        }
+        const float slope = (lrelu && !(best > 0.f)) ? LRELU_SLOPE : 1.0f;
+        const float dz = go[j] * slope;
+        if (APPLY) {
+          const float gi = g[j] * is[j];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float val = gi * (((s == arg) ? dz : 0.f) - m1[j] - zh[s] * m2[j]);
+            v[s][j] = val;
+            acc[0][j] += val;
+          }
+        } else {
+          acc[0][j] += dz;
+          acc[APPLY ? 0 : 1][j] = fmaf(dz, zh[arg], acc[APPLY ? 0 : 1][j]);
+        }
+      }
+      if (APPLY) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) st4(dY + (q * 4 + s) * C + c, v[s]);
+      }
+    }
+    block_reduce_store4<APPLY ? 1 : 2>(acc, cm, red, part, C, c0);
+  }
+}
+
 int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
                                   const float* gamma, const float* beta, int lrelu, const float* dOut, float* part,
                                   hipStream_t s) {
+  if (C % 32 == 0) {
+    DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_bn_pool_bwd_v4_kernel<false>, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
+               invstd, gamma, beta, lrelu, dOut, nullptr, nullptr, 0.f, nullptr, part);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_bn_pool_bwd_reduce_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
              invstd, gamma, beta, lrelu, dOut, part);
   return DVG_OK;
@@ -274,6 +426,11 @@ int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float*
 int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
                                  const float* gamma, const float* beta, int lrelu, const float* dOut, const float* sum_dz,
                                  const float* sum_dzzh, float* dY, float* part_db, hipStream_t s) {
+  if (C % 32 == 0) {
+    DVG_LAUNCH(K_ENC_BN_POOL_BWD_APPLY, enc_bn_pool_bwd_v4_kernel<true>, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
+               invstd, gamma, beta, lrelu, dOut, sum_dz, sum_dzzh, (float)(1.0 / (4.0 * (double)Q)), dY, part_db);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_ENC_BN_POOL_BWD_APPLY, enc_bn_pool_bwd_apply_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
              invstd, gamma, beta, lrelu, dOut, sum_dz, sum_dzzh, (float)(1.0 / (4.0 * (double)Q)), dY, part_db);
   return DVG_OK;
@@ -325,6 +482,12 @@ __global__ __launch_bounds__(256) void dec_bn_act_fwd_kernel(const float* __rest
 
 int launch_dec_bn_act_fwd(const float* Y, int64_t M, int C, int logHW, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const float* mask, float* X, hipStream_t s) {
+  if (C % 32 == 0) {
+    const int64_t b4 = ceil_div(M * (C / 4), 256);
+    DVG_LAUNCH(K_DEC_BN_ACT_FWD, dec_bn_act_fwd_v4_kernel, dim3((unsigned)(b4 > 2048 ? 2048 : b4)), dim3(256), 0, s, Y, M, C,
+               logHW, mean, invstd, gamma, beta, mask, X);
+    return DVG_OK;
+  }
   const int64_t b = ceil_div(M * C, 256);
   DVG_LAUNCH(K_DEC_BN_ACT_FWD, dec_bn_act_fwd_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, Y, M, C,
              logHW, mean, invstd, gamma, beta, mask, X);
@@ -390,8 +553,86 @@ __global__ __launch_bounds__(256) void dec_bn_act_bwd_apply_kernel(const float* 
   }
 }
 
+// ---- decoder stage, float4-of-channels variants
+__global__ __launch_bounds__(256) void dec_bn_act_fwd_v4_kernel(const float* __restrict__ Y, int64_t M, int C, int logHW,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ mask, float* __restrict__ X) {
+  const Chan4 cm(C);
+  const float keep_scale = 1.0f / DROPOUT_KEEP;
+  for (int c0 = 0; c0 < C; c0 += 4 * cm.CQ) {
+    const int c = c0 + 4 * cm.cq;
+    const f32x4v mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    for (int64_t m = (int64_t)blockIdx.x * cm.RL + cm.rl; m < M; m += (int64_t)gridDim.x * cm.RL) {
+      const f32x4v y = ld4(Y + m * C + c);
+      f32x4v mk = {1.f, 1.f, 1.f, 1.f};
+      if (mask) mk = ld4(mask + (m >> logHW) * C + c) * keep_scale;
+      f32x4v o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = fmaf((y[j] - mu[j]) * is[j], g[j], b[j]);
+        if (mask) z *= mk[j];
+        o[j] = z < 0.f ? z * LRELU_SLOPE : z;
+      }
+      st4(X + m * C + c, o);
+    }
+  }
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void dec_bn_act_bwd_v4_kernel(const float* __restrict__ Y, const float* __restrict__ X,
+                                                                int64_t M, int C, int logHW,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ mask,
+                                                                const float* __restrict__ dX,
+                                                                const float* __restrict__ sum_dz,
+                                                                const float* __restrict__ sum_dzzh, float inv_m,
+                                                                float* __restrict__ dY, float* __restrict__ part) {
+  __shared__ float red[2 * 4 * 256];
+  const Chan4 cm(C);
+  const float keep_scale = 1.0f / DROPOUT_KEEP;
+  for (int c0 = 0; c0 < C; c0 += 4 * cm.CQ) {
+    const int c = c0 + 4 * cm.cq;
+    const f32x4v mu = ld4(mean + c), is = ld4(invstd + c);
+    f32x4v gi = {0.f, 0.f, 0.f, 0.f}, m1 = gi, m2 = gi;
+    if (APPLY) { gi = ld4(gamma + c) * is; m1 = ld4(sum_dz + c) * inv_m; m2 = ld4(sum_dzzh + c) * inv_m; }
+    f32x4v acc[APPLY ? 1 : 2];
+#pragma unroll
+    for (int k = 0; k < (APPLY ? 1 : 2); ++k) acc[k] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    for (int64_t m = (int64_t)blockIdx.x * cm.RL + cm.rl; m < M; m += (int64_t)gridDim.x * cm.RL) {
+      const int64_t e = m * C + c;
+      const f32x4v dx = ld4(dX + e), x = ld4(X + e), y = ld4(Y + e);
+      f32x4v mk = {1.f, 1.f, 1.f, 1.f};
+      if (mask) mk = ld4(mask + (m >> logHW) * C + c) * keep_scale;
+      f32x4v v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dz = dx[j] * ((x[j] > 0.f) ? 1.0f : LRELU_SLOPE) * mk[j];
+        if (APPLY) {
+          v[j] = gi[j] * (dz - m1[j] - (y[j] - mu[j]) * is[j] * m2[j]);
+          acc[0][j] += v[j];
+        } else {
+          acc[0][j] += dz;
+          acc[APPLY ? 0 : 1][j] = fmaf(dz, (y[j] - mu[j]) * is[j], acc[APPLY ? 0 : 1][j]);
+        }
+      }
+      if (APPLY) st4(dY + e, v);
+    }
+    block_reduce_store4<APPLY ? 1 : 2>(acc, cm, red, part, C, c0);
+  }
+}
+
 int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
                                  const float* invstd, const float* mask, const float* dX, float* part, hipStream_t s) {
+  if (C % 32 == 0) {
+    DVG_LAUNCH(K_DEC_BN_ACT_BWD_REDUCE, dec_bn_act_bwd_v4_kernel<false>, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
+               mean, invstd, nullptr, mask, dX, nullptr, nullptr, 0.f, nullptr, part);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_DEC_BN_ACT_BWD_REDUCE, dec_bn_act_bwd_reduce_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
              mean, invstd, mask, dX, part);
   return DVG_OK;
@@ -400,6 +641,11 @@ int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int 
 int launch_dec_bn_act_bwd_apply(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
                                 const float* invstd, const float* gamma, const float* mask, const float* dX,
                                 const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db, hipStream_t s) {
+  if (C % 32 == 0) {
+    DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_bn_act_bwd_v4_kernel<true>, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
+               mean, invstd, gamma, mask, dX, sum_dz, sum_dzzh, (float)(1.0 / (double)M), dY, part_db);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_bn_act_bwd_apply_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, X, M, C, logHW,
              mean, invstd, gamma, mask, dX, sum_dz, sum_dzzh, (float)(1.0 / (double)M), dY, part_db);
   return DVG_OK;

@@ -271,15 +271,17 @@ class ModelWrapper:
             spins = self._dvae.latent_to_discrete(latents, self.N_REPLICAS)
             spins_ready = torch.cuda.Event()
             spins_ready.record(main)
-            # (the main-stream work is enqueued first: under hipGraph capture the first child captured after a fork
-            # keeps the parent's hardware queue, and the decoder chain is the critical path)
-            reconstructed_images = self._dvae.decoder(spins)
+            # Order of enqueueing matters under hipGraph capture: the first child captured after a fork keeps the
+            # parent's hardware queue (so one main-stream node -- the gradient-buffer memset -- goes first and the
+            # decoder chain, the critical path, stays on its queue), and a replay submits nodes in capture order (so
+            # the MMD is captured BEFORE the ~50 decoder-forward nodes, not behind them).
             self._dvae_optimizer.zero_grad()
-            mse_loss = F.replicated_mse_loss(reconstructed_images, images)
             side.wait_event(spins_ready)
             with torch.cuda.stream(side):
                 flat = spins.reshape(-1, spins.shape[-1])
                 _mmd_loss = maximum_mean_discrepancy_loss(x=flat, y=samples, kernel=self._tpar["kernel"])
+            reconstructed_images = self._dvae.decoder(spins)
+            mse_loss = F.replicated_mse_loss(reconstructed_images, images)
             main.wait_stream(side)
             dvae_loss = mse_loss + _mmd_loss
             dvae_loss.backward()
