@@ -22,7 +22,7 @@ struct DecPlan {
   int nblk[4];
   size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
-  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB, partW, splitk;
+  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB[4], partL, partW, partF, splitk;
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   size_t total_floats;
@@ -88,7 +88,10 @@ DecPlan dec_plan(int64_t N, int n) {
   p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
-  p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
+  // one bias-gradient partial buffer per layer: their column sums run on the side stream, behind the main chain
+  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);
+  p.partL = bump(o, (size_t)EW_BLOCKS * cmax);
+  p.partF = bump(o, (size_t)EW_BLOCKS * 10);
   p.partW = bump(o, (size_t)EW_BLOCKS * 288);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
@@ -205,13 +208,18 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
   float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
   hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
-  float* partB = W + pl.partB;
   float* partW = W + pl.partW;
 
-  // final ConvTranspose2d(1,1): weight/bias gradient, then gradient wrt Xs[3] (16x16, quad-summed)
-  DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, partW, s));
-  DVG_TRY(launch_colsum2(partW, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4], s));
-  DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
+  // final ConvTranspose2d(1,1): gradient wrt Xs[3] (16x16, quad-summed) on the caller's stream; its weight/bias
+  // gradient on the side stream (main-chain kernel first: see the fork note below)
+  {
+    hipEvent_t start = nullptr;
+    if (s2 != s) DVG_TRY(stream_mark(s, &start));
+    DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
+    if (s2 != s) DVG_TRY(stream_wait_mark(s2, start));
+    DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
+    DVG_TRY(launch_colsum2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4], s2));
+  }
 
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
@@ -225,8 +233,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
     if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
-                                        mask, dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
-    DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
+                                        mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     // Fork: dY is ready.  The caller's-stream kernel is enqueued BEFORE the side-stream ones: when the call is being
     // captured into a hipGraph, the first child captured after a fork inherits the parent's hardware queue, and a
     // data-gradient chain that changes queue at every layer pays a cross-queue signal (~10-15 us) per hop.
@@ -236,6 +243,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     if (l == 3) {
       DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
       if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+      DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
       DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
       DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
       if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[3]));
@@ -248,6 +256,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+    DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
@@ -265,8 +274,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
   {
     hipEvent_t dx_ready = nullptr;  // dX is final
     if (s2 != s) DVG_TRY(stream_mark(s, &dx_ready));
-    DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, partB, s));
-    DVG_TRY(launch_colsum(partB, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s));  // j' = p*n+c -> c*4+p
     if (grad_spins) {
       ConvArgs a;
       a.in = dX; a.wp = W + pl.wpd_lin; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
@@ -275,6 +282,8 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       DVG_TRY(launch_conv_igemm(a, s));
     }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dx_ready));
+    DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, W + pl.partL, s2));
+    DVG_TRY(launch_colsum(W + pl.partL, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s2));  // j' = p*n+c -> c*4+p
     WgradArgs wa;
     wa.in = spins; wa.dy = dX; wa.slabs = W + pl.slabs;
     wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;

@@ -18,7 +18,7 @@ struct EncPlan {
   int nblk[4];
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
-  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB, part320, splitk;
+  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB[4], partP, part320, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -73,7 +73,8 @@ EncPlan enc_plan(int64_t B, int n) {
   p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
-  p.partB = bump(o, (size_t)EW_BLOCKS * cmax);
+  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);  // per layer: reduced on the side stream
+  p.partP = bump(o, (size_t)EW_BLOCKS * 8);
   p.part320 = bump(o, (size_t)EW_BLOCKS * 320);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
@@ -156,11 +157,10 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
   hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
-  float* partB = W + pl.partB;
 
   // projection: dP (B,4,n), d proj_w (4), d proj_b (1)
-  DVG_TRY(launch_enc_proj_bwd(W + pl.Xp[3], B, n, p->proj_w, grad_logits, dX, partA, s));
-  DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b, s));
+  DVG_TRY(launch_enc_proj_bwd(W + pl.Xp[3], B, n, p->proj_w, grad_logits, dX, W + pl.partP, s));
+  bool proj_pending = true;  // its column sums go to the side stream at the first fork
 
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
@@ -173,13 +173,12 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
     if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
-                                         dX, g->bn_b[l], g->bn_g[l], dY, partB, s));
+                                         dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     if (l == 0) {
       DVG_TRY(launch_enc_conv0_wgrad(images, B, dY, W + pl.part320, s));
       DVG_TRY(launch_colsum2(W + pl.part320, EW_BLOCKS, 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
       break;
     }
-    DVG_TRY(launch_colsum(partB, EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s));
     // fork: dY is ready; the caller's-stream kernel goes first (see decoder.cpp: queue inheritance under capture)
     hipEvent_t dy_ready = nullptr;
     if (s2 != s) DVG_TRY(stream_mark(s, &dy_ready));
@@ -191,6 +190,11 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+    if (proj_pending) {
+      DVG_TRY(launch_colsum2(W + pl.partP, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b, s2));
+      proj_pending = false;
+    }
+    DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
     // weight gradient
     WgradArgs wa;
     wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
