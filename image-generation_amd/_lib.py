@@ -139,6 +139,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
          c_float, c_void_p, c_int, c_void_p],
     ),
+    "dvg_stream_anchor": (c_int, [c_void_p]),
     "dvg_prof_enable": (c_int, [c_uint64]),
     "dvg_prof_reset": (c_int, []),
     "dvg_prof_num_kernels": (c_int, []),

@@ -73,4 +73,12 @@ int stream_order_after(hipStream_t waiter, hipStream_t producer) {
   return stream_wait_mark(waiter, e);
 }
 
+__global__ void anchor_kernel() {}
+
 }  // namespace dvg
+
+extern "C" int dvg_stream_anchor(dvg_stream_t stream) {
+  hipLaunchKernelGGL(dvg::anchor_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+  DVG_CHECK_HIP(hipGetLastError());
+  return DVG_OK;
+}

@@ -271,11 +271,13 @@ class ModelWrapper:
             spins = self._dvae.latent_to_discrete(latents, self.N_REPLICAS)
             spins_ready = torch.cuda.Event()
             spins_ready.record(main)
-            # Order of enqueueing matters under hipGraph capture: the first child captured after a fork keeps the
-            # parent's hardware queue (so one main-stream node -- the gradient-buffer memset -- goes first and the
-            # decoder chain, the critical path, stays on its queue), and a replay submits nodes in capture order (so
-            # the MMD is captured BEFORE the ~50 decoder-forward nodes, not behind them).
+            # Order of enqueueing matters under hipGraph capture: the first kernel node captured after a fork keeps
+            # the parent's hardware queue (so an anchor node goes first on the main stream and the decoder chain, the
+            # critical path, stays on its queue), and a replay submits nodes in capture order (so the MMD is captured
+            # BEFORE the ~50 decoder-forward nodes, not behind them).
             self._dvae_optimizer.zero_grad()
+            from . import _lib
+            _lib.check(_lib.lib().dvg_stream_anchor(main.cuda_stream), "dvg_stream_anchor")
             side.wait_event(spins_ready)
             with torch.cuda.stream(side):
                 flat = spins.reshape(-1, spins.shape[-1])

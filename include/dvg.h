@@ -220,6 +220,15 @@ int dvg_adam_step(float *p, const float *g, float *m, float *v, int64_t numel, f
                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, const dvg_step_state_t *dyn, int dyn_slot, dvg_stream_t stream);
 
+/* ------------------------------------------------------------------ stream anchor
+ * Enqueues one empty kernel on `stream`.  For callers that capture a step into a hipGraph with a side stream forked
+ * off `stream`: the HIP graph executor keeps the first KERNEL node captured after a fork on the parent's hardware
+ * queue and replays nodes in capture order, so "record event; dvg_stream_anchor(stream); enqueue the side work;
+ * enqueue the rest of the main work" keeps the main chain on its queue (a queue change costs ~10-15 us per hop, and
+ * far more when it lands behind a long kernel) while the side work is still submitted early.
+ */
+int dvg_stream_anchor(dvg_stream_t stream);
+
 /* ------------------------------------------------------------------ profiler
  * Optional per-kernel HIP-event timing inside the library (used by bench.py for
  * the `roofline` object).  Off by default.  `kernel_mask` bit i enables kernel id i
