@@ -11,6 +11,8 @@
 //                                the B operand as they stand: no LDS transpose)
 //     grad_i = x_i * sum_j w_ij - G_i
 // f32 MFMA is an exact fmaf chain, so for +-1 spins the Gram is exact.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dvg {
@@ -235,10 +237,9 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ pass 1: sum of all distances
-template <bool I8>
 __global__ __launch_bounds__(256) void mmd_distsum_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char dsm[];
-  if ((*a.not_pm1 == 0) != I8) return;  // the other instantiation serves this input
+  const bool I8 = *a.not_pm1 == 0;  // exact int8 Gram for +-1 rows, f32 otherwise (flag written by mmd_prep_kernel)
   double* red = reinterpret_cast<double*>(dsm);                 // [256]
   float* Zs = reinterpret_cast<float*>(dsm + 2048);             // f32 path: [128][33], then Xs [32][33]
   float* Xs = Zs + MMD_BJ * MMD_PITCH;
@@ -284,32 +285,9 @@ __device__ __forceinline__ double mmd_wave_sum(double v) {
   return v;
 }
 
-// coef layout in workspace: [0..7] c_k, [8] bandwidth.  One wavefront; fixed reduction shape.
-__global__ __launch_bounds__(64) void mmd_bandwidth_kernel(const double* __restrict__ part, int nparts, double n_total,
-                                                           float fixed_bw, float factor, int n_kernels,
-                                                           float* __restrict__ coef) {
-  double s = 0.0;
-  for (int k = threadIdx.x; k < nparts; k += 64) s += part[k];
-  s = mmd_wave_sum(s);
-  if (threadIdx.x != 0) return;
-  const double bw = fixed_bw > 0.f ? (double)fixed_bw : s / (n_total * n_total - n_total);
-  const float bwf = (float)bw;
-  coef[8] = bwf;
-  for (int k = 0; k < 8; ++k) {
-    if (k < n_kernels) {
-      const float mult = powf(factor, (float)(k - n_kernels / 2));
-      coef[k] = -1.0f / (bwf * mult);
-    } else {
-      coef[k] = 0.f;
-    }
-  }
-}
-
 // ------------------------------------------------------------------ pass 2: loss sums + gradient
 template <int NFB>
-__global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
-  extern __shared__ __align__(16) float smem[];
-  if (a.pm1_ok && *a.not_pm1 == 0) return;  // +-1 input: mmd_pm1_kernel serves it
+__device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
   float* Zs = smem;                           // [128][33]
   float* Xs = Zs + MMD_BJ * MMD_PITCH;        // [32][33]
   float* Gs = Xs + MMD_BI * MMD_PITCH;        // [NFB*32][33] cross-wave reduction of G^T
@@ -454,13 +432,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Table entry for Hamming distance h (16 bytes): .x = kernel sum * kscale, .y = gradient weight w (f32),
 // .z = bf16 hi (upper half) | bf16 mid (lower half), .w = bf16 lo (lower half); hi + mid + lo == w exactly.
-__global__ __launch_bounds__(256) void mmd_table_kernel(MmdArgs a, uint4* __restrict__ tab) {
-  if (*a.not_pm1 != 0) return;
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h > a.d) return;
-  float ck[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) ck[k] = a.coef[k];
+__device__ __forceinline__ void mmd_table_entry(const MmdArgs& a, const float (&ck)[8], int h, uint4* __restrict__ tab) {
   const float kscale = a.reduce_mean ? 1.0f / (float)a.n_kernels : 1.0f;
   const double dnx = (double)a.nx, dny = (double)a.ny;
   const float a_xx = (float)(2.0 / (a.biased ? dnx * dnx : dnx * (dnx - 1.0)));
@@ -486,6 +458,37 @@ __global__ __launch_bounds__(256) void mmd_table_kernel(MmdArgs a, uint4* __rest
     e.w = lo >> 16;
     tab[(size_t)which * (a.d + 1) + h] = e;
   }
+}
+
+// Bandwidth, kernel coefficients and (for +-1 inputs) the pair table in ONE block: wave 0 reduces the distance
+// partials and publishes the coefficients, then all 256 threads fill the d + 1 table rows.
+// coef layout in workspace: [0..7] c_k, [8] bandwidth.
+__global__ __launch_bounds__(256) void mmd_bandwidth_table_kernel(MmdArgs a, const double* __restrict__ part, int nparts,
+                                                                  double n_total, float fixed_bw, float factor,
+                                                                  float* __restrict__ coef, uint4* __restrict__ tab) {
+  __shared__ float ck_s[8];
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 64) s += part[k];
+    s = mmd_wave_sum(s);
+    if (threadIdx.x == 0) {
+      const double bw = fixed_bw > 0.f ? (double)fixed_bw : s / (n_total * n_total - n_total);
+      const float bwf = (float)bw;
+      coef[8] = bwf;
+      for (int k = 0; k < 8; ++k) {
+        float cv = 0.f;
+        if (k < a.n_kernels) cv = -1.0f / (bwf * powf(factor, (float)(k - a.n_kernels / 2)));
+        coef[k] = cv;
+        ck_s[k] = cv;
+      }
+    }
+  }
+  __syncthreads();
+  if (!tab || *a.not_pm1 != 0) return;
+  float ck[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ck[k] = ck_s[k];
+  for (int h = threadIdx.x; h <= a.d; h += 256) mmd_table_entry(a, ck, h, tab);
 }
 
 // bf16 transposed copy: zt[(jb * d + f) * 32 + 16 s + 8 h + e] = row[32 jb + 16 s + 8 (e>>2) + 4 h + (e&3)][f]
@@ -518,9 +521,7 @@ __global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* _
 }
 
 template <int NFB>
-__global__ __launch_bounds__(256, 1) void mmd_pm1_kernel(MmdArgs a) {
-  extern __shared__ __align__(16) unsigned char pm1_smem[];
-  if (*a.not_pm1 != 0) return;  // general floats: mmd_main_kernel serves this input
+__device__ __forceinline__ void mmd_pm1_body(const MmdArgs& a, unsigned char* pm1_smem) {
   const int d = a.d;
   const int pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
   const int zp = pw + 16, xp = d + 16;
@@ -706,6 +707,21 @@ __global__ __launch_bounds__(256, 1) void mmd_pm1_kernel(MmdArgs a) {
   }
 }
 
+template <int NFB>
+__global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char main_smem[];
+  mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem));
+}
+
+// One launch serves both kinds of input: the prep kernel's device flag picks the body (no host synchronisation, and
+// no second "twin" launch whose blocks would queue behind the LDS they never use).
+template <int NFB>
+__global__ __launch_bounds__(256, 1) void mmd_pair_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char pair_smem[];
+  if (a.pm1_ok && *a.not_pm1 == 0) mmd_pm1_body<NFB>(a, pair_smem);
+  else mmd_main_body<NFB>(a, reinterpret_cast<float*>(pair_smem));
+}
+
 // ------------------------------------------------------------------ finalize
 __global__ __launch_bounds__(256) void mmd_final_kernel(const double* __restrict__ loss_part, int nparts, int64_t nx,
                                                         int64_t ny, int biased, float* __restrict__ loss_out,
@@ -739,6 +755,12 @@ struct MmdPlan {
   int64_t ztb_x, ztb_y;  // 32-row blocks of the transposed copy (whole 128-row tiles)
 };
 
+// column splits of the pair kernel aim for this many blocks (env DVG_MMD_BLOCKS overrides: tuning runs)
+static int64_t mmd_target_blocks() {
+  static const int64_t v = [] { const char* e = getenv("DVG_MMD_BLOCKS"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+  return v < 1 ? 1 : v;
+}
+
 static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   MmdPlan p;
   const int fbt = d / 32;
@@ -747,8 +769,8 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.rbx = ceil_div(nx, MMD_BI);
   p.rby = ceil_div(ny, MMD_BI);
   const int64_t tiles = ceil_div(nx, MMD_BJ) + ceil_div(ny, MMD_BJ);
-  // column splits: aim for >= ~1024 blocks, never more splits than tiles
-  int64_t S = ceil_div(1024, p.rbx * p.zslices);
+  // column splits: aim for mmd_target_blocks() blocks, never more splits than tiles
+  int64_t S = ceil_div(mmd_target_blocks(), p.rbx * p.zslices);
   if (S > tiles) S = tiles;
   if (S < 1) S = 1;
   if (S > 16) S = 16;
@@ -779,7 +801,7 @@ template <int NFB>
 static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   const size_t lds = sizeof(float) * (size_t)(MMD_BJ * MMD_PITCH + MMD_BI * MMD_PITCH + NFB * 32 * MMD_PITCH + 4 * 32 + 2) +
                      sizeof(double) * 256;
-  auto kern = mmd_main_kernel<NFB>;
+  auto kern = mmd_main_kernel<NFB>;  // d beyond the spin path's LDS budget: the f32 body alone
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double N = (double)(a.nx + a.ny);
@@ -789,17 +811,18 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
 }
 
 template <int NFB>
-static int launch_pm1(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
+static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   const int d = a.d, pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
   const size_t zbytes = (size_t)MMD_BJ * (pw + 16), gbytes = sizeof(float) * NFB * 32 * MMD_PITCH;
-  const size_t lds = 2 * (size_t)(d + 1) * sizeof(uint4) + sizeof(float) * 128 + sizeof(double) * 256 +
-                     (size_t)MMD_BI * (d + 16) + (zbytes > gbytes ? zbytes : gbytes);
-  auto kern = mmd_pm1_kernel<NFB>;
+  const size_t lds_s = 2 * (size_t)(d + 1) * sizeof(uint4) + sizeof(float) * 128 + sizeof(double) * 256 +
+                       (size_t)MMD_BI * (d + 16) + (zbytes > gbytes ? zbytes : gbytes);
+  const size_t lds_m = sizeof(float) * (size_t)(MMD_BJ * MMD_PITCH + MMD_BI * MMD_PITCH + NFB * 32 * MMD_PITCH + 4 * 32 + 2) +
+                       sizeof(double) * 256;
+  const size_t lds = lds_s > lds_m ? lds_s : lds_m;
+  auto kern = mmd_pair_kernel<NFB>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int zs = d / (32 * NFB);
-  // both twins are credited the algorithmic FLOPs; the one that stands down on the device flag returns in a few
-  // microseconds and shows an impossible rate, which bench.py uses to drop it
   const double N = (double)(a.nx + a.ny);
   const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;
   DVG_LAUNCH_WORK(K_MMD_PM1, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
@@ -858,31 +881,30 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     const size_t lds_f = 2048 + sizeof(float) * (MMD_BJ + MMD_BI) * MMD_PITCH;
     const size_t lds_i = 2048 + (size_t)(MMD_BJ + MMD_BI) * (pw + 16);
     if (lds_i > 64 * 1024)
-      DVG_CHECK_HIP(hipFuncSetAttribute((const void*)mmd_distsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i));
-    DVG_LAUNCH(K_MMD_DISTSUM, mmd_distsum_kernel<false>, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S1), dim3(256), lds_f, s, a);
-    DVG_LAUNCH(K_MMD_DISTSUM, mmd_distsum_kernel<true>, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S1), dim3(256), lds_i, s, a);
+      DVG_CHECK_HIP(hipFuncSetAttribute((const void*)mmd_distsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i));
+    const size_t lds_d = lds_f > lds_i ? lds_f : lds_i;
+    DVG_LAUNCH(K_MMD_DISTSUM, mmd_distsum_kernel, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S1), dim3(256), lds_d, s, a);
   }
-  DVG_LAUNCH(K_MMD_FINAL, mmd_bandwidth_kernel, dim3(1), dim3(64), 0, s, (const double*)(w + p.off_dist), ndist,
-             (double)(nx + ny), cfg->bandwidth, cfg->factor, cfg->n_kernels, (float*)(w + p.off_coef));
-  if (p.pm1_ok)
-    DVG_LAUNCH(K_MMD_FINAL, mmd_table_kernel, dim3((unsigned)ceil_div(dim + 1, 256)), dim3(256), 0, s, a, (uint4*)(w + p.off_tab));
+  DVG_LAUNCH(K_MMD_FINAL, mmd_bandwidth_table_kernel, dim3(1), dim3(256), 0, s, a, (const double*)(w + p.off_dist), ndist,
+             (double)(nx + ny), cfg->bandwidth, cfg->factor, (float*)(w + p.off_coef),
+             p.pm1_ok ? (uint4*)(w + p.off_tab) : (uint4*)nullptr);
   int rc;
-  switch (p.nfb) {
-    case 2: rc = launch_main<2>(a, p, s); break;
-    case 4: rc = launch_main<4>(a, p, s); break;
-    default: rc = launch_main<8>(a, p, s); break;
-  }
-  DVG_TRY(rc);
   if (p.pm1_ok) {
-    // feature blocks per launch slice: the largest of 8/4/2/1 that divides d/32 (no feature guards in the kernel;
+    // feature blocks per launch slice: the largest of 8/4/2/1 that divides d/32 (no feature guards in the spin body;
     // 16 blocks = 256 accumulator registers makes the compiler shuffle accumulators through scratch)
     const int fbt = dim / 32;
-    if (fbt % 8 == 0) rc = launch_pm1<8>(a, p, s);
-    else if (fbt % 4 == 0) rc = launch_pm1<4>(a, p, s);
-    else if (fbt % 2 == 0) rc = launch_pm1<2>(a, p, s);
-    else rc = launch_pm1<1>(a, p, s);
-    DVG_TRY(rc);
+    if (fbt % 8 == 0) rc = launch_pair<8>(a, p, s);
+    else if (fbt % 4 == 0) rc = launch_pair<4>(a, p, s);
+    else if (fbt % 2 == 0) rc = launch_pair<2>(a, p, s);
+    else rc = launch_pair<1>(a, p, s);
+  } else {
+    switch (p.nfb) {
+      case 2: rc = launch_main<2>(a, p, s); break;
+      case 4: rc = launch_main<4>(a, p, s); break;
+      default: rc = launch_main<8>(a, p, s); break;
+    }
   }
+  DVG_TRY(rc);
   const int64_t numel = nx * (int64_t)dim;
   const unsigned fgrid = (grad_x && p.S > 1) ? (unsigned)(ceil_div(numel, 256) > 2048 ? 2048 : ceil_div(numel, 256)) : 1u;
   DVG_LAUNCH(K_MMD_FINAL, mmd_final_kernel, dim3(fgrid), dim3(256), 0, s, (const double*)(w + p.off_loss),
