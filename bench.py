@@ -150,7 +150,7 @@ def main():
             step_idx += 1
 
     if model.use_graph:
-        run(5)  # 3 eager steps + the capture + first replay: not part of the W warm-up steps
+        run(4 + model.N_GRAPHS)  # 3 eager steps + the captures + first replays: not part of the W warm-up steps
     run(args.warmup)
     torch.cuda.synchronize()
     L.dvg_prof_reset()

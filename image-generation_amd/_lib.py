@@ -189,6 +189,7 @@ class StepState:
     """Host mirror + device copy of ``dvg_step_state_t`` (include/dvg.h)."""
 
     FORMAT = "<IIQQ2f2f"  # sweep0, reserved, gumbel_offset, dropout_offset, adam_step_size[2], adam_bc2_sqrt[2]
+    RING = 16
 
     def __init__(self, device):
         import struct
@@ -196,7 +197,11 @@ class StepState:
         import torch
 
         self._struct = struct.Struct(self.FORMAT)
-        self.host = torch.zeros(self._struct.size, dtype=torch.uint8).pin_memory()
+        # The host may run several replays ahead of the device: each write stages through its own pinned slot, and a
+        # slot is rewritten only after the async copy that read it has executed (event per slot).
+        self._ring = [torch.zeros(self._struct.size, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self._events = [None] * self.RING
+        self._n = 0
         self.dev = torch.zeros(self._struct.size, dtype=torch.uint8, device=device)
 
     @property
@@ -206,8 +211,17 @@ class StepState:
     def write(self, sweep0, gumbel_offset, dropout_offset, step_size, bc2_sqrt):
         raw = self._struct.pack(int(sweep0) & 0xFFFFFFFF, 0, int(gumbel_offset), int(dropout_offset), float(step_size[0]),
                                 float(step_size[1]), float(bc2_sqrt[0]), float(bc2_sqrt[1]))
-        self.host.numpy()[:] = memoryview(raw)
-        self.dev.copy_(self.host, non_blocking=True)
+        import torch
+
+        k = self._n % self.RING
+        self._n += 1
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        self._ring[k].numpy()[:] = memoryview(raw)
+        self.dev.copy_(self._ring[k], non_blocking=True)
+        if self._events[k] is None:
+            self._events[k] = torch.cuda.Event()
+        self._events[k].record()
 
 
 def check(rc: int, what: str = "") -> None:

@@ -303,8 +303,21 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   // (DVG_GIBBS_GENERIC=1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
   static const bool force_generic = [] { const char* e = getenv("DVG_GIBBS_GENERIC"); return e && e[0] == '1'; }();
   const bool fast = !force_generic;
-  if (mc <= 16) return launch_gibbs<16, 4>(a, s, fast, mc);
-  if (mc <= 32) return launch_gibbs<32, 4>(a, s, fast, mc);
+  // Waves per workgroup (DVG_GIBBS_WAVES = 1, 2, 4 or 8 overrides for tuning runs).  Measured on the c2 step with the
+  // draw overlapped with the encoder forward: 4 -> 1.237 ms, 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for
+  // issue slots, fatter workgroups do not pay for the CUs they free.
+  static const int waves_env = [] { const char* e = getenv("DVG_GIBBS_WAVES"); return e ? atoi(e) : 0; }();
+  const int waves = waves_env ? waves_env : 4;
   if (big) return launch_gibbs<64, 2>(a, s, fast, mc);
-  return launch_gibbs<64, 4>(a, s, fast, mc);
+#define DVG_GIBBS_DISPATCH(LPC)                                              \
+  switch (waves) {                                                           \
+    case 1: return launch_gibbs<LPC, 1>(a, s, fast, mc);                     \
+    case 2: return launch_gibbs<LPC, 2>(a, s, fast, mc);                     \
+    case 8: return launch_gibbs<LPC, 8>(a, s, fast, mc);                     \
+    default: return launch_gibbs<LPC, 4>(a, s, fast, mc);                    \
+  }
+  if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
+  if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }
+  DVG_GIBBS_DISPATCH(64)
+#undef DVG_GIBBS_DISPATCH
 }

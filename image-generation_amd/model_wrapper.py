@@ -59,6 +59,10 @@ class ModelWrapper:
         dist: optional ``parallel.DataParallel`` context (one process per GPU).
     """
 
+    # executable instances of the captured step, replayed round-robin (see _capture); 2 measured no faster than 1
+    # on MI355X / ROCm 7.2 (1.265 vs 1.220 ms per c2 step: the host already runs ahead of the device)
+    N_GRAPHS = 1
+
     def __init__(self, qpu: str, n_latents: Optional[int] = None, training_parameter_file: Optional[str] = None,
                  dist=None) -> None:
         self.qpu = qpu
@@ -82,7 +86,8 @@ class ModelWrapper:
         # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
         self.use_graph = False
         self._graph = None
-        self._graph_out = None
+        self._graphs = []         # (executable graph, its static input, its static outputs), replayed round-robin
+        self._replays = 0
         self._graph_failed = False
         self._static_images = None
         self._dyn = None
@@ -336,11 +341,17 @@ class ModelWrapper:
         self._dyn.write(sweep0=c[0], gumbel_offset=c[2], dropout_offset=c[3], step_size=(step_size, 0.0), bc2_sqrt=(bc2, 1.0))
 
     def _capture(self, images):
+        """Capture one more instance of the autoencoder half.  ``N_GRAPHS`` instances are replayed round-robin: a
+        launch of an executable graph waits on the host for that SAME executable's previous run, so with a single
+        instance the ~120 nodes of step k+1 are only submitted once step k has drained and the short forward
+        kernels run at the host's submission rate; with two, step k+1 is fully queued while step k executes."""
         from . import _lib
 
-        self._dyn = _lib.StepState(self._device)
-        self._static_images = torch.empty_like(images)
-        self._static_images.copy_(images)
+        if self._dyn is None:
+            self._dyn = _lib.StepState(self._device)
+        static_images = torch.empty_like(images)
+        static_images.copy_(images)
+        self._static_images = static_images
         saved = self._host_counters()
         self._write_dyn()
         torch.cuda.synchronize(self._device)
@@ -348,14 +359,16 @@ class ModelWrapper:
         _lib.DYN = self._dyn.ptr
         try:
             with torch.cuda.graph(graph):
-                mse, dvae, mmd, spins = self._dvae_half(self._static_images)
+                mse, dvae, mmd, spins = self._dvae_half(static_images)
         finally:
             _lib.DYN = None
             self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
-        self._graph, self._graph_out = graph, (mse, dvae, mmd, spins.detach())
+        self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach())))
+        self._graph = graph
 
     def _step_graphed(self, images):
-        if self._graph is None:
+        slot = self._replays % self.N_GRAPHS
+        if len(self._graphs) <= slot:
             try:
                 self._capture(images)
             except Exception as exc:  # capture is an optimisation: fall back to eager, loudly, once
@@ -368,13 +381,15 @@ class ModelWrapper:
                 self._log("dvae_losses", dvae_loss)
                 self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
                 return mse_loss, spins
-        self._static_images.copy_(images)
+        graph, static_images, outs = self._graphs[slot]
+        self._replays += 1
+        static_images.copy_(images)
         self._write_dyn()
-        self._graph.replay()
+        graph.replay()
         c = self._host_counters()
         self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
-        mse, dvae, mmd, spins = self._graph_out
-        self.losses["mse_losses"].append(mse)   # static tensors: valid until the next replay (sync_losses is off)
+        mse, dvae, mmd, spins = outs
+        self.losses["mse_losses"].append(mse)   # static tensors: valid for N_GRAPHS replays (sync_losses is off)
         self.losses["dvae_losses"].append(dvae)
         self.last.update(mse=mse, mmd=mmd)
         return mse, spins
