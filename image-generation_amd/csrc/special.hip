@@ -174,50 +174,99 @@ int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const 
 // ------------------------------------------------------------------------------ decoder conv3 (32 -> 1)
 // X [N*64 (8x8 Morton)][32], upsampled x2 on the fly; Wt (32,1,3,3); Y [N*256 (16x16 Morton)]
 // ConvTranspose (stride 1, pad 1):  out(y,x) = sum_{ci,kh,kw} in(y+1-kh, x+1-kw) Wt[ci][0][kh][kw]
+// Folded form (conv.h: fold_src): an output pixel of parity class (pa, pb) reads only the 2x2 source pixels
+// (i-1+pa+dr, j-1+pb+dc) with the 9 kernel taps pre-summed onto them.  One image per block iteration: its 8x8x32 source
+// map is staged in LDS once (the old gather re-read every source row 36 times through L1); wave w computes the 64
+// outputs of class w with its 4x32 folded weights in registers; the 256 outputs leave through LDS as one contiguous row.
 __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restrict__ X, int64_t N,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ Y, float* __restrict__ stats_part) {
-  __shared__ __align__(16) float ws[9 * 32];  // [tap = kh*3+kw][ci]
-  __shared__ float red[2 * 256];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += 256) ws[(i % 9) * 32 + i / 9] = w[i];  // w[ci*9 + tap]
+  constexpr int XP = 36;  // row pitch in floats: 16-byte aligned rows, conflict-free b128 reads across source rows
+  __shared__ __align__(16) float xs[64 * XP];
+  __shared__ float w9[288];    // w[ci*9 + kh*3 + kw]
+  __shared__ float wfs[512];
+  __shared__ float outs[256];
+  __shared__ float red[2 * 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cls = __builtin_amdgcn_readfirstlane(tid >> 6), pa = cls >> 1, pb = cls & 1;
+  for (int i = tid; i < 288; i += 256) w9[i] = w[i];
   __syncthreads();
-  const int64_t m = (int64_t)blockIdx.x * 256 + tid;  // N*256 pixels: one image per block
-  const int64_t img = m >> 8;
-  const uint32_t p = (uint32_t)(m & 255);
-  const int y = (int)morton_y(p), x = (int)morton_x(p);
-  float acc = bias[0];
+  // folded weights wfs[class][t][ci] = sum of the forward-GEMM taps (r, s) that land on source (dr, dc); forward tap
+  // (r, s) of the ConvTranspose is checkpoint tap (kh, kw) = (2 - r, 2 - s).  Built once per block, two entries per
+  // thread, then each wave keeps its class's 4 x 32 in registers.
+  for (int e = tid; e < 512; e += 256) {
+    const int ci = e & 31, t = (e >> 5) & 3, cc = e >> 7;
+    const int dr = t >> 1, dc = t & 1, qa = cc >> 1, qb = cc & 1;
+    float acc = 0.f;
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int yy = y + 1 - kh, xx = x + 1 - kw;
-      if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16) {
-        const float4* row = reinterpret_cast<const float4*>(X + (img * 64 + (morton((uint32_t)yy, (uint32_t)xx) >> 2)) * 32);
-        const float4* wr = reinterpret_cast<const float4*>(ws + (kh * 3 + kw) * 32);
+      for (int sx = 0; sx < 3; ++sx)
+        if (fold_src(qa, r) == dr && fold_src(qb, sx) == dc) acc += w9[ci * 9 + (8 - (r * 3 + sx))];
+    wfs[e] = acc;
+  }
+  __syncthreads();
+  float wf[4][32];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ci = 0; ci < 32; ++ci) wf[t][ci] = wfs[(cls * 4 + t) * 32 + ci];
+  const float b0 = bias[0];
+  const int ys = (int)morton_y((uint32_t)lane), xq = (int)morton_x((uint32_t)lane);
+  int src[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = ys - 1 + pa + (t >> 1), xx = xq - 1 + pb + (t & 1);
+    src[t] = (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) ? (int)morton((uint32_t)yy, (uint32_t)xx) : -1;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();  // previous image's xs / outs readers are done
+    {  // 64 rows x 32 floats = 512 float4: two per thread, coalesced
+      const float4* g = reinterpret_cast<const float4*>(X + img * 64 * 32);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k;
+        *reinterpret_cast<float4*>(xs + (e >> 3) * XP + (e & 7) * 4) = g[e];
+      }
+    }
+    __syncthreads();
+    float acc = b0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (src[t] >= 0) {
+        const float4* row = reinterpret_cast<const float4*>(xs + src[t] * XP);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float4 a = row[k], b = wr[k];
-          acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+          const float4 a = row[k];
+          acc = fmaf(a.x, wf[t][4 * k], acc); acc = fmaf(a.y, wf[t][4 * k + 1], acc);
+          acc = fmaf(a.z, wf[t][4 * k + 2], acc); acc = fmaf(a.w, wf[t][4 * k + 3], acc);
         }
       }
     }
-  Y[m] = acc;
-  red[tid] = acc;
-  red[256 + tid] = acc * acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) { red[tid] += red[tid + s]; red[256 + tid] += red[256 + tid + s]; }
+    outs[4 * lane + cls] = acc;  // Morton: output pixel = 4 * source pixel + class
+    s1 += acc;
+    s2 = fmaf(acc, acc, s2);
     __syncthreads();
+    Y[img * 256 + tid] = outs[tid];
   }
-  if (tid == 0) { stats_part[(size_t)blockIdx.x * 2] = red[0]; stats_part[(size_t)blockIdx.x * 2 + 1] = red[256]; }
+  // per-block BatchNorm partials (sum, sum of squares) over every image this block produced
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  if (lane == 0) { red[cls] = s1; red[4 + cls] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    stats_part[(size_t)blockIdx.x * 2] = (red[0] + red[1]) + (red[2] + red[3]);
+    stats_part[(size_t)blockIdx.x * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+  }
 }
 
-int dec_conv3_blocks(int64_t N) { return (int)N; }
+int dec_conv3_blocks(int64_t N) { return (int)(N < 1024 ? N : 1024); }
 
 int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s) {
-  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel, dim3((unsigned)N), dim3(256), 0, s, X, N, w, b, Y, stats_part);
+  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel, dim3((unsigned)dec_conv3_blocks(N)), dim3(256), 0, s, X, N, w, b, Y,
+             stats_part);
   return DVG_OK;
 }
 
