@@ -361,66 +361,91 @@ int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* pa
 
 // ------------------------------------------------------------------------------ decoder final conv (1 -> 1)
 // X [N*256 (16x16 Morton)] upsampled to 32x32; out (N,32,32) row-major
+// One image per block iteration, its 16x16 source map in LDS with a zero halo (row-major 18x18): a thread produces 4
+// consecutive output pixels of a row from 3 x 4 source values (the nearest upsample makes neighbouring outputs share
+// them) and stores one float4 -- instead of 36 bounds-checked global gathers.
 __global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restrict__ X, int64_t N,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ out) {
-  const int64_t total = N * 1024;
+  __shared__ float xs[18 * 18];
+  const int tid = threadIdx.x;
   float wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wv[t] = w[t];
   const float bb = bias[0];
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t img = e >> 10;
-    const int y = (int)((e >> 5) & 31), x = (int)(e & 31);
-    float acc = bb;
+  for (int e = tid; e < 18 * 18; e += 256) xs[e] = 0.f;  // the halo stays zero for every image
+  const int sy_ = (int)morton_y((uint32_t)tid), sx_ = (int)morton_x((uint32_t)tid);  // staging: source pixel `tid`
+  const int y = tid >> 3, x0 = (tid & 7) * 4;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();
+    xs[(sy_ + 1) * 18 + sx_ + 1] = X[img * 256 + tid];
+    __syncthreads();
+    float acc[4] = {bb, bb, bb, bb};
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* row = xs + (((y + 1 - kh) >> 1) + 1) * 18 + (x0 >> 1);  // source columns x0/2-1 .. x0/2+2 (+1 halo)
+      const float v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+      // output x0+j, tap kw reads upsampled column x0+j+1-kw, i.e. source column (x0+j+1-kw) >> 1
+      const float src[6] = {v0, v1, v1, v2, v2, v3};  // upsampled columns x0-1 .. x0+4
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int yy = y + 1 - kh, xx = x + 1 - kw;
-        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32)
-          acc = fmaf(X[img * 256 + morton((uint32_t)(yy >> 1), (uint32_t)(xx >> 1))], wv[kh * 3 + kw], acc);
-      }
-    out[e] = acc;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[j] = fmaf(src[j + 2 - kw], wv[kh * 3 + kw], acc[j]);
+    }
+    *reinterpret_cast<float4*>(out + img * 1024 + y * 32 + x0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
 }
 
 int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s) {
-  const int64_t g = ceil_div(N * 1024, 256);
-  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, X, N, w, b, out);
+  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, X, N, w, b, out);
   return DVG_OK;
 }
 
-// dX[q] = sum over the quad's 4 pixels and taps of dOut(y+kh-1, x+kw-1) w[kh][kw]
+// dX[q] = sum over the quad's 4 pixels and taps of dOut(y+kh-1, x+kw-1) w[kh][kw]: a 4x4 stencil on dOut around the
+// quad with the taps pre-summed per offset (rows {w0}, {w0+w1}, {w1+w2}, {w2}, same for columns).  The image's dOut sits
+// in LDS with a zero halo (34x34); thread = source pixel.
 __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __restrict__ dOut, int64_t N,
                                                               const float* __restrict__ w, float* __restrict__ dX) {
-  const int64_t total = N * 256;
-  float wv[9];
+  __shared__ float gs[34 * 34];
+  const int tid = threadIdx.x;
+  float wf[4][4];  // wf[u+1][v+1], u, v in -1..2: offset of the dOut pixel from the quad's top-left pixel
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = w[t];
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t img = e >> 8;
-    const uint32_t ps = (uint32_t)(e & 255);
-    const int ys = (int)morton_y(ps), xs = (int)morton_x(ps);
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int sy = (u - 1) - (kh - 1), sx = (v - 1) - (kw - 1);  // which pixel of the quad this tap belongs to
+          if (sy >= 0 && sy < 2 && sx >= 0 && sx < 2) acc += w[kh * 3 + kw];
+        }
+      wf[u][v] = acc;
+    }
+  for (int e = tid; e < 34 * 34; e += 256) gs[e] = 0.f;
+  const int ys = (int)morton_y((uint32_t)tid), xq = (int)morton_x((uint32_t)tid);
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();
+    {  // 1024 floats: one float4 per thread, row-major rows of 32
+      const float4 v = reinterpret_cast<const float4*>(dOut + img * 1024)[tid];
+      float* d = gs + ((tid >> 3) + 1) * 34 + (tid & 7) * 4 + 1;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
     float acc = 0.f;
 #pragma unroll
-    for (int sy = 0; sy < 2; ++sy)
+    for (int u = 0; u < 4; ++u) {
+      const float* row = gs + (2 * ys + u) * 34 + 2 * xq;  // (2ys + u - 1) + 1 halo, (2xq - 1) + 1 halo
 #pragma unroll
-      for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int yy = 2 * ys + sy + kh - 1, xx = 2 * xs + sx + kw - 1;
-            if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) acc = fmaf(dOut[img * 1024 + yy * 32 + xx], wv[kh * 3 + kw], acc);
-          }
-    dX[e] = acc;
+      for (int v = 0; v < 4; ++v) acc = fmaf(row[v], wf[u][v], acc);
+    }
+    dX[img * 256 + tid] = acc;
   }
 }
 
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s) {
-  const int64_t g = ceil_div(N * 256, 256);
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, dOut, N, w, dX);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, dOut, N, w, dX);
   return DVG_OK;
 }
 
