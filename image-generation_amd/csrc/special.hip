@@ -9,61 +9,81 @@ namespace dvg {
 
 // ------------------------------------------------------------------------------ encoder conv0
 // images (B,32,32) row-major {0,1}; W (32,1,3,3); Y [B*1024 (Morton)][32]
+// As a GEMM: out[32 pixels][32 channels] = A[32 pixels][K = 10] x B[10][32], A = the 9 shifted input pixels and a
+// column of ones, B = the 9 taps and the bias: five f32 MFMAs (k = 2 each) per 32-pixel tile, operands straight from
+// global memory / registers (no LDS), two tiles in flight per wave.  The kernel is bound by its 128 B/pixel of output.
+typedef float f32x16c __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restrict__ img, int64_t B,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ Y, float* __restrict__ stats_part) {
-  __shared__ float ws[32 * 9 + 32];
-  __shared__ float tile[256 * 33];
-  __shared__ float red[2 * 8 * 32];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += 256) ws[i] = w[i];
-  if (tid < 32) ws[288 + tid] = bias[tid];
-  __syncthreads();
-  const int64_t m = (int64_t)blockIdx.x * 256 + tid;  // B*1024 is a multiple of 256
-  const int64_t b = m >> 10;
-  const uint32_t p = (uint32_t)(m & 1023);
-  const int y = (int)morton_y(p), x = (int)morton_x(p);
-  float in[9];
+  __shared__ float red[2 * 4 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  // B operand of MFMA j: B[k = 2j + hh][co = c]
+  float bw[5];
+  int dy[5], dx[5];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    in[t] = (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) ? img[b * 1024 + yy * 32 + xx] : 0.f;
+  for (int j = 0; j < 5; ++j) {
+    const int t = 2 * j + hh;
+    bw[j] = t < 9 ? w[c * 9 + t] : bias[c];
+    dy[j] = t < 9 ? t / 3 - 1 : 0;
+    dx[j] = t < 9 ? t % 3 - 1 : 0;
   }
-#pragma unroll 4
-  for (int co = 0; co < 32; ++co) {
-    float v = ws[288 + co];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v = fmaf(in[t], ws[co * 9 + t], v);
-    tile[tid * 33 + co] = v;
-  }
-  __syncthreads();
-  // coalesced store + per-channel partial sums: thread (co = tid&31, part = tid>>5) walks 32 pixels
-  const int co = tid & 31, part = tid >> 5;
+  const int64_t tiles = B * 32;  // 32 pixels each (B * 1024 pixels, Morton order within an image)
   float s1 = 0.f, s2 = 0.f;
-  float* dst = Y + ((int64_t)blockIdx.x * 256) * 32;
-  for (int k = 0; k < 32; ++k) {
-    const int px = part * 32 + k;
-    const float v = tile[px * 33 + co];
-    dst[px * 32 + co] = v;
-    s1 += v;
-    s2 = fmaf(v, v, s2);
+  constexpr int TU = 2;
+  for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
+    float av[TU][5];
+    bool ok[TU][5];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int64_t tile = t0 + u < tiles ? t0 + u : tiles - 1;
+      const int64_t m = tile * 32 + c;  // A[row = c][k = 2j + hh]
+      const uint32_t p = (uint32_t)(m & 1023);
+      const int y = (int)morton_y(p), x = (int)morton_x(p);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int yy = y + dy[j], xx = x + dx[j];
+        ok[u][j] = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+        av[u][j] = img[(m >> 10) * 1024 + (ok[u][j] ? yy * 32 + xx : 0)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      if (t0 + u < tiles) {  // wave-uniform
+        f32x16c acc = {0};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float a = (2 * j + hh == 9) ? 1.0f : (ok[u][j] ? av[u][j] : 0.f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[j], acc, 0, 0, 0);
+        }
+        float* dst = Y + ((t0 + u) * 32) * 32 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[r];
+          dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
+    }
   }
-  red[part * 32 + co] = s1;
-  red[256 + part * 32 + co] = s2;
+  // per-block BatchNorm partials: lanes c and c + 32 hold the same channel
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (hh == 0) { red[wave * 32 + c] = s1; red[128 + wave * 32 + c] = s2; }
   __syncthreads();
   if (tid < 32) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int k = 0; k < 8; ++k) { t1 += red[k * 32 + tid]; t2 += red[256 + k * 32 + tid]; }
-    stats_part[((size_t)blockIdx.x * 32 + tid) * 2] = t1;
-    stats_part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] = t2;
+    stats_part[((size_t)blockIdx.x * 32 + tid) * 2] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    stats_part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] =
+        (red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid]);
   }
 }
 
-int enc_conv0_blocks(int64_t B) { return (int)(B * 4); }
+int enc_conv0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > 1024 ? 1024 : b); }
 
 int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s) {
-  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_conv0_fwd_kernel, dim3((unsigned)(B * 4)), dim3(256), 0, s, images, B, w, b, Y,
+  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_conv0_fwd_kernel, dim3((unsigned)enc_conv0_blocks(B)), dim3(256), 0, s, images, B, w, b, Y,
              stats_part);
   return DVG_OK;
 }
@@ -84,21 +104,33 @@ __global__ __launch_bounds__(256) void enc_conv0_wgrad_kernel(const float* __res
   const int64_t p1 = p0 + per < P ? p0 + per : P;
   const int dy = c < 9 ? c / 3 - 1 : 0, dx = c < 9 ? c % 3 - 1 : 0;
   f32x16s acc = {0};
-  for (int64_t p = p0; p < p1; p += 2) {
-    const int64_t m = p + hh;
-    const bool live = m < p1;
-    const float av = live ? dY[m * 32 + c] : 0.f;  // A[co = c][k = hh]
-    float bv = 0.f;                                 // B[k = hh][col = c]
-    if (live && c < 10) {
-      if (c == 9) {
-        bv = 1.0f;
-      } else {
-        const uint32_t q = (uint32_t)(m & 1023);
-        const int yy = (int)morton_y(q) + dy, xx = (int)morton_x(q) + dx;
-        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32) bv = img[(m >> 10) * 1024 + yy * 32 + xx];
-      }
+  // 8 pixel pairs per iteration: all 16 loads are issued (from clamped, always-valid addresses) before the first
+  // MFMA needs one -- the one-pair loop paid a full global-load latency per MFMA.
+  constexpr int UN = 8;
+  for (int64_t p = p0; p < p1; p += 2 * UN) {
+    float av[UN], bv[UN];
+    bool al[UN], bl[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t m = p + 2 * u + hh;
+      const bool live = m < p1;
+      const int64_t mc = live ? m : p0;
+      av[u] = dY[mc * 32 + c];  // A[co = c][k = hh]
+      const uint32_t q = (uint32_t)(mc & 1023);
+      const int yy = (int)morton_y(q) + dy, xx = (int)morton_x(q) + dx;
+      const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+      bv[u] = img[(mc >> 10) * 1024 + (inb ? yy * 32 + xx : 0)];  // B[k = hh][col = c]
+      al[u] = live;
+      bl[u] = live && c < 9 && inb;
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    // masks are applied here, after every load has been issued (a select next to its load would make the in-order
+    // issue wait for it before the next load goes out)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float a = al[u] ? av[u] : 0.f;
+      const float b = (c == 9) ? (al[u] ? 1.0f : 0.0f) : (bl[u] ? bv[u] : 0.f);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
   }
   // D[row = co][col = t]: lane holds column c, rows (r&3) + 8*(r>>2) + 4*hh
 #pragma unroll
