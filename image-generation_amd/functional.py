@@ -57,6 +57,30 @@ def mmd_loss(x, y, n_kernels=7, factor=2.0, bandwidth=None, squared=False, reduc
     return _MMD.apply(x, y, n_kernels, factor, bandwidth, squared, reduce_mean, biased)
 
 
+def mmd_loss_and_grad(x, y, n_kernels=7, factor=2.0, bandwidth=None, squared=False, reduce_mean=False, biased=False):
+    """(loss, d loss / d x) from the one fused call, outside autograd: for callers that seed the backward pass
+    themselves (``torch.autograd.backward(x, grad)``) instead of paying a ones_like + multiply per loss term."""
+    L = lib()
+    xd = require_cuda(x.detach().float().contiguous(), "x")
+    yd = require_cuda(y.detach().float().contiguous(), "y")
+    if xd.dim() != 2 or yd.dim() != 2 or xd.shape[1] != yd.shape[1]:
+        raise ValueError("maximum_mean_discrepancy_loss expects x (nx, d) and y (ny, d)")
+    nx, d = xd.shape
+    ny = yd.shape[0]
+    cfg = MmdCfg(int(n_kernels), float(factor), float(bandwidth if bandwidth is not None else -1.0),
+                 int(bool(squared)), int(bool(reduce_mean)), int(bool(biased)))
+    loss = torch.empty((), dtype=torch.float32, device=xd.device)
+    grad = torch.empty_like(xd)
+    nbytes = L.dvg_mmd_workspace_bytes(nx, ny, d)
+    if nbytes == 0:
+        raise _lib.DvgError(f"MMD: unsupported shape nx={nx} ny={ny} d={d} (d must be a multiple of 32)")
+    ws = _ws(nbytes, xd.device)
+    with torch.cuda.device(xd.device):
+        check(L.dvg_mmd_fwd_bwd(xd.data_ptr(), nx, yd.data_ptr(), ny, d, ctypes.byref(cfg), loss.data_ptr(),
+                                grad.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(xd.device)), "dvg_mmd_fwd_bwd")
+    return loss, grad
+
+
 # ----------------------------------------------------------------------------- latent -> discrete
 
 
@@ -195,3 +219,20 @@ def replicated_mse_loss(reconstructed, images):
     """mse_loss(reconstructed, images.unsqueeze(1).repeat(1, R, 1, 1, 1)) without building the repeat
     (/root/reference/src/model_wrapper.py:302-305)."""
     return _MSE.apply(reconstructed, images)
+
+
+def replicated_mse_loss_and_grad(reconstructed, images):
+    """(loss, d loss / d reconstructed) outside autograd (see :func:`mmd_loss_and_grad`)."""
+    L = lib()
+    rd = require_cuda(reconstructed.detach().float().contiguous(), "reconstructed")
+    im = require_cuda(images.detach().float().contiguous(), "images")
+    B, R = rd.shape[0], rd.shape[1]
+    if rd.numel() != B * R * 1024 or im.numel() != B * 1024:
+        raise ValueError("mse_loss expects reconstructed (B,R,1,32,32) and images (B,1,32,32)")
+    loss = torch.empty((), dtype=torch.float32, device=rd.device)
+    grad = torch.empty_like(rd)
+    ws = _ws(L.dvg_mse_workspace_bytes(), rd.device)
+    with torch.cuda.device(rd.device):
+        check(L.dvg_mse_fwd_bwd(rd.data_ptr(), im.data_ptr(), B, R, 1.0, loss.data_ptr(), grad.data_ptr(),
+                                ws.data_ptr(), ws.numel(), stream_ptr(rd.device)), "dvg_mse_fwd_bwd")
+    return loss, grad

@@ -184,3 +184,10 @@ def maximum_mean_discrepancy_loss(x: torch.Tensor, y: torch.Tensor, kernel: Gaus
     """MMD^2(x, y) under ``kernel`` with gradient wrt x (/root/reference/src/model_wrapper.py:320)."""
     return F.mmd_loss(x, y, n_kernels=kernel.n_kernels, factor=kernel.factor, bandwidth=kernel.bandwidth,
                       squared=kernel.squared, reduce_mean=(kernel.reduce == "mean"), biased=biased)
+
+
+def maximum_mean_discrepancy_loss_and_grad(x: torch.Tensor, y: torch.Tensor, kernel: GaussianKernel, biased: bool = False):
+    """Same value as :func:`maximum_mean_discrepancy_loss` plus its gradient wrt ``x``, both detached (the fused
+    kernel computes them together anyway)."""
+    return F.mmd_loss_and_grad(x, y, n_kernels=kernel.n_kernels, factor=kernel.factor, bandwidth=kernel.bandwidth,
+                               squared=kernel.squared, reduce_mean=(kernel.reduce == "mean"), biased=biased)
