@@ -13,7 +13,8 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int8, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvg.so")
+# DVG_LIBRARY: development override (A/B runs of two builds in one process launch); the product path is in-tree
+LIB_PATH = os.environ.get("DVG_LIBRARY") or os.path.join(_HERE, "libdvg.so")
 
 _lib = None
 
