@@ -8,12 +8,14 @@
 // the next chunk under the MFMA loop.  Epilogues: +bias, per-channel (sum, sum^2) partials for
 // BatchNorm, or the 2x2 quad-sum that is the adjoint of Upsample(x2).
 // (weight-gradient kernels, slab reduction and weight packing: conv_wgrad.hip)
+#include <cstdlib>
+
 #include "conv_tile.h"
 
 namespace dvg {
 
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool DEEP>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -72,16 +74,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
 
-  // Software pipeline.  DEEP = false (one register stage): phase `it` issues the global loads of K-chunk pair `it`, runs
+  // Software pipeline with ONE load site: phase `it` issues the global loads of K-chunk pair `it` into registers, runs
   // the MFMAs of pair it-1 out of LDS while they fly, then (barrier) parks pair `it` in LDS.
-  // DEEP = true (two register stages): phase `it` issues the global loads of K-chunks 2it+2, 2it+3 (the
-  // NEXT phase's pair) into one register stage, runs the MFMAs of pair it-1 out of LDS, then (barrier) parks pair
-  // `it` -- loaded one whole phase earlier, into the other stage -- in LDS.  A load therefore has two MFMA phases
-  // (~4000 cycles at the 64x64 tile) to land before it is waited for; with one stage the wait at the LDS store was
-  // 500-1000 of the ~3500-4800 cycles of a phase (s_memtime stamps).  The two stages are named A/B and the loop is
-  // unrolled by two, so every register array index is a compile-time constant (no scratch).  Measured: large launches
-  // (c3: 1M-row layers, HBM-resident operands) +13 % on the 128x64 tile; small L2-resident launches (c2) lose 3-5 % to the
-  // extra registers (occupancy) -- launch_conv_igemm picks per launch.
+  // Tried and measured on MI355X (A/B inside one box, c2 and c3 steps), all no better than this form:
+  //   * a second register stage (loads get two MFMA phases to land): +-0 at c3, -3 % at c2 (registers -> occupancy);
+  //   * issuing the loads one by one between the MFMA k-steps (sched_group_barrier VMEM groups): +-0 at c2, the
+  //     128-row tiles 17-20 % slower at c3.
   // split-K (small-M layers): grid.z slices the K iterations; each slice writes a raw partial slab
   const int it_per = (niter + a.ksplit - 1) / a.ksplit;
   const int it_beg = (int)blockIdx.z * it_per, it_end = it_beg + it_per < niter ? it_beg + it_per : niter;
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
     }                                                                                                                 \
   } while (0)
 
-  if constexpr (!DEEP) {
+  {
     f32x4 aA[2][RA], bA[2][RB];
     float mA[2][RA];
     for (int it = it_beg; it <= it_end; ++it) {
@@ -165,27 +163,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
       if (it < it_end) IGEMM_STORE(aA, bA, mA);
       __syncthreads();
     }
-  } else {
-    f32x4 aA[2][RA], bA[2][RB], aB[2][RA], bB[2][RB];
-    float mA[2][RA], mB[2][RA];
-    if (it_beg < it_end) IGEMM_LOAD(aA, bA, mA, it_beg);
-    for (int it = it_beg; it < it_end; it += 2) {
-      // even phase: stage A holds pair `it`
-      if (it + 1 < it_end) IGEMM_LOAD(aB, bB, mB, it + 1);
-      if (it > it_beg) IGEMM_MFMA();
-      __syncthreads();
-      IGEMM_STORE(aA, bA, mA);
-      __syncthreads();
-      if (it + 1 < it_end) {
-        // odd phase: stage B holds pair `it + 1`
-        if (it + 2 < it_end) IGEMM_LOAD(aA, bA, mA, it + 2);
-        IGEMM_MFMA();
-        __syncthreads();
-        IGEMM_STORE(aB, bB, mB);
-        __syncthreads();
-      }
-    }
-    if (it_beg < it_end) IGEMM_MFMA();  // the last pair
   }
 #undef IGEMM_LOAD
 #undef IGEMM_STORE
@@ -360,15 +337,10 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const unsigned cm = a.fold == 1 ? 4u : 1u;
   const int bm = cfg == 1 ? 64 : 128, bn = cfg == 2 ? 32 : 64;
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
-  // two-stage register pipeline for launches of many rounds of blocks (operands stream from HBM); see the kernel
-  const bool deep = (int64_t)grid.x * grid.y * grid.z >= 4096;
-  switch (cfg * 2 + (deep ? 1 : 0)) {
-    case 0: DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2, false>), grid, dim3(256), 0, s, a); break;
-    case 1: DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, s, a); break;
-    case 2: DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, s, a); break;
-    case 3: DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, s, a); break;
-    case 4: DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, s, a); break;
-    default: DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, s, a); break;
+  switch (cfg) {
+    case 0: DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+    case 1: DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+    default: DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a); break;
   }
   if (a.ksplit > 1) {
     // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks

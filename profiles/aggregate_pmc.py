@@ -1,0 +1,41 @@
+"""Aggregate two rocprofv3 PMC passes (--pmc FETCH_SIZE / --pmc WRITE_SIZE, each with --kernel-trace) of
+`bench.py --eager` into HBM bytes per launch per kernel.
+
+    python profiles/aggregate_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+
+Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
+report KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled; WRITE_SIZE is exact.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            a = acc[r["Kernel_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f_kib, n = fetch.get(k, (0.0, 0))
+        w_kib, n2 = write.get(k, (0.0, 0))
+        out[k] = {"launches": max(n, n2), "FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
+                  "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(f"{len(out)} kernels -> {sys.argv[3]}")
+
+
+if __name__ == "__main__":
+    main()
