@@ -136,7 +136,7 @@ def main():
 
     L = _lib.lib()
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
-    is_gemm = lambda nm: nm.startswith("conv_igemm_kernel") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1")  # noqa: E731
+    is_gemm = lambda nm: nm.startswith("conv_igemm_kernel") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm)) if not args.breakdown else (1 << len(names)) - 1
     # Steps without a GRBM update are replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); the GRBM steps (every 10th) run eagerly.  --eager disables the graph.
@@ -190,11 +190,12 @@ def main():
             per_kernel[nm] = {"total_ms": ms.value, "launches": cnt.value, "work": work.value}
     if dp.rank == 0:
         # dominant kernel = the GEMM kernel (one template instantiation = one rocprof kernel name) with the
-        # largest total time; achieved = its algorithmic FLOPs (2*M*Cin*Cout*taps per launch, summed by the
-        # library over the timed launches) / its HIP-event time over the timed region
-        # The MMD pair kernel exists as two device-gated twins (general f32 rows / +-1 spin rows: int8 Gram + bf16x3
-        # gradient GEMM); both are enqueued and the one not serving the input returns at once.  Its "rate" exceeds
-        # the MFMA peak, which is how it is recognised and dropped here.
+        # largest total time; achieved = its executed FLOPs (2*rows*Cin*Cout*taps per launch -- the folded-upsample
+        # layers are credited their 4 or 16 folded taps, not the 9 they replace -- summed by the library over the
+        # timed launches) / its HIP-event time over the timed region.
+        # The MMD pair kernel serves +-1 spin rows on the int8 / bf16 MFMAs ("mmd_pm1", priced against the bf16 peak)
+        # and general rows on the f32 MFMA ("mmd_main"); a candidate whose rate exceeds its peak is a mislabelled
+        # launch and is dropped.
         peak_of = lambda nm: PEAK_BF16_MFMA_TFLOPS if nm == "mmd_pm1" else PEAK_F32_MFMA_TFLOPS  # noqa: E731
         cands = {k: v for k, v in per_kernel.items() if is_gemm(k) and v["work"] > 0
                  and v["work"] / (v["total_ms"] * 1e-3) / 1e12 <= peak_of(k)}
@@ -220,7 +221,8 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['desc']}", "global_batch": cfg["B"] * args.gpus,
                        "n_latents": cfg["n"], "n_replicas": cfg["R"], "num_reads_per_gpu": cfg["C"],
                        "gibbs_sweeps": cfg["sweeps"], "parallelism": f"dp{args.gpus}",
-                       "launch": "hipGraph replay (GRBM steps eager)" if model.use_graph else "eager",
+                       "launch": ("hipGraph replay of the autoencoder half (GRBM update of every 10th step eager behind it)"
+                                  if model.use_graph else "eager"),
                        "net_gflop_per_step": net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9},
             "roofline": roofline,
         }

@@ -283,22 +283,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Tile configuration: 0 = 128x64, 1 = 64x64, 2 = 128x32 (Cout = 32), 3 = 32x64 (two waves) for launches whose 64-row
+// tiling would leave most CUs without a block (small-M layers: a finer tiling fills the chip without the split-K slabs
+// and their reduce pass).  DVG_IGEMM_NO32=1 disables 3 (A/B runs).
 static int igemm_cfg(int64_t M, int Cout) {
-  if (Cout % 64 == 0) return (ceil_div(M, 128) * (Cout / 64) >= 512) ? 0 : 1;
-  return 2;
+  static const bool no32 = [] { const char* e = getenv("DVG_IGEMM_NO32"); return e && e[0] == '1'; }();
+  if (Cout % 64) return 2;
+  if (ceil_div(M, 128) * (Cout / 64) >= 512) return 0;
+  static const int64_t thr32 = [] { const char* e = getenv("DVG_IGEMM_THR32"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
+  if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
+  return 3;
 }
+static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
+static int igemm_bn(int cfg) { return cfg == 2 ? 32 : 64; }
 
-int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_cfg(M, Cout) == 1 ? 64 : 128); }
+int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_bm(igemm_cfg(M, Cout))); }
 
 // fold = 1: tile config chosen on the OUTPUT pixel count (4 per source pixel); row blocks never straddle a class
 bool conv_fold_ok(int64_t Msrc) { return Msrc > 0 && Msrc % 128 == 0; }
-int conv_stats_blocks_fold(int64_t Msrc, int Cout) { return 4 * (int)ceil_div(Msrc, igemm_cfg(4 * Msrc, Cout) == 1 ? 64 : 128); }
+int conv_stats_blocks_fold(int64_t Msrc, int Cout) { return 4 * (int)ceil_div(Msrc, igemm_bm(igemm_cfg(4 * Msrc, Cout))); }
 
 // K-split of the forward / data-gradient kernel: only for launches that would leave most CUs idle
 // (fold = 1 callers pass M = 4 * source pixels, ntaps = 4: same block count and K depth as the launch)
 int conv_igemm_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   const int cfg = igemm_cfg(M, Cout);
-  const int64_t blocks = ceil_div(M, cfg == 1 ? 64 : 128) * (Cout / (cfg == 2 ? 32 : 64));
+  const int64_t blocks = ceil_div(M, igemm_bm(cfg)) * (Cout / igemm_bn(cfg));
   const int niter = (ntaps * (Cin / 32) + 1) / 2;
   if (blocks >= 192 || niter < 6) return 1;  // measured: splitting a launch with >= 256 blocks loses to its reduce pass
   int64_t k = ceil_div(512, blocks);
@@ -335,17 +344,18 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const unsigned kz = (unsigned)a.ksplit;
   const int cfg = igemm_cfg(Mg, a.Cout);
   const unsigned cm = a.fold == 1 ? 4u : 1u;
-  const int bm = cfg == 1 ? 64 : 128, bn = cfg == 2 ? 32 : 64;
+  const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
   switch (cfg) {
     case 0: DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
     case 1: DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+    case 3: DVG_LAUNCH_WORK(K_IGEMM_32x64, flops, (conv_igemm_kernel<32, 64, 1, 2>), grid, dim3(128), 0, s, a); break;
     default: DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a); break;
   }
   if (a.ksplit > 1) {
     // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks
     const int64_t rows_out = a.poolsum ? a.M / 4 : Mg;
-    const int bm = (cfg == 1 ? 64 : 128) / (a.poolsum ? 4 : 1);
+    const int bm = igemm_bm(cfg) / (a.poolsum ? 4 : 1);
     DVG_LAUNCH(K_MISC, splitk_reduce_kernel, dim3((unsigned)ceil_div(rows_out, bm), a.Cout / 32), dim3(256), 0, s, a.splitk_ws, a.ksplit,
                rows_out, a.Cout, a.bias, a.out, a.poolsum ? nullptr : a.stats, bm);
   }
