@@ -140,7 +140,8 @@ def main():
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm)) if not args.breakdown else (1 << len(names)) - 1
     # Steps without a GRBM update are replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); the GRBM steps (every 10th) run eagerly.  --eager disables the graph.
-    model.use_graph = not args.eager and dp.world_size == 1 and not dp.force
+    # (several GPUs: two graphs per step with the eager RCCL all-reduce of the flat gradient buffer between them)
+    model.use_graph = not args.eager
     step_idx = 0
 
     def run(k):
@@ -203,7 +204,7 @@ def main():
         ach = cands[dom]["work"] / (cands[dom]["total_ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak_of(dom), "unit": "TFLOP/s",
                     "frac": ach / peak_of(dom), "traffic": None,
-                    "timing": ("HIP events over the timed region" if args.eager or args.gpus > 1 else
+                    "timing": ("HIP events over the timed region" if args.eager else
                                f"HIP events over an eager pass of {prof_steps} steps right after the timed region "
                                "(graph replays cannot carry per-kernel events)"),
                     "avg_launch_us": cands[dom]["total_ms"] * 1e3 / cands[dom]["launches"],
@@ -231,9 +232,22 @@ def main():
         if args.breakdown:
             with open(args.breakdown, "w") as f:
                 json.dump({"ms_per_step": elapsed / args.steps * 1e3, "profiled_steps": prof_steps, "kernels": per_kernel}, f, indent=1)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
+    # The JSON line is the LAST thing this process prints: RCCL writes a version banner through C stdio, which is
+    # fully buffered when stdout is a pipe or file and would otherwise be flushed at exit, i.e. AFTER the line.
     dp.shutdown()
     os.unlink(tmp.name)
+    sys.stdout.flush()
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

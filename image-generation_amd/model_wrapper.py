@@ -87,7 +87,8 @@ class ModelWrapper:
         # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
         self.use_graph = False
         self._graph = None
-        self._graphs = []         # (executable graph, its static input, its static outputs), replayed round-robin
+        self._graphs = []         # (executable graph, its static input, its static outputs, Adam tail graph or None)
+        self._capturing_split = False
         self._replays = 0
         self._graph_failed = False
         self._static_images = None
@@ -324,10 +325,9 @@ class ModelWrapper:
     # ------------------------------------------------------------------ hipGraph replay of the autoencoder half
     def _graph_eligible(self, opt_step, epoch, images) -> bool:
         """The captured graph covers the autoencoder half of every step (on a GRBM step the quasi-NLL update runs
-        eagerly behind the replay, on the replay's static spins); noise-injected (parity) steps and multi-GPU runs
-        take the eager path."""
+        eagerly behind the replay, on the replay's static spins); noise-injected (parity) steps take the eager path.
+        With several GPUs the step is two graphs with the (eager) all-reduce between them."""
         return (self.use_graph and self._device.type == "cuda" and self.noise_hook is None and not self._graph_failed
-                and (self.dist is None or self.dist.world_size == 1)
                 and self._eager_steps >= 3 and not self.sync_losses
                 and (self._static_images is None or images.shape == self._static_images.shape))
 
@@ -361,14 +361,24 @@ class ModelWrapper:
         self._write_dyn()
         torch.cuda.synchronize(self._device)
         graph = torch.cuda.CUDAGraph()
+        tail = None
         _lib.DYN = self._dyn.ptr
         try:
+            # Data-parallel runs: graph 1 ends with the gradients packed into the optimizer's flat buffer; the ONE
+            # all-reduce of the step runs eagerly on RCCL's stream; graph 2 is the Adam launch (the 1/world_size of
+            # the mean is its grad_scale argument).  Three host calls per step instead of ~120.
+            self._capturing_split = self._dist_active()
             with torch.cuda.graph(graph):
                 mse, dvae, mmd, spins = self._dvae_half(static_images)
+            if self._capturing_split:
+                tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tail):
+                    self._dvae_optimizer.step(grad_scale=1.0 / self.dist.world_size, gathered=True)
         finally:
+            self._capturing_split = False
             _lib.DYN = None
             self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
-        self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach())))
+        self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach()), tail))
         self._graph = graph
 
     def _step_graphed(self, images):
@@ -386,11 +396,16 @@ class ModelWrapper:
                 self._log("dvae_losses", dvae_loss)
                 self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
                 return mse_loss, spins
-        graph, static_images, outs = self._graphs[slot]
+        graph, static_images, outs, tail = self._graphs[slot]
         self._replays += 1
         static_images.copy_(images)
         self._write_dyn()
         graph.replay()
+        if tail is not None:
+            import torch.distributed as tdist
+
+            tdist.all_reduce(self._dvae_optimizer.flat_grad, op=tdist.ReduceOp.SUM)
+            tail.replay()
         c = self._host_counters()
         self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
         mse, dvae, mmd, spins = outs
@@ -416,9 +431,14 @@ class ModelWrapper:
     def _log(self, key: str, value: torch.Tensor):
         self.losses[key].append(value.item() if self.sync_losses else value.detach())
 
+    def _dist_active(self) -> bool:
+        return self.dist is not None and (self.dist.world_size > 1 or getattr(self.dist, "force", False))
+
     def _reduce_and_step(self, opt):
-        if self.dist is not None and (self.dist.world_size > 1 or getattr(self.dist, "force", False)):
+        if self._dist_active():
             flat = opt.gather_grads()
+            if self._capturing_split and opt is self._dvae_optimizer:
+                return  # multi-GPU graph replay: the collective and the Adam step follow the first graph (see _capture)
             self.dist.all_reduce_mean(flat)  # ONE collective over the flat gradient buffer
             opt.step(gathered=True)
         else:
