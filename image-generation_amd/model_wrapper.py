@@ -125,6 +125,48 @@ class ModelWrapper:
         self._dvae.load_state_dict(torch.load(file_path / "dvae.pth", weights_only=True))
         self._grbm.load_state_dict(grbm_sd)
 
+    # -- exact resume: an EXTRA file next to the reference-schema checkpoint, never read by the UI
+    def save_training_state(self, file_path) -> None:
+        """``train_state.pth``: everything beyond the two state_dicts that the next step depends on -- Adam moments
+        and step counts, the persistent Gibbs chains and every counter that positions a device random stream -- so
+        that ``load`` + ``load_training_state`` continues the run bit for bit."""
+        file_path = Path(file_path)
+        file_path.mkdir(exist_ok=True, parents=True)
+        s = self.sampler
+        helper = self._tpar.get("persistent_qpu_sample_helper")
+        state = {
+            "opt_step": int(self._tpar["opt_step"]),
+            "dvae_optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._dvae_optimizer.state_dict().items()},
+            "grbm_optimizer": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._grbm_optimizer.state_dict().items()},
+            "sampler": {"state": None if s._state is None else s._state.cpu(), "sweep_count": s.sweep_count, "calls": s.calls},
+            "gumbel_calls": self._dvae._gumbel_calls, "gumbel_seed": self._dvae.gumbel_seed,
+            "dropout_calls": self._dvae.decoder._dropout_calls, "dropout_seed": self._dvae.decoder.dropout_seed,
+            "helper_iterations": None if helper is None else int(helper.iterations_since_last_resampling),
+            "losses": {k: [float(v) for v in vals] for k, vals in self.losses.items()},
+        }
+        torch.save(state, file_path / "train_state.pth")
+
+    def load_training_state(self, file_path) -> None:
+        """Counterpart of :meth:`save_training_state`; call after ``load`` and ``train_init``."""
+        state = torch.load(Path(file_path) / "train_state.pth", weights_only=False)
+        self._tpar["opt_step"] = state["opt_step"]
+        for opt, key in ((self._dvae_optimizer, "dvae_optimizer"), (self._grbm_optimizer, "grbm_optimizer")):
+            sd = state[key]
+            opt.load_state_dict({k: (v.to(self._device) if torch.is_tensor(v) else v) for k, v in sd.items()})
+        s = self.sampler
+        s._state = None if state["sampler"]["state"] is None else state["sampler"]["state"].to(self._device)
+        s.sweep_count, s.calls = state["sampler"]["sweep_count"], state["sampler"]["calls"]
+        self._dvae._gumbel_calls, self._dvae.gumbel_seed = state["gumbel_calls"], state["gumbel_seed"]
+        self._dvae.decoder._dropout_calls, self._dvae.decoder.dropout_seed = state["dropout_calls"], state["dropout_seed"]
+        helper = self._tpar.get("persistent_qpu_sample_helper")
+        if helper is not None and state["helper_iterations"] is not None:
+            helper.iterations_since_last_resampling = state["helper_iterations"]
+        self.losses = {k: list(v) for k, v in state["losses"].items()}
+        # the learning rates in force are the ones the schedule set after the last completed step
+        if state["opt_step"] > 0:
+            self._dvae_optimizer.param_groups[0]["lr"] = self._tpar["dvae_lr_schedule"][state["opt_step"] - 1]
+            self._grbm_optimizer.param_groups[0]["lr"] = self._tpar["grbm_lr_schedule"][state["opt_step"] - 1]
+
     def _rebuild_on_edges(self, ei, ej):
         from .graphs import build_plan
         from .sampler import GibbsSampler

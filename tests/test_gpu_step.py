@@ -135,3 +135,49 @@ def test_training_driver_and_model_files(tmp_path, golden_dir):
     losses = json.load(open(tmp_path / "run" / "losses.json"))
     assert len(losses["mse_losses"]) == 40 and len(losses["dvae_losses"]) == 40
     assert (tmp_path / "run" / "dvae.pth").exists() and (tmp_path / "run" / "grbm.pth").exists()
+
+
+def test_exact_resume_from_training_state(tmp_path, golden_dir):
+    """save + save_training_state after 7 steps, reload into a fresh wrapper, 5 more steps (one of them a GRBM step):
+    bit-identical to the uninterrupted 12-step run (the extra state file rides beside the
+    reference-schema checkpoint)."""
+    params = os.path.join(golden_dir, "step_params.yaml")
+
+    def fresh():
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=params)
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 12, seed=9)).reshape(12, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(12)])
+        m.train_init(1)
+        m.sync_losses = False
+        return m, imgs
+
+    def final(m):
+        torch.cuda.synchronize()
+        sd = {k: v.clone() for k, v in m._dvae.state_dict().items()}
+        sd.update({"grbm." + k: v.clone() for k, v in m._grbm.state_dict().items()})
+        sd["chains"] = m.sampler._state.clone()
+        return sd
+
+    a, imgs = fresh()
+    for k in range(12):
+        a.step((imgs[k], None), epoch=0)
+    want = final(a)
+
+    b, _ = fresh()
+    for k in range(7):
+        b.step((imgs[k], None), epoch=0)
+    b.save(tmp_path / "ckpt")
+    b.save_training_state(tmp_path / "ckpt")
+    c, _ = fresh()
+    c.load(tmp_path / "ckpt")
+    c.set_dataloader([(imgs[k], None) for k in range(12)])
+    c.train_init(1)
+    c.sync_losses = False
+    c.load_training_state(tmp_path / "ckpt")
+    for k in range(7, 12):
+        c.step((imgs[k], None), epoch=0)
+    got = final(c)
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
