@@ -410,11 +410,13 @@ class ModelWrapper:
             # all-reduce of the step runs eagerly on RCCL's stream; graph 2 is the Adam launch (the 1/world_size of
             # the mean is its grad_scale argument).  Three host calls per step instead of ~120.
             self._capturing_split = self._dist_active()
-            with torch.cuda.graph(graph):
+            # (thread_local: RCCL's watchdog thread may touch the runtime while this thread captures)
+            mode = dict(capture_error_mode="thread_local") if self._capturing_split else {}
+            with torch.cuda.graph(graph, **mode):
                 mse, dvae, mmd, spins = self._dvae_half(static_images)
             if self._capturing_split:
                 tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(tail):
+                with torch.cuda.graph(tail, **mode):
                     self._dvae_optimizer.step(grad_scale=1.0 / self.dist.world_size, gathered=True)
         finally:
             self._capturing_split = False
