@@ -20,11 +20,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int BK = 64;                 // K per iteration: two 32-channel chunks (possibly of different taps)
-  constexpr int AP = BK + 1, BP = BN + 4;
+  // A rows are 16-byte aligned so the staging stores are ds_write_b128; the MFMA A-operand reads (one float per lane,
+  // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
+  constexpr int AP = BK + 4, BP = BN + 4;
   constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per 32-chunk
   constexpr int RB = 8 * BN / NT;        // float4 loads of B per thread per 32-chunk
   static_assert(RB * NT == 8 * BN && RA * NT == 8 * BM, "tile loaders must divide evenly");
-  __shared__ float As[BM * AP];
+  __shared__ __align__(16) float As[BM * AP];
   __shared__ __align__(16) float Bs[BK * BP];
   __shared__ float red[WM * BN * 2];
   constexpr int NBS = 16;                // taps per row in the neighbour table (9, 4 or 16 used)
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
         const int row = (tid + NT * q) >> 3;                                                                          \
         float* p = As + row * AP + h * 32 + ac4 * 4;                                                                  \
         const float mk = AMASK[h][q];                                                                                 \
-        p[0] = AREG[h][q].x * mk; p[1] = AREG[h][q].y * mk; p[2] = AREG[h][q].z * mk; p[3] = AREG[h][q].w * mk;       \
+        *reinterpret_cast<f32x4*>(p) = AREG[h][q] * mk;                                                               \
       }                                                                                                               \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
         const int idx = tid + NT * q;                                                                                 \
