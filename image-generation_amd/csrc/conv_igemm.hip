@@ -15,25 +15,37 @@
 namespace dvg {
 
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int NT = WM * WN * 64;
+// WK = wave groups along K inside the block (each works on its own 64-deep half of a 128-deep K slab, partial
+// accumulators combined through LDS at the end).  Only WK = 1 is launched: the idea was to give small launches the
+// latency hiding that co-resident blocks provide (standalone 128->128 3x3 layer: 70 TFLOP/s at 1 block/CU, 83 at 2, 94
+// at 4, 100 from 8 up), but groups that share the block's barriers stay IN PHASE -- all waves issue loads together and
+// run MFMAs together -- and WK = 2 measured 0 % on that layer and -3.5 % on the c2 step.  (The other route, pairs of
+// half-K blocks combined in-kernel through an arrival counter, is correct and deterministic but 2x slower: its
+// agent-scope release fence writes back the XCD's L2.)
+template <int BM, int BN, int WM, int WN, int WK>
+__global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NT = WM * WN * WK * 64, NTG = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int BK = 64;                 // K per iteration: two 32-channel chunks (possibly of different taps)
+  constexpr int BK = 64;                 // K per wave group and iteration: two 32-channel chunks (possibly of different taps)
+  constexpr int KH = 2 * WK, BKT = BK * WK;  // chunks / K extent staged per iteration by the whole block
   // A rows are 16-byte aligned so the staging stores are ds_write_b128; the MFMA A-operand reads (one float per lane,
   // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
-  constexpr int AP = BK + 4, BP = BN + 4;
+  constexpr int AP = BKT + 4, BP = BN + 4;
   constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per 32-chunk
-  constexpr int RB = 8 * BN / NT;        // float4 loads of B per thread per 32-chunk
-  static_assert(RB * NT == 8 * BN && RA * NT == 8 * BM, "tile loaders must divide evenly");
-  __shared__ __align__(16) float As[BM * AP];
-  __shared__ __align__(16) float Bs[BK * BP];
-  __shared__ float red[WM * BN * 2];
+  constexpr int RB = (8 * BN + NT - 1) / NT;  // float4 loads of B per thread per 32-chunk
+  constexpr bool BPART = RB * NT != 8 * BN;   // fewer B float4s than threads (32-column tile, 512 threads)
+  static_assert(RA * NT == 8 * BM && (!BPART || RB == 1), "tile loaders must divide evenly");
   constexpr int NBS = 16;                // taps per row in the neighbour table (9, 4 or 16 used)
-  __shared__ int nbr[BM * NBS];          // source row of every (tile row, tap), -1 = zero padding
+  extern __shared__ __align__(16) unsigned char igemm_smem[];  // conv_igemm_lds_bytes<...>() bytes
+  float* As = reinterpret_cast<float*>(igemm_smem);            // [BM][AP]
+  float* Bs = As + BM * AP;                                    // [BKT][BP]
+  float* red = Bs + BKT * BP;                                  // [WM][BN][2]
+  int* nbr = reinterpret_cast<int*>(red + WM * BN * 2);        // [BM][NBS] source row of every (tile row, tap), -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN, hh = lane >> 5, c = lane & 31;
+  const int kg = wave / (WM * WN), wv = wave - kg * (WM * WN);  // K group, wave within the (WM x WN) tile grid
+  const int wm = wv / WN, wn = wv % WN, hh = lane >> 5, c = lane & 31;
+  const bool active = kg == 0;           // after the cross-group reduction only group 0 stores
   // fold = 1: grid.x = 4 output parity classes x row blocks of source pixels
   const int mblocks = (int)((a.M + BM - 1) / BM);
   const int cls = a.fold == 1 ? (int)blockIdx.x / mblocks : 0;
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   const char* in_bytes = reinterpret_cast<const char*>(a.in);
   const char* wp_bytes = reinterpret_cast<const char*>(a.wp);
   const uint32_t row_bytes = (uint32_t)a.Cin * 4u, wrow_bytes = (uint32_t)a.Cout * 4u;
-  const int nci = a.Cin >> 5, nchunk = a.ntaps * nci, niter = (nchunk + 1) >> 1;
+  const int nci = a.Cin >> 5, nchunk = a.ntaps * nci, niter = (nchunk + KH - 1) / KH;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
 #define IGEMM_LOAD(AREG, BREG, AMASK, IT)                                                                             \
   do {                                                                                                                \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                   \
-      const int kc = 2 * (IT) + h;                                                                                    \
+    _Pragma("unroll") for (int h = 0; h < KH; ++h) {                                                                  \
+      const int kc = KH * (IT) + h;                                                                                   \
       const bool live = kc < nchunk;                                                                                  \
       const int tap = live ? kc / nci : 0, cc = live ? kc - tap * nci : 0;                                            \
       /* 32-bit byte offsets from the (wave-uniform) tensor bases: every tensor here is < 4 GiB */                    \
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
       const uint32_t b_row0 =                                                                                         \
           (uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;             \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
-        const int idx = tid + NT * q;                                                                                 \
+        const int idx = BPART ? (tid < 8 * BN ? tid : 8 * BN - 1) : tid + NT * q;  /* clamped: spare threads re-read */ \
         const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                         \
         BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u)); \
       }                                                                                                               \
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   // (the second half of an odd last pair multiplies A-zeros: its B rows only have to be finite -- a re-read of tap 0)
 #define IGEMM_STORE(AREG, BREG, AMASK)                                                                                \
   do {                                                                                                                \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                                   \
+    _Pragma("unroll") for (int h = 0; h < KH; ++h) {                                                                  \
       _Pragma("unroll") for (int q = 0; q < RA; ++q) {                                                                \
         const int row = (tid + NT * q) >> 3;                                                                          \
         float* p = As + row * AP + h * 32 + ac4 * 4;                                                                  \
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
         const int idx = tid + NT * q;                                                                                 \
         const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                         \
-        *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];                                   \
+        if (!BPART || idx < 8 * BN) *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];       \
       }                                                                                                               \
     }                                                                                                                 \
   } while (0)
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   // then [MFMAs of step s] (hipcc otherwise re-serialises read -> wait -> MFMA; mask 0x100 = DS read, 0x008 = MFMA)
 #define IGEMM_MFMA()                                                                                                  \
   do {                                                                                                                \
-    const float* ap = As + (wm * TM * 32 + c) * AP + hh;                                                              \
-    const float* bp = Bs + hh * BP + wn * TN * 32 + c;                                                                \
+    const float* ap = As + (wm * TM * 32 + c) * AP + kg * BK + hh;                                                    \
+    const float* bp = Bs + (kg * BK + hh) * BP + wn * TN * 32 + c;                                                    \
     float av[2][TM], bv[2][TN];                                                                                       \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = ap[i * 32 * AP];                                        \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = bp[j * 32];                                             \
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
   } while (0)
 
   {
-    f32x4 aA[2][RA], bA[2][RB];
-    float mA[2][RA];
+    f32x4 aA[KH][RA], bA[KH][RB];
+    float mA[KH][RA];
     for (int it = it_beg; it <= it_end; ++it) {
       if (it < it_end) IGEMM_LOAD(aA, bA, mA, it);
       if (it > it_beg) IGEMM_MFMA();
@@ -170,7 +182,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #undef IGEMM_STORE
 #undef IGEMM_MFMA
 
-  // ---------------- epilogue
+  if constexpr (WK > 1) {
+    // combine the K groups through LDS (the staging tiles are dead: the loop ended on a barrier)
+    float* xch = As;  // [TM][TN][16][NTG]
+    for (int g = 1; g < WK; ++g) {
+      if (kg == g) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[((i * TN + j) * 16 + r) * NTG + (tid - g * NTG)] = acc[i][j][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * TN + j) * 16 + r) * NTG + tid];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---------------- epilogue (K groups other than 0 only keep the barriers company)
   if (a.ksplit > 1) {  // raw partial sums (quad-summed if asked); bias and BN partials happen in splitk_reduce_kernel
     const int64_t rows_out = a.poolsum ? a.M >> 2 : (a.fold == 1 ? a.M << 2 : a.M);
     float* slab = a.splitk_ws + (size_t)blockIdx.z * rows_out * a.Cout;
@@ -184,13 +221,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
           for (int g = 0; g < 4; ++g) {
             const float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
             const int64_t m = m0 + wm * TM * 32 + i * 32 + 8 * g + 4 * hh;
-            if (m < a.M) slab[(m >> 2) * a.Cout + col] = v;
+            if (active && m < a.M) slab[(m >> 2) * a.Cout + col] = v;
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
-            if (m < a.M) slab[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = acc[i][j][r];
+            if (active && m < a.M) slab[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = acc[i][j][r];
           }
         }
       }
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
         for (int g = 0; g < 4; ++g) {
           const float v = (acc[i][j][4 * g] + acc[i][j][4 * g + 1]) + (acc[i][j][4 * g + 2] + acc[i][j][4 * g + 3]);
           const int64_t m = m0 + wm * TM * 32 + i * 32 + 8 * g + 4 * hh;
-          if (m < a.M) a.out[(m >> 2) * a.Cout + col] = v;
+          if (active && m < a.M) a.out[(m >> 2) * a.Cout + col] = v;
         }
       }
     return;
@@ -223,7 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
-        if (m < a.M) {
+        if (active && m < a.M) {
           const float v = acc[i][j][r] + bias;
           a.out[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = v;
           s1[j] += v;
@@ -236,7 +273,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvArgs a) {
     for (int j = 0; j < TN; ++j) {
       s1[j] += __shfl_xor(s1[j], 32, 64);
       s2[j] += __shfl_xor(s2[j], 32, 64);
-      if (hh == 0) {
+      if (active && hh == 0) {
         red[(wm * BN + wn * TN * 32 + j * 32 + c) * 2] = s1[j];
         red[(wm * BN + wn * TN * 32 + j * 32 + c) * 2 + 1] = s2[j];
       }
@@ -296,6 +333,24 @@ static int igemm_cfg(int64_t M, int Cout) {
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;
 }
+template <int BM, int BN, int WM, int WN, int WK>
+static constexpr size_t conv_igemm_lds_bytes() {
+  return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
+}
+
+template <int BM, int BN, int WM, int WN, int WK>
+static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, hipStream_t s) {
+  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK>();
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK>;
+  static bool attr_set = false;  // one instantiation = one static
+  if (lds > 64 * 1024 && !attr_set) {
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  DVG_LAUNCH_WORK(id, flops, kern, grid, dim3(WM * WN * WK * 64), lds, s, a);
+  return DVG_OK;
+}
+
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
 static int igemm_bn(int cfg) { return cfg == 2 ? 32 : 64; }
 
@@ -348,12 +403,14 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const unsigned cm = a.fold == 1 ? 4u : 1u;
   const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
+  int rc;
   switch (cfg) {
-    case 0: DVG_LAUNCH_WORK(K_IGEMM_128x64, flops, (conv_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
-    case 1: DVG_LAUNCH_WORK(K_IGEMM_64x64, flops, (conv_igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
-    case 3: DVG_LAUNCH_WORK(K_IGEMM_32x64, flops, (conv_igemm_kernel<32, 64, 1, 2>), grid, dim3(128), 0, s, a); break;
-    default: DVG_LAUNCH_WORK(K_IGEMM_128x32, flops, (conv_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a); break;
+    case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
+    case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1>(K_IGEMM_64x64, flops, grid, a, s); break;
+    case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1>(K_IGEMM_32x64, flops, grid, a, s); break;
+    default: rc = launch_igemm_cfg<128, 32, 4, 1, 1>(K_IGEMM_128x32, flops, grid, a, s); break;
   }
+  DVG_TRY(rc);
   if (a.ksplit > 1) {
     // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks
     const int64_t rows_out = a.poolsum ? a.M / 4 : Mg;
