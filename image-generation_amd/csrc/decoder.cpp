@@ -66,7 +66,7 @@ DecPlan dec_plan(int64_t N, int n) {
     p.Xs[l] = bump(o, (size_t)p.M[l] * C);
     p.mean[l] = bump(o, C);
     p.invstd[l] = bump(o, C);
-    p.stats[l] = bump(o, (size_t)p.nblk[l] * C * 2);
+    p.stats[l] = bump(o, (size_t)(p.nblk[l] + BN_FOLD_ROWS) * C * 2);  // + scratch rows of launch_bn_finalize
     p.mask[l] = bump(o, (size_t)N * C);
     if (l < 3) {
       p.wp[l] = bump(o, (size_t)16 * ch[l] * C);   // 9 taps, or 16 folded (class, tap) pairs

@@ -201,8 +201,47 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// Long partial lists (large batches: 10^4..10^5 row blocks): fold them to BN_FOLD_ROWS rows first.  Block g sums rows
+// [g R, (g+1) R) of the [nblk][2C] matrix with the 2C values of a row spread over consecutive lanes (coalesced), in
+// double, fixed order; the rows land behind the list and bn_finalize_kernel then runs on those.
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(const float* __restrict__ part, int nblk, int C2,
+                                                               float* __restrict__ out) {
+  __shared__ double red[256];
+  const int rows_per = (nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = r0 + rows_per < nblk ? r0 + rows_per : nblk;
+  const int CW = C2 < 256 ? C2 : 256, RL = 256 / CW, cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+  for (int c0 = 0; c0 < C2; c0 += CW) {
+    double acc = 0.0;
+    if (rl < RL && c0 + cl < C2) {
+      const float* col = part + c0 + cl;
+      int k = r0 + rl;
+      for (; k + 3 * RL < r1; k += 4 * RL) {  // four loads in flight per thread
+        const float v0 = col[(size_t)k * C2], v1 = col[(size_t)(k + RL) * C2], v2 = col[(size_t)(k + 2 * RL) * C2],
+                    v3 = col[(size_t)(k + 3 * RL) * C2];
+        acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+      }
+      for (; k < r1; k += RL) acc += (double)col[(size_t)k * C2];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c0 + cl < C2) {
+      double t = 0.0;
+      for (int j = 0; j < RL; ++j) t += red[j * CW + cl];
+      out[(size_t)blockIdx.x * C2 + c0 + cl] = (float)t;
+    }
+    __syncthreads();
+  }
+}
+
 int launch_bn_finalize(const float* stats_part, int nblk, int C, int64_t M, int training, float* mean, float* invstd,
                        float* running_mean, float* running_var, int64_t* nbt, hipStream_t s) {
+  if (training && nblk >= 1024) {
+    float* folded = const_cast<float*>(stats_part) + (size_t)nblk * C * 2;
+    DVG_LAUNCH(K_BN_FINALIZE, bn_fold_partials_kernel, dim3(BN_FOLD_ROWS), dim3(256), 0, s, stats_part, nblk, 2 * C, folded);
+    DVG_LAUNCH(K_BN_FINALIZE, bn_finalize_kernel, dim3((unsigned)ceil_div(C, 4)), dim3(256), 0, s, folded, BN_FOLD_ROWS, C,
+               (double)M, training, mean, invstd, running_mean, running_var, nbt);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_BN_FINALIZE, bn_finalize_kernel, dim3((unsigned)ceil_div(C, 4)), dim3(256), 0, s, stats_part, nblk, C,
              (double)M, training, mean, invstd, running_mean, running_var, nbt);
   return DVG_OK;

@@ -48,7 +48,7 @@ EncPlan enc_plan(int64_t B, int n) {
     p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
     p.mean[l] = bump(o, C);
     p.invstd[l] = bump(o, C);
-    p.stats[l] = bump(o, (size_t)p.nblk[l] * C * 2);
+    p.stats[l] = bump(o, (size_t)(p.nblk[l] + BN_FOLD_ROWS) * C * 2);  // + scratch rows of launch_bn_finalize
     p.wp[l] = p.wpd[l] = 0;
     p.ksplit[l] = 0;
     if (l > 0) {

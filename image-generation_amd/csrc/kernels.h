@@ -5,6 +5,7 @@
 namespace dvg {
 
 constexpr int EW_BLOCKS = 512;       // fixed grid of the reducing elementwise kernels (partials per block)
+constexpr int BN_FOLD_ROWS = 256;    // scratch rows behind the BN partials: launch_bn_finalize folds long lists first
 constexpr float BN_EPS = 1e-5f;      // torch.nn.BatchNorm2d defaults (/root/reference/src/encoder.py:32)
 constexpr float BN_MOMENTUM = 0.1f;
 constexpr float LRELU_SLOPE = 0.01f;  // torch.nn.LeakyReLU() default (/root/reference/src/encoder.py:36)
@@ -24,6 +25,7 @@ int launch_rowsum_partial(const float* mat, int64_t rows, int cols, float* part,
 int launch_permute_vec(const float* in, int count, int A, int B, float* out, hipStream_t s);
 
 // BatchNorm statistics from per-block (sum, sum^2) partials; updates running stats when training.
+// `stats_part` must have BN_FOLD_ROWS spare rows behind its nblk rows (used when nblk is large).
 int launch_bn_finalize(const float* stats_part, int nblk, int C, int64_t M, int training, float* mean, float* invstd,
                        float* running_mean, float* running_var, int64_t* nbt, hipStream_t s);
 

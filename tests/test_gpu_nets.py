@@ -125,6 +125,24 @@ def test_encoder_matches_oracle_full_gradients(n, B):
         assert int(enc.state_dict()[f"conv.{4*l+1}.num_batches_tracked"]) == int(p[f"conv.{4*l+1}.num_batches_tracked"])
 
 
+def test_encoder_forward_large_batch_folds_bn_partials():
+    """B = 288 gives the first layer >= 1024 per-block BatchNorm partial rows, which launch_bn_finalize folds in a
+    first pass: forward logits and running statistics against the oracle (forward only: at this many pooling windows
+    no batch is free of float32 near-ties, whose gradient routing is rounding noise on either side)."""
+    n, B = 64, 288
+    params = gen.make_params(n, "encoder", 21)
+    enc = _load(Encoder(n), params).train()
+    p = _oracle_params(params)
+    x = torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = nets.encoder_forward(p, x, training=True)
+        got = enc(x.cuda())
+    _close(got.cpu(), want, 5e-5, "logits")
+    for l in range(4):
+        for stat in ("running_mean", "running_var"):
+            _close(enc.state_dict()[f"conv.{4*l+1}.{stat}"].cpu(), p[f"conv.{4*l+1}.{stat}"], 2e-5, stat)
+
+
 def test_encoder_maxpool_exact_ties_route_to_first_element():
     """Constant images make every interior pooling window an exact tie; torch gives the gradient to the
     first window element (scan order).  A different tie rule changes the weight gradients at O(1)."""
