@@ -32,7 +32,7 @@ def test_version_and_error_string():
     assert isinstance(L.dvg_last_error(), bytes)
     assert L.dvg_prof_num_kernels() > 10
     names = {L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())}
-    assert "gibbs_sweeps" in names and "conv_igemm_kernel<64,64,2,2>" in names
+    assert "gibbs_sweeps" in names and "conv_igemm_kernel<64,64,2,2,1>" in names
 
 
 def test_argument_validation_without_gpu():
