@@ -23,8 +23,12 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict
       g1 = gumbels[2 * e + 1];
     } else {
       const u32x4 r = philox4x32_10((uint32_t)e, off_lo, off_hi ^ (uint32_t)(e >> 32), STREAM_GUMBEL, k0, k1);
-      const float u0 = __fmul_rn(__uint2float_rn(r.x >> 8) + 0.5f, 5.9604644775390625e-08f);
-      const float u1 = __fmul_rn(__uint2float_rn(r.y >> 8) + 0.5f, 5.9604644775390625e-08f);
+      // u = (k + 1/2) 2^-23 with k the top 23 bits: every value is exact in float32 and strictly inside (0, 1), so the
+      // Gumbel noise is finite (|g| < 17).  A 24-bit k does NOT work: 16777215 + 0.5 rounds to 2^24, u = 1, g = +inf,
+      // and (inf - inf) in the softmax below poisons the whole encoder gradient -- a 2^-24 event per draw, i.e. a few
+      // per cent per training step at B R n = 2.6e5 (found by a soak run; regression test in tests/test_gpu_losses.py).
+      const float u0 = __fmul_rn(__uint2float_rn(r.x >> 9) + 0.5f, 1.1920928955078125e-07f);
+      const float u1 = __fmul_rn(__uint2float_rn(r.y >> 9) + 0.5f, 1.1920928955078125e-07f);
       g0 = -logf(-logf(u0));
       g1 = -logf(-logf(u1));
     }

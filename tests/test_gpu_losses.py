@@ -125,6 +125,24 @@ def test_gumbel_device_rng_statistics():
     assert torch.equal(s, F.gumbel_latent_to_discrete(logits, R, seed=123, offset=5))
 
 
+def test_gumbel_device_noise_is_finite_over_1e8_draws():
+    """Regression: the device uniform must lie strictly inside (0, 1).  With a 24-bit mantissa draw, (2^24 - 1) + 0.5
+    rounds to 2^24 -> u = 1 -> Gumbel noise +inf -> NaN in the straight-through derivative, about once per 1.7e7 draws.
+    6.7e7 draws per call here (two calls): the old formula fails this with probability 1 - exp(-8)."""
+    B, R, n = 4096, 8, 1024
+    logits = torch.zeros(B, n, device="cuda")
+    L = _lib.lib()
+    for offset in (0, 1):
+        spins = torch.empty(B, R, n, device="cuda")
+        dspin = torch.empty_like(spins)
+        _lib.check(L.dvg_gumbel_fwd(logits.data_ptr(), B, n, R, F.GUMBEL_TAU, None, 1234, offset, spins.data_ptr(),
+                                    dspin.data_ptr(), None, _lib.stream_ptr(logits.device)), "dvg_gumbel_fwd")
+        assert bool(((spins == 1) | (spins == -1)).all())
+        assert bool(torch.isfinite(dspin).all())
+        assert float(dspin.max()) <= 2 * 0.25 / F.GUMBEL_TAU + 1e-3 and float(dspin.min()) >= 0.0
+        assert abs(float(spins.mean())) < 1e-3  # zero logits: fair coin
+
+
 def test_heaviside():
     l = torch.tensor([[0.3, -0.2, 0.0, 1e-9, -5.0, 2.5]], device="cuda", requires_grad=True)
     o = F.heaviside_latent_to_discrete(l, 1)

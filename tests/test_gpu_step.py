@@ -128,6 +128,8 @@ def test_training_driver_and_model_files(tmp_path, golden_dir):
     rep = execute_training(m, 2, details_path=str(tmp_path / "problem_details.json"), verbose=False)
     assert len(rep) == 2 and rep[0]["Epoch"] == "1/2" and rep[1]["Batch Size"] == 8
     assert len(m.losses["mse_losses"]) == 40 and m.losses["mse_losses"][-1] < 0.7 * m.losses["mse_losses"][0]
+    for name, v in list(m._dvae.state_dict().items()) + list(m._grbm.state_dict().items()):
+        assert not v.is_floating_point() or bool(torch.isfinite(v).all()), name  # (a NaN encoder still lowers the MSE)
     create_model_files(m, tmp_path / "run", n_epochs=2)
     params = json.load(open(tmp_path / "run" / "parameters.json"))
     assert set(params) == {"n_latents", "n_epochs", "prefactor", "qpu", "num_read", "loss_function", "image_size",
@@ -181,3 +183,27 @@ def test_exact_resume_from_training_state(tmp_path, golden_dir):
     got = final(c)
     for k in want:
         assert torch.equal(want[k], got[k]), k
+
+
+def test_soak_c2_shape_stays_finite(golden_dir, tmp_path):
+    """120 graph-replayed steps at the bench shape (B=256, n=128, R=8: 2.6e5 Gumbel draws per step): every parameter
+    stays finite.  This is the run that exposed the u = 1 Gumbel draw (see test_gpu_losses.py)."""
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(golden_dir, "step_params.yaml")))
+    cfg.update(BATCH_SIZE=256, N_REPLICAS=8, NUM_READS=256, GIBBS_SWEEPS=10)
+    with open(tmp_path / "params.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    m = ModelWrapper("Advantage_system4", n_latents=128, training_parameter_file=str(tmp_path / "params.yaml"))
+    g = torch.Generator().manual_seed(0)
+    batches = [((torch.rand(256, 1, 32, 32, generator=g) < 0.13).float().cuda(), None) for _ in range(8)]
+    m.set_dataloader(batches * 15)
+    m.train_init(1)
+    m.sync_losses = False
+    m.use_graph = True
+    for k in range(120):
+        m.step(batches[k % 8], epoch=0)
+    torch.cuda.synchronize()
+    for name, v in list(m._dvae.state_dict().items()) + list(m._grbm.state_dict().items()):
+        assert not v.is_floating_point() or bool(torch.isfinite(v).all()), name
+    assert bool(torch.isfinite(m.last["mse"])) and bool(torch.isfinite(m.last["mmd"]))
