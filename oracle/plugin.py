@@ -117,8 +117,8 @@ def gaussian_kernel_matrix(
         N = D.shape[0]
         bw = D.detach().sum() / (N * N - N)
     else:
-        bw = torch.as_tensor(bandwidth, dtype=D.dtype)
-    bws = bw * kernel_factors(n_kernels, factor).to(D.dtype)
+        bw = torch.as_tensor(bandwidth, dtype=D.dtype, device=D.device)
+    bws = bw * kernel_factors(n_kernels, factor).to(device=D.device, dtype=D.dtype)
     K = torch.exp(-D.unsqueeze(0) / bws.reshape(-1, 1, 1))
     return K.sum(0) if reduce == "sum" else K.mean(0)
 

@@ -1,0 +1,124 @@
+"""Parity at the BASELINE.json sizes (c2: B=256, n=128, R=8; c3-scale MMD and sampler), where the CPU oracle would take
+minutes: the SAME oracle code (oracle/nets.py, oracle/plugin.py: plain torch ops) is run in float64 on the GPU through
+stock PyTorch-ROCm -- an independent implementation of every operator (MIOpen / rocBLAS) -- plus size-independent
+properties (permutation equivariance, symmetry) and the bit-exact C restatement of the sampler."""
+import numpy as np
+import pytest
+import torch
+
+import gen
+from image_generation_amd import functional as F, graphs, sampler as smp
+from image_generation_amd.modules import Decoder, Encoder
+from oracle import cref, gibbs, nets, plugin
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(module, params):
+    module.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in params.items()})
+    return module.cuda()
+
+
+def _p64(params):
+    return {k: (torch.from_numpy(np.array(v)).double().cuda().requires_grad_("running" not in k)
+                if np.array(v).dtype == np.float32 else torch.from_numpy(np.array(v)).cuda()) for k, v in params.items()}
+
+
+def _rel_l2(got, want):
+    got, want = got.double(), want.double()
+    return float((got - want).norm() / (want.norm() + 1e-300))
+
+
+def test_decoder_c2_size_matches_float64_oracle_on_device():
+    n, B, R = 128, 256, 8
+    params = gen.make_params(n, "decoder", 77)
+    dec = _load(Decoder(n), params).train()
+    p = _p64(params)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 3)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 4)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(9)).cuda()
+    s64 = spins.double().requires_grad_(True)
+    want = nets.decoder_forward(p, s64, training=True, dropout_masks=[m.double() for m in masks])
+    (want * go.double()).sum().backward()
+    sg = spins.clone().requires_grad_(True)
+    dec.inject_dropout_masks(masks)
+    got = dec(sg)
+    (got * go).sum().backward()
+    assert _rel_l2(got.detach(), want.detach()) < 2e-6
+    assert float((got.detach().double() - want.detach()).abs().max()) < 3e-5 * float(want.detach().abs().max())
+    # gradients: LeakyReLU kinks (pre-activations within float32 rounding of 0 pick the other slope) put a handful of
+    # O(1) element errors into the float32-vs-float64 comparison, so the bar is an L2 one plus a count of outliers
+    assert _rel_l2(sg.grad, s64.grad) < 2e-3
+    rel = (sg.grad.double() - s64.grad).abs() / (s64.grad.abs() + 1e-3 * s64.grad.abs().max())
+    assert float((rel > 1e-2).double().mean()) < 1e-3
+    for name, prm in dec.named_parameters():
+        if name.startswith("convtrans") and name.endswith("bias") and name.split(".")[1] in ("0", "5", "10", "15"):
+            continue  # bias in front of a BatchNorm: true gradient is zero, ours is rounding noise
+        assert _rel_l2(prm.grad, p[name].grad) < 2e-3, name
+
+
+def test_encoder_c2_size_matches_float64_oracle_on_device():
+    n, B = 128, 256
+    params = gen.make_params(n, "encoder", 78)
+    enc = _load(Encoder(n), params).train()
+    p = _p64(params)
+    x = torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    gl = torch.randn(B, n, generator=torch.Generator().manual_seed(1)).cuda()
+    want = nets.encoder_forward(p, x.double(), training=True)
+    (want * gl.double()).sum().backward()
+    got = enc(x)
+    (got * gl).sum().backward()
+    assert float((got.detach().double() - want.detach()).abs().max()) < 5e-5 * float(want.detach().abs().max())
+    # gradients: a few float32 near-tie pooling windows route differently, so the bar is an L2 one
+    for name, prm in enc.named_parameters():
+        if name.startswith("conv") and name.endswith("bias") and int(name.split(".")[1]) % 4 == 0:
+            continue
+        assert _rel_l2(prm.grad, p[name].grad) < 5e-3, name
+
+
+@pytest.mark.parametrize("nx,ny,d", [(2048, 256, 128), (32768, 256, 512)])
+def test_mmd_full_size_properties(nx, ny, d):
+    """Permutation of the rows of x permutes the gradient rows and leaves the loss alone; MMD(x, y) = MMD(y, x);
+    at the c2 size also the float64 value computed by the oracle on the device."""
+    g = torch.Generator().manual_seed(nx)
+    x = ((torch.rand(nx, d, generator=g) < 0.4).float() * 2 - 1).cuda()
+    y = ((torch.rand(ny, d, generator=g) < 0.55).float() * 2 - 1).cuda()
+    xa = x.clone().requires_grad_(True)
+    la = F.mmd_loss(xa, y)
+    la.backward()
+    perm = torch.randperm(nx, generator=g).cuda()
+    xb = x[perm].clone().requires_grad_(True)
+    lb = F.mmd_loss(xb, y)
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(la)) + 1e-9
+    assert float((xb.grad - xa.grad[perm]).abs().max()) <= 2e-5 * float(xa.grad.abs().max()) + 1e-12
+    ls = F.mmd_loss(y.clone().requires_grad_(True), x)
+    assert abs(float(la) - float(ls)) <= 1e-5 * abs(float(la)) + 1e-8
+    if nx <= 4096:
+        x64 = x.double().requires_grad_(True)
+        want = plugin.mmd_loss(x64, y.double())
+        want.backward()
+        assert abs(float(la) - float(want)) <= 1e-5 * abs(float(want))
+        assert float((xa.grad.double() - x64.grad).abs().max()) <= 2e-5 * float(x64.grad.abs().max())
+
+
+def test_gibbs_full_c3_size_bit_exact():
+    """512-spin Zephyr sub-graph, 256 chains, 200 sweeps per draw (BASELINE.json configs[2]) against the C restatement."""
+    seed, n, C, sweeps = 775321899904, 512, 256, 200
+    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(n, seed, graphs.zephyr_graph(12)))
+    nodes, ei, ej = graphs.edges_of(mg)
+    plan = graphs.build_plan(n, ei, ej)
+    rng = np.random.default_rng(1)
+    h = (0.05 * rng.uniform(-1, 1, n)).astype(np.float32)
+    J = (5.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)
+    s = smp.GibbsSampler(plan, nodes, beta=20.0, sweeps=sweeps, seed=seed, persistent=True, chain_offset=0,
+                         h_range=(-4, 4), j_range=(-1, 1))
+    lin, quad = torch.from_numpy(h).cuda(), torch.from_numpy(J).cuda()
+    hs, Js = gibbs.scaled_fields(h, J, 0.05, (-4, 4), (-1, 1))
+    ids = np.arange(C, dtype=np.uint32)
+    want = cref.init_state(ids, n, seed)
+    for call in range(2):
+        got = s.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
+        want = cref.gibbs_sweeps(want, ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
+                                 plan.adj_eid, seed, call * sweeps, sweeps)
+        assert int((got != want.astype(np.float32)).sum()) == 0
