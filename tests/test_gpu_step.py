@@ -207,3 +207,36 @@ def test_soak_c2_shape_stays_finite(golden_dir, tmp_path):
     for name, v in list(m._dvae.state_dict().items()) + list(m._grbm.state_dict().items()):
         assert not v.is_floating_point() or bool(torch.isfinite(v).all()), name
     assert bool(torch.isfinite(m.last["mse"])) and bool(torch.isfinite(m.last["mmd"]))
+
+
+def test_heaviside_mode_steps_and_sharpened_generation(tmp_path, golden_dir):
+    """LATENT_TO_DISCRETE: heaviside (/root/reference/src/utils/common.py:143-175) with one replica: the step runs
+    (straight-through gradient), parameters move and stay finite; generation with `sharpen` obeys the reference's
+    two-threshold rule (/root/reference/src/model_wrapper.py:382-385): values in {0} U [lower, upper] U {1}."""
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(golden_dir, "step_params.yaml")))
+    cfg.update(LATENT_TO_DISCRETE="heaviside", N_REPLICAS=1)
+    with open(tmp_path / "params.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=str(tmp_path / "params.yaml"))
+    B = m.BATCH_SIZE
+    imgs = torch.from_numpy(gen.make_images(B * 6, seed=3)).reshape(6, B, 1, 32, 32).cuda()
+    m.set_dataloader([(imgs[k], None) for k in range(6)])
+    m.train_init(1)
+    before = {k: v.clone() for k, v in m._dvae.state_dict().items()}
+    for k in range(6):
+        loss = m.step((imgs[k], None), epoch=0)
+        assert bool(torch.isfinite(torch.as_tensor(loss)))
+    after = m._dvae.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before if "weight" in k and k.startswith("_encoder"))
+    assert all(bool(torch.isfinite(v).all()) for v in after.values() if v.is_floating_point())
+    out = m.generate_images(sharpen=True, lower=0.35, upper=0.65)
+    assert out.shape == (m.NUM_READS, 1, 32, 32)
+    ok = (out == 0) | (out == 1) | ((out > 0.35) & (out <= 0.65))
+    assert bool(ok.all())
+    with pytest.raises(ValueError):
+        cfg.update(N_REPLICAS=2)
+        with open(tmp_path / "bad.yaml", "w") as f:
+            yaml.safe_dump(cfg, f)
+        ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=str(tmp_path / "bad.yaml")).setup()
