@@ -138,8 +138,8 @@ def main():
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
     is_gemm = lambda nm: nm.startswith("conv_igemm_kernel") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm)) if not args.breakdown else (1 << len(names)) - 1
-    # Steps without a GRBM update are replayed from a captured hipGraph (one graph launch instead of ~120 kernel
-    # launches); the GRBM steps (every 10th) run eagerly.  --eager disables the graph.
+    # The autoencoder half of every step is replayed from a captured hipGraph (one graph launch instead of ~120 kernel
+    # launches); on every 10th step the GRBM quasi-NLL update runs eagerly behind it.  --eager disables the graph.
     # (several GPUs: two graphs per step with the eager RCCL all-reduce of the flat gradient buffer between them)
     model.use_graph = not args.eager
     step_idx = 0

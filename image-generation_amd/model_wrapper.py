@@ -388,10 +388,10 @@ class ModelWrapper:
         self._dyn.write(sweep0=c[0], gumbel_offset=c[2], dropout_offset=c[3], step_size=(step_size, 0.0), bc2_sqrt=(bc2, 1.0))
 
     def _capture(self, images):
-        """Capture one more instance of the autoencoder half.  ``N_GRAPHS`` instances are replayed round-robin: a
-        launch of an executable graph waits on the host for that SAME executable's previous run, so with a single
-        instance the ~120 nodes of step k+1 are only submitted once step k has drained and the short forward
-        kernels run at the host's submission rate; with two, step k+1 is fully queued while step k executes."""
+        """Capture one more instance of the autoencoder half.  ``N_GRAPHS`` instances can be replayed round-robin
+        (each with its own static input / outputs); the idea -- a second executable so that step k+1 is submitted
+        while step k still runs -- measured no gain (the host is already ~0.25 ms per step ahead of the device), so
+        one instance is the default."""
         from . import _lib
 
         if self._dyn is None:
