@@ -240,3 +240,32 @@ def test_heaviside_mode_steps_and_sharpened_generation(tmp_path, golden_dir):
         with open(tmp_path / "bad.yaml", "w") as f:
             yaml.safe_dump(cfg, f)
         ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=str(tmp_path / "bad.yaml")).setup()
+
+
+@pytest.mark.parametrize("qpu,n,B,R", [("Advantage2_system1", 1024, 16, 2), ("Advantage_system4", 256, 48, 3),
+                                       ("Advantage2_system1", 96, 10, 1)])
+def test_odd_shapes_train_end_to_end(tmp_path, golden_dir, qpu, n, B, R):
+    """Shapes off the beaten path -- 1024 spins (sampler's generic schedule, MMD beyond its register-fragment forms),
+    a batch that is no multiple of anything, n = 96 (not a power of two), Zephyr and Pegasus -- eager and graph-replayed:
+    every parameter stays finite and the graph is actually captured."""
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(golden_dir, "step_params.yaml")))
+    cfg.update(BATCH_SIZE=B, N_REPLICAS=R, NUM_READS=40, GIBBS_SWEEPS=7)
+    with open(tmp_path / "params.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    m = ModelWrapper(qpu, n_latents=n, training_parameter_file=str(tmp_path / "params.yaml"))
+    g = torch.Generator().manual_seed(0)
+    batches = [((torch.rand(B, 1, 32, 32, generator=g) < 0.13).float().cuda(), None) for _ in range(25)]
+    m.set_dataloader(batches)
+    m.train_init(1)
+    for k in range(12):
+        m.step(batches[k], epoch=0)
+    m.sync_losses, m.use_graph = False, True
+    for k in range(12, 25):
+        m.step(batches[k], epoch=0)
+    torch.cuda.synchronize()
+    assert m._graph is not None and not m._graph_failed
+    for name, v in list(m._dvae.state_dict().items()) + list(m._grbm.state_dict().items()):
+        assert not v.is_floating_point() or bool(torch.isfinite(v).all()), name
+    assert all(bool(torch.isfinite(m.last[k])) for k in ("mse", "mmd", "nll"))
