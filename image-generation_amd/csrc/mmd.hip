@@ -805,10 +805,208 @@ __device__ __forceinline__ void mmd_pm1_body(const MmdArgs& a, unsigned char* pm
   }
 }
 
+// Spin path, d = 128..512 (multiples of 128): feature-quarter form.  The four waves still split a column tile's 128 rows
+// for the Gram and the table lookups, but for the gradient GEMM each wave owns a QUARTER OF THE FEATURES over ALL 128
+// rows: the waves publish their packed bf16 weight fragments (already in B-operand layout: 6 x 16 bytes per lane) to
+// LDS, one barrier, and every wave multiplies all 24 of them with its own rows of the transposed copy.  Per tile the
+// staging, Gram and lookups then run ONCE instead of once per 256-feature slice (they were 2/3 of the kernel at
+// d = 512 by ablation: 684 us -> 444 without the GEMM, 516 without the Gram MFMAs), the accumulators shrink from 128
+// to 16 NFBW registers, and the end-of-kernel cross-wave reduction of G^T disappears.
+template <int NFBW>  // feature blocks per wave = d / 128
+__device__ __forceinline__ void mmd_pm1_fq_body(const MmdArgs& a, unsigned char* pm1_smem) {
+  constexpr int NFB = 4 * NFBW;
+  const int d = a.d;
+  const int pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
+  const int zp = pw + 16, xp = d + 16;
+  // LDS: pair table | row sums | reduction scratch | X rows (all features) | Z panel (aliased by the G^T reduction)
+  uint4* tab_s = reinterpret_cast<uint4*>(pm1_smem);                       // [2][d+1]
+  float* rs_s = reinterpret_cast<float*>(tab_s + 2 * (d + 1));             // [4][32]
+  double* red = reinterpret_cast<double*>(rs_s + 128);                     // [256]
+  int8_t* Xs8 = reinterpret_cast<int8_t*>(red + 256);                      // [32][d+16]
+  int8_t* Zs8 = Xs8 + MMD_BI * xp;                                         // [128][pw+16]
+  float* Gs = reinterpret_cast<float*>(Zs8);                               // [NFB*32][33] (after the tile loop)
+  i32x4* wx = reinterpret_cast<i32x4*>(Zs8 + (((size_t)MMD_BJ * zp > sizeof(float) * NFB * 32 * MMD_PITCH ? (size_t)MMD_BJ * zp : sizeof(float) * NFB * 32 * MMD_PITCH) + 15) / 16 * 16);  // [4 jb][2 s][3 terms][64 lanes]
+
+  const int64_t rbx = (a.nx + MMD_BI - 1) / MMD_BI;
+  const int64_t rb = blockIdx.x;
+  const bool rows_x = rb < rbx;
+  if (blockIdx.z > 0) return;  // the z extent of the grid only serves the f32 body of general inputs
+  constexpr int zslice = 0;
+  const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * MMD_BI;
+  const int64_t goff_i = rows_x ? 0 : a.nx;
+  const int64_t tx = (a.nx + MMD_BJ - 1) / MMD_BJ, ty = (a.ny + MMD_BJ - 1) / MMD_BJ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  const int64_t gi = base_i + c;
+  const bool vi = gi < cnt_i;
+  const int f0 = (tid >> 6) * NFBW * 32;  // this wave's feature quarter
+  const bool want_grad = rows_x && a.grad_part != nullptr;
+
+  // ---- one-time staging: pair table and this block's 32 rows (int8, every feature)
+  for (int e = tid; e < 2 * (d + 1); e += 256) tab_s[e] = a.tab[e];
+  for (int c0 = 0; c0 < d; c0 += MMD_I8_PANEL) {
+    const int cw = d - c0 < MMD_I8_PANEL ? d - c0 : MMD_I8_PANEL;
+    I8Stage<MMD_BI> xst;
+    xst.load(a.zi8 + goff_i * d + c0, d, base_i, cnt_i, cw >> 4);
+    xst.store(Xs8 + c0, xp, cw >> 4);
+  }
+
+  f32x16 G[NFBW];
+#pragma unroll
+  for (int fb = 0; fb < NFBW; ++fb) G[fb] = (f32x16){0};
+  float rowsum = 0.f;
+  double l_xx = 0.0, l_xy = 0.0, l_yy = 0.0;
+
+  const int64_t t_begin = rows_x ? 0 : tx;
+  I8Stage<MMD_BJ> zst;
+  {
+    const int64_t t0 = t_begin + blockIdx.y;
+    if (t0 < tx + ty) {
+      const bool x0 = t0 < tx;
+      zst.load(a.zi8 + (x0 ? 0 : a.nx) * d, d, (x0 ? t0 : t0 - tx) * MMD_BJ, x0 ? a.nx : a.ny, pw >> 4);
+    }
+  }
+  for (int64_t t = t_begin + blockIdx.y; t < tx + ty; t += gridDim.y) {
+    const bool cols_x = t < tx;
+    const int64_t cnt_j = cols_x ? a.nx : a.ny, base_j = (cols_x ? t : t - tx) * MMD_BJ;
+    const int64_t goff_j = cols_x ? 0 : a.nx;
+
+    // ---- Gram tile on the int8 MFMA, 512-feature panels of the 128 column rows through LDS
+    i32x16 acc = {0};
+    for (int c0 = 0; c0 < d; c0 += MMD_I8_PANEL) {
+      const int cw = d - c0 < MMD_I8_PANEL ? d - c0 : MMD_I8_PANEL;
+      const int n16 = cw >> 4;
+      if (c0 > 0) zst.load(a.zi8 + goff_j * d + c0, d, base_j, cnt_j, n16);  // panel 0 was prefetched
+      __syncthreads();
+      zst.store(Zs8, zp, n16);
+      __syncthreads();
+      const int8_t* za = Zs8 + (wave * 32 + c) * zp + hh * 16;
+      const int8_t* xb = Xs8 + c * xp + c0 + hh * 16;
+      for (int s = 0; s < (cw >> 5); ++s)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const i32x4*>(za + s * 32),
+                                                    *reinterpret_cast<const i32x4*>(xb + s * 32), acc, 0, 0, 0);
+    }
+    {  // prefetch the next tile's first panel; it lands while this tile's lookups and gradient GEMM run
+      const int64_t tn = t + gridDim.y;
+      if (tn < tx + ty) {
+        const bool nx_ = tn < tx;
+        zst.load(a.zi8 + (nx_ ? 0 : a.nx) * d, d, (nx_ ? tn : tn - tx) * MMD_BJ, nx_ ? a.nx : a.ny, pw >> 4);
+      }
+    }
+
+    // ---- per-pair phase: one table lookup
+    const bool same = (rows_x == cols_x);
+    const uint4* tb = tab_s + (cols_x ? 0 : d + 1);
+    // (branch-free: masks instead of selects, so the 16 lookups stay one straight line of ds_read_b128)
+    uint32_t himid[16], lo[16];
+    float lsum = 0.f;
+    const int nj = (int)(cnt_j - base_j < MMD_BJ ? cnt_j - base_j : MMD_BJ);
+    const int64_t dd = gi - base_j;
+    const int dloc = (same && !a.biased && dd >= 0 && dd < MMD_BJ) ? (int)dd : -1;  // column excluded from the loss
+    const i32x4* tb4 = reinterpret_cast<const i32x4*>(tb);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = wave * 32 + crow(r, hh);
+      const int h = (d - acc[r]) >> 1;
+      const i32x4 e = tb4[h];
+      const uint32_t vm = (vi && jl < nj) ? 0xffffffffu : 0u;
+      const uint32_t lm = jl != dloc ? vm : 0u;
+      const uint32_t wm = rows_x ? vm : 0u;  // a row against itself has h = 0, whose table weight is already 0
+      lsum += __uint_as_float((uint32_t)e[0] & lm);
+      rowsum += __uint_as_float((uint32_t)e[1] & wm);
+      himid[r] = (uint32_t)e[2] & wm;
+      lo[r] = (uint32_t)e[3] & wm;
+    }
+    if (rows_x) { if (cols_x) l_xx += (double)lsum; else l_xy += (double)lsum; }
+    else l_yy += (double)lsum;
+
+    if (want_grad) {
+      // ---- gradient GEMM on the bf16 MFMA: G^T[f][i] += sum_j z_j[f] * (hi + mid + lo)[j][i]
+      i32x4 Bw[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 8 * s + 2 * q;
+          Bw[s][0][q] = (int)__builtin_amdgcn_perm(himid[r + 1], himid[r], 0x07060302u);
+          Bw[s][1][q] = (int)__builtin_amdgcn_perm(himid[r + 1], himid[r], 0x05040100u);
+          Bw[s][2][q] = (int)__builtin_amdgcn_perm(lo[r + 1], lo[r], 0x05040100u);
+        }
+      // publish this wave's 6 B-operand fragments, then every wave reads all 24 (conflict-free: lane-linear)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int term = 0; term < 3; ++term) wx[((wave * 2 + s) * 3 + term) * 64 + lane] = Bw[s][term];
+      __syncthreads();
+      const uint16_t* zbase = a.zt + (((cols_x ? 0 : a.ztb_y) + base_j / 32) * d + f0 + c) * 32 + 8 * hh;
+      i32x4 av[2][2][NFBW];
+      auto load_jb = [&](int jb, i32x4 (&dst)[2][NFBW]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int fb = 0; fb < NFBW; ++fb)
+            dst[s][fb] = *reinterpret_cast<const i32x4*>(zbase + ((size_t)jb * d + fb * 32) * 32 + 16 * s);
+      };
+      load_jb(0, av[0]);
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        if (jb + 1 < 4) load_jb(jb + 1, av[(jb + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            const i32x4 bw = wx[((jb * 2 + s) * 3 + term) * 64 + lane];
+#pragma unroll
+            for (int fb = 0; fb < NFBW; ++fb)
+              G[fb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[jb & 1][s][fb]),
+                                                              __builtin_bit_cast(bf16x8, bw), G[fb], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // ---- loss partial sums (feature slice 0 only, so each pair is counted once)
+  const double sxx = block_sum(l_xx, red), sxy = block_sum(l_xy, red), syy = block_sum(l_yy, red);
+  if (tid == 0 && zslice == 0) {
+    double* lp = a.loss_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+    lp[0] = sxx; lp[1] = sxy; lp[2] = syy;
+  }
+  if (!want_grad) return;
+
+  // ---- combine the 4 waves (each saw a different 32-column slice of every tile), deterministic order
+  rowsum += __shfl_xor(rowsum, 32, 64);
+  if (hh == 0) rs_s[wave * 32 + c] = rowsum;
+  __syncthreads();  // Gs aliases the Z panel: every wave is done reading it
+#pragma unroll
+  for (int fb = 0; fb < NFBW; ++fb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Gs[(wave * NFBW * 32 + fb * 32 + crow(r, hh)) * MMD_PITCH + c] = G[fb][r];
+  __syncthreads();
+  // grad[i][f] = x[i][f] * rowsum_i - G^T[f][i]
+  float* out = a.grad_part + (size_t)blockIdx.y * a.nx * d;
+  for (int e = tid; e < MMD_BI * NFB * 32; e += 256) {
+    const int i = e / (NFB * 32), fl = e % (NFB * 32);
+    const int64_t gr = base_i + i;
+    const int ff = fl;
+    if (gr < a.nx && ff < d) {
+      const float rsum = (rs_s[i] + rs_s[32 + i]) + (rs_s[64 + i] + rs_s[96 + i]);
+      out[gr * d + ff] = a.x[gr * d + ff] * rsum - Gs[fl * MMD_PITCH + i];
+    }
+  }
+}
+
 template <int NFB>
 __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char main_smem[];
   mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem));
+}
+
+template <int NFBW>
+__global__ __launch_bounds__(256, 1) void mmd_pair_fq_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char fq_smem[];
+  if (*a.not_pm1 == 0) mmd_pm1_fq_body<NFBW>(a, fq_smem);
+  else mmd_main_body<(NFBW * 4 > 8 ? 8 : NFBW * 4)>(a, reinterpret_cast<float*>(fq_smem));
 }
 
 // One launch serves both kinds of input: the prep kernel's device flag picks the body (no host synchronisation, and
@@ -908,6 +1106,27 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
+template <int NFBW>
+static int launch_pair_fq(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
+  constexpr int NFB = 4 * NFBW, NFBM = NFB > 8 ? 8 : NFB;
+  const int d = a.d, pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
+  const size_t zbytes = (size_t)MMD_BJ * (pw + 16), gbytes = sizeof(float) * NFB * 32 * MMD_PITCH;
+  const size_t zg = ((zbytes > gbytes ? zbytes : gbytes) + 15) / 16 * 16;
+  const size_t lds_s = 2 * (size_t)(d + 1) * sizeof(uint4) + sizeof(float) * 128 + sizeof(double) * 256 +
+                       (size_t)MMD_BI * (d + 16) + zg + sizeof(i32x4) * 24 * 64;
+  const size_t lds_m = sizeof(float) * (size_t)(MMD_BJ * MMD_PITCH + MMD_BI * MMD_PITCH + NFBM * 32 * MMD_PITCH + 4 * 32 + 2) +
+                       sizeof(double) * 256;
+  const size_t lds = lds_s > lds_m ? lds_s : lds_m;
+  auto kern = mmd_pair_fq_kernel<NFBW>;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int zs = (d / 32 + NFBM - 1) / NFBM;  // slices the f32 body needs
+  const double N = (double)(a.nx + a.ny);
+  const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;
+  DVG_LAUNCH_WORK(K_MMD_PM1, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
+  return DVG_OK;
+}
+
 template <int NFB>
 static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   const int d = a.d, pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
@@ -991,7 +1210,16 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     // feature blocks per launch slice: the largest of 8/4/2/1 that divides d/32 (no feature guards in the spin body;
     // 16 blocks = 256 accumulator registers makes the compiler shuffle accumulators through scratch)
     const int fbt = dim / 32;
-    if (fbt % 8 == 0) rc = launch_pair<8>(a, p, s);
+    // d = 128, 256, 384, 512: feature-quarter form (DVG_MMD_NO_FQ=1: the sliced form, A/B runs)
+    static const bool no_fq = [] { const char* e = getenv("DVG_MMD_NO_FQ"); return e && e[0] == '1'; }();
+    if (!no_fq && dim % 128 == 0 && dim <= 512) {
+      switch (dim / 128) {
+        case 1: rc = launch_pair_fq<1>(a, p, s); break;
+        case 2: rc = launch_pair_fq<2>(a, p, s); break;
+        case 3: rc = launch_pair_fq<3>(a, p, s); break;
+        default: rc = launch_pair_fq<4>(a, p, s); break;
+      }
+    } else if (fbt % 8 == 0) rc = launch_pair<8>(a, p, s);
     else if (fbt % 4 == 0) rc = launch_pair<4>(a, p, s);
     else if (fbt % 2 == 0) rc = launch_pair<2>(a, p, s);
     else rc = launch_pair<1>(a, p, s);
