@@ -237,35 +237,43 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ pass 1: sum of all distances
-// Spin rows, d <= 1024: 128 rows per block.  Each wave owns 32 of them with their int8 values resident in REGISTERS as
-// MFMA B fragments for the whole kernel; the 128-row column panel is staged once in LDS and serves all four waves (the
-// 32-row form streamed every column row 4x as often: at c3 17 GB of L2 traffic per call).  The pair distance is
-// symmetric, so same-set blocks walk only the column tiles at or right of their own diagonal tile (x2 for the tiles
-// strictly right of it) and the y-rows-by-x-columns rectangle is left to its transpose (x2 there).
+// Spin rows, d <= 1024: 128 rows per block pass.  Each wave owns 32 of them with their int8 values resident in REGISTERS
+// as MFMA B fragments; the 128-row column panel is staged once in LDS and serves all four waves (the 32-row form
+// streamed every column row 4x as often: at c3 17 GB of L2 traffic per call).  The pair distance is symmetric, so over
+// the concatenated row set (x then y) row block g walks only the column tiles g .. T-1 (x2 for the tiles strictly right
+// of its own).  That is a triangle: block `b` of the grid takes row blocks b AND T-1-b, T+1 tiles in all for every
+// block (the unfolded walk made block 0 the critical path at twice the mean length).  The distance of a pair is a
+// function of its Hamming distance h = (d - <a,b>) / 2 alone, so it comes from a (d+1)-entry LDS table built by the
+// block (same correctly-rounded sqrtf values as computing them per pair, which cost more VALU time than the MFMAs);
+// neighbouring h sit in neighbouring banks, so the gather is conflict-free in practice.  NS <= 16 fits two blocks per
+// CU (registers and LDS): one block's lookups run under the other's MFMAs.
 template <int NS>  // 32-feature steps held in registers: d <= 32 NS
 __device__ __forceinline__ void mmd_distsum_spin128(const MmdArgs& a, unsigned char* dsm) {
   double* red = reinterpret_cast<double*>(dsm);                 // [256]
-  int8_t* Zs8 = reinterpret_cast<int8_t*>(dsm + 2048);          // [128][pw+16]
+  float* Dtab = reinterpret_cast<float*>(dsm + 2048);           // [d+1]
   const int d = a.d, pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL, zp = pw + 16;
-  const int64_t rbx = (a.nx + 127) / 128, rby = (a.ny + 127) / 128;
-  const int64_t rb = blockIdx.x;
+  int8_t* Zs8 = reinterpret_cast<int8_t*>(dsm + 2048 + ((d + 1) * 4 + 15) / 16 * 16);  // [128][pw+16]
+  for (int h = threadIdx.x; h <= d; h += 256) {
+    const float d2 = (float)(4 * h);  // |a|^2 + |b|^2 - 2ab with |.|^2 = d: exact
+    Dtab[h] = a.squared ? d2 : sqrtf(d2);
+  }
+  const int64_t tx = (a.nx + MMD_BJ - 1) / MMD_BJ, ty = (a.ny + MMD_BJ - 1) / MMD_BJ, T = tx + ty;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, c = lane & 31;
+  const int nsteps = d >> 5;
   double total = 0.0;
-  if (rb < rbx + rby) {
-    const bool rows_x = rb < rbx;
-    const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * 128, goff_i = rows_x ? 0 : a.nx;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, c = lane & 31;
+  for (int seg = 0; seg < 2; ++seg) {
+    const int64_t g = seg == 0 ? (int64_t)blockIdx.x : T - 1 - (int64_t)blockIdx.x;
+    if (g >= T || (seg == 1 && g <= (int64_t)blockIdx.x)) break;  // (block-uniform)
+    const bool rows_x = g < tx;
+    const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? g : g - tx) * 128, goff_i = rows_x ? 0 : a.nx;
     const int64_t gi = base_i + wave * 32 + c;
     const bool vi = gi < cnt_i;
-    const int nsteps = d >> 5;
     i32x4 xb[NS];
     {
       const int8_t* xrow = a.zi8 + (goff_i + (vi ? gi : cnt_i - 1)) * d + hh * 16;
 #pragma unroll
       for (int s = 0; s < NS; ++s) xb[s] = s < nsteps ? *reinterpret_cast<const i32x4*>(xrow + s * 32) : (i32x4){0, 0, 0, 0};
     }
-    const int64_t tx = (a.nx + MMD_BJ - 1) / MMD_BJ, ty = (a.ny + MMD_BJ - 1) / MMD_BJ;
-    // x rows: own tile .. end of x, then every y tile (x2); y rows: own tile .. end of y
-    const int64_t t_first = rows_x ? rb : tx + (rb - rbx);
     I8Stage<MMD_BJ> zst;
     auto tile_src = [&](int64_t t, const int8_t*& src, int64_t& base_j, int64_t& cnt_j) {
       const bool cx = t < tx;
@@ -273,13 +281,13 @@ __device__ __forceinline__ void mmd_distsum_spin128(const MmdArgs& a, unsigned c
       base_j = (cx ? t : t - tx) * MMD_BJ;
       cnt_j = cx ? a.nx : a.ny;
     };
-    int64_t t = t_first + blockIdx.y;
-    if (t < tx + ty) {
+    int64_t t = g + blockIdx.y;
+    if (t < T) {
       const int8_t* src; int64_t bj, cj;
       tile_src(t, src, bj, cj);
       zst.load(src, d, bj, cj, pw >> 4);
     }
-    for (; t < tx + ty; t += gridDim.y) {
+    for (; t < T; t += gridDim.y) {
       const int8_t* src; int64_t base_j, cnt_j;
       tile_src(t, src, base_j, cnt_j);
       i32x16 acc[4];
@@ -305,23 +313,29 @@ __device__ __forceinline__ void mmd_distsum_spin128(const MmdArgs& a, unsigned c
       }
       {  // prefetch the next tile's first panel under the distance sums
         const int64_t tn = t + gridDim.y;
-        if (tn < tx + ty) {
+        if (tn < T) {
           const int8_t* nsrc; int64_t nbj, ncj;
           tile_src(tn, nsrc, nbj, ncj);
           zst.load(nsrc, d, nbj, ncj, pw >> 4);
         }
       }
-      const float wgt = t == t_first ? 1.0f : 2.0f;  // the own (diagonal) tile holds both orders of its pairs
+      const float wgt = t == g ? 1.0f : 2.0f;  // the own (diagonal) tile holds both orders of its pairs
       float part = 0.f;
+      if (base_i + 128 <= cnt_i && base_j + MMD_BJ <= cnt_j) {  // whole tile valid (block-uniform): no masks
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t gj = base_j + jt * 32 + crow(r, hh);
-          const float d2 = (float)(2 * (d - acc[jt][r]));  // |a|^2 + |b|^2 - 2ab with |.|^2 = d: exact
-          const float D = a.squared ? d2 : sqrtf(d2);
-          part += (vi && gj < cnt_j) ? D : 0.f;
-        }
+          for (int r = 0; r < 16; ++r) part += Dtab[(d - acc[jt][r]) >> 1];
+      } else {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t gj = base_j + jt * 32 + crow(r, hh);
+            const float D = Dtab[(d - acc[jt][r]) >> 1];
+            part += (vi && gj < cnt_j) ? D : 0.f;
+          }
+      }
       total += (double)(part * wgt);
     }
   }
@@ -329,52 +343,61 @@ __device__ __forceinline__ void mmd_distsum_spin128(const MmdArgs& a, unsigned c
   if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sum;
 }
 
-__global__ __launch_bounds__(256) void mmd_distsum_kernel(MmdArgs a) {
-  extern __shared__ __align__(16) unsigned char dsm[];
-  const bool I8 = *a.not_pm1 == 0;  // exact int8 Gram for +-1 rows, f32 otherwise (flag written by mmd_prep_kernel)
-  if (I8 && a.d <= 1024) {
-    if (a.d <= 128) mmd_distsum_spin128<4>(a, dsm);
-    else if (a.d <= 512) mmd_distsum_spin128<16>(a, dsm);
-    else mmd_distsum_spin128<32>(a, dsm);
-    return;
-  }
+// General rows (f32 Gram), or spin rows wider than the register-resident form takes (int8 Gram through LDS): 32-row
+// blocks, grid-stride over them so the launch geometry can be the spin form's.
+__device__ __forceinline__ void mmd_distsum_generic(const MmdArgs& a, unsigned char* dsm, bool I8) {
   double* red = reinterpret_cast<double*>(dsm);                 // [256]
   float* Zs = reinterpret_cast<float*>(dsm + 2048);             // f32 path: [128][33], then Xs [32][33]
   float* Xs = Zs + MMD_BJ * MMD_PITCH;
   int8_t* Zs8 = reinterpret_cast<int8_t*>(dsm + 2048);          // int8 path: [128][pw+16], then Xs8 [32][pw+16]
   int8_t* Xs8 = Zs8 + MMD_BJ * ((a.d < MMD_I8_PANEL ? a.d : MMD_I8_PANEL) + 16);
-  const int64_t rbx = (a.nx + MMD_BI - 1) / MMD_BI;
-  const int64_t rb = blockIdx.x;
-  const bool rows_x = rb < rbx;
-  const float* src_i = rows_x ? a.x : a.y;
-  const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * MMD_BI;
-  const float* sq_i = rows_x ? a.sq : a.sq + a.nx;
+  const int64_t rbx = (a.nx + MMD_BI - 1) / MMD_BI, rby = (a.ny + MMD_BI - 1) / MMD_BI;
   const int64_t tx = (a.nx + MMD_BJ - 1) / MMD_BJ, ty = (a.ny + MMD_BJ - 1) / MMD_BJ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, c = lane & 31;
-  const int64_t gi = base_i + c;
-  const float sqi = gi < cnt_i ? sq_i[gi] : 0.f;
   double total = 0.0;
-  for (int64_t t = blockIdx.y; t < tx + ty; t += gridDim.y) {
-    const bool cols_x = t < tx;
-    const float* src_j = cols_x ? a.x : a.y;
-    const int64_t cnt_j = cols_x ? a.nx : a.ny, base_j = (cols_x ? t : t - tx) * MMD_BJ;
-    const float* sq_j = cols_x ? a.sq : a.sq + a.nx;
-    f32x16 T;
-    if (I8) T = gram_tile_i8(a.zi8, rows_x ? 0 : a.nx, cnt_i, base_i, cols_x ? 0 : a.nx, cnt_j, base_j, a.d, Zs8, Xs8);
-    else T = gram_tile(src_i, cnt_i, base_i, src_j, cnt_j, base_j, a.d, Zs, Xs);
-    float part = 0.f;
+  for (int64_t rb = blockIdx.x; rb < rbx + rby; rb += gridDim.x) {
+    const bool rows_x = rb < rbx;
+    const float* src_i = rows_x ? a.x : a.y;
+    const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * MMD_BI;
+    const float* sq_i = rows_x ? a.sq : a.sq + a.nx;
+    const int64_t gi = base_i + c;
+    const float sqi = gi < cnt_i ? sq_i[gi] : 0.f;
+    for (int64_t t = blockIdx.y; t < tx + ty; t += gridDim.y) {
+      const bool cols_x = t < tx;
+      const float* src_j = cols_x ? a.x : a.y;
+      const int64_t cnt_j = cols_x ? a.nx : a.ny, base_j = (cols_x ? t : t - tx) * MMD_BJ;
+      const float* sq_j = cols_x ? a.sq : a.sq + a.nx;
+      f32x16 Tt;
+      if (I8) Tt = gram_tile_i8(a.zi8, rows_x ? 0 : a.nx, cnt_i, base_i, cols_x ? 0 : a.nx, cnt_j, base_j, a.d, Zs8, Xs8);
+      else Tt = gram_tile(src_i, cnt_i, base_i, src_j, cnt_j, base_j, a.d, Zs, Xs);
+      float part = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t gj = base_j + wave * 32 + crow(r, hh);
-      if (gi < cnt_i && gj < cnt_j) {
-        const float d2 = fmaxf(sqi + sq_j[gj] - 2.0f * T[r], 0.f);
-        part += a.squared ? d2 : sqrtf(d2);
+      for (int r = 0; r < 16; ++r) {
+        const int64_t gj = base_j + wave * 32 + crow(r, hh);
+        if (gi < cnt_i && gj < cnt_j) {
+          const float d2 = fmaxf(sqi + sq_j[gj] - 2.0f * Tt[r], 0.f);
+          part += a.squared ? d2 : sqrtf(d2);
+        }
       }
+      total += (double)part;
+      __syncthreads();  // the next tile restages Zs / Xs
     }
-    total += (double)part;
   }
   const double s = block_sum(total, red);
   if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// One launch serves both kinds of input (device flag written by mmd_prep_kernel: exact int8 Gram for +-1 rows).
+template <int NS>
+__global__ __launch_bounds__(256, NS <= 16 ? 2 : 1) void mmd_distsum_spin_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char dsm[];
+  if (*a.not_pm1 == 0) mmd_distsum_spin128<NS>(a, dsm);
+  else mmd_distsum_generic(a, dsm, false);
+}
+
+__global__ __launch_bounds__(256) void mmd_distsum_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char dsm[];
+  mmd_distsum_generic(a, dsm, *a.not_pm1 == 0);
 }
 
 __device__ __forceinline__ double mmd_wave_sum(double v) {
@@ -1045,7 +1068,7 @@ __global__ __launch_bounds__(256) void mmd_final_kernel(const double* __restrict
 
 struct MmdPlan {
   int nfb, zslices, S, S1;
-  int64_t rbx, rby;
+  int64_t rbx, rby, GX1;
   size_t off_sq, off_coef, off_dist, off_loss, off_grad, off_flag, off_zi8, off_zt, off_tab, total;
   int pm1_ok;
   int64_t ztb_x, ztb_y;  // 32-row blocks of the transposed copy (whole 128-row tiles)
@@ -1071,18 +1094,29 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   if (S < 1) S = 1;
   if (S > 16) S = 16;
   p.S = (int)S;
-  int64_t S1 = ceil_div(1024, p.rbx + p.rby);
-  if (S1 > tiles) S1 = tiles;
+  p.pm1_ok = d <= 1024;  // LDS: table + resident X rows + one Z panel
+  // pass 1 (distance sum): spin-capable shapes launch the folded 128-row form, ceil(T/2) x S1 blocks of about
+  // (T+1)/S1 tiles each, two blocks per CU wanted; other shapes one block per 32-row block
+  int64_t S1;
+  if (p.pm1_ok) {
+    p.GX1 = (tiles + 1) / 2;
+    S1 = ceil_div(512, p.GX1);
+    if (S1 > tiles + 1) S1 = tiles + 1;
+    if (S1 > 32) S1 = 32;
+  } else {
+    p.GX1 = p.rbx + p.rby;
+    S1 = ceil_div(1024, p.GX1);
+    if (S1 > tiles) S1 = tiles;
+    if (S1 > 16) S1 = 16;
+  }
   if (S1 < 1) S1 = 1;
-  if (S1 > 16) S1 = 16;
   p.S1 = (int)S1;
   size_t o = 0;
   p.off_sq = o; o = align_up(o + sizeof(float) * (size_t)(nx + ny), 256);
   p.off_coef = o; o = align_up(o + sizeof(float) * 16, 256);
-  p.off_dist = o; o = align_up(o + sizeof(double) * (size_t)(p.S1 * (p.rbx + p.rby)), 256);
+  p.off_dist = o; o = align_up(o + sizeof(double) * (size_t)(p.S1 * p.GX1), 256);
   p.off_loss = o; o = align_up(o + sizeof(double) * 3 * (size_t)(p.S * (p.rbx + p.rby)), 256);
   p.off_grad = o; o = align_up(o + (p.S > 1 ? sizeof(float) * (size_t)p.S * (size_t)nx * (size_t)d : 0), 256);
-  p.pm1_ok = d <= 1024;  // LDS: table + resident X rows + one Z panel
   p.ztb_x = ceil_div(nx, MMD_BJ) * 4;
   p.ztb_y = ceil_div(ny, MMD_BJ) * 4;
   p.off_flag = o; o = align_up(o + sizeof(int), 256);
@@ -1193,14 +1227,29 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
                dim3(256), 0, s, a, (uint16_t*)(w + p.off_zt));
   int ndist = 0;
   if (!(cfg->bandwidth > 0.f)) {
-    ndist = (int)(p.S1 * (p.rbx + p.rby));
+    ndist = (int)(p.S1 * p.GX1);
     const int pw = dim < MMD_I8_PANEL ? dim : MMD_I8_PANEL;
     const size_t lds_f = 2048 + sizeof(float) * (MMD_BJ + MMD_BI) * MMD_PITCH;
-    const size_t lds_i = 2048 + (size_t)(MMD_BJ + MMD_BI) * (pw + 16);
-    if (lds_i > 64 * 1024)
-      DVG_CHECK_HIP(hipFuncSetAttribute((const void*)mmd_distsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_i));
-    const size_t lds_d = lds_f > lds_i ? lds_f : lds_i;
-    DVG_LAUNCH(K_MMD_DISTSUM, mmd_distsum_kernel, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S1), dim3(256), lds_d, s, a);
+    const dim3 grid((unsigned)p.GX1, (unsigned)p.S1);
+    if (p.pm1_ok) {
+      const size_t lds_s = 2048 + ((size_t)(dim + 1) * 4 + 15) / 16 * 16 + (size_t)MMD_BJ * (pw + 16);
+      const size_t lds_d = lds_f > lds_s ? lds_f : lds_s;
+      auto launch = [&](auto kern) -> int {
+        if (lds_d > 64 * 1024)
+          DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+        DVG_LAUNCH(K_MMD_DISTSUM, kern, grid, dim3(256), lds_d, s, a);
+        return DVG_OK;
+      };
+      if (dim <= 128) DVG_TRY(launch(mmd_distsum_spin_kernel<4>));
+      else if (dim <= 512) DVG_TRY(launch(mmd_distsum_spin_kernel<16>));
+      else DVG_TRY(launch(mmd_distsum_spin_kernel<32>));
+    } else {
+      const size_t lds_i = 2048 + (size_t)(MMD_BJ + MMD_BI) * (pw + 16);
+      const size_t lds_d = lds_f > lds_i ? lds_f : lds_i;
+      if (lds_d > 64 * 1024)
+        DVG_CHECK_HIP(hipFuncSetAttribute((const void*)mmd_distsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+      DVG_LAUNCH(K_MMD_DISTSUM, mmd_distsum_kernel, grid, dim3(256), lds_d, s, a);
+    }
   }
   DVG_LAUNCH(K_MMD_FINAL, mmd_bandwidth_table_kernel, dim3(1), dim3(256), 0, s, a, (const double*)(w + p.off_dist), ndist,
              (double)(nx + ny), cfg->bandwidth, cfg->factor, (float*)(w + p.off_coef),
