@@ -482,34 +482,70 @@ int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* 
 }
 
 // dw[kh][kw] = sum dOut(y,x) Xup(y+1-kh, x+1-kw); db = sum dOut;  part [EW_BLOCKS][10]
+// One image per block pass: the 16x16 source image goes to LDS (row-major, zero border, double-buffered: one barrier
+// per image); thread (i, j) owns source pixel (i, j), i.e. the 2x2 output quad that upsamples it, whose 4 x 9 taps
+// all fall in that pixel's 3x3 neighbourhood: 9 LDS reads + 36 FMAs per thread and image, the next image's global
+// loads in flight meanwhile.  (The per-output-pixel form -- 9 guarded, Morton-addressed global gathers per element --
+// took 1.1 ms at c3, 17x its HBM time.)
 __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __restrict__ X, int64_t N,
                                                               const float* __restrict__ dOut, float* __restrict__ part) {
+  __shared__ float Xs[2][18 * 18];
   __shared__ float red[10 * 256];
-  const int64_t total = N * 1024;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 2 * 18 * 18; e += 256) (&Xs[0][0])[e] = 0.f;  // borders stay zero
+  __syncthreads();
+  const int spos = ((int)morton_y((uint32_t)tid) + 1) * 18 + (int)morton_x((uint32_t)tid) + 1;  // where X[img][tid] lives
+  const int i = tid >> 4, j = tid & 15;
   float acc[10];
 #pragma unroll
   for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t img = e >> 10;
-    const int y = (int)((e >> 5) & 31), x = (int)(e & 31);
-    const float g = dOut[e];
+  int64_t img = blockIdx.x;
+  float xv = 0.f;
+  float2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f};
+  if (img < N) {
+    xv = X[img * 256 + tid];
+    g0 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i) * 32 + 2 * j);
+    g1 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i + 1) * 32 + 2 * j);
+  }
+  for (int buf = 0; img < N; img += gridDim.x, buf ^= 1) {
+    Xs[buf][spos] = xv;
+    const float g[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
+    const int64_t nimg = img + gridDim.x;
+    if (nimg < N) {
+      xv = X[nimg * 256 + tid];
+      g0 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i) * 32 + 2 * j);
+      g1 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i + 1) * 32 + 2 * j);
+    }
+    __syncthreads();
+    float sn[3][3];  // source pixels (i-1 .. i+1, j-1 .. j+1)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int yy = y + 1 - kh, xx = x + 1 - kw;
-        if (yy >= 0 && yy < 32 && xx >= 0 && xx < 32)
-          acc[kh * 3 + kw] = fmaf(g, X[img * 256 + morton((uint32_t)(yy >> 1), (uint32_t)(xx >> 1))], acc[kh * 3 + kw]);
+      for (int c = 0; c < 3; ++c) sn[r][c] = Xs[buf][(i + r) * 18 + j + c];
+    // output (2i+a, 2j+b), tap (kh, kw) reads upsampled (2i+a+1-kh, 2j+b+1-kw) = source ((2i+a+1-kh)>>1, ...):
+    // neighbourhood row 1,1,0 for a = 0 and 2,1,1 for a = 1 (kh = 0,1,2); same along the columns
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int r = a == 0 ? (kh == 2 ? 0 : 1) : (kh == 0 ? 2 : 1);
+            const int c = b == 0 ? (kw == 2 ? 0 : 1) : (kw == 0 ? 2 : 1);
+            acc[kh * 3 + kw] = fmaf(g[a][b], sn[r][c], acc[kh * 3 + kw]);
+          }
+        acc[9] += g[a][b];
       }
-    acc[9] += g;
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) red[k * 256 + threadIdx.x] = acc[k];
+  for (int k = 0; k < 10; ++k) red[k * 256 + tid] = acc[k];
   __syncthreads();
-  if (threadIdx.x < 10) {
+  if (tid < 10) {
     float t = 0.f;
-    for (int j = 0; j < 256; ++j) t += red[threadIdx.x * 256 + j];
-    part[(size_t)blockIdx.x * 10 + threadIdx.x] = t;
+    for (int q = 0; q < 256; ++q) t += red[tid * 256 + q];
+    part[(size_t)blockIdx.x * 10 + tid] = t;
   }
 }
 

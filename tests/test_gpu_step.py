@@ -107,6 +107,34 @@ def test_graph_replay_is_bit_identical_to_eager(golden_dir):
         assert torch.equal(sd_e[k], sd_g[k]), k
 
 
+def test_deferred_mmd_join_is_bit_identical(golden_dir):
+    """Joining the MMD stream behind the decoder's backward (the form large pair counts take) changes the schedule,
+    not the arithmetic: same losses and same weights as the single backward call, eager and replayed."""
+    def run(defer, use_graph):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 8, seed=5)).reshape(8, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(8)])
+        m.train_init(1)
+        m.sync_losses = False
+        m.use_graph = use_graph
+        m.defer_mmd_join = defer
+        out = []
+        for k in range(8):
+            m.step((imgs[k], None), epoch=0)
+            out.append((float(m.last["mse"]), float(m.last["mmd"])))
+        torch.cuda.synchronize()
+        return out, {k: v.clone() for k, v in m._dvae.state_dict().items()}
+
+    ref, sd_ref = run(False, False)
+    for use_graph in (False, True):
+        got, sd = run(True, use_graph)
+        assert got == ref
+        for k in sd_ref:
+            assert torch.equal(sd_ref[k], sd[k]), (k, use_graph)
+
+
 def test_training_driver_and_model_files(tmp_path, golden_dir):
     """execute_training + create_model_files: the reference's loop and side-file formats; the loss goes down."""
     import json
