@@ -33,6 +33,11 @@ CONFIGS = {
                desc="MNIST-shaped 32x32 synthetic, B=256, 128-spin Pegasus sub-graph GRBM, R=8, 256 reads, 50-sweep PCD Gibbs"),
     "c3": dict(B=4096, n=512, R=8, C=256, sweeps=200, qpu="Advantage2_system1", persistent=True,
                desc="MNIST-shaped 32x32 synthetic, B=4096, 512-spin Zephyr sub-graph GRBM, R=8, 256 reads, 200-sweep PCD Gibbs"),
+    # configs[3] is c3 per GPU on 8 GPUs: `--config c3 --gpus 8`.  configs[4], per-GPU slice (16384 chains / 8 GPUs):
+    # the sampler-bound case (every step draws 2048 chains of 1024 spins; the MMD sees 2048 x 2048 rows of d = 1024)
+    "c5": dict(B=256, n=1024, R=8, C=2048, sweeps=50, qpu="Advantage2_system1", persistent=True,
+               desc="Fashion-MNIST-shaped 32x32 synthetic, B=256, 1024-spin Zephyr sub-graph GRBM, R=8, 2048 chains per GPU, "
+                    "50-sweep PCD Gibbs"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the spin-path MMD gradient GEMM runs there)

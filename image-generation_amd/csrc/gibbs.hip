@@ -308,7 +308,16 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   // issue slots, fatter workgroups do not pay for the CUs they free.
   static const int waves_env = [] { const char* e = getenv("DVG_GIBBS_WAVES"); return e ? atoi(e) : 0; }();
   const int waves = waves_env ? waves_env : 4;
-  if (big) return launch_gibbs<64, 2>(a, s, fast, mc);
+  // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
+  // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
+  // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw)
+  if (big) {
+    const int wv = waves_env ? waves_env : 16;
+    if (wv <= 2) return launch_gibbs<64, 2>(a, s, fast, mc);
+    if (wv <= 4) return launch_gibbs<64, 4>(a, s, fast, mc);
+    if (wv <= 8) return launch_gibbs<64, 8>(a, s, fast, mc);
+    return launch_gibbs<64, 16>(a, s, fast, mc);
+  }
 #define DVG_GIBBS_DISPATCH(LPC)                                              \
   switch (waves) {                                                           \
     case 1: return launch_gibbs<LPC, 1>(a, s, fast, mc);                     \

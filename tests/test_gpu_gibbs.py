@@ -26,7 +26,7 @@ def _model(plan, rng):
 
 @pytest.mark.parametrize("fam,n,C,sweeps", [("pegasus", 64, 37, 3), ("zephyr", 128, 256, 5), ("pegasus", 256, 130, 4),
                                              ("zephyr", 512, 64, 3), ("zephyr", 1024, 9, 2), ("pegasus", 128, 256, 50),
-                                             ("zephyr", 512, 33, 13)])
+                                             ("zephyr", 512, 33, 13), ("zephyr", 1024, 41, 5)])  # last: 16-wave workgroups, ragged last one
 def test_gibbs_bit_exact(fam, n, C, sweeps):
     plan, nodes = _plan(fam, n)
     rng = np.random.default_rng(n)
