@@ -22,7 +22,7 @@ struct DecPlan {
   int nblk[4];
   size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
-  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB[4], partL, partW, partF, splitk;
+  size_t dXbuf, dYl[4], slabs, partA, partB[4], partL, partW, partF, splitk;
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   size_t total_floats;
@@ -52,7 +52,7 @@ DecPlan dec_plan(int64_t N, int n) {
   p.bias_lin = bump(o, (size_t)4 * n);
   p.ksplit_lin = wgrad_ksplit(N, n, 4 * n, 1);
   size_t max_slab = (size_t)p.ksplit_lin * n * 4 * n;
-  size_t max_dx = (size_t)N * 4 * n, max_dy = 0;
+  size_t max_dx = (size_t)N * 4 * n;
   size_t max_split = conv_splitk_floats(N, n, 4 * n, 1, 0);
   { const size_t sd = conv_splitk_floats(N, 4 * n, n, 1, 0); if (sd > max_split) max_split = sd; }
   int cmax = 4 * n;
@@ -80,12 +80,12 @@ DecPlan dec_plan(int64_t N, int n) {
       if (sk_d > max_split) max_split = sk_d;
     }
     const size_t act = (size_t)p.M[l] * C;
-    if (act > max_dy) max_dy = act;
     if (act > max_dx) max_dx = act;  // dXs[l] has the shape of Xs[l]
   }
   p.dXbuf = bump(o, max_dx);
-  p.dYbuf = bump(o, max_dy);
-  p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
+  // one dY buffer per layer: a layer's weight gradient (side stream) may still be reading its dY when the data-gradient
+  // chain reaches the next layers, and a shared buffer would make the caller's stream wait on the side stream
+  for (int l = 0; l < 4; ++l) p.dYl[l] = bump(o, (size_t)p.M[l] * ch[l + 1]);
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   // one bias-gradient partial buffer per layer: their column sums run on the side stream, behind the main chain
@@ -205,8 +205,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
   hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
-  float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
-  hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
   float* partW = W + pl.partW;
 
@@ -226,12 +224,10 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     const float* Y = W + pl.Y[l];
     const float* Xs = W + pl.Xs[l];
     const float* mask = W + pl.mask[l];  // backward only exists for a training-mode forward
-    float* dY = dYpp[l & 1];
+    float* dY = W + pl.dYl[l];
     DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
                                          partA, s));
     DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
-    // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
-    if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                         mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     // Fork: dY is ready.  The caller's-stream kernel is enqueued BEFORE the side-stream ones: when the call is being
@@ -246,7 +242,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
       DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
       DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
-      if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[3]));
       continue;
     }
     ConvArgs a;
@@ -268,7 +263,6 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
       DVG_TRY(launch_conv_wgrad(wa, s2));
       DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s2));
     }
-    if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[l]));
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
   {

@@ -18,7 +18,7 @@ struct EncPlan {
   int nblk[4];
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
-  size_t dXbuf, dYbuf, dYbuf2, slabs, partA, partB[4], partP, part320, splitk;
+  size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -35,7 +35,7 @@ EncPlan enc_plan(int64_t B, int n) {
   const int ch[5] = {1, 32, 64, 128, n};
   for (int i = 0; i < 5; ++i) p.ch[i] = ch[i];
   size_t o = 0;
-  size_t max_dx = 0, max_dy = 0, max_slab = 0, max_split = 0;
+  size_t max_dx = 0, max_slab = 0, max_split = 0;
   int cmax = 0;
   for (int l = 0; l < 4; ++l) {
     p.L[l] = 5 - l;
@@ -63,14 +63,13 @@ EncPlan enc_plan(int64_t B, int n) {
       const size_t dx = (size_t)p.M[l] * ch[l];  // gradient wrt the layer's input (same resolution)
       if (dx > max_dx) max_dx = dx;
     }
-    const size_t dy = (size_t)p.M[l] * C;
-    if (dy > max_dy) max_dy = dy;
   }
   const size_t dp = (size_t)p.Q[3] * n;  // gradient wrt the pooled map feeding the projection
   if (dp > max_dx) max_dx = dp;
   p.dXbuf = bump(o, max_dx);
-  p.dYbuf = bump(o, max_dy);
-  p.dYbuf2 = bump(o, max_dy);  // ping-pong: a layer's weight gradient (side stream) may still be reading its dY
+  // one dY buffer per layer: a layer's weight gradient (side stream) may still be reading its dY when the data-gradient
+  // chain reaches the next layers, and a shared buffer would make the caller's stream wait on the side stream
+  for (int l = 0; l < 4; ++l) p.dYl[l] = bump(o, (size_t)p.M[l] * ch[l + 1]);
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);  // per layer: reduced on the side stream
@@ -154,8 +153,6 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
-  float* dYpp[2] = {W + pl.dYbuf, W + pl.dYbuf2};
-  hipEvent_t wgrad_done[4] = {nullptr, nullptr, nullptr, nullptr};
   float* partA = W + pl.partA;
 
   // projection: dP (B,4,n), d proj_w (4), d proj_b (1)
@@ -165,13 +162,11 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     const float* Y = W + pl.Y[l];
-    float* dY = dYpp[l & 1];
+    float* dY = W + pl.dYl[l];
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
     DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                           dX, partA, s));
     DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
-    // dY[l & 1] was last read by layer l+2's weight gradient on the side stream
-    if (l <= 1 && s2 != s) DVG_TRY(stream_wait_mark(s, wgrad_done[l + 2]));
     DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                          dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     if (l == 0) {
@@ -201,7 +196,6 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
     DVG_TRY(launch_conv_wgrad(wa, s2));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
-    if (s2 != s) DVG_TRY(stream_mark(s2, &wgrad_done[l]));
   }
   DVG_TRY(stream_order_after(s, s2));  // join
   return DVG_OK;
