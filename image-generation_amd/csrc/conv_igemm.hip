@@ -94,6 +94,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   //   * a second register stage (loads get two MFMA phases to land): +-0 at c3, -3 % at c2 (registers -> occupancy);
   //   * issuing the loads one by one between the MFMA k-steps (sched_group_barrier VMEM groups): +-0 at c2, the
   //     128-row tiles 17-20 % slower at c3.
+  //   * two LDS stages with ONE barrier per iteration (park pair it+1 in the other stage right behind the MFMAs of
+  //     pair it; 75 KB per 64x64 block): +-0 at c2 for every launch-size cut-off tried (300 / 600 / all blocks).
   // split-K (small-M layers): grid.z slices the K iterations; each slice writes a raw partial slab
   const int it_per = (niter + a.ksplit - 1) / a.ksplit;
   const int it_beg = (int)blockIdx.z * it_per, it_end = it_beg + it_per < niter ? it_beg + it_per : niter;
