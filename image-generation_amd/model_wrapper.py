@@ -529,6 +529,30 @@ class ModelWrapper:
         return images
 
 
+    @torch.no_grad()
+    def reconstruct_images(self, batch: Optional[torch.Tensor] = None, sharpen: bool = False, lower: float = 0.35,
+                           upper: float = 0.65) -> torch.Tensor:
+        """Eval-mode encode -> discretise -> decode of one batch of training images, interleaved with the originals:
+        the compute of /root/reference/src/model_wrapper.py:447-481 (plotting left to the caller).  Returns
+        (2 B, 1, 32, 32) on the device in the reference's ``(b i)`` order: original 0, reconstruction 0, original 1, ...;
+        the reconstruction's last pixel column is set to 1 (the reference's separator line, :465)."""
+        if batch is None:
+            batch = next(iter(self._dataloader))[0]
+        batch = batch.to(self._device)
+        self._dvae.eval()
+        self._grbm.eval()
+        _, _, reconstructed = self._dvae(batch)
+        reconstructed = reconstructed.clone()
+        reconstructed[:, :, :, :, -1] = 1.0
+        rec = reconstructed.clip(0.0, 1.0).squeeze(1)
+        images = torch.stack((batch, rec), dim=1).reshape(-1, *batch.shape[1:])
+        if sharpen:
+            over = (images > upper).to(images.dtype)
+            under = (images > lower).to(images.dtype)
+            images = (over + (1 - over) * images) * under
+        return images
+
+
 class _DeferredAdam:
     """Placeholder used when no GPU is present (CPU-side construction / checkpoint tests): it keeps
     the optimizer surface (``param_groups``, ``zero_grad``) and refuses to step: no CPU fallback."""

@@ -263,6 +263,23 @@ def test_heaviside_mode_steps_and_sharpened_generation(tmp_path, golden_dir):
     assert out.shape == (m.NUM_READS, 1, 32, 32)
     ok = (out == 0) | (out == 1) | ((out > 0.35) & (out <= 0.65))
     assert bool(ok.all())
+    # reconstruction path (/root/reference/src/model_wrapper.py:447-481): eval-mode encode -> heaviside -> decode,
+    # interleaved with the originals, against the CPU oracle on the trained weights
+    from oracle import nets, plugin as oplugin
+    grid = m.reconstruct_images(imgs[0])
+    assert grid.shape == (2 * B, 1, 32, 32)
+    assert torch.equal(grid[0::2], imgs[0])
+    sd = {k: v.detach().cpu().clone() for k, v in m._dvae.state_dict().items()}
+    logits = nets.encoder_forward(sd, imgs[0].cpu(), training=False, prefix="_encoder.")
+    assert float(logits.abs().min()) > 1e-4, "a logit on the heaviside threshold would make the comparison ill-posed"
+    spins = oplugin.heaviside_latent_to_discrete(logits, 1)
+    want = nets.decoder_forward(sd, spins, training=False, prefix="_decoder.").clone()
+    want[:, :, :, :, -1] = 1.0
+    want = want.clip(0.0, 1.0).squeeze(1)
+    got = grid[1::2].cpu()
+    assert float((got - want).abs().max()) < 2e-5
+    sharp = m.reconstruct_images(imgs[0], sharpen=True)
+    assert bool(((sharp == 0) | (sharp == 1) | ((sharp > 0.35) & (sharp <= 0.65))).all())
     with pytest.raises(ValueError):
         cfg.update(N_REPLICAS=2)
         with open(tmp_path / "bad.yaml", "w") as f:
