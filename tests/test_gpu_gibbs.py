@@ -77,6 +77,39 @@ def test_sample_ising_dict_path_and_sampleset():
     assert ss.variables == nodes and ss.vartype == "SPIN" and len(ss) == 16
 
 
+def test_shim_composite_draw_matches_oracle():
+    """dwave.system shim: DWaveSampler(name) + FixedEmbeddingComposite(one-to-one embedding).sample_ising draws with the
+    GPU sampler on the induced sub-graph -- bit-exact against the C restatement."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "image-generation_amd", "shims"))
+    try:
+        import dwave.system as dsys
+        from image_generation_amd import graphs
+        dsys.LOCAL_SOLVER.update(sweeps=3, beta=20.0, seed=77, persistent=False)
+        qpu = dsys.DWaveSampler(solver="Advantage_system4")
+        sub = graphs.greedy_get_subgraph(64, 11, qpu.to_networkx_graph())
+        _mapped, mapping = graphs.get_graph_mapping(sub)  # physical -> logical 0..63
+        comp = dsys.FixedEmbeddingComposite(qpu, {l_: [p] for p, l_ in mapping.items()})
+        plan = comp._build().plan
+        rng = np.random.default_rng(5)
+        h, J = _model(plan, rng)
+        hs, Js = gibbs.scaled_fields(h, J, 0.05, (-4, 4), (-1, 1))
+        hd = {k: float(hs[k]) for k in range(64)}
+        Jd = {(int(a), int(b)): float(Js[e]) for e, (a, b) in enumerate(zip(plan.edge_i, plan.edge_j))}
+        ss = comp.sample_ising(hd, Jd, num_reads=16, answer_mode="raw", auto_scale=False, annealing_time=1, label="x")
+        ids = np.arange(16, dtype=np.uint32)
+        want = cref.gibbs_sweeps(cref.init_state(ids, 64, 77), ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr,
+                                 plan.adj_idx, plan.adj_eid, 77, 0, 3)
+        assert ss.variables == list(range(64)) and ss.vartype == "SPIN"
+        assert np.array_equal(ss.record.sample.astype(np.int8), want.astype(np.int8))
+    finally:
+        sys.path.pop(0)
+        for name in [m for m in sys.modules if m.split(".")[0] in ("dwave", "dimod")]:
+            del sys.modules[name]
+
+
 def test_energy_and_suffstats():
     plan, nodes = _plan("zephyr", 128)
     rng = np.random.default_rng(3)
