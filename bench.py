@@ -44,6 +44,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the spi
 PEAK_HBM_GBS = 8000.0
 
 
+def baseline_metric():
+    """BASELINE.json's own wording of the metric (the file ships with the repository); a fixed id otherwise."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "dvae_grbm_train_step_images_per_s"
+
+
 def write_yaml(cfg, path):
     base = yaml.safe_load(open(os.path.join(ROOT, "image-generation_amd", "training_parameters.yaml")))
     base.update(BATCH_SIZE=cfg["B"], N_REPLICAS=cfg["R"], NUM_READS=cfg["C"], GIBBS_SWEEPS=cfg["sweeps"],
@@ -221,7 +230,8 @@ def main():
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, args.config)
         ips = args.gpus * cfg["B"] * args.steps / elapsed
         out = {
-            "metric": "dvae_grbm_train_step_images_per_s", "value": ips, "unit": "images/s", "n_gpus": args.gpus,
+            "metric": baseline_metric(), "metric_id": "dvae_grbm_train_step_images_per_s", "value": ips,
+            "unit": "images/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "global_batch": cfg["B"] * args.gpus,
