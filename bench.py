@@ -111,6 +111,19 @@ def cpu_baseline(cfg, seconds=20.0):
                       f"{dt / steps * 1e3:.0f} ms/step"}
 
 
+def loss_parity():
+    """The "loss parity vs CPU" half of the metric: 12 training steps on this GPU against the committed fixture of the
+    reference's own ``ModelWrapper.step`` driven over the CPU oracle on identical batches, Gumbel noise and dropout
+    masks (tests/golden/make_golden.py), and a sampler draw against the C restatement.  Checker only: the timed
+    region above never touches it."""
+    import __graft_entry__ as entry
+
+    r = entry.parity_check(steps=12)
+    return {"steps": r["steps"], "max_rel_dev": r["max_rel_dev"], "tolerance": 1e-5,
+            "gibbs_spin_mismatches": r["gibbs_spin_mismatches"], "gibbs_spins_checked": r["gibbs_spins_checked"],
+            "against": "tests/golden/step_n64.npz (reference step orchestration over the CPU oracle, B=8, n=64, R=2)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +257,7 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+            out["loss_parity"] = loss_parity()
         if args.breakdown:
             with open(args.breakdown, "w") as f:
                 json.dump({"ms_per_step": elapsed / args.steps * 1e3, "profiled_steps": prof_steps, "kernels": per_kernel}, f, indent=1)
