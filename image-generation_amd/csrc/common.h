@@ -50,6 +50,7 @@ enum KernelId : int {
   K_IGEMM_64x64,    // conv_igemm_kernel<64,64,2,2>
   K_IGEMM_128x32,   // conv_igemm_kernel<128,32,4,1>
   K_IGEMM_32x64,    // conv_igemm_kernel<32,64,1,2>
+  K_IGEMM_128x128,  // conv_igemm_kernel<128,128,2,2>
   K_WGRAD_2x2,      // conv_wgrad_kernel<2,2>
   K_WGRAD_2x1,
   K_WGRAD_1x2,

@@ -324,12 +324,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// Tile configuration: 0 = 128x64, 1 = 64x64, 2 = 128x32 (Cout = 32), 3 = 32x64 (two waves) for launches whose 64-row
+// Tile configuration: 0 = 128x64, 4 = 128x128 (large launches), 1 = 64x64, 2 = 128x32 (Cout = 32), 3 = 32x64 (two waves) for launches whose 64-row
 // tiling would leave most CUs without a block (small-M layers: a finer tiling fills the chip without the split-K slabs
 // and their reduce pass).  DVG_IGEMM_NO32=1 disables 3 (A/B runs).
 static int igemm_cfg(int64_t M, int Cout) {
   static const bool no32 = [] { const char* e = getenv("DVG_IGEMM_NO32"); return e && e[0] == '1'; }();
   if (Cout % 64) return 2;
+  // 4 = 128x128 (wave tile 64x64: half the LDS operand reads and half the L2 -> LDS bytes per FLOP of 128x64) once
+  // the launch still has >= 512 blocks of that size (two per CU are resident: 79 KB of LDS, 231 VGPRs).  c3: the
+  // launches that qualify run at 82 instead of 59 TFLOP/s in-situ, step 22.9 -> 22.55 ms; 256 / 128 measured no
+  // better, c2 has no such launch.  (DVG_IGEMM_THR128 overrides: tuning runs.)
+  static const int64_t thr128 = [] { const char* e = getenv("DVG_IGEMM_THR128"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+  if (Cout % 128 == 0 && ceil_div(M, 128) * (Cout / 128) >= thr128) return 4;
   if (ceil_div(M, 128) * (Cout / 64) >= 512) return 0;
   static const int64_t thr32 = [] { const char* e = getenv("DVG_IGEMM_THR32"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
@@ -354,7 +360,7 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
 }
 
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
-static int igemm_bn(int cfg) { return cfg == 2 ? 32 : 64; }
+static int igemm_bn(int cfg) { return cfg == 2 ? 32 : cfg == 4 ? 128 : 64; }
 
 int conv_stats_blocks(int64_t M, int Cout) { return (int)ceil_div(M, igemm_bm(igemm_cfg(M, Cout))); }
 
@@ -410,6 +416,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
     case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1>(K_IGEMM_64x64, flops, grid, a, s); break;
     case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1>(K_IGEMM_32x64, flops, grid, a, s); break;
+    case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1>(K_IGEMM_128x128, flops, grid, a, s); break;
     default: rc = launch_igemm_cfg<128, 32, 4, 1, 1>(K_IGEMM_128x32, flops, grid, a, s); break;
   }
   DVG_TRY(rc);

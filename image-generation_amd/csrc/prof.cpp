@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 static const char* kNames[K_COUNT] = {
     "gibbs_sweeps", "grbm_energy", "grbm_suffstats", "gumbel_fwd", "gumbel_bwd", "mmd_prep",
     "mmd_distsum", "mmd_main", "mmd_pm1", "mmd_final", "conv_igemm_kernel<128,64,2,2,1>", "conv_igemm_kernel<64,64,2,2,1>",
-    "conv_igemm_kernel<128,32,4,1,1>", "conv_igemm_kernel<32,64,1,2,1>", "conv_wgrad_kernel<2,2>", "conv_wgrad_kernel<2,1>", "conv_wgrad_kernel<1,2>",
+    "conv_igemm_kernel<128,32,4,1,1>", "conv_igemm_kernel<32,64,1,2,1>", "conv_igemm_kernel<128,128,2,2,1>", "conv_wgrad_kernel<2,2>", "conv_wgrad_kernel<2,1>", "conv_wgrad_kernel<1,2>",
     "conv_wgrad_kernel<1,1>", "conv_wgrad_fold_kernel",
     "wgrad_reduce", "weight_pack", "bn_finalize", "enc_conv0_fwd", "enc_conv0_wgrad",
     "enc_bn_pool_fwd", "enc_bn_pool_bwd_reduce", "enc_bn_pool_bwd_apply", "enc_proj_fwd",

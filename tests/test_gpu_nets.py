@@ -205,3 +205,19 @@ def test_cpu_tensors_fail_loudly():
     enc = Encoder(64)
     with pytest.raises(DvgError):
         enc(torch.zeros(2, 1, 32, 32))
+
+
+def test_wide_tile_configuration_in_a_child_process():
+    """The 128x128 convolution tile serves launches of >= 512 such blocks (c3-scale batches); DVG_IGEMM_THR128=1 sends
+    every 128-multiple layer of the small fixtures through it.  The switch is read once per process: child run."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DVG_IGEMM_THR128"):
+        pytest.skip("already inside the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DVG_IGEMM_THR128="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_nets.py"), "-q", "-m", "gpu",
+                        "-k", "matches_oracle_full_gradients or matches_reference_fixture"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
