@@ -141,6 +141,8 @@ SIGNATURES = {
          c_float, c_void_p, c_int, c_void_p],
     ),
     "dvg_stream_anchor": (c_int, [c_void_p]),
+    "dvg_set_conv_precision": (c_int, [c_int]),
+    "dvg_get_conv_precision": (c_int, []),
     "dvg_prof_enable": (c_int, [c_uint64]),
     "dvg_prof_reset": (c_int, []),
     "dvg_prof_num_kernels": (c_int, []),

@@ -99,7 +99,12 @@ struct ConvArgs {
   int fold = 0;
   float* splitk_ws;   // scratch of conv_splitk_floats() floats, or null: never split K
   int ksplit;         // set by launch_conv_igemm
+  // bf16 = 1: "bf16 GEMM inputs, f32 accumulate" (conv_precision_bf16()): `wp` then points at the bf16 K-major pack
+  // Wp16[tap][b][a] (PackJob.bf16t) and the activations are rounded to bf16 (RNE) on their way into LDS
+  int bf16 = 0;
 };
+// process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
+bool conv_precision_bf16();
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);
 // fold = 1 launches: M source pixels; usable when conv_fold_ok (whole row blocks per class)
@@ -128,9 +133,10 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);
 // Wp[tap][a][b] <- checkpoint-layout weight
-int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s);
+int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t = 0);
 // several packs in ONE launch (forward and data-gradient packs of a whole network)
-struct PackJob { const float* w; float* wp; WeightMap map; };
+// bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer)
+struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; };
 constexpr int MAX_PACK_JOBS = 8;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);
 

@@ -22,8 +22,11 @@ namespace dvg {
 // run MFMAs together -- and WK = 2 measured 0 % on that layer and -3.5 % on the c2 step.  (The other route, pairs of
 // half-K blocks combined in-kernel through an arrival counter, is correct and deterministic but 2x slower: its
 // agent-scope release fence writes back the XCD's L2.)
-template <int BM, int BN, int WM, int WN, int WK>
+// BF = true: bf16 operands in LDS (activations rounded on the way in, weights pre-packed K-major as bf16),
+// v_mfma_f32_32x32x16_bf16, f32 accumulators: same tiles, loaders of A, neighbour table and epilogues.
+template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
 __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(!BF || WK == 1, "bf16 form: no K wave groups");
   constexpr int NT = WM * WN * WK * 64, NTG = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int BK = 64;                 // K per wave group and iteration: two 32-channel chunks (possibly of different taps)
@@ -32,14 +35,18 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
   constexpr int AP = BKT + 4, BP = BN + 4;
   constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per 32-chunk
-  constexpr int RB = (8 * BN + NT - 1) / NT;  // float4 loads of B per thread per 32-chunk
-  constexpr bool BPART = RB * NT != 8 * BN;   // fewer B float4s than threads (32-column tile, 512 threads)
+  constexpr int NB16 = BF ? 4 * BN : 8 * BN;  // 16-byte loads of B per 32-chunk (bf16: 64 bytes per column)
+  constexpr int RB = (NB16 + NT - 1) / NT;    // ... per thread
+  constexpr bool BPART = RB * NT != NB16;     // fewer B loads than threads (32-column tile, 512 threads)
+  constexpr int AP16 = BKT + 8;               // bf16 form: row pitch of both tiles in bf16 elements (144 bytes)
   static_assert(RA * NT == 8 * BM && (!BPART || RB == 1), "tile loaders must divide evenly");
   constexpr int NBS = 16;                // taps per row in the neighbour table (9, 4 or 16 used)
   extern __shared__ __align__(16) unsigned char igemm_smem[];  // conv_igemm_lds_bytes<...>() bytes
   float* As = reinterpret_cast<float*>(igemm_smem);            // [BM][AP]
   float* Bs = As + BM * AP;                                    // [BKT][BP]
-  float* red = Bs + BKT * BP;                                  // [WM][BN][2]
+  uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 form: [BM][AP16], then Bs16 [BN][AP16] (K-major)
+  uint16_t* Bs16 = As16 + BM * AP16;
+  float* red = BF ? reinterpret_cast<float*>(Bs16 + BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
   int* nbr = reinterpret_cast<int*>(red + WM * BN * 2);        // [BM][NBS] source row of every (tile row, tap), -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,9 +127,16 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       const uint32_t b_row0 =                                                                                         \
           (uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;             \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
-        const int idx = BPART ? (tid < 8 * BN ? tid : 8 * BN - 1) : tid + NT * q;  /* clamped: spare threads re-read */ \
-        const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                         \
-        BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u)); \
+        const int idx = BPART ? (tid < NB16 ? tid : NB16 - 1) : tid + NT * q;  /* clamped: spare threads re-read */   \
+        if constexpr (BF) {  /* Wp16[tap][col][ci]: 4 x 16 bytes per column and chunk */                              \
+          const int col = idx >> 2, q4 = idx & 3;                                                                     \
+          const uint32_t off = ((uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cout + n0 + col) * (uint32_t)a.Cin +  \
+                                (uint32_t)(cc * 32 + q4 * 8)) * 2u;                                                   \
+          BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + off);                                               \
+        } else {                                                                                                      \
+          const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
+          BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u)); \
+        }                                                                                                             \
       }                                                                                                               \
     }                                                                                                                 \
   } while (0)
@@ -133,14 +147,26 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     _Pragma("unroll") for (int h = 0; h < KH; ++h) {                                                                  \
       _Pragma("unroll") for (int q = 0; q < RA; ++q) {                                                                \
         const int row = (tid + NT * q) >> 3;                                                                          \
-        float* p = As + row * AP + h * 32 + ac4 * 4;                                                                  \
         const float mk = AMASK[h][q];                                                                                 \
-        *reinterpret_cast<f32x4*>(p) = AREG[h][q] * mk;                                                               \
+        const f32x4 v = AREG[h][q] * mk;                                                                              \
+        if constexpr (BF) {                                                                                           \
+          uint2 pk;                                                                                                   \
+          pk.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);                           \
+          pk.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);                           \
+          *reinterpret_cast<uint2*>(As16 + row * AP16 + h * 32 + ac4 * 4) = pk;                                       \
+        } else {                                                                                                      \
+          *reinterpret_cast<f32x4*>(As + row * AP + h * 32 + ac4 * 4) = v;                                            \
+        }                                                                                                             \
       }                                                                                                               \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
         const int idx = tid + NT * q;                                                                                 \
-        const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                         \
-        if (!BPART || idx < 8 * BN) *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];       \
+        if constexpr (BF) {                                                                                           \
+          if (!BPART || idx < NB16)                                                                                   \
+            *reinterpret_cast<f32x4*>(Bs16 + (idx >> 2) * AP16 + h * 32 + (idx & 3) * 8) = BREG[h][q];                \
+        } else {                                                                                                      \
+          const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
+          if (!BPART || idx < NB16) *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];      \
+        }                                                                                                             \
       }                                                                                                               \
     }                                                                                                                 \
   } while (0)
@@ -174,7 +200,28 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     float mA[KH][RA];
     for (int it = it_beg; it <= it_end; ++it) {
       if (it < it_end) IGEMM_LOAD(aA, bA, mA, it);
-      if (it > it_beg) IGEMM_MFMA();
+      if (it > it_beg) {
+        if constexpr (BF) {
+          // four 16-deep k-steps per 64-deep slab; operands are 16-byte LDS reads (8 bf16 of this lane's row / column)
+          const uint16_t* ap = As16 + (wm * TM * 32 + c) * AP16 + 8 * hh;
+          const uint16_t* bp = Bs16 + (wn * TN * 32 + c) * AP16 + 8 * hh;
+#pragma unroll
+          for (int s = 0; s < BK / 16; ++s) {
+            bf16x8v av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8v*>(ap + i * 32 * AP16 + 16 * s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const bf16x8v*>(bp + j * 32 * AP16 + 16 * s);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
+          IGEMM_MFMA();
+        }
+      }
       __syncthreads();
       if (it < it_end) IGEMM_STORE(aA, bA, mA);
       __syncthreads();
@@ -341,15 +388,16 @@ static int igemm_cfg(int64_t M, int Cout) {
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;
 }
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
 static constexpr size_t conv_igemm_lds_bytes() {
+  if (BF) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
 static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK>();
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK>;
+  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, BF>();
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, BF>;
   static bool attr_set = false;  // one instantiation = one static
   if (lds > 64 * 1024 && !attr_set) {
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -387,6 +435,7 @@ size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) 
 
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
+  if (conv_precision_bf16()) a.bf16 = 1;  // the packs were written in the matching format (launch_weight_pack*)
   const bool taps_ok = a.fold == 1 ? a.ntaps == 4 : a.fold == 2 ? a.ntaps == 16 : (a.ntaps == 9 || a.ntaps == 1);
   if (a.fold && (a.ups || a.poolsum || !conv_fold_ok(a.M))) {
     set_error("conv_igemm: fold=%d needs ups=poolsum=0 and whole 128-row blocks (M=%lld)", a.fold, (long long)a.M);
@@ -412,6 +461,15 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
   int rc;
+  if (a.bf16) {
+    switch (cfg) {
+      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, true>(K_IGEMM_128x64, flops, grid, a, s); break;
+      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, true>(K_IGEMM_64x64, flops, grid, a, s); break;
+      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, true>(K_IGEMM_32x64, flops, grid, a, s); break;
+      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, true>(K_IGEMM_128x128, flops, grid, a, s); break;
+      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, true>(K_IGEMM_128x32, flops, grid, a, s); break;
+    }
+  } else
   switch (cfg) {
     case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
     case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1>(K_IGEMM_64x64, flops, grid, a, s); break;

@@ -5,9 +5,17 @@
 namespace dvg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // register-resident (a float4 array can end up in scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));  // operand of v_mfma_f32_32x32x16_bf16  // register-resident (a float4 array can end up in scratch)
 
 __device__ __forceinline__ int crow16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// float32 -> bfloat16, round to nearest even (NaN stays NaN): the bf16-input mode of the forward / data-gradient GEMMs
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float v) {
+  const uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 // Diagnostic build only (-DDVG_STAMP): per-phase cycle sums of the main loop, written to ConvArgs.stats
 // (which the diagnostic harness points at a debug buffer: 8 uint64 per block).  Never in the product build.

@@ -465,13 +465,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ wp) {
+__global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ wp,
+                                                          int bf16t) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int b = (int)(e % map.Cb);
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
-    wp[e] = packed_weight(w, map, tap, a, b);
+    const float v = packed_weight(w, map, tap, a, b);
+    if (bf16t) reinterpret_cast<uint16_t*>(wp)[((int64_t)tap * map.Cb + b) * map.Ca + a] = f32_to_bf16_rne(v);
+    else wp[e] = v;
   }
 }
 
@@ -485,7 +488,9 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
     const int b = (int)(e % map.Cb);
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
-    j.wp[e] = packed_weight(j.w, map, tap, a, b);
+    const float v = packed_weight(j.w, map, tap, a, b);
+    if (j.bf16t) reinterpret_cast<uint16_t*>(j.wp)[((int64_t)tap * map.Cb + b) * map.Ca + a] = f32_to_bf16_rne(v);
+    else j.wp[e] = v;
   }
 }
 
@@ -495,6 +500,7 @@ int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s) {
   int64_t biggest = 0;
   for (int k = 0; k < njobs; ++k) {
     pj.job[k] = jobs[k];
+    if (conv_precision_bf16()) pj.job[k].bf16t = 1;  // every pack feeds launch_conv_igemm
     const int64_t t = (int64_t)jobs[k].map.ntaps * jobs[k].map.Ca * jobs[k].map.Cb;
     if (t > biggest) biggest = t;
   }
@@ -522,9 +528,10 @@ int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, 
   return DVG_OK;
 }
 
-int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s) {
+int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t) {
+  if (conv_precision_bf16()) bf16t = 1;
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
-  DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w, map, wp);
+  DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w, map, wp, bf16t);
   return DVG_OK;
 }
 

@@ -1,0 +1,37 @@
+// Process-wide arithmetic mode of the forward / data-gradient convolution GEMMs.
+//   0 (default)  float32 operands on the f32 MFMA: the <= 1e-5 relative loss parity of the north star.
+//   1            "bf16 GEMM inputs, f32 accumulate" (BASELINE.json configs[1]): activations and weights
+//                are rounded to bf16 (round to nearest even) on their way into LDS, products and sums stay f32
+//                (v_mfma_f32_32x32x16_bf16).  Weight gradients, BatchNorm, losses, Adam stay float32.
+// A forward call and its backward call must run in the same mode (the backward reuses the forward's weight packs).
+#include <atomic>
+#include <cstdlib>
+
+#include "conv.h"
+
+namespace dvg {
+namespace {
+std::atomic<int> g_mode{-1};
+}
+
+bool conv_precision_bf16() {
+  int m = g_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("DVG_CONV_BF16");
+    m = (e && e[0] == '1') ? 1 : 0;
+    g_mode.store(m, std::memory_order_relaxed);
+  }
+  return m == 1;
+}
+}  // namespace dvg
+
+extern "C" int dvg_set_conv_precision(int mode) {
+  if (mode != DVG_PRECISION_F32 && mode != DVG_PRECISION_BF16_INPUTS) {
+    dvg::set_error("dvg_set_conv_precision: unknown mode %d", mode);
+    return DVG_E_INVALID;
+  }
+  dvg::g_mode.store(mode, std::memory_order_relaxed);
+  return DVG_OK;
+}
+
+extern "C" int dvg_get_conv_precision(void) { return dvg::conv_precision_bf16() ? DVG_PRECISION_BF16_INPUTS : DVG_PRECISION_F32; }

@@ -229,6 +229,19 @@ int dvg_adam_step(float *p, const float *g, float *m, float *v, int64_t numel, f
  */
 int dvg_stream_anchor(dvg_stream_t stream);
 
+/* ------------------------------------------------------------------ arithmetic mode of the convolution GEMMs
+ * Process-wide switch read by dvg_encoder_fwd/bwd and dvg_decoder_fwd/bwd (a forward call and its backward call must
+ * run in the same mode).  DVG_PRECISION_F32 (default): float32 operands, the <= 1e-5 relative loss parity against the
+ * reference's CPU path.  DVG_PRECISION_BF16_INPUTS: "bf16 GEMM inputs, f32 accumulate" for the forward and
+ * data-gradient GEMMs of encoder and decoder -- what a `torch.autocast(bfloat16)` run of src/encoder.py:28-30 /
+ * src/decoder.py:28,34-38 would feed its convolutions; weight gradients, BatchNorm, losses and Adam stay float32.
+ * Environment DVG_CONV_BF16=1 selects the bf16 mode at first use.
+ */
+#define DVG_PRECISION_F32 0
+#define DVG_PRECISION_BF16_INPUTS 1
+int dvg_set_conv_precision(int mode);
+int dvg_get_conv_precision(void);
+
 /* ------------------------------------------------------------------ profiler
  * Optional per-kernel HIP-event timing inside the library (used by bench.py for
  * the `roofline` object).  Off by default.  `kernel_mask` bit i enables kernel id i

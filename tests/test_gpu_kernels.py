@@ -72,3 +72,74 @@ def test_linear_as_one_tap_gemm():
     assert _rel(dx.cpu(), x.grad) < 2e-6
     gw = dev.conv_wgrad(x.detach().cuda(), gyp, 4, w.shape, N, n, 4 * n, 0, ntaps=1)
     assert _rel(gw.cpu(), w.grad) < 3e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# "bf16 GEMM inputs, f32 accumulate" (dvg_set_conv_precision(DVG_PRECISION_BF16_INPUTS)): the forward and data-gradient
+# GEMMs must equal a float32 convolution of the bf16-ROUNDED operands (exact products, f32 sums) to summation-order
+# rounding; against the unrounded float32 result they sit at bf16's 2^-9 relative operand error.
+
+class _bf16_inputs:
+    def __enter__(self):
+        from image_generation_amd import _lib
+        self.lib = _lib.lib()
+        assert self.lib.dvg_set_conv_precision(1) == 0 and self.lib.dvg_get_conv_precision() == 1
+
+    def __exit__(self, *exc):
+        assert self.lib.dvg_set_conv_precision(0) == 0
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8),
+                                             (256, 128, 128, 4), (64, 128, 128, 4), (40, 128, 128, 8)])
+def test_bf16_inputs_conv2d_fwd_dgrad(N, Cin, Cout, side):
+    torch.manual_seed(N)
+    x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    y_r = F.conv2d(_r(x), _r(w), b, padding=1)                      # bf16-rounded operands, f32 arithmetic
+    dx_r = torch.nn.grad.conv2d_input(x.shape, _r(w), _r(gy), padding=1)
+    y_f = F.conv2d(x, w, b, padding=1)
+    L, M = side.bit_length() - 1, N * side * side
+    with _bf16_inputs():
+        out, st = dev.conv_igemm(dev.nchw_to_morton(x).cuda(), w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+        dx = dev.conv_igemm(dev.nchw_to_morton(gy).cuda(), w.cuda(), 1, M, Cout, Cin, L)
+    got = dev.morton_to_nchw(out.cpu(), N, Cout, side)
+    assert _rel(got, y_r) < 3e-6
+    assert 1e-5 < _rel(got, y_f) < 2e-2                             # it really ran on rounded operands
+    s = st.sum(0).cpu()
+    assert _rel(s[:, 0], y_r.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y_r ** 2).sum((0, 2, 3))) < 1e-5
+    assert _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side), dx_r) < 3e-6
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(4, 128, 64, 4), (3, 64, 32, 8), (2, 96, 128, 2)])
+def test_bf16_inputs_convtranspose_with_fused_upsample(N, Cin, Cout, side):
+    torch.manual_seed(side)
+    xs = torch.randn(N, Cin, side // 2, side // 2); w = torch.randn(Cin, Cout, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    xr = _r(xs).requires_grad_(True)
+    y_r = F.conv_transpose2d(F.interpolate(xr, scale_factor=2, mode="nearest"), _r(w), b, padding=1)
+    y_r.backward(_r(gy))
+    L, M = side.bit_length() - 1, N * side * side
+    with _bf16_inputs():
+        out = dev.conv_igemm(dev.nchw_to_morton(xs).cuda(), w.cuda(), 2, M, Cin, Cout, L, ups=1, bias=b.cuda())
+        dx = dev.conv_igemm(dev.nchw_to_morton(gy).cuda(), w.cuda(), 3, M, Cout, Cin, L, poolsum=1)
+    assert _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side), y_r.detach()) < 3e-6
+    assert _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side // 2), xr.grad) < 5e-6
+
+
+def test_bf16_inputs_linear_as_one_tap_gemm():
+    torch.manual_seed(0)
+    N, n = 37, 64
+    x = torch.randn(N, n); w = torch.randn(4 * n, n) / n**0.5
+    gy = torch.randn(N, 4 * n)
+    y_r = F.linear(_r(x), _r(w))
+    gyp = gy.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n).contiguous()
+    dx_r = _r(gy) @ _r(w)
+    with _bf16_inputs():
+        out = dev.conv_igemm(x.cuda(), w.cuda(), 4, N, n, 4 * n, 0, ntaps=1)
+        dx = dev.conv_igemm(gyp.cuda(), w.cuda(), 5, N, 4 * n, n, 0, ntaps=1)
+    assert _rel(out.cpu(), y_r.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n)) < 3e-6
+    assert _rel(dx.cpu(), dx_r) < 3e-6

@@ -207,6 +207,208 @@ def test_cpu_tensors_fail_loudly():
         enc(torch.zeros(2, 1, 32, 32))
 
 
+def _cos(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _ConvTBf16(torch.autograd.Function):
+    """ConvTranspose2d with "bf16 GEMM inputs, f32 accumulate" in forward and data-gradient, float32 weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return torch.nn.functional.conv_transpose2d(_r16(x), _r16(w), b, stride=1, padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.nn.functional as F
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = _r16(x).detach().requires_grad_(True)
+            dx, = torch.autograd.grad(F.conv_transpose2d(xr, _r16(w), None, stride=1, padding=1), xr, _r16(gy))
+            wf = w.detach().requires_grad_(True)
+            dw, = torch.autograd.grad(F.conv_transpose2d(x.detach(), wf, None, stride=1, padding=1), wf, gy)
+        return dx, dw, (gy.sum((0, 2, 3)) if ctx.has_b else None)
+
+
+def _fold_class_weight(w, pa, pb):
+    """The 3x3 kernel a folded layer effectively applies to output pixels of parity class (pa, pb): taps that read the
+    same SOURCE pixel of the x2-upsampled input are summed in float32, the sum is rounded to bf16 and sits on one tap
+    of the group (the others are zero) -- the arithmetic of the library's WM_CONVT_FOLD_* packs."""
+    groups = lambda par: ([[0, 1], [2]] if par == 0 else [[0], [1, 2]])  # noqa: E731  (kernel rows / columns per source row)
+    out = torch.zeros_like(w)
+    for gr in groups(pa):
+        for gc in groups(pb):
+            acc = torch.zeros_like(w[:, :, 0, 0])
+            for kh in gr:
+                for kw in gc:
+                    acc = acc + w[:, :, kh, kw]
+            out[:, :, gr[0], gc[0]] = _r16(acc)
+    return out
+
+
+class _ConvTFoldBf16(torch.autograd.Function):
+    """ConvTranspose2d on a x2-nearest-upsampled map, as the folded bf16-input layers compute it."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        import torch.nn.functional as F
+        ctx.save_for_backward(x, w)
+        y = None
+        for pa in (0, 1):
+            for pb in (0, 1):
+                yc = F.conv_transpose2d(_r16(x), _fold_class_weight(w, pa, pb), None, stride=1, padding=1)
+                y = torch.zeros_like(yc) if y is None else y
+                y[..., pa::2, pb::2] = yc[..., pa::2, pb::2]
+        return y + b.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.nn.functional as F
+        x, w = ctx.saved_tensors
+        gyr = _r16(gy)
+        dx = torch.zeros_like(x)
+        for pa in (0, 1):
+            for pb in (0, 1):
+                g = torch.zeros_like(gyr)
+                g[..., pa::2, pb::2] = gyr[..., pa::2, pb::2]
+                dx = dx + F.conv2d(g, _fold_class_weight(w, pa, pb), None, stride=1, padding=1)
+        with torch.enable_grad():
+            wf = w.detach().requires_grad_(True)
+            dw, = torch.autograd.grad(F.conv_transpose2d(x.detach(), wf, None, stride=1, padding=1), wf, gy)
+        return dx, dw, gy.sum((0, 2, 3))
+
+
+class _LinBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(_r16(x), _r16(w), b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        return _r16(gy) @ _r16(w), gy.flatten(0, -2).t() @ x.flatten(0, -2), gy.flatten(0, -2).sum(0)
+
+
+def test_bf16_input_mode_decoder_against_an_emulating_oracle(monkeypatch):
+    """dvg_set_conv_precision(DVG_PRECISION_BF16_INPUTS): the decoder's Linear and its GEMM-shaped transposed
+    convolutions take bf16 operands in forward and data-gradient (f32 accumulate, f32 weight gradients); the 32->1 and
+    1->1 layers, BatchNorm and everything else stay float32.  The oracle is run with exactly that arithmetic emulated
+    (operands rounded to bf16, float32 convolutions; for the layers the library folds over the x2 upsample, the
+    pre-summed taps are what gets rounded).  Against the plain float32 oracle the same run sits at bf16's operand
+    precision -- neither equal nor garbage."""
+    import types
+    import torch.nn.functional as F
+    from image_generation_amd import _lib
+    L = _lib.lib()
+    n, B, R = 128, 16, 4
+    params = gen.make_params(n, "decoder", 21 + n)
+    masks = [torch.from_numpy(m) for m in gen.make_masks(B * R, 8)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(2))
+
+    def oracle(emulate):
+        p = _oracle_params(params)
+        spins = torch.from_numpy(gen.make_spins(B, R, n, 7)).requires_grad_(True)
+        fs = types.SimpleNamespace(**{k: getattr(F, k) for k in dir(F) if not k.startswith("_")})
+        if emulate:
+            fs.conv_transpose2d = lambda x, w, b, stride=1, padding=1: (  # 128->128 at 2x2; folded 128->64, 64->32; rest f32
+                F.conv_transpose2d(x, w, b, stride=stride, padding=padding) if w.shape[1] < 32
+                else _ConvTBf16.apply(x, w, b) if x.shape[-1] == 2 else _ConvTFoldBf16.apply(x, w, b))
+            fs.linear = lambda x, w, b: _LinBf16.apply(x, w, b)
+        monkeypatch.setattr(nets, "F", fs)
+        y = nets.decoder_forward(p, spins, training=True, dropout_masks=masks)
+        (y * go).sum().backward()
+        return y.detach(), spins.grad, {k: v.grad for k, v in p.items() if v.requires_grad}
+
+    y32, gs32, _ = oracle(False)
+    y16, gs16, gp16 = oracle(True)
+    assert L.dvg_set_conv_precision(1) == 0
+    try:
+        dec = _load(Decoder(n), params).train()
+        sg = torch.from_numpy(gen.make_spins(B, R, n, 7)).cuda().requires_grad_(True)
+        dec.inject_dropout_masks([m.cuda() for m in masks])
+        got = dec(sg)
+        (got * go.cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        assert L.dvg_set_conv_precision(0) == 0
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    # (not tighter: an activation within float32 summation noise of a bf16 rounding boundary lands on the other side)
+    assert rel(got.detach().cpu(), y16) < 1.5e-3
+    assert 1e-4 < rel(got.detach().cpu(), y32) < 3e-2
+    assert _cos(sg.grad.cpu(), gs16) > 0.9999 and _cos(sg.grad.cpu(), gs32) < 0.999
+    for name, prm in dec.named_parameters():
+        if name.endswith("bias") and name.startswith("convtrans") and name.split(".")[1] in ("0", "5", "10", "15"):
+            continue                                   # zero true gradient (bias feeding a BatchNorm)
+        assert _cos(prm.grad.cpu(), gp16[name]) > 0.9999, name
+
+
+class _ConvBf16(torch.autograd.Function):
+    """Conv2d with bf16 operands in forward and data-gradient, float32 weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.conv2d(_r16(x), _r16(w), b, stride=1, padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv2d_input(x.shape, _r16(w), _r16(gy), stride=1, padding=1)
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=1, padding=1)
+        return dx, dw, gy.sum((0, 2, 3))
+
+
+def test_bf16_input_mode_encoder_against_an_emulating_oracle(monkeypatch):
+    """Encoder counterpart: the 32->64, 64->128 and 128->n convolutions take bf16 operands in forward and data-gradient;
+    the 1->32 convolution, the projection, BatchNorm, pooling and the weight gradients stay float32."""
+    import types
+    import torch.nn.functional as F
+    from image_generation_amd import _lib
+    L = _lib.lib()
+    n, B = 128, 24
+    params = gen.make_params(n, "encoder", 11 + n)
+    x = (torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(3)) < 0.2).float()
+    gl = torch.randn(B, n, generator=torch.Generator().manual_seed(1))
+
+    def oracle(emulate):
+        p = _oracle_params(params)
+        fs = types.SimpleNamespace(**{k: getattr(F, k) for k in dir(F) if not k.startswith("_")})
+        if emulate:
+            fs.conv2d = lambda xx, w, b, stride=1, padding=1: (
+                _ConvBf16.apply(xx, w, b) if w.shape[1] >= 32 else F.conv2d(xx, w, b, stride=stride, padding=padding))
+        monkeypatch.setattr(nets, "F", fs)
+        y = nets.encoder_forward(p, x, training=True)
+        (y * gl).sum().backward()
+        return y.detach(), {k: v.grad for k, v in p.items() if v.requires_grad}
+
+    y32, _ = oracle(False)
+    y16, gp16 = oracle(True)
+    assert L.dvg_set_conv_precision(1) == 0
+    try:
+        enc = _load(Encoder(n), params).train()
+        got = enc(x.cuda())
+        (got * gl.cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        assert L.dvg_set_conv_precision(0) == 0
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    assert rel(got.detach().cpu(), y16) < 3e-3 and 1e-4 < rel(got.detach().cpu(), y32) < 5e-2
+    for name, prm in enc.named_parameters():
+        if name.startswith("conv") and name.endswith("bias") and int(name.split(".")[1]) % 4 == 0:
+            continue  # zero true gradient (bias feeding a BatchNorm)
+        # (a max-pool window whose two largest bf16-path values swap order between the two float32 summation orders
+        # re-routes one gradient element: rare, and the reason this is a cosine rather than an element-wise bound)
+        assert _cos(prm.grad.cpu(), gp16[name]) > 0.999, (name, _cos(prm.grad.cpu(), gp16[name]))
+
+
 def test_wide_tile_configuration_in_a_child_process():
     """The 128x128 convolution tile serves launches of >= 512 such blocks (c3-scale batches); DVG_IGEMM_THR128=1 sends
     every 128-multiple layer of the small fixtures through it.  The switch is read once per process: child run."""
