@@ -227,6 +227,20 @@ class StepState:
         self._events[k].record()
 
 
+def set_conv_precision(mode: str) -> None:
+    """Operands of the forward / data-gradient convolution GEMMs, process-wide (include/dvg.h, dvg_set_conv_precision):
+    ``"f32"`` (default; the 1e-5 loss parity) or ``"bf16"`` (bf16 inputs, f32 accumulate; weight gradients stay f32).
+    A forward pass and its backward pass must run in the same mode."""
+    modes = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+    if mode not in modes:
+        raise ValueError(f"conv precision must be one of {sorted(modes)}, got {mode!r}")
+    check(lib().dvg_set_conv_precision(modes[mode]), "dvg_set_conv_precision")
+
+
+def get_conv_precision() -> str:
+    return "bf16" if lib().dvg_get_conv_precision() == 1 else "f32"
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().dvg_last_error().decode("utf-8", "replace")

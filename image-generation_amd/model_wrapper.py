@@ -187,6 +187,11 @@ class ModelWrapper:
         self._device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         if self.LATENT_TO_DISCRETE in ["heaviside"] and self.N_REPLICAS != 1:
             raise ValueError("heaviside latent-to-discrete can only be used with n_replicas=1")
+        precision = self._params.get("CONV_PRECISION")  # absent (the reference's YAML): the library's mode stands
+        if precision is not None and self._device.type == "cuda":
+            from . import _lib
+
+            _lib.set_conv_precision(str(precision))
         dvae = DiscreteVariationalAutoencoder(
             encoder=Encoder(n_latents=self.n_latents),
             decoder=Decoder(n_latents=self.n_latents),

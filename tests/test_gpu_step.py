@@ -135,6 +135,49 @@ def test_deferred_mmd_join_is_bit_identical(golden_dir):
             assert torch.equal(sd_ref[k], sd[k]), (k, use_graph)
 
 
+def test_bf16_conv_precision_trains_and_tracks_f32(tmp_path, golden_dir):
+    """CONV_PRECISION: bf16 in the YAML switches the library's forward / data-gradient GEMMs to bf16 inputs (f32
+    accumulate).  Same batches, same noise streams: the losses follow the float32 run at bf16's precision (percent level,
+    not 1e-5), stay finite, and the captured-graph path serves the mode too."""
+    import yaml
+    from image_generation_amd import _lib
+
+    def run(precision, use_graph):
+        cfg = yaml.safe_load(open(os.path.join(golden_dir, "step_params.yaml")))
+        cfg.update(CONV_PRECISION=precision)
+        path = tmp_path / f"p_{precision}_{use_graph}.yaml"
+        with open(path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=str(path))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 12, seed=6)).reshape(12, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(12)])
+        m.train_init(1)
+        assert _lib.get_conv_precision() == precision
+        m.sync_losses = False
+        m.use_graph = use_graph
+        out = []
+        for k in range(12):
+            m.step((imgs[k], None), epoch=0)
+            out.append((float(m.last["mse"]), float(m.last["mmd"])))
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v).all()) for v in m._dvae.state_dict().values() if v.is_floating_point())
+        return np.array(out)
+
+    try:
+        f32 = run("f32", False)
+        b16 = run("bf16", False)
+        b16g = run("bf16", True)
+    finally:
+        _lib.set_conv_precision("f32")
+    assert np.array_equal(b16, b16g)                                   # replay == eager in the bf16 mode as well
+    dev = np.abs(b16 - f32) / np.abs(f32)
+    assert 1e-6 < dev[:, 0].max() < 0.1 and dev[:, 1].max() < 0.5, dev  # follows f32 at bf16 precision; not identical
+    with pytest.raises(ValueError):
+        _lib.set_conv_precision("fp8")
+
+
 def test_training_driver_and_model_files(tmp_path, golden_dir):
     """execute_training + create_model_files: the reference's loop and side-file formats; the loss goes down."""
     import json

@@ -1,4 +1,4 @@
-"""Graph-replayed training steps (default 600 at the bench shape c2; `soak.py <config> <steps>`) on structured synthetic images; prints the losses every 100 steps
+"""Graph-replayed training steps (default 600 at the bench shape c2; `soak.py <config> <steps> [f32|bf16]`) on structured synthetic images; prints the losses every 100 steps
 and asserts that every parameter is finite (the run that exposed the u = 1 Gumbel draw)."""
 import sys, torch, tempfile
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -8,7 +8,7 @@ from image_generation_amd.data import synthetic_images
 CFG = sys.argv[1] if len(sys.argv) > 1 else "c2"
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 cfg = dict(bench.CONFIGS[CFG])
-tmp = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False); tmp.close(); bench.write_yaml(cfg, tmp.name)
+tmp = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False); tmp.close(); bench.write_yaml(cfg, tmp.name, sys.argv[3] if len(sys.argv) > 3 else "f32")
 m = ModelWrapper(cfg["qpu"], n_latents=cfg["n"], training_parameter_file=tmp.name)
 # structured images (blobs) so that there is something to learn
 g = torch.Generator().manual_seed(0)
