@@ -74,7 +74,8 @@ def pmc_traffic(kernel, config):
     path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config}.json")
     if not os.path.exists(path):
         return None, None
-    norm = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").split("(")[0]  # noqa: E731
+    # (rocprof spells out the kernel's trailing bf16-operands template flag; the f32 instantiation is the one priced)
+    norm = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").split("(")[0].replace(",false>", ">")  # noqa: E731
     for name, rec in json.load(open(path)).items():
         if norm(name) == norm(kernel):
             return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)

@@ -13,6 +13,7 @@ python bench.py --config c2 --breakdown $OUT/${R}_hip_event_breakdown_c2.json > 
 python bench.py --config c1 > $OUT/c1.log 2>&1; last $OUT/c1.log $OUT/${R}_bench_c1.json
 python bench.py --config c3 --no-cpu-baseline --steps 10 > $OUT/c3.log 2>&1; last $OUT/c3.log $OUT/${R}_bench_c3.json
 python bench.py --config c5 --no-cpu-baseline --steps 20 > $OUT/c5.log 2>&1; last $OUT/c5.log $OUT/${R}_bench_c5.json
+python bench.py --config c3 --precision bf16 --no-cpu-baseline --steps 10 > $OUT/c3b.log 2>&1; last $OUT/c3b.log $OUT/${R}_bench_c3_bf16_inputs.json
 # 2. rocprofv3 kernel stats of the same c2 command
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --config c2 --no-cpu-baseline > $OUT/c2_rocprof.log 2>&1
