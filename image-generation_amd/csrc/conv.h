@@ -105,6 +105,8 @@ struct ConvArgs {
 };
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();
+void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
+bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);
 // fold = 1 launches: M source pixels; usable when conv_fold_ok (whole row blocks per class)

@@ -125,6 +125,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
                                size_t ws_bytes, const dvg_step_state_t* dyn, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  conv_precision_note_forward(ws);
   DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
@@ -197,6 +198,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
                                size_t ws_bytes, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  DVG_REQUIRE(conv_precision_matches_forward(ws), "decoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
   DVG_REQUIRE(spins && grad_out && g, "decoder_bwd: null argument");
   DVG_REQUIRE(g->lin_w && g->lin_b, "decoder_bwd: null linear gradient buffer");
   for (int l = 0; l < 5; ++l) DVG_REQUIRE(g->conv_w[l] && g->conv_b[l], "decoder_bwd: null conv gradient buffer %d", l);

@@ -6,12 +6,30 @@
 // A forward call and its backward call must run in the same mode (the backward reuses the forward's weight packs).
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "conv.h"
 
 namespace dvg {
+bool conv_precision_bf16();
 namespace {
 std::atomic<int> g_mode{-1};
+std::mutex g_ws_mutex;
+std::unordered_map<const void*, int> g_ws_mode;  // mode of the last forward call per workspace
+}
+
+// A backward call reuses the weight packs its forward call left in the workspace, so it must run in the mode that wrote
+// them: the forward notes its mode per workspace pointer, the backward checks it (host-side bookkeeping only).
+void conv_precision_note_forward(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (g_ws_mode.size() > 4096) g_ws_mode.clear();
+  g_ws_mode[ws] = conv_precision_bf16() ? 1 : 0;
+}
+bool conv_precision_matches_forward(const void* ws) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  auto it = g_ws_mode.find(ws);
+  return it == g_ws_mode.end() || it->second == (conv_precision_bf16() ? 1 : 0);
 }
 
 bool conv_precision_bf16() {

@@ -409,6 +409,21 @@ def test_bf16_input_mode_encoder_against_an_emulating_oracle(monkeypatch):
         assert _cos(prm.grad.cpu(), gp16[name]) > 0.999, (name, _cos(prm.grad.cpu(), gp16[name]))
 
 
+def test_operand_mode_must_not_change_between_forward_and_backward():
+    from image_generation_amd import _lib
+    L = _lib.lib()
+    n = 64
+    enc = _load(Encoder(n), gen.make_params(n, "encoder", 5)).train()
+    x = (torch.rand(4, 1, 32, 32, generator=torch.Generator().manual_seed(3)) < 0.2).float().cuda()
+    y = enc(x)
+    assert L.dvg_set_conv_precision(1) == 0
+    try:
+        with pytest.raises(_lib.DvgError, match="operand mode"):
+            y.sum().backward()
+    finally:
+        assert L.dvg_set_conv_precision(0) == 0
+
+
 def test_wide_tile_configuration_in_a_child_process():
     """The 128x128 convolution tile serves launches of >= 512 such blocks (c3-scale batches); DVG_IGEMM_THR128=1 sends
     every 128-multiple layer of the small fixtures through it.  The switch is read once per process: child run."""
