@@ -184,6 +184,7 @@ def main():
     model.set_dataloader(batches * ((args.steps + args.warmup + 64) // pool + 2))
     model.train_init(n_epochs=1)
     model.sync_losses = False  # no .item() host syncs inside the step
+    model.keep_step_losses = False  # ... and no per-step copies of the loss scalars into the history lists
 
     L = _lib.lib()
     _lib.check(L.dvg_set_conv_precision(1 if args.precision == "bf16" else 0), "dvg_set_conv_precision")

@@ -86,6 +86,10 @@ class ModelWrapper:
         # use_graph: replay the autoencoder half of the step from a captured hipGraph (needs sync_losses = False);
         # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
         self.use_graph = False
+        # Replayed steps write their losses into the graph's static output tensors.  keep_step_losses = True (default)
+        # appends a COPY per step to self.losses (two tiny device copies, ~0.5 % of a c2 step), as the reference's lists
+        # hold one value per step; False appends nothing (throughput runs: self.last still holds the latest values).
+        self.keep_step_losses = True
         self._graph = None
         self._graphs = []         # (executable graph, its static input, its static outputs, Adam tail graph or None)
         self._capturing_split = False
@@ -481,8 +485,9 @@ class ModelWrapper:
         c = self._host_counters()
         self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
         mse, dvae, mmd, spins = outs
-        self.losses["mse_losses"].append(mse)   # static tensors: valid for N_GRAPHS replays (sync_losses is off)
-        self.losses["dvae_losses"].append(dvae)
+        if self.keep_step_losses:  # the outputs are static tensors, overwritten by the next replay: log copies
+            self.losses["mse_losses"].append(mse.clone())
+            self.losses["dvae_losses"].append(dvae.clone())
         self.last.update(mse=mse, mmd=mmd)
         return mse, spins
 

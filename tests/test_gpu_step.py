@@ -99,10 +99,13 @@ def test_graph_replay_is_bit_identical_to_eager(golden_dir):
         sd.update({"grbm." + k: v.clone() for k, v in m._grbm.state_dict().items()})  # steps 0 and 10 train the GRBM
         return out, sd, m
 
-    eager, sd_e, _ = run(False)
+    eager, sd_e, me = run(False)
     graphed, sd_g, mg = run(True)
     assert mg._graph is not None and not mg._graph_failed, "the step was not captured"
     assert eager == graphed
+    # the loss history holds one value per step in both modes (replays overwrite their static outputs: copies are logged)
+    hist = lambda m: [float(v) for v in m.losses["mse_losses"]]  # noqa: E731
+    assert hist(me) == hist(mg) == [e[0] for e in eager] and len(set(hist(mg))) > 8
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
 
