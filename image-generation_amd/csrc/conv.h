@@ -102,6 +102,8 @@ struct ConvArgs {
   // bf16 = 1: "bf16 GEMM inputs, f32 accumulate" (conv_precision_bf16()): `wp` then points at the bf16 K-major pack
   // Wp16[tap][b][a] (PackJob.bf16t) and the activations are rounded to bf16 (RNE) on their way into LDS
   int bf16 = 0;
+  // bias_perm = n > 0: column j = p*n + c takes bias[c*4 + p] (the decoder's Linear(n, 4n) bias in checkpoint order)
+  int bias_perm = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();

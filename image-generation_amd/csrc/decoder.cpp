@@ -146,10 +146,9 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
   }
-  DVG_TRY(launch_permute_vec(p->lin_b, 4 * n, n, 4, W + pl.bias_lin, s));  // bias'[p*n + c] = b[c*4 + p]
   {
     ConvArgs a;
-    a.in = spins; a.wp = W + pl.wp_lin; a.bias = W + pl.bias_lin; a.out = W + pl.X0; a.stats = nullptr;
+    a.in = spins; a.wp = W + pl.wp_lin; a.bias = p->lin_b; a.bias_perm = n; a.out = W + pl.X0; a.stats = nullptr;  // bias'[p*n + c] = b[c*4 + p]
     a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
