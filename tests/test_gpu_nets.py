@@ -434,7 +434,8 @@ def test_wide_tile_configuration_in_a_child_process():
         pytest.skip("already inside the child")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DVG_IGEMM_THR128="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_nets.py"), "-q", "-m", "gpu",
-                        "-k", "matches_oracle_full_gradients or matches_reference_fixture"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_nets.py"),
+                        os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-m", "gpu", "-k",
+                        "decoder_matches_oracle_full_gradients or matches_reference_fixture or bf16 or conv2d_fwd_dgrad_wgrad"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)  # (f32 and bf16-input forms)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
