@@ -2,6 +2,8 @@
 // fixed-order slab reduction back into the checkpoint layout, and the weight packing kernels
 // (/root/reference/src/encoder.py:28-30, /root/reference/src/decoder.py:28, :34-38).
 // Separate translation unit from conv_igemm.hip so the two can carry different code-generation options (Makefile).
+#include <cstdlib>
+
 #include "conv_tile.h"
 
 namespace dvg {
@@ -431,7 +433,12 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * a.ntaps;
   if (a.ntaps == 9) {
     const dim3 g9((unsigned)((a.Cin / ba) * (a.Cout / bb)), (unsigned)a.ksplit);
-    if (a64 && b64) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad9_kernel<2, 2, 1>), g9, dim3(256), 0, s, a);
+    // 64x64 channel tile: two tap groups (8 waves, 5 / 4 accumulator tiles per wave, two waves per SIMD) instead of one
+    // (4 waves x 9 tiles, one per SIMD): +10 % on the kernel in-situ (c3 53 -> 59, c2 41 -> 45 TFLOP/s), steps neutral
+    // to -1 %.  DVG_WGRAD9_WT2=0 restores the 4-wave form (A/B runs).
+    static const bool wt2 = [] { const char* e = getenv("DVG_WGRAD9_WT2"); return !e || e[0] != '0'; }();
+    if (a64 && b64 && wt2) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad9_kernel<2, 2, 2>), g9, dim3(512), 0, s, a);
+    else if (a64 && b64) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad9_kernel<2, 2, 1>), g9, dim3(256), 0, s, a);
     else if (a64) DVG_LAUNCH_WORK(K_WGRAD_2x1, flops, (conv_wgrad9_kernel<2, 1, 2>), g9, dim3(256), 0, s, a);
     else if (b64) DVG_LAUNCH_WORK(K_WGRAD_1x2, flops, (conv_wgrad9_kernel<1, 2, 2>), g9, dim3(256), 0, s, a);
     else DVG_LAUNCH_WORK(K_WGRAD_1x1, flops, (conv_wgrad9_kernel<1, 1, 4>), g9, dim3(256), 0, s, a);
