@@ -82,6 +82,20 @@ def pmc_traffic(kernel, config):
     return None, None
 
 
+def pmc_mfma_busy(kernel, config):
+    """Matrix-pipe utilisation of `kernel` (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)) from the
+    committed rocprofv3 PMC pass of `bench.py --eager` (profiles/aggregate_mfma.py): dispatches are serialised under
+    PMC collection, so this is the kernel alone, launch ramp included."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_mfma_busy_{config}.json")
+    if not os.path.exists(path):
+        return None
+    norm = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").replace("dvg::", "").split("(")[0].replace(",false>", ">")  # noqa: E731
+    for name, rec in json.load(open(path)).items():
+        if norm(name) == norm(kernel):
+            return rec["mfma_busy_frac"]
+    return None
+
+
 def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle (a port: stock PyTorch CPU ops + the C Gibbs restatement) on this box's host cores."""
     from image_generation_amd import graphs
@@ -268,6 +282,7 @@ def main():
                                               "ms_per_step": v["total_ms"] / prof_steps,
                                               "avg_launch_us": v["total_ms"] * 1e3 / v["launches"]} for k, v in cands.items()}}
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic(dom, args.config)
+        roofline["mfma_busy_pmc"] = pmc_mfma_busy(dom, args.config) if args.precision == "f32" else None
         ips = args.gpus * cfg["B"] * args.steps / elapsed
         out = {
             "metric": baseline_metric(), "metric_id": "dvae_grbm_train_step_images_per_s", "value": ips,
