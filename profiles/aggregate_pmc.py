@@ -1,7 +1,7 @@
 """Aggregate two rocprofv3 PMC passes (--pmc FETCH_SIZE / --pmc WRITE_SIZE, each with --kernel-trace) of
 `bench.py --eager` into HBM bytes per launch per kernel.
 
-    python profiles/aggregate_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+    python profiles/aggregate_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json [kernel_trace.csv]
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters
 report KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled; WRITE_SIZE is exact.
@@ -33,6 +33,21 @@ def main():
         w_kib, n2 = write.get(k, (0.0, 0))
         out[k] = {"launches": max(n, n2), "FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
                   "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
+    if len(sys.argv) > 4:
+        # optional: the kernel_trace.csv of one of the passes -> average dispatch duration (serialised under PMC collection,
+        # i.e. each kernel alone) and the HBM rate it implies against the 8 TB/s peak
+        dur = defaultdict(lambda: [0.0, 0])
+        with open(sys.argv[4]) as f:
+            for r in csv.DictReader(f):
+                d = dur[r["Kernel_Name"]]
+                d[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                d[1] += 1
+        for k, rec in out.items():
+            if dur[k][1]:
+                us = dur[k][0] / dur[k][1] / 1e3
+                rec["avg_us_alone"] = us
+                rec["hbm_GBps"] = rec["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
+                rec["hbm_frac_of_8TBps"] = rec["hbm_GBps"] / 8000.0
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(f"{len(out)} kernels -> {sys.argv[3]}")
 

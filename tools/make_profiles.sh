@@ -23,10 +23,13 @@ cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${R}_rocprofv3_kernel_sta
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -- python3 $ROOT/bench.py --config c2 --eager --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -- python3 $ROOT/bench.py --config c2 --eager --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_m -- python3 $ROOT/bench.py --config c2 --eager --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f3 -- python3 $ROOT/bench.py --config c3 --eager --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w3 -- python3 $ROOT/bench.py --config c3 --eager --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_m3 -- python3 $ROOT/bench.py --config c3 --eager --no-cpu-baseline --steps 3 --warmup 2 > /dev/null 2>&1
 cd $ROOT
 python profiles/aggregate_mfma.py $(ls $OUT/pmc_m3/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_mfma_busy_c3.json
 python profiles/aggregate_mfma.py $(ls $OUT/pmc_m/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_mfma_busy_c2.json
-python profiles/aggregate_pmc.py $(ls $OUT/pmc_f/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_w/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_traffic_c2.json
-rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/pmc_m $OUT/pmc_m3 $OUT/*.log
+python profiles/aggregate_pmc.py $(ls $OUT/pmc_f/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_w/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_traffic_c2.json $(ls $OUT/pmc_w/*/*kernel_trace.csv | head -1)
+python profiles/aggregate_pmc.py $(ls $OUT/pmc_f3/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_w3/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_traffic_c3.json $(ls $OUT/pmc_w3/*/*kernel_trace.csv | head -1)
+rm -rf $OUT/stats $OUT/pmc_f $OUT/pmc_w $OUT/pmc_m $OUT/pmc_m3 $OUT/pmc_f3 $OUT/pmc_w3 $OUT/*.log
 ls -la $OUT
