@@ -88,6 +88,7 @@ class DecoderGrads(ctypes.Structure):
 _I32P = POINTER(c_int32)
 SIGNATURES = {
     "dvg_version": (c_int, []),
+    "dvg_source_hash": (c_char_p, []),
     "dvg_last_error": (c_char_p, []),
     "dvg_graph_create": (c_int, [c_int, c_int, _I32P, _I32P, _I32P, _I32P, c_int, _I32P, _I32P, _I32P, POINTER(c_void_p)]),
     "dvg_graph_destroy": (c_int, [c_void_p]),

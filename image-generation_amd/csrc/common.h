@@ -83,6 +83,7 @@ enum KernelId : int {
 // when DVG_NO_SIDE_STREAM is set); stream_order_after(w, p) makes everything enqueued on `w` from now on wait for what
 // has been enqueued on `p` so far (no-op when w == p).  Capture-safe.
 bool side_enabled();
+void side_stream_warm();  // create the current device's side stream + event ring now (outside any capture)
 hipStream_t side_stream(hipStream_t fallback);
 int stream_order_after(hipStream_t waiter, hipStream_t producer);
 // The same in two halves: mark a point of `producer` now, make `waiter` wait for exactly that point later.

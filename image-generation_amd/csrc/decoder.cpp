@@ -116,6 +116,7 @@ int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws
 }  // namespace
 
 extern "C" size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents) {
+  dvg::side_stream_warm();  // the backward's fork/join context exists before any step is captured
   if (N < 1 || n_latents < 32 || n_latents % 32) return 0;
   return dec_plan(N, n_latents).total_floats * sizeof(float);
 }

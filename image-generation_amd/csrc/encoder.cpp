@@ -98,6 +98,7 @@ int check_common(const dvg_encoder_params_t* p, int n, int64_t B, const void* ws
 }  // namespace
 
 extern "C" size_t dvg_encoder_workspace_bytes(int64_t B, int n_latents) {
+  dvg::side_stream_warm();  // the backward's fork/join context exists before any step is captured
   if (B < 1 || n_latents < 32 || n_latents % 32) return 0;
   return enc_plan(B, n_latents).total_floats * sizeof(float);
 }

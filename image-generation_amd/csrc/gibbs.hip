@@ -69,10 +69,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
+  // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
+  // non-persistent draws do not all restart from one configuration)
+  const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if (valid) {
     if (a.init) {
       for (int i = l; i < n; i += LPC) {
-        u32x4 r = philox4x32_10((uint32_t)i, cid, 0u, STREAM_INIT, a.k0, a.k1);
+        u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
         st[i] = (r.x >> 31) ? 1 : -1;
       }
     } else {
@@ -84,7 +87,6 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   __builtin_amdgcn_wave_barrier();
 
   if (valid) {
-    const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
     for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
       const uint32_t tq = t >> 2, tw = t & 3u;
       for (int k = 0; k < a.n_colours; ++k) {
@@ -164,10 +166,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
+  // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
+  // non-persistent draws do not all restart from one configuration)
+  const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if (valid) {
     if (a.init) {
       for (int i = l; i < n; i += LPC) {
-        u32x4 r = philox4x32_10((uint32_t)i, cid, 0u, STREAM_INIT, a.k0, a.k1);
+        u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
         st[i] = (r.x >> 31) ? 1 : -1;
       }
     } else {
@@ -180,7 +185,6 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   if (!valid) return;
 
   const int passes = a.passes, n_slots = a.n_colours * passes;
-  const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if constexpr (MAXS > GIBBS_MAXS) {
     // many-slot form: one packed register per slot (spin | CSR start << 16; the CSR end and the field offset are
     // re-read from LDS per update) beside the four Philox words -- 5 MAXS registers instead of 8 MAXS
@@ -330,7 +334,8 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)ceil_div(a.n_chains, CPB);
-  DVG_LAUNCH(K_GIBBS, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  // work = spin updates of the draw (bench.py's sampler roofline)
+  DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
   return DVG_OK;
 }
 

@@ -1140,6 +1140,14 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
+// Executed matrix work of a spin-path pair launch in bf16-MFMA-equivalent FLOPs (what bench.py prices against the
+// 2.5 PFLOP/s dense bf16 peak): the int8 Gram of every visited pair (x rows against all rows, y rows against y rows)
+// runs at twice the bf16 rate, hence the 0.5; the gradient GEMM runs `terms` bf16 products per pair and feature.
+static double mmd_pm1_work(const MmdArgs& a, int terms) {
+  const double nx = (double)a.nx, ny = (double)a.ny, d = (double)a.d;
+  return 0.5 * 2.0 * (nx * (nx + ny) + ny * ny) * d + (a.grad_part ? terms * 2.0 * nx * (nx + ny) * d : 0.0);
+}
+
 template <int NFBW>
 static int launch_pair_fq(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   constexpr int NFB = 4 * NFBW, NFBM = NFB > 8 ? 8 : NFB;
@@ -1155,9 +1163,7 @@ static int launch_pair_fq(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int zs = (d / 32 + NFBM - 1) / NFBM;  // slices the f32 body needs
-  const double N = (double)(a.nx + a.ny);
-  const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;
-  DVG_LAUNCH_WORK(K_MMD_PM1, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
+  DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 3), kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
   return DVG_OK;
 }
 
@@ -1174,9 +1180,7 @@ static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int zs = d / (32 * NFB);
-  const double N = (double)(a.nx + a.ny);
-  const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;
-  DVG_LAUNCH_WORK(K_MMD_PM1, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
+  DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 3), kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)zs), dim3(256), lds, s, a);
   return DVG_OK;
 }
 

@@ -70,7 +70,11 @@ using namespace dvg;
 
 extern "C" {
 
-int dvg_version(void) { return 100; /* 0.1.0 */ }
+int dvg_version(void) { return 110; /* 0.1.1 */ }
+#ifndef DVG_SRC_HASH
+#error "DVG_SRC_HASH must be defined by the build (image-generation_amd/Makefile)"
+#endif
+const char* dvg_source_hash(void) { return DVG_SRC_HASH; }
 const char* dvg_last_error(void) { return g_err; }
 
 int dvg_prof_enable(uint64_t kernel_mask) { g_mask = kernel_mask; return DVG_OK; }

@@ -6,7 +6,9 @@
 // the call is still "a sequence of work on `stream`".  The pattern is capture-safe: under hipStreamBeginCapture the
 // event wait pulls the side stream into the capture and the join closes the fork, so the captured graph simply gets
 // two parallel branches.  DVG_NO_SIDE_STREAM=1 keeps everything on the caller's stream (A/B measurements, debugging).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -15,11 +17,14 @@ namespace dvg {
 namespace {
 constexpr int kMaxDevices = 16;
 constexpr int kEvents = 64;
+// The library is entered from the caller's thread (forward) and from the autograd engine's worker thread (backward):
+// creation is serialised by a mutex and published through an acquire/release flag, the event-ring cursor is atomic.
 struct SideCtx {
   hipStream_t side = nullptr;
-  hipEvent_t ev[kEvents];
-  int next = 0;
-  bool ready = false;
+  hipEvent_t ev[kEvents] = {};
+  std::atomic<unsigned> next{0};
+  std::atomic<bool> ready{false};
+  std::mutex mu;
 };
 SideCtx g_ctx[kMaxDevices];
 
@@ -27,15 +32,23 @@ SideCtx* ctx() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
   SideCtx& c = g_ctx[dev];
-  if (!c.ready) {
-    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    for (int i = 0; i < kEvents; ++i)
-      if (hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    c.ready = true;
-  }
+  if (c.ready.load(std::memory_order_acquire)) return &c;
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (c.ready.load(std::memory_order_relaxed)) return &c;
+  // what an earlier, partially failed attempt created is reused, not leaked
+  if (!c.side && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) { c.side = nullptr; return nullptr; }
+  for (int i = 0; i < kEvents; ++i)
+    if (!c.ev[i] && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) != hipSuccess) { c.ev[i] = nullptr; return nullptr; }
+  c.ready.store(true, std::memory_order_release);
   return &c;
 }
 }  // namespace
+
+bool side_enabled();
+
+// Creates the device's side stream and event ring now (never under a stream capture: the workspace-size queries and
+// dvg_graph_create call this, and they always precede the first captured step).
+void side_stream_warm() { if (side_enabled()) (void)ctx(); }
 
 bool side_enabled() {
   static const bool off = [] {
@@ -54,8 +67,7 @@ hipStream_t side_stream(hipStream_t fallback) {
 int stream_mark(hipStream_t producer, hipEvent_t* mark) {
   SideCtx* c = ctx();
   DVG_REQUIRE(c, "side stream: no context for this device");
-  hipEvent_t e = c->ev[c->next];
-  c->next = (c->next + 1) % kEvents;
+  hipEvent_t e = c->ev[c->next.fetch_add(1, std::memory_order_relaxed) % kEvents];
   DVG_CHECK_HIP(hipEventRecord(e, producer));
   *mark = e;
   return DVG_OK;

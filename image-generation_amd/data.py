@@ -19,18 +19,24 @@ import torch
 
 
 class TensorBatches:
-    """Minimal DataLoader stand-in: shuffled, ``drop_last`` batches of a device-resident tensor."""
+    """Minimal DataLoader stand-in: shuffled, ``drop_last`` batches of a device-resident tensor.
 
-    def __init__(self, images: torch.Tensor, labels: torch.Tensor, batch_size: int, shuffle: bool = True, seed: int = 0):
+    Data parallelism: every rank draws the SAME permutation per epoch (same seed) and takes every ``world_size``-th
+    entry starting at ``rank`` -- disjoint shards, ``(n // world_size) // batch_size`` batches per rank and epoch."""
+
+    def __init__(self, images: torch.Tensor, labels: torch.Tensor, batch_size: int, shuffle: bool = True, seed: int = 0,
+                 rank: int = 0, world_size: int = 1):
         self.images, self.labels, self.batch_size, self.shuffle = images, labels, int(batch_size), shuffle
+        self.rank, self.world_size = int(rank), max(1, int(world_size))
         self._gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
 
     def __len__(self):
-        return self.images.shape[0] // self.batch_size
+        return (self.images.shape[0] // self.world_size) // self.batch_size
 
     def __iter__(self):
         n = self.images.shape[0]
         order = torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)
+        order = order[self.rank::self.world_size][: (n // self.world_size)]
         order = order.to(self.images.device)
         for k in range(len(self)):
             idx = order[k * self.batch_size: (k + 1) * self.batch_size]
@@ -67,7 +73,7 @@ def load_mnist(root: str = "data", image_size: int = 32) -> Optional[torch.Tenso
 
 
 def get_dataloader(image_size: int, batch_size: int, dataset_size: Optional[int] = None, seed: int = 0,
-                   device=None, root: str = "data") -> TensorBatches:
+                   device=None, root: str = "data", rank: int = 0, world_size: int = 1) -> TensorBatches:
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
     images = load_mnist(root, image_size)
     if images is None:
@@ -75,4 +81,5 @@ def get_dataloader(image_size: int, batch_size: int, dataset_size: Optional[int]
     if dataset_size:
         images = images[:dataset_size]
     labels = torch.zeros(images.shape[0], dtype=torch.int64)
-    return TensorBatches(images.to(device), labels.to(device), batch_size, shuffle=True, seed=seed)
+    return TensorBatches(images.to(device), labels.to(device), batch_size, shuffle=True, seed=seed, rank=rank,
+                         world_size=world_size)

@@ -25,6 +25,7 @@ from .persistent_sampler import PersistentQPUSampleHelper
 from .plugin import (DiscreteVariationalAutoencoder, GaussianKernel, GraphRestrictedBoltzmannMachine,
                      maximum_mean_discrepancy_loss, maximum_mean_discrepancy_loss_and_grad)
 from .sampler import get_sampler_and_sampler_kwargs
+from .viz import LOWER_THRESHOLD, UPPER_THRESHOLD  # /root/reference/demo_configs.py:62-63
 
 _DEFAULT_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "training_parameters.yaml")
 
@@ -91,8 +92,13 @@ class ModelWrapper:
         # hold one value per step; False appends nothing (throughput runs: self.last still holds the latest values).
         self.keep_step_losses = True
         self._graph = None
-        self._graphs = []         # (executable graph, its static input, its static outputs, Adam tail graph or None)
+        # (executable graph, its static input, its static outputs, Adam tail graph or None, the device addresses the
+        # capture baked in: see _graph_addresses)
+        self._graphs = []
         self._capturing_split = False
+        self._pending = []        # data-parallel: optimizers whose packed gradients await the step's ONE all-reduce
+        self._pending_tail = None
+        self._joint_grad = None   # [dvae gradients | GRBM gradients]: the buffer of that all-reduce
         self._replays = 0
         self._graph_failed = False
         self._static_images = None
@@ -113,12 +119,16 @@ class ModelWrapper:
         """Two ``state_dict`` files, as /root/reference/src/model_wrapper.py:148-162."""
         file_path = Path(file_path)
         file_path.mkdir(exist_ok=True, parents=True)
+        self.sync_buffers()
         torch.save({k: v.detach().cpu().clone() for k, v in self._dvae.state_dict().items()}, file_path / "dvae.pth")
         torch.save({k: v.detach().cpu().clone() for k, v in self._grbm.state_dict().items()}, file_path / "grbm.pth")
 
     def load(self, file_path) -> None:
+        """/root/reference/src/model_wrapper.py:164-175 (``setup``, the dataset, the two ``state_dict``s)."""
         file_path = Path(file_path)
         self.setup()
+        if self._dataloader is None:
+            self._load_dataset(batch_size=self.BATCH_SIZE, dataset_size=self.DATASET_SIZE)
         grbm_sd = torch.load(file_path / "grbm.pth", weights_only=True)
         if grbm_sd["_edge_idx_i"].numel() != self._grbm._edge_idx_i.numel() or not (
             torch.equal(grbm_sd["_edge_idx_i"].cpu(), self._grbm._edge_idx_i.cpu())
@@ -128,6 +138,30 @@ class ModelWrapper:
             self._rebuild_on_edges(grbm_sd["_edge_idx_i"].cpu().numpy(), grbm_sd["_edge_idx_j"].cpu().numpy())
         self._dvae.load_state_dict(torch.load(file_path / "dvae.pth", weights_only=True))
         self._grbm.load_state_dict(grbm_sd)
+        self._invalidate_graphs()
+
+    def _invalidate_graphs(self) -> None:
+        """Drops every captured step.  A captured hipGraph holds raw device addresses (parameter views and Adam
+        moments in the optimizers' flat buffers, the GRBM parameters, the persistent chains, the step-state block):
+        whatever replaces one of those tensors calls this, and the next eligible step captures afresh."""
+        self._graph = None
+        self._graphs = []
+        self._static_images = None
+        self._eager_steps = 0
+        self._replays = 0
+        self._graph_failed = False
+        self._pending = []
+        self._pending_tail = None
+
+    def _graph_addresses(self):
+        """Device addresses a captured step reads or writes outside its own static tensors; compared before every
+        replay (a mismatch -- e.g. the sampler re-allocated its chains for another ``num_reads`` -- re-captures)."""
+        s = self.sampler
+        return (self._dvae_optimizer.flat.data_ptr(), self._dvae_optimizer.flat_grad.data_ptr(),
+                self._dvae_optimizer.exp_avg.data_ptr(), self._dvae_optimizer.exp_avg_sq.data_ptr(),
+                self._grbm._linear.data_ptr(), self._grbm._quadratic.data_ptr(),
+                0 if (s._state is None or not s.persistent) else s._state.data_ptr(),  # (restarted chains: a fresh tensor per draw)
+                0 if self._dyn is None else self._dyn.ptr)
 
     # -- exact resume (SURVEY.md §8f-3): an EXTRA file next to the reference-schema checkpoint, never read by the UI
     def save_training_state(self, file_path) -> None:
@@ -166,6 +200,7 @@ class ModelWrapper:
         if helper is not None and state["helper_iterations"] is not None:
             helper.iterations_since_last_resampling = state["helper_iterations"]
         self.losses = {k: list(v) for k, v in state["losses"].items()}
+        self._invalidate_graphs()  # the chains (and possibly the moments) live in new tensors
         # the learning rates in force are the ones the schedule set after the last completed step
         if state["opt_step"] > 0:
             self._dvae_optimizer.param_groups[0]["lr"] = self._tpar["dvae_lr_schedule"][state["opt_step"] - 1]
@@ -222,6 +257,29 @@ class ModelWrapper:
         self._dvae.gumbel_seed = int(self.RANDOM_SEED) + 7919 * rank
         self._dvae.decoder.dropout_seed = int(self.RANDOM_SEED) + 104729 * rank
         self._make_optimizers()
+        self.sync_replicas()
+
+    # ------------------------------------------------------------------ data-parallel replica consistency
+    def _bn_buffers(self):
+        return [b for _, b in self._dvae.named_buffers()]
+
+    def sync_replicas(self) -> None:
+        """Every rank starts from rank 0's model: one broadcast per flat parameter buffer plus the BatchNorm buffers.
+        (``setup`` may run before or after the seeding of ``train_init`` -- reference quirk 7 -- so identical seeding
+        is not relied upon.)  No-op without a process group."""
+        if not self._dist_active() or self._device.type != "cuda":
+            return
+        self.dist.broadcast_(self._dvae_optimizer.flat)
+        self.dist.broadcast_(self._grbm_optimizer.flat)
+        self.sync_buffers()
+
+    def sync_buffers(self) -> None:
+        """BatchNorm running statistics are rank 0's (they are read only in eval mode; each rank's training-mode
+        batch statistics stay local, DDP semantics): broadcast before a checkpoint or an eval-mode entry point."""
+        if not self._dist_active():
+            return
+        for b in self._bn_buffers():
+            self.dist.broadcast_(b)
 
     def local_num_reads(self) -> int:
         """Chains per rank.  Data parallelism is weak-scaled: every rank keeps the full per-GPU
@@ -229,10 +287,22 @@ class ModelWrapper:
         return int(self.NUM_READS)
 
     def _make_optimizers(self):
-        cls = FlatAdam if self._device.type == "cuda" else _DeferredAdam
-        self._dvae_optimizer = cls(self._dvae.parameters(), lr=self.AUTOENCODER_INITIAL_LR,
-                                   weight_decay=self.AUTOENCODER_WEIGHT_DECAY)
-        self._grbm_optimizer = cls(self._grbm.parameters(), lr=self.BM_INITIAL_LR, weight_decay=self.BM_WEIGHT_DECAY)
+        self._invalidate_graphs()
+        if self._device.type != "cuda":
+            self._dvae_optimizer = _DeferredAdam(self._dvae.parameters(), lr=self.AUTOENCODER_INITIAL_LR,
+                                                 weight_decay=self.AUTOENCODER_WEIGHT_DECAY)
+            self._grbm_optimizer = _DeferredAdam(self._grbm.parameters(), lr=self.BM_INITIAL_LR,
+                                                 weight_decay=self.BM_WEIGHT_DECAY)
+            return
+        # Both optimizers pack their gradients into ONE buffer, [encoder + decoder | GRBM h, J], so that a
+        # data-parallel step -- also one that trains the GRBM -- is a single all-reduce.
+        nd = sum(p.numel() for p in self._dvae.parameters())
+        ng = sum(p.numel() for p in self._grbm.parameters())
+        self._joint_grad = torch.zeros(nd + ng, dtype=torch.float32, device=self._device)
+        self._dvae_optimizer = FlatAdam(self._dvae.parameters(), lr=self.AUTOENCODER_INITIAL_LR,
+                                        weight_decay=self.AUTOENCODER_WEIGHT_DECAY, grad_buffer=self._joint_grad[:nd])
+        self._grbm_optimizer = FlatAdam(self._grbm.parameters(), lr=self.BM_INITIAL_LR, weight_decay=self.BM_WEIGHT_DECAY,
+                                        grad_buffer=self._joint_grad[nd:])
 
     def set_dataloader(self, dataloader) -> None:
         """Any iterable of ``(images (B,1,32,32) in {0,1}, labels)`` with ``len()``."""
@@ -241,7 +311,9 @@ class ModelWrapper:
     def _load_dataset(self, batch_size: int, dataset_size: Optional[int] = None) -> None:
         from .data import get_dataloader
 
-        self._dataloader = get_dataloader(self.IMAGE_SIZE, batch_size, dataset_size, seed=self.RANDOM_SEED)
+        rank, world = (self.dist.rank, self.dist.world_size) if self.dist is not None else (0, 1)
+        self._dataloader = get_dataloader(self.IMAGE_SIZE, batch_size, dataset_size, seed=self.RANDOM_SEED, rank=rank,
+                                          world_size=world)  # disjoint shards of one permutation per epoch
 
     def train_init(self, n_epochs: int) -> None:
         """/root/reference/src/model_wrapper.py:229-277."""
@@ -307,6 +379,12 @@ class ModelWrapper:
             grbm_loss.backward()
             self._reduce_and_step(self._grbm_optimizer)
             self.last.update(nll=grbm_loss.detach())
+        # Data-parallel: everything this step produced -- the encoder/decoder gradients and, on a GRBM step, the
+        # sufficient-statistic differences behind them in the same buffer -- goes through ONE all-reduce, then the
+        # Adam launches.  (The autoencoder's Adam thus runs after the GRBM's backward on such a step; neither reads what
+        # the other writes -- the GRBM branch works on ``spins.detach()`` and its own parameters -- so the result is the
+        # reference's order bit for bit.)
+        self._flush_dist()
 
         for param_group in self._dvae_optimizer.param_groups:
             param_group["lr"] = self._tpar["dvae_lr_schedule"][opt_step]
@@ -454,7 +532,7 @@ class ModelWrapper:
             self._capturing_split = False
             _lib.DYN = None
             self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
-        self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach()), tail))
+        self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach()), tail, self._graph_addresses()))
         self._graph = graph
 
     def _step_graphed(self, images):
@@ -472,16 +550,24 @@ class ModelWrapper:
                 self._log("dvae_losses", dvae_loss)
                 self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
                 return mse_loss, spins
-        graph, static_images, outs, tail = self._graphs[slot]
+        if self._graphs[slot][4] != self._graph_addresses():
+            # a tensor the capture baked in was replaced behind our back (e.g. the sampler re-allocated its chains):
+            # drop the captures and run this step eagerly; the next eligible one captures afresh
+            self._invalidate_graphs()
+            mse_loss, dvae_loss, _mmd_loss, spins = self._dvae_half(images)
+            self._log("mse_losses", mse_loss)
+            self._log("dvae_losses", dvae_loss)
+            self.last.update(mse=mse_loss.detach(), mmd=_mmd_loss.detach())
+            self._eager_steps += 1
+            return mse_loss, spins
+        graph, static_images, outs, tail, _addr = self._graphs[slot]
         self._replays += 1
         static_images.copy_(images)
         self._write_dyn()
         graph.replay()
-        if tail is not None:
-            import torch.distributed as tdist
-
-            tdist.all_reduce(self._dvae_optimizer.flat_grad, op=tdist.ReduceOp.SUM)
-            tail.replay()
+        if tail is not None:  # data-parallel: the collective and the captured Adam launch follow in _flush_dist
+            self._pending.append(self._dvae_optimizer)
+            self._pending_tail = tail
         c = self._host_counters()
         self._set_host_counters((c[0] + self.sampler.sweeps, c[1] + 1, c[2] + 1, c[3] + 1, c[4] + 1))
         mse, dvae, mmd, spins = outs
@@ -513,19 +599,40 @@ class ModelWrapper:
 
     def _reduce_and_step(self, opt):
         if self._dist_active():
-            flat = opt.gather_grads()
-            if self._capturing_split and opt is self._dvae_optimizer:
-                return  # multi-GPU graph replay: the collective and the Adam step follow the first graph (see _capture)
-            self.dist.all_reduce_mean(flat)  # ONE collective over the flat gradient buffer
-            opt.step(gathered=True)
+            opt.gather_grads()  # packed into this optimizer's part of the joint buffer; see _flush_dist
+            if not self._capturing_split:  # (under capture the replay re-registers it: _step_graphed)
+                self._pending.append(opt)
         else:
             opt.step()
 
+    def _flush_dist(self):
+        """The step's ONE collective (RCCL all-reduce, sum) and the Adam launches behind it; the 1/world_size of the
+        mean is the Adam kernel's ``grad_scale``."""
+        if not self._pending:
+            return
+        both = len(self._pending) == 2
+        buf = self._joint_grad if both else self._pending[0].flat_grad
+        self.dist.all_reduce_sum(buf)
+        scale = 1.0 / self.dist.world_size
+        for opt in self._pending:
+            if opt is self._dvae_optimizer and self._pending_tail is not None:
+                self._pending_tail.replay()  # the captured Adam launch (same grad_scale)
+            else:
+                opt.step(grad_scale=scale, gathered=True)
+        self._pending = []
+        self._pending_tail = None
+
     # ------------------------------------------------------------------ generation (tensor-returning core)
     @torch.no_grad()
-    def generate_images(self, sharpen: bool = False, lower: float = 0.35, upper: float = 0.65) -> torch.Tensor:
+    def generate_images(self, sharpen: bool = False, lower: float = LOWER_THRESHOLD, upper: float = UPPER_THRESHOLD) -> torch.Tensor:
         """Sampler -> decoder -> clip, the compute of /root/reference/src/model_wrapper.py:355-385
         (plotting left to the caller).  Returns (NUM_READS, 1, 32, 32) on the device."""
+        images, _samples = self._generate(sharpen, lower, upper)
+        return images
+
+    @torch.no_grad()
+    def _generate(self, sharpen: bool, lower: float, upper: float):
+        self.sync_buffers()
         self._dvae.eval()
         self._grbm.eval()
         samples = self._grbm.sample(self.sampler, prefactor=self.PREFACTOR, device=self._device,
@@ -536,19 +643,21 @@ class ModelWrapper:
             over = (images > upper).to(images.dtype)   # heaviside(x, 0): strict
             under = (images > lower).to(images.dtype)
             images = (over + (1 - over) * images) * under
-        return images
-
+        return images, samples
 
     @torch.no_grad()
-    def reconstruct_images(self, batch: Optional[torch.Tensor] = None, sharpen: bool = False, lower: float = 0.35,
-                           upper: float = 0.65) -> torch.Tensor:
+    def reconstruct_images(self, batch: Optional[torch.Tensor] = None, sharpen: bool = False,
+                           lower: float = LOWER_THRESHOLD, upper: float = UPPER_THRESHOLD) -> torch.Tensor:
         """Eval-mode encode -> discretise -> decode of one batch of training images, interleaved with the originals:
         the compute of /root/reference/src/model_wrapper.py:447-481 (plotting left to the caller).  Returns
         (2 B, 1, 32, 32) on the device in the reference's ``(b i)`` order: original 0, reconstruction 0, original 1, ...;
         the reconstruction's last pixel column is set to 1 (the reference's separator line, :465)."""
         if batch is None:
+            if self._dataloader is None:
+                self._load_dataset(batch_size=self.BATCH_SIZE, dataset_size=self.DATASET_SIZE)
             batch = next(iter(self._dataloader))[0]
         batch = batch.to(self._device)
+        self.sync_buffers()
         self._dvae.eval()
         self._grbm.eval()
         _, _, reconstructed = self._dvae(batch)
@@ -561,6 +670,69 @@ class ModelWrapper:
             under = (images > lower).to(images.dtype)
             images = (over + (1 - over) * images) * under
         return images
+
+
+    # ------------------------------------------------------------------ the reference's figure-returning entry points
+    # (called by /root/reference/src/utils/callback_helpers.py:206-215 and /root/reference/demo_callbacks.py:781-785:
+    # same names, arguments, side files and return types; the compute is generate_images / reconstruct_images above)
+    @staticmethod
+    def _image_figure(grid: torch.Tensor, save_to_file: str = ""):
+        import plotly.express as px
+
+        fig = px.imshow(grid.permute(1, 2, 0).cpu().numpy())
+        fig.update_xaxes(showticklabels=False)
+        fig.update_yaxes(showticklabels=False)
+        fig.update_layout(margin={"t": 0, "l": 0, "b": 0, "r": 0})
+        if save_to_file:
+            with open(save_to_file, "w") as f:
+                f.write(fig.to_json())
+        return fig
+
+    def generate_output(self, latent_qpu_file: str, sharpen: bool = False, save_to_file: str = ""):
+        """/root/reference/src/model_wrapper.py:355-399: one sampler draw -> decoder (eval) -> clip [-> sharpen] -> a
+        16-per-row grid as a plotly figure; the first sample's spins go to ``latent_qpu_file`` (JSON list)."""
+        import json
+
+        from . import viz
+
+        images, samples = self._generate(sharpen, viz.LOWER_THRESHOLD, viz.UPPER_THRESHOLD)
+        with open(latent_qpu_file, "w") as f:
+            json.dump(samples[0].tolist(), f)
+        return self._image_figure(viz.make_grid(images.cpu(), nrow=16), save_to_file)
+
+    def generate_reconstucted_samples(self, sharpen: bool = False, save_to_file: str = ""):
+        """/root/reference/src/model_wrapper.py:447-491 (the reference's spelling): first batch of the dataloader,
+        eval-mode reconstruction, originals and reconstructions interleaved in a 16-per-row grid without padding;
+        the sharpening, when asked for, is applied to the grid as the reference does."""
+        from . import viz
+
+        images = self.reconstruct_images(None, sharpen=False)
+        grid = viz.make_grid(images.cpu(), nrow=16, padding=0)
+        if sharpen:
+            grid = viz.sharpen(grid)
+        return self._image_figure(grid, save_to_file)
+
+    def generate_loss_plot(self, save_to_file_mse: str = "", save_to_file_total: str = "", old_loss_data=None):
+        """/root/reference/src/model_wrapper.py:401-445: the MSE and MSE + MMD curves as two plotly figures."""
+        import plotly.graph_objects as go
+
+        mse_losses = [float(v) for v in self.losses["mse_losses"]]
+        dvae_losses = [float(v) for v in self.losses["dvae_losses"]]
+        if old_loss_data:
+            mse_losses = list(old_loss_data["mse_losses"]) + mse_losses
+            dvae_losses = list(old_loss_data["dvae_losses"]) + dvae_losses
+        figs = []
+        for ys, path in ((mse_losses, save_to_file_mse), (dvae_losses, save_to_file_total)):
+            fig = go.Figure()
+            fig.add_trace(go.Scatter(x=list(range(len(mse_losses))), y=ys))
+            fig.update_xaxes(title_text="Batch")
+            fig.update_yaxes(title_text="Loss")
+            fig.update_layout(margin={"t": 0, "l": 0, "b": 0, "r": 0})
+            if path:
+                with open(path, "w") as f:
+                    f.write(fig.to_json())
+            figs.append(fig)
+        return figs[0], figs[1]
 
 
 class _DeferredAdam:

@@ -17,7 +17,7 @@ from . import _lib
 
 class FlatAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, grad_buffer: Optional[torch.Tensor] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params]
         if not self.params:
             raise ValueError("FlatAdam got an empty parameter list")
@@ -28,7 +28,12 @@ class FlatAdam:
         self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # grad_buffer: a caller-provided view (ModelWrapper packs both optimizers' gradients into ONE buffer so that a
+        # data-parallel step is one all-reduce)
+        if grad_buffer is not None and (grad_buffer.numel() != self.numel or grad_buffer.dtype != torch.float32
+                                        or grad_buffer.device != dev or not grad_buffer.is_contiguous()):
+            raise ValueError("FlatAdam: grad_buffer must be a contiguous float32 view of numel elements on the parameters' device")
+        self.flat_grad = grad_buffer if grad_buffer is not None else torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.offsets = []

@@ -14,9 +14,17 @@
  *     inside dvg_graph_create;
  *   - return value: 0 (DVG_OK) or a negative DVG_E_* code; the message is
  *     available from dvg_last_error() (thread-local); nothing throws or exits;
- *   - no global mutable state besides the optional profiler; HIP is initialised
- *     lazily by the first call in each process (the Dash app runs training in a
- *     spawned worker: /root/reference/app.py:37-43).
+ *   - process-wide state, all of it listed here: (1) the optional per-kernel
+ *     profiler (dvg_prof_*), (2) the GEMM-operand mode set by
+ *     dvg_set_conv_precision (one atomic int; a forward call and its backward
+ *     call must run in the same mode, which the library checks per workspace),
+ *     (3) one library-owned side stream + event ring per device, created under
+ *     a mutex by the first *_workspace_bytes query or backward call on that
+ *     device and used for the fork/join inside dvg_encoder_bwd /
+ *     dvg_decoder_bwd.  Nothing else persists between calls; entry points are
+ *     re-entrant per (stream, workspace).  HIP is initialised lazily by the
+ *     first call in each process (the Dash app runs training in a spawned
+ *     worker: /root/reference/app.py:37-43).
  */
 #ifndef DVG_H
 #define DVG_H
@@ -37,6 +45,9 @@ extern "C" {
 typedef void *dvg_stream_t; /* hipStream_t */
 
 int dvg_version(void);
+/* sha256 (first 16 hex digits) of the kernel sources this library was built from (csrc, include/dvg.h): profiles
+ * under profiles/ carry the hash of the library they were measured on, bench.py drops the ones that do not match. */
+const char *dvg_source_hash(void);
 const char *dvg_last_error(void);
 
 /* Device-resident per-step values, for steps replayed from a captured hipGraph.  A function handed a
@@ -76,7 +87,8 @@ int dvg_graph_destroy(dvg_graph_t *g);
  *     hs = clamp(prefactor*h, h_lo, h_hi), Js = clamp(prefactor*J, j_lo, j_hi)
  *     (the plugin's to_ising) and samples p(s) ~ exp(-beta (hs.s + s.Js.s)).
  *   state (n_chains, n) int8 +-1: in/out (persistent chains).  init != 0 draws
- *     the start state from the INIT stream first.
+ *     the start state from the INIT stream first, keyed by (spin, chain id, sweep0):
+ *     chains restarted on every draw (non-persistent mode) start each draw elsewhere.
  *   samples_out (n_chains, n) float32 +-1, or NULL.
  *   sweep0: global index of the first sweep (keeps the random stream moving).
  */

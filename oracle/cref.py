@@ -41,12 +41,12 @@ def spec_exp(z):
     return np.float32(lib().dvgo_spec_exp(ctypes.c_float(float(z))))
 
 
-def init_state(chain_ids, n, seed):
+def init_state(chain_ids, n, seed, sweep0=0):
     chain_ids = np.ascontiguousarray(chain_ids, dtype=np.uint32)
     st = np.empty((len(chain_ids), n), dtype=np.int8)
     lib().dvgo_init_state(
         ctypes.c_int(len(chain_ids)), ctypes.c_int(n), _p(st, ctypes.c_int8), _p(chain_ids, ctypes.c_uint32),
-        ctypes.c_uint64(seed),
+        ctypes.c_uint64(seed), ctypes.c_uint32(int(sweep0) & 0xFFFFFFFF),
     )
     return st
 

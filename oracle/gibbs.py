@@ -69,12 +69,14 @@ def scaled_fields(h, J, prefactor, h_range=None, j_range=None):
     return hs, Js
 
 
-def init_state(chain_ids, n, seed):
-    """Random +-1 start: bit 31 of philox(ctr=(i, chain, 0, STREAM_INIT))[0]."""
+def init_state(chain_ids, n, seed, sweep0=0):
+    """Random +-1 start: bit 31 of philox(ctr=(i, chain, sweep0, STREAM_INIT))[0].  ``sweep0`` is the index of the
+    first sweep the chains will run (0 for chains started at the beginning of a run), so a sampler that restarts its
+    chains on every draw (non-persistent mode) starts each draw from a different configuration."""
     chain_ids = np.asarray(chain_ids, dtype=np.uint32)
     i = np.arange(n, dtype=np.uint32)[None, :]
     r0, _, _, _ = philox4x32_10(
-        i, chain_ids[:, None], np.uint32(0), np.uint32(STREAM_INIT), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+        i, chain_ids[:, None], np.uint32(int(sweep0) & 0xFFFFFFFF), np.uint32(STREAM_INIT), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     )
     return np.where((r0 >> np.uint32(31)) != 0, 1, -1).astype(np.int8)
 

@@ -101,11 +101,11 @@ int dvgo_gibbs(int C, int n, int8_t *state, const uint32_t *chain_ids, const flo
   return 0;
 }
 
-void dvgo_init_state(int C, int n, int8_t *state, const uint32_t *chain_ids, uint64_t seed) {
+void dvgo_init_state(int C, int n, int8_t *state, const uint32_t *chain_ids, uint64_t seed, uint32_t sweep0) {
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   for (int c = 0; c < C; ++c)
     for (int i = 0; i < n; ++i) {
-      uint32_t ctr[4] = {(uint32_t)i, chain_ids[c], 0u, 1u /* STREAM_INIT */};
+      uint32_t ctr[4] = {(uint32_t)i, chain_ids[c], sweep0, 1u /* STREAM_INIT */};
       philox4x32_10(ctr, k0, k1);
       state[(size_t)c * n + i] = (ctr[0] >> 31) ? 1 : -1;
     }

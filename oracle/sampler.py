@@ -30,7 +30,7 @@ class OracleGibbsSampler:
         Js = np.asarray([J[(nodes[i], nodes[j])] for i, j in zip(p.edge_i, p.edge_j)], dtype=np.float32)
         chain_ids = np.arange(num_reads, dtype=np.uint32) + np.uint32(self.chain_offset)
         if self.state is None or not self.persistent or self.state.shape[0] != num_reads:
-            self.state = cref.init_state(chain_ids, p.n, self.seed)
+            self.state = cref.init_state(chain_ids, p.n, self.seed, self.sweep_count)
         self.state = cref.gibbs_sweeps(
             self.state, chain_ids, hs, Js, self.beta, p.order, p.class_ptr, p.adj_ptr, p.adj_idx, p.adj_eid,
             self.seed, self.sweep_count, self.sweeps,

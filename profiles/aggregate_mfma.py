@@ -10,8 +10,19 @@ so the dispatch lasted GRBM_GUI_ACTIVE / 8 cycles at the clock it actually ran a
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+
+def kernels_hash():
+    """dvg_source_hash() of the library in this tree = the build the profile was measured on (bench.py ignores a
+    profile whose hash differs from the library it runs)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import image_generation_amd  # noqa: F401
+    from image_generation_amd import _lib
+
+    return _lib.lib().dvg_source_hash().decode()
 
 N_SIMD = 256 * 4
 
@@ -32,7 +43,8 @@ def main():
         out[k] = {"launches": n, "mfma_busy_cycles_avg": busy / n, "dispatch_cycles_avg": act / 8 / n,
                   "mfma_busy_frac": busy / (N_SIMD * act / 8)}
     with open(sys.argv[2], "w") as f:
-        json.dump(dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_avg"] * kv[1]["launches"])), f, indent=1)
+        ranked = dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_avg"] * kv[1]["launches"]))
+        json.dump({"kernels_hash": kernels_hash(), "kernels": ranked}, f, indent=1)
     print(f"{len(out)} MFMA kernels -> {sys.argv[2]}")
 
 

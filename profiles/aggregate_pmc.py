@@ -8,8 +8,19 @@ report KiB; FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled; 
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+
+def kernels_hash():
+    """dvg_source_hash() of the library in this tree = the build the profile was measured on (bench.py ignores a
+    profile whose hash differs from the library it runs)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import image_generation_amd  # noqa: F401
+    from image_generation_amd import _lib
+
+    return _lib.lib().dvg_source_hash().decode()
 
 
 def per_kernel(path, counter):
@@ -48,7 +59,7 @@ def main():
                 rec["avg_us_alone"] = us
                 rec["hbm_GBps"] = rec["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
                 rec["hbm_frac_of_8TBps"] = rec["hbm_GBps"] / 8000.0
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    json.dump({"kernels_hash": kernels_hash(), "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(f"{len(out)} kernels -> {sys.argv[3]}")
 
 

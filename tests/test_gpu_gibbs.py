@@ -75,6 +75,14 @@ def test_sample_ising_dict_path_and_sampleset():
                              plan.adj_ptr, plan.adj_idx, plan.adj_eid, 5, 0, 2)
     assert np.array_equal(ss.record.sample, want)
     assert ss.variables == nodes and ss.vartype == "SPIN" and len(ss) == 16
+    # non-persistent: the second draw restarts the chains from a configuration keyed by its first sweep index (2), not
+    # from the first draw's start
+    ss2 = s.sample_ising(hd, Jd, num_reads=16, answer_mode="raw", auto_scale=False, annealing_time=1, label="x")
+    start2 = cref.init_state(ids, 64, 5, sweep0=2)
+    assert not np.array_equal(start2, cref.init_state(ids, 64, 5))
+    want2 = cref.gibbs_sweeps(start2, ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
+                              plan.adj_eid, 5, 2, 2)
+    assert np.array_equal(ss2.record.sample, want2)
 
 
 def test_shim_composite_draw_matches_oracle():

@@ -48,11 +48,12 @@ def test_step_losses_match_reference_orchestration(fx, golden_dir):
     assert abs(mse[0] - fx["mse"][0]) <= 1e-5 * abs(fx["mse"][0])
     assert abs(dvae[0] - fx["dvae"][0]) <= 1e-5 * abs(fx["dvae"][0])
     assert abs(nll[0] - fx["nll"][0]) <= 1e-5 * abs(fx["nll"][0])
-    # later steps inherit the fp32 rounding differences of every earlier update (Adam normalises
-    # gradients, so tiny differences are not damped); the trajectories stay together to ~1e-4
-    np.testing.assert_allclose(mse, fx["mse"], rtol=5e-4)
-    np.testing.assert_allclose(dvae, fx["dvae"], rtol=5e-4)
-    np.testing.assert_allclose(nll, fx["nll"], rtol=5e-4)
+    # later steps inherit the fp32 rounding differences of every earlier update (Adam normalises gradients, so tiny
+    # differences are not damped); the north star's 1e-5 relative holds over all 12 steps all the same (measured on
+    # MI355X: mse 1.4e-7, mse + mmd 3.3e-6, nll 8.8e-8 -- bench.py reports the same three numbers as `loss_parity`)
+    np.testing.assert_allclose(mse, fx["mse"], rtol=1e-5)
+    np.testing.assert_allclose(dvae, fx["dvae"], rtol=1e-5)
+    np.testing.assert_allclose(nll, fx["nll"], rtol=1e-5)
     assert model.sampler.calls == int(fx["sampler_calls"])  # one draw per step + one more on GRBM steps
     # learning rates: schedule value of the LAST step index (applied after the step)
     np.testing.assert_allclose([model._dvae_optimizer.param_groups[0]["lr"], model._grbm_optimizer.param_groups[0]["lr"]],
@@ -360,3 +361,87 @@ def test_odd_shapes_train_end_to_end(tmp_path, golden_dir, qpu, n, B, R):
     for name, v in list(m._dvae.state_dict().items()) + list(m._grbm.state_dict().items()):
         assert not v.is_floating_point() or bool(torch.isfinite(v).all()), name
     assert all(bool(torch.isfinite(m.last[k])) for k in ("mse", "mmd", "nll"))
+
+
+def test_reference_named_generation_entry_points(tmp_path, golden_dir):
+    """``generate_output`` / ``generate_reconstucted_samples`` / ``generate_loss_plot`` as the reference's driver calls
+    them (/root/reference/src/utils/callback_helpers.py:206-215): plotly figures, JSON side files, the first sample's
+    spins in ``latent_qpu_file``; the pictures hold exactly what generate_images / reconstruct_images compute."""
+    pytest.importorskip("plotly")
+    import json
+
+    from image_generation_amd import viz
+
+    m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+    B = m.BATCH_SIZE
+    imgs = torch.from_numpy(gen.make_images(B * 3, seed=3)).reshape(3, B, 1, 32, 32)
+    m.set_dataloader([(imgs[k], torch.zeros(B)) for k in range(3)])
+    m.train_init(1)
+    for k in range(3):
+        m.step((imgs[k], None), epoch=0)
+    # generate_output draws from the (persistent) sampler: replay the same draw for the expected picture
+    state, cnt, calls = m.sampler._state.clone(), m.sampler.sweep_count, m.sampler.calls
+    want = m.generate_images(sharpen=True)
+    m.sampler._state.copy_(state)
+    m.sampler.sweep_count, m.sampler.calls = cnt, calls
+    fig = m.generate_output(latent_qpu_file=str(tmp_path / "latent.json"), sharpen=True, save_to_file=str(tmp_path / "gen.json"))
+    z = np.asarray(fig.data[0].z if fig.data[0].z is not None else [])
+    grid = viz.make_grid(want.cpu(), nrow=16).permute(1, 2, 0).numpy()
+    latent = json.load(open(tmp_path / "latent.json"))
+    assert len(latent) == 64 and set(latent) <= {-1.0, 1.0}
+    saved = json.load(open(tmp_path / "gen.json"))
+    assert saved["layout"]["margin"] == {"t": 0, "l": 0, "b": 0, "r": 0} and saved["layout"]["xaxis"]["showticklabels"] is False
+    if z.size:  # (plotly stores small RGB pictures as an array, large ones as a PNG source)
+        np.testing.assert_allclose(z, grid * (255.0 if z.max() > 1.5 else 1.0), atol=1.0 if z.max() > 1.5 else 1e-6)
+    assert grid.shape == (34 + 2, 16 * 34 + 2, 3)  # 16 reads: one row of 16 cells of 32 + 2 padding
+    # reconstructions: first batch of the dataloader, (b i) interleaved, no padding
+    fig2 = m.generate_reconstucted_samples(sharpen=False, save_to_file=str(tmp_path / "rec.json"))
+    assert os.path.exists(tmp_path / "rec.json") and fig2.layout.margin.t == 0
+    rec = m.reconstruct_images(imgs[0])
+    assert viz.make_grid(rec.cpu(), nrow=16, padding=0).shape == (3, 32, 16 * 32)
+    f_mse, f_tot = m.generate_loss_plot()
+    assert len(f_mse.data[0].y) == 3 and len(f_tot.data[0].y) == 3
+    np.testing.assert_allclose(list(f_mse.data[0].y), m.losses["mse_losses"], rtol=1e-6)
+
+
+def test_captured_graph_is_dropped_when_its_tensors_are_replaced(tmp_path, golden_dir):
+    """A captured step bakes in device addresses (optimizer flat buffers, chains, GRBM parameters).  Whatever replaces
+    those tensors -- ``load``, ``load_training_state``, a rebuilt optimizer -- must drop the capture: the run continues
+    bit-identically to a run that never used graphs."""
+    def make(use_graph):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 24, seed=8)).reshape(24, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(24)])
+        m.train_init(1)
+        m.sync_losses = False
+        m.use_graph = use_graph
+        return m, imgs
+
+    def run(use_graph):
+        m, imgs = make(use_graph)
+        for k in range(8):
+            m.step((imgs[k], None), epoch=0)
+        if use_graph:
+            assert m._graph is not None
+        m.save(tmp_path / f"ck{int(use_graph)}")
+        m.save_training_state(tmp_path / f"ck{int(use_graph)}")
+        # resume IN PLACE: new modules, new flat buffers, new chain tensor -- every address the capture held is stale
+        m.load(tmp_path / f"ck{int(use_graph)}")
+        assert m._graph is None and m._graphs == []
+        m.load_training_state(tmp_path / f"ck{int(use_graph)}")
+        out = []
+        for k in range(8, 20):
+            m.step((imgs[k], None), epoch=0)
+            out.append((float(m.last["mse"]), float(m.last["mmd"])))
+        if use_graph:
+            assert m._graph is not None and not m._graph_failed  # captured afresh on the new tensors
+        torch.cuda.synchronize()
+        return out, {k: v.clone() for k, v in m._dvae.state_dict().items()}
+
+    eager, sd_e = run(False)
+    graphed, sd_g = run(True)
+    assert eager == graphed
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k

@@ -49,6 +49,8 @@ def test_numpy_equals_c_bit_exact(fam, n):
     chain_ids = np.arange(7, dtype=np.uint32) + 1000
     s0 = gibbs.init_state(chain_ids, n, seed=775321899904)
     assert np.array_equal(s0, cref.init_state(chain_ids, n, 775321899904))
+    s7 = gibbs.init_state(chain_ids, n, seed=775321899904, sweep0=7)  # restarted chains: keyed by the first sweep index
+    assert np.array_equal(s7, cref.init_state(chain_ids, n, 775321899904, sweep0=7)) and not np.array_equal(s7, s0)
     a = gibbs.gibbs_sweeps(s0.copy(), chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 3, 6)
     b = cref.gibbs_sweeps(s0.copy(), chain_ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx, plan.adj_eid, 775321899904, 3, 6)
     assert np.array_equal(a, b)
