@@ -37,6 +37,7 @@ struct MmdArgs {
   const int8_t* zi8;    // [nx + ny][d] int8 copy of (x ; y), valid when *not_pm1 == 0
   const int* not_pm1;   // device flag written by mmd_prep_kernel: 0 <=> every entry of x and y is exactly +-1
   int pm1_ok;           // host: shape is served by the +-1 kernels (so the f32 kernels may stand down on the flag)
+  int gate_main;        // host: mmd_main_kernel runs behind a spin-only kernel and stands down when *not_pm1 == 0
   const uint16_t* zt;   // bf16 transposed copy [32-row block][d][32] of (x ; y), each padded to whole 128-row tiles
   int64_t ztb_y;        // first 32-row block of y inside zt
   const uint4* tab;     // [2][d + 1] pair table for +-1 rows (see mmd_table_kernel)
@@ -1019,9 +1020,306 @@ __device__ __forceinline__ void mmd_pm1_fq_body(const MmdArgs& a, unsigned char*
   }
 }
 
+// ================================================================== spin path, large row counts: 128-row blocks
+// One workgroup owns 128 rows of x (each of its four waves 32 of them, for the whole kernel) and streams the column
+// rows past them in chunks of 32.  Per chunk and wave:
+//     Gram   S[j][i]   (32 x 32, K = d)   int8 MFMA, A = the chunk's int8 rows from LDS, B = the wave's own rows, which
+//                                          stay in REGISTERS as B fragments for the whole kernel (d / 8 VGPRs);
+//     lookup w(h(S))                       one 16-byte LDS table read per pair (kernel sum, weight as 3 bf16 terms);
+//     G^T[f][i] += Z^T[f][j] W[j][i]       (d x 32, K = 32) bf16 MFMA, A = the chunk's transposed bf16 copy from LDS,
+//                                          B = the weights as they sit in the Gram accumulator's layout.
+// Against the 32-row forms above this reads every column row once per 128 (not 32) rows of x -- they were bound by
+// the L2 -> LDS traffic of their panels as much as by the matrix pipe -- keeps all of G^T (d x 32 per
+// wave = 16 d / 32 accumulator registers) in the wave that needs it, so there is no exchange of weight fragments and no
+// cross-wave reduction, and needs ONE workgroup barrier per chunk.  Both chunk images come in by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass), double buffered, issued a whole chunk ahead; the
+// bank-conflict-avoiding swizzles are applied to the per-lane SOURCE address (the DMA's LDS destination is
+// lane-linear).  The wave software-pipelines across chunks: the Gram of chunk t+1 is issued ahead of the gradient GEMM
+// of chunk t, and the table lookups of chunk t+1 are interleaved with that GEMM's MFMAs, so the matrix pipe has
+// independent work while the lookups' LDS latencies elapse.
+template <int NFT>
+struct W128 {
+  static constexpr int D = 32 * NFT;
+  static constexpr int TAB_BYTES = (2 * (D + 1) * 16 + 1023) / 1024 * 1024;
+  static constexpr int RED_BYTES = 2048;
+  static constexpr int Z8_BYTES = 32 * D;        // one chunk of int8 rows [32][D]
+  static constexpr int ZT_BYTES = 64 * D;        // one chunk of the transposed bf16 copy [D][32]
+  static constexpr int OFF_RED = TAB_BYTES, OFF_Z8 = OFF_RED + RED_BYTES, OFF_ZT = OFF_Z8 + 2 * Z8_BYTES;
+  static constexpr int LDS_BYTES = OFF_ZT + 2 * ZT_BYTES;
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NFT>
+__device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned char* smem) {
+  using L = W128<NFT>;
+  constexpr int D = L::D;
+  const i32x4* tab_s = reinterpret_cast<const i32x4*>(smem);
+  double* red = reinterpret_cast<double*>(smem + L::OFF_RED);
+  unsigned char* z8buf = smem + L::OFF_Z8;
+  unsigned char* ztbuf = smem + L::OFF_ZT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  const int64_t rbx = (a.nx + 127) / 128;
+  const int64_t rb = blockIdx.x;
+  const bool rows_x = rb < rbx;
+  const int sp = blockIdx.y;
+  if (!rows_x && sp > 0) return;  // y-row blocks only feed the loss: one split walks all of their (few) chunks
+  const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * 128, goff_i = rows_x ? 0 : a.nx;
+  const int64_t gi = base_i + wave * 32 + c;  // this lane's row (column of the Gram / weight tiles)
+  const bool vi = gi < cnt_i;
+  const bool want_grad = rows_x && a.grad_part != nullptr;
+  // chunk range of this block: x-row blocks see the x chunks then the y chunks, split evenly over gridDim.y
+  const int64_t ncx = (a.nx + 31) / 32, ncy = (a.ny + 31) / 32;
+  int64_t t0, t1;
+  if (rows_x) {
+    const int64_t nc = ncx + ncy, per = (nc + gridDim.y - 1) / gridDim.y;
+    t0 = sp * per; t1 = t0 + per < nc ? t0 + per : nc;
+  } else {
+    t0 = ncx; t1 = ncx + ncy;
+  }
+  const int T = t1 > t0 ? (int)(t1 - t0) : 0;
+
+  // ---- one-time staging: pair table -> LDS, this wave's 32 rows -> B fragments in registers
+  for (int e = tid; e < 2 * (D + 1); e += 256) reinterpret_cast<uint4*>(smem)[e] = a.tab[e];
+  i32x4 xb[NFT];
+  {
+    const int8_t* xrow = a.zi8 + (goff_i + (vi ? gi : cnt_i - 1)) * D + hh * 16;
+#pragma unroll
+    for (int s = 0; s < NFT; ++s) xb[s] = *reinterpret_cast<const i32x4*>(xrow + s * 32);
+  }
+
+  // ---- LDS-DMA of one chunk's images.  Destination = wave-uniform base + 16 lane (1 KiB per instruction); the source
+  // address carries the swizzle: 16-byte slot `sl` of row `r` is stored at slot sl ^ f(r).
+  //   int8 rows [32][D]: f(r) = r & 15 when a row is a whole number of 256-byte bank rows, else (r >> 1) & 7;
+  //   transposed bf16 [D][32] (64-byte rows): f(r) = (r >> 2) & 3.
+  // Per-lane pieces are constant over the kernel: (row, swizzled slot) -> a 32-bit source offset inside the chunk and the
+  // LDS piece; per chunk only a wave-uniform base pointer changes (scalar registers), plus a clamp on the last,
+  // partial chunk of x or y.
+  int z8off[NFT / 4], z8row[NFT / 4], ztoff[NFT / 2];
+#pragma unroll
+  for (int q = 0; q < NFT / 4; ++q) {
+    const int byte = (wave * (NFT / 4) + q) * 1024 + lane * 16;  // position in the [32][D] image
+    const int r = byte / D, sl = (byte % D) >> 4;
+    const int fz = (D % 256 == 0) ? (r & 15) : ((r >> 1) & 7);
+    z8row[q] = r;
+    z8off[q] = r * D + ((sl ^ fz) << 4);
+  }
+#pragma unroll
+  for (int q = 0; q < NFT / 2; ++q) {
+    const int f = (wave * (NFT / 2) + q) * 16 + (lane >> 2), sl = lane & 3;  // 1 KiB piece = 16 feature rows of 64 bytes
+    ztoff[q] = f * 64 + ((sl ^ ((f >> 2) & 3)) << 4);
+  }
+  auto issue_z8 = [&](int64_t t, int buf) {
+    const bool cx = t < ncx;
+    const int64_t jrow0 = (cx ? t : t - ncx) * 32, cnt_j = cx ? a.nx : a.ny;
+    const int8_t* base = a.zi8 + ((cx ? 0 : a.nx) + jrow0) * D;  // wave-uniform
+    unsigned char* dst = z8buf + buf * L::Z8_BYTES + wave * (NFT / 4) * 1024;
+    if (jrow0 + 32 <= cnt_j) {
+#pragma unroll
+      for (int q = 0; q < NFT / 4; ++q) dma16(base + z8off[q], dst + q * 1024);
+    } else {  // rows past the end re-read the last row (those pairs are masked in the lookups)
+      const int last = (int)(cnt_j - 1 - jrow0);
+#pragma unroll
+      for (int q = 0; q < NFT / 4; ++q) {
+        const int r = z8row[q] < last ? z8row[q] : last;
+        dma16(base + (z8off[q] - z8row[q] * D + r * D), dst + q * 1024);
+      }
+    }
+  };
+  auto issue_zt = [&](int64_t t, int buf) {
+    const bool cx = t < ncx;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.zt) +
+                                ((cx ? 0 : a.ztb_y) + (cx ? t : t - ncx)) * (int64_t)D * 64;  // wave-uniform
+    unsigned char* dst = ztbuf + buf * L::ZT_BYTES + wave * (NFT / 2) * 1024;
+#pragma unroll
+    for (int q = 0; q < NFT / 2; ++q) dma16(base + ztoff[q], dst + q * 1024);
+  };
+
+  // per-lane LDS read offsets (constant over the kernel)
+  const int fz_c = (D % 256 == 0) ? (c & 15) : ((c >> 1) & 7);
+  const int sw_c = (c >> 2) & 3;
+  const int aoff0 = c * 64 + ((hh ^ sw_c) << 4), aoff1 = c * 64 + (((2 + hh) ^ sw_c) << 4);
+
+  auto gram = [&](int buf) -> i32x16 {
+    const unsigned char* zrow = z8buf + buf * L::Z8_BYTES + c * D;
+    i32x16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < NFT; ++s) {
+      const i32x4 za = *reinterpret_cast<const i32x4*>(zrow + (((2 * s + hh) ^ fz_c) << 4));
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[s], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  f32x16 G[NFT];
+#pragma unroll
+  for (int ft = 0; ft < NFT; ++ft) G[ft] = (f32x16){0};
+  float rowsum = 0.f;
+  double l_xx = 0.0, l_xy = 0.0, l_yy = 0.0;
+
+  // Lookup state of one chunk: masks are block-uniform per chunk except the row-validity / diagonal terms
+  struct ChunkMeta { bool cols_x; int nj; int dloc; bool masked; };
+  auto chunk_meta = [&](int64_t t) -> ChunkMeta {
+    ChunkMeta m;
+    m.cols_x = t < ncx;
+    const int64_t jrow0 = (m.cols_x ? t : t - ncx) * 32, cnt_j = m.cols_x ? a.nx : a.ny;
+    m.nj = (int)(cnt_j - jrow0 < 32 ? cnt_j - jrow0 : 32);
+    const bool same = rows_x == m.cols_x;
+    const int64_t dd = gi - jrow0;
+    m.dloc = (same && !a.biased && dd >= 0 && dd < 32) ? (int)dd : -1;
+    // block-uniform: does any lane of the block need a mask in this chunk?
+    const bool diag_here = same && !a.biased && jrow0 + 32 > base_i && jrow0 < base_i + 128;
+    m.masked = m.nj < 32 || base_i + 128 > cnt_i || diag_here;
+    return m;
+  };
+
+  // one pair-row r of the lookup phase: table read + sums + weight pieces
+  uint32_t himid[16], lo[16];
+  float lsum = 0.f;
+  auto look1 = [&](const i32x16& S, int r, const i32x4* tb4, const ChunkMeta& m) {
+    const int h = (D - S[r]) >> 1;
+    const i32x4 e = tb4[h];
+    if (m.masked) {
+      const int jl = crow(r, hh);
+      const uint32_t vm = (vi && jl < m.nj) ? 0xffffffffu : 0u;
+      const uint32_t lm = jl != m.dloc ? vm : 0u;
+      const uint32_t wm = rows_x ? vm : 0u;
+      lsum += __uint_as_float((uint32_t)e[0] & lm);
+      rowsum += __uint_as_float((uint32_t)e[1] & wm);
+      himid[r] = (uint32_t)e[2] & wm;
+      lo[r] = (uint32_t)e[3] & wm;
+    } else {
+      lsum += __int_as_float(e[0]);
+      rowsum += __int_as_float(e[1]);
+      himid[r] = (uint32_t)e[2];
+      lo[r] = (uint32_t)e[3];
+    }
+  };
+  auto pack_w = [&](i32x4 (&Bw)[2][3]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * s + 2 * q;
+        Bw[s][0][q] = (int)__builtin_amdgcn_perm(himid[r + 1], himid[r], 0x07060302u);
+        Bw[s][1][q] = (int)__builtin_amdgcn_perm(himid[r + 1], himid[r], 0x05040100u);
+        Bw[s][2][q] = (int)__builtin_amdgcn_perm(lo[r + 1], lo[r], 0x05040100u);
+      }
+  };
+  auto flush_lsum = [&](const ChunkMeta& m) {
+    if (rows_x) { if (m.cols_x) l_xx += (double)lsum; else l_xy += (double)lsum; }
+    else l_yy += (double)lsum;
+    lsum = 0.f;
+  };
+
+  i32x4 Bw[2][3];
+  if (T > 0) {
+    // ---- prologue: chunk t0's images (and chunk t0+1's int8 rows), its Gram and lookups
+    issue_z8(t0, 0);
+    if (want_grad) issue_zt(t0, 0);
+    if (T > 1) issue_z8(t0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // also publishes the pair table
+    {
+      const ChunkMeta m = chunk_meta(t0);
+      const i32x16 S = gram(0);
+      const i32x4* tb4 = tab_s + (m.cols_x ? 0 : D + 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) look1(S, r, tb4, m);
+      flush_lsum(m);
+      pack_w(Bw);
+    }
+    for (int k = 0; k < T; ++k) {
+      const int64_t t = t0 + k;
+      // buffers of this iteration: transposed copy of chunk t in ztbuf[k & 1], int8 rows of chunk t+1 in z8buf[(k+1) & 1]
+      if (k + 1 < T && want_grad) issue_zt(t + 1, (k + 1) & 1);  // (that buffer's last reader was iteration k-1)
+      if (k + 2 < T) issue_z8(t + 2, k & 1);                      // (ditto: Gram of chunk t ran in iteration k-1)
+      const bool more = k + 1 < T;
+      ChunkMeta m = chunk_meta(more ? t + 1 : t);
+      i32x16 S = {0};
+      if (more) S = gram((k + 1) & 1);
+      const i32x4* tb4 = tab_s + (m.cols_x ? 0 : D + 1);
+      if (want_grad) {
+        const unsigned char* zt0 = ztbuf + (k & 1) * L::ZT_BYTES;
+        constexpr int RPT = 16 / NFT > 0 ? 16 / NFT : 1;  // pair-rows looked up per feature tile (NFT = 16: one)
+#pragma unroll
+        for (int ft = 0; ft < NFT; ++ft) {
+          const i32x4 a0 = *reinterpret_cast<const i32x4*>(zt0 + ft * 2048 + aoff0);
+          const i32x4 a1 = *reinterpret_cast<const i32x4*>(zt0 + ft * 2048 + aoff1);
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0),
+                                                            __builtin_bit_cast(bf16x8, Bw[0][term]), G[ft], 0, 0, 0);
+            G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1),
+                                                            __builtin_bit_cast(bf16x8, Bw[1][term]), G[ft], 0, 0, 0);
+          }
+          if (more) {
+#pragma unroll
+            for (int u = 0; u < RPT; ++u)
+              if (ft * RPT + u < 16) look1(S, ft * RPT + u, tb4, m);
+          }
+        }
+      } else if (more) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) look1(S, r, tb4, m);
+      }
+      if (more) {
+        flush_lsum(m);
+        pack_w(Bw);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // ---- loss partial sums
+  const double sxx = block_sum(l_xx, red), sxy = block_sum(l_xy, red), syy = block_sum(l_yy, red);
+  if (tid == 0) {
+    double* lp = a.loss_part + ((size_t)sp * gridDim.x + blockIdx.x) * 3;
+    lp[0] = sxx; lp[1] = sxy; lp[2] = syy;
+  }
+  if (!want_grad) return;
+
+  // ---- grad[i][f] = x[i][f] * rowsum_i - G^T[f][i]; a lane holds features 32 ft + 8 q + 4 hh + (0..3) of its row in
+  // accumulator registers 4 q .. 4 q + 3: one 16-byte store each.  x is +-1: its sign comes from the int8 copy.
+  rowsum += __shfl_xor(rowsum, 32, 64);
+  if (vi) {
+    float* out = a.grad_part + (size_t)sp * a.nx * D + gi * D;
+    const int8_t* xs = a.zi8 + gi * D;
+#pragma unroll
+    for (int ft = 0; ft < NFT; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 32 * ft + 8 * q + 4 * hh;
+        const uint32_t sg = *reinterpret_cast<const uint32_t*>(xs + f);
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool neg = (sg >> (8 * u + 7)) & 1u;
+          o[u] = (neg ? -rowsum : rowsum) - G[ft][4 * q + u];
+        }
+        *reinterpret_cast<f32x4*>(out + f) = o;
+      }
+  }
+}
+
+template <int NFT>
+__global__ __launch_bounds__(256, 1) void mmd_pair_w128_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char w128_smem[];
+  if (*a.not_pm1 != 0) return;  // general rows: the f32 kernel launched behind this one serves them
+  mmd_pm1_w128_body<NFT>(a, w128_smem);
+}
+
 template <int NFB>
 __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char main_smem[];
+  if (a.gate_main && *a.not_pm1 == 0) return;  // +-1 rows: the spin kernel in front of this launch has done the work
   mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem));
 }
 
@@ -1072,7 +1370,15 @@ struct MmdPlan {
   size_t off_sq, off_coef, off_dist, off_loss, off_grad, off_flag, off_zi8, off_zt, off_tab, total;
   int pm1_ok;
   int64_t ztb_x, ztb_y;  // 32-row blocks of the transposed copy (whole 128-row tiles)
+  int w128, S2;          // 128-row-block pair kernel (large spin problems) and its column splits
+  int64_t rb128x, rb128y;
 };
+
+// DVG_MMD_W128 = 1 / 0 forces the 128-row-block pair kernel on (wherever the shape allows it) / off: tests, A/B runs
+static int mmd_w128_env() {
+  static const int v = [] { const char* e = getenv("DVG_MMD_W128"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  return v;
+}
 
 // column splits of the pair kernel aim for this many blocks (env DVG_MMD_BLOCKS overrides: tuning runs)
 static int64_t mmd_target_blocks() {
@@ -1095,6 +1401,22 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   if (S > 16) S = 16;
   p.S = (int)S;
   p.pm1_ok = d <= 1024;  // LDS: table + resident X rows + one Z panel
+  // 128-row-block pair kernel: d = 128 .. 512 in steps of 128 (16 d / 32 accumulator registers per lane), and enough
+  // rows of x that 128-row blocks fill the chip with at most 4 column splits of >= 16 chunks each
+  p.rb128x = ceil_div(nx, 128);
+  p.rb128y = ceil_div(ny, 128);
+  {
+    const int64_t chunks = ceil_div(nx, 32) + ceil_div(ny, 32);
+    int64_t S2 = ceil_div(mmd_target_blocks(), p.rb128x);
+    if (S2 > chunks / 16) S2 = chunks / 16;
+    if (S2 < 1) S2 = 1;
+    const bool shape_ok = d % 128 == 0 && d <= 512;
+    const int env = mmd_w128_env();
+    p.w128 = shape_ok && (env == 1 || (env != 0 && S2 <= 4 && p.rb128x * S2 >= 128));
+    if (env == 1 && shape_ok) { S2 = S2 > 16 ? 16 : S2; }
+    else if (S2 > 4) S2 = 4;
+    p.S2 = (int)S2;
+  }
   // pass 1 (distance sum): spin-capable shapes launch the folded 128-row form, ceil(T/2) x S1 blocks of about
   // (T+1)/S1 tiles each, two blocks per CU wanted; other shapes one block per 32-row block
   int64_t S1;
@@ -1115,8 +1437,16 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.off_sq = o; o = align_up(o + sizeof(float) * (size_t)(nx + ny), 256);
   p.off_coef = o; o = align_up(o + sizeof(float) * 16, 256);
   p.off_dist = o; o = align_up(o + sizeof(double) * (size_t)(p.S1 * p.GX1), 256);
-  p.off_loss = o; o = align_up(o + sizeof(double) * 3 * (size_t)(p.S * (p.rbx + p.rby)), 256);
-  p.off_grad = o; o = align_up(o + (p.S > 1 ? sizeof(float) * (size_t)p.S * (size_t)nx * (size_t)d : 0), 256);
+  {
+    size_t nparts = (size_t)(p.S * (p.rbx + p.rby));
+    if (p.w128 && (size_t)(p.S2 * (p.rb128x + p.rb128y)) > nparts) nparts = (size_t)(p.S2 * (p.rb128x + p.rb128y));
+    if (p.w128 && (size_t)(p.S2 * (p.rbx + p.rby)) > nparts) nparts = (size_t)(p.S2 * (p.rbx + p.rby));
+    p.off_loss = o; o = align_up(o + sizeof(double) * 3 * nparts, 256);
+  }
+  {
+    const int smax = p.w128 && p.S2 > p.S ? p.S2 : p.S;
+    p.off_grad = o; o = align_up(o + (smax > 1 ? sizeof(float) * (size_t)smax * (size_t)nx * (size_t)d : 0), 256);
+  }
   p.ztb_x = ceil_div(nx, MMD_BJ) * 4;
   p.ztb_y = ceil_div(ny, MMD_BJ) * 4;
   p.off_flag = o; o = align_up(o + sizeof(int), 256);
@@ -1167,6 +1497,17 @@ static int launch_pair_fq(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
+template <int NFT>
+static int launch_pair_w128(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
+  auto kern = mmd_pair_w128_kernel<NFT>;
+  constexpr int lds = W128<NFT>::LDS_BYTES;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 3), kern, dim3((unsigned)(p.rb128x + p.rb128y), (unsigned)p.S2), dim3(256),
+                  (size_t)lds, s, a);
+  return DVG_OK;
+}
+
 template <int NFB>
 static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   const int d = a.d, pw = d < MMD_I8_PANEL ? d : MMD_I8_PANEL;
@@ -1211,12 +1552,14 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   a.n_kernels = cfg->n_kernels; a.squared = cfg->squared; a.reduce_mean = cfg->reduce_mean; a.biased = cfg->biased;
   a.pow2 = cfg->factor == 2.0f;
   a.loss_part = (double*)(w + p.off_loss);
-  a.grad_part = grad_x ? (p.S > 1 ? (float*)(w + p.off_grad) : grad_x) : nullptr;
-  a.S = p.S;
+  const int S_eff = p.w128 ? p.S2 : p.S;  // column splits of the pair kernel that will run for spin rows
+  a.grad_part = grad_x ? (S_eff > 1 ? (float*)(w + p.off_grad) : grad_x) : nullptr;
+  a.S = S_eff;
   a.dist_part = (double*)(w + p.off_dist);
   a.zi8 = (const int8_t*)(w + p.off_zi8);
   a.not_pm1 = (const int*)(w + p.off_flag);
   a.pm1_ok = p.pm1_ok;
+  a.gate_main = 0;
   a.zt = (const uint16_t*)(w + p.off_zt);
   a.ztb_y = p.ztb_x;
   a.tab = (const uint4*)(w + p.off_tab);
@@ -1259,7 +1602,33 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
              (double)(nx + ny), cfg->bandwidth, cfg->factor, (float*)(w + p.off_coef),
              p.pm1_ok ? (uint4*)(w + p.off_tab) : (uint4*)nullptr);
   int rc;
-  if (p.pm1_ok) {
+  int loss_parts = (int)(p.S * (p.rbx + p.rby));
+  if (p.w128) {
+    // (the two kernels below number their loss partials by their own grids and exactly one of them runs: the slots the
+    // other layout would have filled must read as zero in the final sum)
+    if ((int)(p.S2 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * (p.rb128x + p.rb128y));
+    if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
+    DVG_CHECK_HIP(hipMemsetAsync(w + p.off_loss, 0, sizeof(double) * 3 * (size_t)loss_parts, s));
+    // Large spin problems: 128-row blocks.  General (not +-1) rows cannot be known on the host without a sync, so the
+    // f32 kernel is launched behind it with the same split count and stands down on the device flag (its blocks exit at
+    // once; it writes the same loss_part / grad_part slots when it does run).
+    switch (dim / 128) {
+      case 1: rc = launch_pair_w128<4>(a, p, s); break;
+      case 2: rc = launch_pair_w128<8>(a, p, s); break;
+      case 3: rc = launch_pair_w128<12>(a, p, s); break;
+      default: rc = launch_pair_w128<16>(a, p, s); break;
+    }
+    DVG_TRY(rc);
+    MmdArgs g = a;
+    g.gate_main = 1;
+    MmdPlan pg = p;
+    pg.S = p.S2;
+    switch (p.nfb) {
+      case 2: rc = launch_main<2>(g, pg, s); break;
+      case 4: rc = launch_main<4>(g, pg, s); break;
+      default: rc = launch_main<8>(g, pg, s); break;
+    }
+  } else if (p.pm1_ok) {
     // feature blocks per launch slice: the largest of 8/4/2/1 that divides d/32 (no feature guards in the spin body;
     // 16 blocks = 256 accumulator registers makes the compiler shuffle accumulators through scratch)
     const int fbt = dim / 32;
@@ -1285,9 +1654,8 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   }
   DVG_TRY(rc);
   const int64_t numel = nx * (int64_t)dim;
-  const unsigned fgrid = (grad_x && p.S > 1) ? (unsigned)(ceil_div(numel, 256) > 2048 ? 2048 : ceil_div(numel, 256)) : 1u;
+  const unsigned fgrid = (grad_x && S_eff > 1) ? (unsigned)(ceil_div(numel, 256) > 2048 ? 2048 : ceil_div(numel, 256)) : 1u;
   DVG_LAUNCH(K_MMD_FINAL, mmd_final_kernel, dim3(fgrid), dim3(256), 0, s, (const double*)(w + p.off_loss),
-             (int)(p.S * (p.rbx + p.rby)), nx, ny, cfg->biased, loss_out, (const float*)(w + p.off_grad), p.S, numel,
-             grad_x);
+             loss_parts, nx, ny, cfg->biased, loss_out, (const float*)(w + p.off_grad), S_eff, numel, grad_x);
   return DVG_OK;
 }
