@@ -76,6 +76,51 @@ def test_encoder_c2_size_matches_float64_oracle_on_device():
         assert _rel_l2(prm.grad, p[name].grad) < 5e-3, name
 
 
+def test_mmd_c3_size_against_float64_on_sampled_rows():
+    """c3's MMD (32768 x 256 rows of 512 spins: the 128-row-block pair kernel at its natural size) against the
+    estimator evaluated in float64 on the device: the loss, and the gradient of 96 sampled rows of x (first / last rows
+    of row blocks, the very last row, random ones) -- the terms of the loss that involve a sampled row, differentiated by
+    autograd with the oracle's own distance / kernel-factor functions."""
+    nx, ny, d = 32768, 256, 512
+    g = torch.Generator().manual_seed(3)
+    x = ((torch.rand(nx, d, generator=g) < 0.4).float() * 2 - 1).cuda()
+    x[100:108] = x[99]  # duplicated rows
+    y = ((torch.rand(ny, d, generator=g) < 0.55).float() * 2 - 1).cuda()
+    xa = x.clone().requires_grad_(True)
+    la = F.mmd_loss(xa, y)
+    la.backward()
+    z = torch.cat([x, y]).double()
+    N = nx + ny
+    # bandwidth = mean distance over all ordered pairs i != j, in float64 (the Gram of +-1 rows is exact in float32)
+    dsum = torch.zeros((), dtype=torch.float64, device="cuda")
+    for r0 in range(0, N, 4096):
+        dsum += plugin.pairwise_distance(z[r0:r0 + 4096], z, False).sum()
+    bw = dsum / (N * N - N)
+    bws = bw * plugin.kernel_factors(7, 2.0).to("cuda", torch.float64)
+    kern = lambda a_, b_: torch.exp(-plugin.pairwise_distance(a_, b_, False).unsqueeze(0) / bws.reshape(-1, 1, 1)).sum(0)  # noqa: E731
+    sxx = syy = sxy = 0.0
+    for r0 in range(0, nx, 2048):
+        k = kern(z[r0:r0 + 2048], z)
+        sxx += float(k[:, :nx].sum()) - float(k[:, r0:r0 + 2048].diagonal().sum())
+        sxy += float(k[:, nx:].sum())
+    kyy = kern(z[nx:], z[nx:])
+    syy = float(kyy.sum() - kyy.trace())
+    want = sxx / (nx * (nx - 1)) + syy / (ny * (ny - 1)) - 2.0 * sxy / (nx * ny)
+    assert abs(float(la) - want) <= 1e-5 * abs(want), (float(la), want)
+    idx = torch.cat([torch.tensor([0, 31, 32, 127, 128, 99, 100, 107, nx - 129, nx - 128, nx - 1]),
+                     torch.randint(0, nx, (85,), generator=g)]).unique().cuda()
+    xs = z[idx].clone().requires_grad_(True)
+    kx = kern(xs, z[:nx])
+    sel = torch.zeros(nx, dtype=torch.bool, device="cuda")
+    sel[idx] = True
+    # pairs (i in sel, j not in sel) appear twice in sum_{i != j} k(x_i, x_j); pairs inside sel once per order
+    kss = kern(xs, xs)
+    part = (2.0 * kx[:, ~sel].sum() + kss.sum() - kss.trace()) / (nx * (nx - 1)) - 2.0 * kern(xs, z[nx:]).sum() / (nx * ny)
+    part.backward()
+    got = xa.grad[idx].double()
+    assert float((got - xs.grad).abs().max()) <= 2e-5 * float(xs.grad.abs().max())
+
+
 @pytest.mark.parametrize("nx,ny,d", [(2048, 256, 128), (32768, 256, 512)])
 def test_mmd_full_size_properties(nx, ny, d):
     """Permutation of the rows of x permutes the gradient rows and leaves the loss alone; MMD(x, y) = MMD(y, x);

@@ -40,6 +40,54 @@ def test_mmd_default_matches_oracle(nx, ny, d):
     assert (g - gwant).abs().max() <= 2e-5 * scale + 1e-9
 
 
+@pytest.mark.parametrize("nx,ny,d", [(300, 77, 128), (1000, 256, 256), (513, 33, 384), (2053, 256, 512), (128, 130, 512),
+                                      (97, 5, 256)])
+@pytest.mark.parametrize("kw", [dict(), dict(biased=True), dict(squared=True)])
+def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
+    """The 128-row-block spin pair kernel (large problems: c3) forced on small, ragged shapes -- partial row blocks,
+    partial last chunks of x and of y, the diagonal inside a chunk, column splits, both feature slices of d > 256 --
+    against the float64 oracle; and against the 32-row-block kernels on the same inputs."""
+    rng = np.random.default_rng(nx + d)
+    x = _spins(rng, nx, d, 0.35)
+    x[: nx // 4] = x[0]  # duplicated rows: Hamming distance 0 off the diagonal
+    y = _spins(rng, ny, d, 0.6)
+    want, gwant = _ref_mmd(x, y, **kw)
+    w32, _ = _ref_mmd(x, y, dtype=torch.float32, **kw)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DVG_MMD_W128", flag)
+        xg = x.cuda().requires_grad_(True)
+        loss = F.mmd_loss(xg, y.cuda(), **kw)
+        loss.backward()
+        out[flag] = (float(loss.detach()), xg.grad.cpu().double())
+    for flag, (lv, g) in out.items():
+        err = abs(lv - float(want))
+        assert err <= max(1e-5 * abs(float(want)), 2e-7, 2 * abs(float(w32) - float(want))), (flag, lv, float(want))
+        assert (g - gwant).abs().max() <= 2e-5 * gwant.abs().max() + 1e-9, flag
+    assert abs(out["1"][0] - out["0"][0]) <= 2e-6 * abs(out["0"][0]) + 1e-9
+    assert (out["1"][1] - out["0"][1]).abs().max() <= 4e-6 * gwant.abs().max() + 1e-10
+
+
+def test_mmd_128_row_block_kernel_loss_only_and_float_rows(monkeypatch):
+    """No gradient asked for (loss-only walk), and general float rows under the forced flag (the spin kernel stands down
+    on the device flag and the f32 kernel behind it serves the call)."""
+    monkeypatch.setenv("DVG_MMD_W128", "1")
+    rng = np.random.default_rng(5)
+    x, y = _spins(rng, 700, 256, 0.4), _spins(rng, 90, 256, 0.5)
+    want, gwant = _ref_mmd(x, y)
+    with torch.no_grad():
+        lv = F.mmd_loss(x.cuda(), y.cuda())
+    assert abs(float(lv) - float(want)) <= 1e-5 * abs(float(want)) + 2e-7
+    xf = x.clone()
+    xf[3, 7] = 0.25
+    want, gwant = _ref_mmd(xf, y)
+    xg = xf.cuda().requires_grad_(True)
+    loss = F.mmd_loss(xg, y.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want)) <= 2e-5 * abs(float(want)) + 1e-6
+    assert (xg.grad.cpu().double() - gwant).abs().max() <= 5e-5 * gwant.abs().max() + 1e-9
+
+
 @pytest.mark.parametrize("kw", [dict(squared=True), dict(biased=True), dict(reduce="mean"), dict(bandwidth=3.5),
                                 dict(n_kernels=3, factor=3.0)])
 def test_mmd_switches(kw):
