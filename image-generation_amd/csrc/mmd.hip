@@ -1176,38 +1176,47 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   float rowsum = 0.f;
   double l_xx = 0.0, l_xy = 0.0, l_yy = 0.0;
 
-  // Lookup state of one chunk.  Masking is table-driven, so that the steady-state iteration is ONE straight-line
-  // instruction stream with no variants (variants of the loop body make the register allocator copy all of G^T between
-  // them every iteration, and any branch inside the body stops the scheduler from interleaving lookups with MFMAs):
-  //   * an invalid pair (row of x past the end, column past the end of the last chunk, or the dummy "next chunk" of the
-  //     last iteration) reads table entry D+1, which is all zero: no loss term, no row-sum term, zero weight;
-  //   * the diagonal pair of an unbiased estimate reads entry D+2 = entry 0 (Hamming distance 0) with its kernel sum
-  //     zeroed: out of the loss, weight as entry 0 has it.
-  struct ChunkMeta { bool cols_x; int njv; int dloc; };  // njv: valid columns of the chunk for THIS lane's row (0 if the row is invalid)
+  // Masking.  The steady-state iteration is ONE straight-line instruction stream with no per-pair masks (variants of
+  // the loop body make the register allocator copy all of G^T between them every iteration; a branch inside the body
+  // stops the scheduler from interleaving lookups with MFMAs; per-pair compare / select pairs made the loop
+  // issue-bound: the MFMAs leave room for ~6 other instructions each).  Instead:
+  //   * a row of x past the end: its lane's kernel sums are dropped when they are flushed (one select per chunk); its
+  //     weights only reach columns of G^T that are never stored;
+  //   * the rare chunks with invalid COLUMNS (the ragged last chunk of x or y, the dummy chunks that pad the pipeline)
+  //     or with the diagonal pair of an unbiased estimate get their Gram tile rewritten before the lookups, in a
+  //     block-uniform branch outside the MFMA stream: an invalid pair becomes S = -(D+2), i.e. "Hamming distance" D+1,
+  //     whose table entry is all zero; the diagonal pair becomes S = -(D+4), entry D+2 = entry 0 with a zero kernel sum.
+  struct ChunkMeta { bool cols_x, fix; int nj, dloc; };
   auto chunk_meta = [&](int64_t t, bool exists) -> ChunkMeta {
     ChunkMeta m;
     m.cols_x = t < ncx;
     const int64_t jrow0 = (m.cols_x ? t : t - ncx) * 32, cnt_j = m.cols_x ? a.nx : a.ny;
-    const int nj = (int)(cnt_j - jrow0 < 32 ? cnt_j - jrow0 : 32);
-    m.njv = (exists && vi) ? nj : 0;
+    m.nj = exists ? (int)(cnt_j - jrow0 < 32 ? cnt_j - jrow0 : 32) : 0;
     const bool same = rows_x == m.cols_x;
-    const int64_t dd = gi - jrow0;
-    m.dloc = (same && !a.biased && dd >= 0 && dd < 32) ? (int)dd : -1;
+    const bool diag_here = exists && same && !a.biased && jrow0 + 32 > base_i && jrow0 < base_i + 128;  // block-uniform
+    m.dloc = diag_here ? (int)(gi - jrow0) : -1;  // (outside [0, 32) for the waves / lanes the chunk does not cross)
+    m.fix = m.nj < 32 || diag_here;
     return m;
   };
+  auto fixup = [&](i32x16& S, const ChunkMeta& m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = crow(r, hh);
+      int v = S[r];
+      v = jl == m.dloc ? -(D + 4) : v;
+      v = jl < m.nj ? v : -(D + 2);
+      S[r] = v;
+    }
+  };
 
-  // One pair-row r of the lookup phase: table read, loss / row sums, and -- every second row -- the pair's weight pieces
-  // packed straight into the next chunk's B-operand registers (k-permuted layout of the Gram accumulator: see the
-  // comment on the spin path above).  Split in two so that a row's table read is issued a feature tile -- six MFMAs --
-  // ahead of its use.
+  // One pair-row r of the lookup phase: table read (byte offset 8 (D - S) = 16 h), then loss / row sums and -- every
+  // second row -- the pair's weight pieces packed straight into the next chunk's B-operand registers (k-permuted layout
+  // of the Gram accumulator: see the comment on the spin path above).  Split in two so that a row's table read is issued
+  // a feature tile -- six MFMAs -- ahead of its use.
   float lsum = 0.f;
   uint32_t hm_prev = 0, lo_prev = 0;
-  auto look_issue = [&](const i32x16& S, int r, const i32x4* tb4, const ChunkMeta& m) -> i32x4 {
-    const int jl = crow(r, hh);
-    int idx = (D - S[r]) >> 1;
-    idx = jl == m.dloc ? D + 2 : idx;
-    idx = jl < m.njv ? idx : D + 1;
-    return tb4[idx];
+  auto look_issue = [&](const i32x16& S, int r, const unsigned char* tb) -> i32x4 {
+    return *reinterpret_cast<const i32x4*>(tb + __mul24(S[r], -8));
   };
   auto look_use = [&](const i32x4& e, int r, i32x4 (&Bn)[2][3]) {
     lsum += __int_as_float(e[0]);
@@ -1222,9 +1231,13 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       hm_prev = hm; lo_prev = lw;
     }
   };
+  // (tb = table base + 8 D: the byte offset of Gram value S is then -8 S)
+  auto table_base = [&](const ChunkMeta& m) -> const unsigned char* {
+    return smem + (m.cols_x ? 0 : TABN * 16) + 8 * D;
+  };
   double l_cx = 0.0, l_cy = 0.0;  // kernel sums against x columns / y columns
   auto flush_lsum = [&](const ChunkMeta& m) {
-    const double dl = (double)lsum;
+    const double dl = vi ? (double)lsum : 0.0;
     l_cx += m.cols_x ? dl : 0.0;
     l_cy += m.cols_x ? 0.0 : dl;
     lsum = 0.f;
@@ -1232,7 +1245,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 
   i32x4 Bw[2][3];
   if (T > 0) {
-    // ---- prologue: chunk t0's images (and chunk t0+1's int8 rows), its Gram and lookups
+    // ---- prologue: images of chunks t0 and t0+1, Gram + lookups of chunk t0, Gram of chunk t0+1
     issue_z8(t0, 0);
     if (want_grad) issue_zt(t0, 0);
     if (T > 1) issue_z8(t0 + 1, 1);
@@ -1240,42 +1253,57 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     __builtin_amdgcn_s_barrier();  // also publishes the pair table
     {
       const ChunkMeta m = chunk_meta(t0, true);
-      const i32x16 S = gram(0);
-      const i32x4* tb4 = tab_s + (m.cols_x ? 0 : TABN);
+      i32x16 S = gram(0);
+      if (m.fix) fixup(S, m);
+      const unsigned char* tb = table_base(m);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb4, m), r, Bw);
+      for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb), r, Bw);
       flush_lsum(m);
     }
     if (want_grad) {
+      i32x16 Sa = gram(1), Sb = {0};  // Sa: Gram tile of chunk t0+1 (stale bytes if T == 1: masked by its fixup)
+      __builtin_amdgcn_s_barrier();   // every wave is done with z8buf[0]: chunk t0+2 may land there
+      if (T > 2) issue_z8(t0 + 2, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       // pair-rows [rb(ft), rb(ft+1)) are looked up beside feature tile ft: 16 rows spread evenly over the NFT tiles
       auto rb = [](int ft) { return (16 * ft + NFT - 1) / NFT; };
       constexpr int RMAX = (16 + NFT - 1) / NFT;
-      for (int k = 0; k < T; ++k) {
+      constexpr int GPT = NST / NFT;  // Gram k-steps (MFMAs) beside each feature tile
+      // Iteration k: gradient GEMM of chunk t = t0+k (weights Bw, transposed copy in ztbuf[k&1]) || lookups of chunk t+1
+      // (its Gram tile Scur, fixed up first if need be) -> next weights || Gram of chunk t+2 (int8 rows in z8buf[k&1])
+      // -> Snext.  Chunks past t1 are dummies: no DMA, every pair masked, zero weights.
+      auto iteration = [&](int k, i32x16& Scur, i32x16& Snext) {
         const int64_t t = t0 + k;
-        // buffers of this iteration: transposed copy of chunk t in ztbuf[k & 1], int8 rows of chunk t+1 in z8buf[(k+1) & 1]
         if (k + 1 < T) issue_zt(t + 1, (k + 1) & 1);  // (that buffer's last reader was iteration k-1)
-        if (k + 2 < T) issue_z8(t + 2, k & 1);        // (ditto: Gram of chunk t ran in iteration k-1)
-        // Gram + lookups of chunk t+1 (in the last iteration a dummy: every pair invalid, stale LDS bytes, zero weights)
+        if (k + 3 < T) issue_z8(t + 3, (k + 1) & 1);  // (ditto: the Gram of chunk t+1 ran in iteration k-1)
         const bool more = k + 1 < T;
         const ChunkMeta m = chunk_meta(more ? t + 1 : t, more);
+        if (m.fix) fixup(Scur, m);
+        const unsigned char* tb = table_base(m);
         const unsigned char* zt0 = ztbuf + (k & 1) * L::ZT_BYTES;
-        const i32x16 S = gram((k + 1) & 1);
-        const i32x4* tb4 = tab_s + (m.cols_x ? 0 : TABN);
+        const unsigned char* zrow = z8buf + (k & 1) * L::Z8_BYTES + c * D;
         i32x4 Bn[2][3];
         i32x4 ent[RMAX];   // table entries requested beside tile ft, consumed beside tile ft + 1
-        i32x4 an[2], ac[2];
+        i32x4 an[2], ac[2], zn[GPT], zc[GPT];
         ac[0] = *reinterpret_cast<const i32x4*>(zt0 + aoff0);
         ac[1] = *reinterpret_cast<const i32x4*>(zt0 + aoff1);
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) zc[u] = *reinterpret_cast<const i32x4*>(zrow + (((2 * u + hh) ^ fz_c) << 4));
+        Snext = (i32x16){0};
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
           if (ft + 1 < NFT) {
             an[0] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff0);
             an[1] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff1);
+#pragma unroll
+            for (int u = 0; u < GPT; ++u)
+              zn[u] = *reinterpret_cast<const i32x4*>(zrow + (((2 * ((ft + 1) * GPT + u) + hh) ^ fz_c) << 4));
           }
           i32x4 enew[RMAX];
 #pragma unroll
           for (int u = 0; u < RMAX; ++u)
-            if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(S, rb(ft) + u, tb4, m);
+            if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(Scur, rb(ft) + u, tb);
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
             G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[0]),
@@ -1283,6 +1311,9 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
             G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[1]),
                                                             __builtin_bit_cast(bf16x8, Bw[1][term]), G[ft], 0, 0, 0);
           }
+#pragma unroll
+          for (int u = 0; u < GPT; ++u)
+            Snext = __builtin_amdgcn_mfma_i32_32x32x32_i8(zc[u], xb[ft * GPT + u], Snext, 0, 0, 0);
           if (ft > 0) {
 #pragma unroll
             for (int u = 0; u < RMAX; ++u)
@@ -1291,6 +1322,8 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 #pragma unroll
           for (int u = 0; u < RMAX; ++u) ent[u] = enew[u];
           ac[0] = an[0]; ac[1] = an[1];
+#pragma unroll
+          for (int u = 0; u < GPT; ++u) zc[u] = zn[u];
           __builtin_amdgcn_sched_barrier(0);  // pin the tile order: unpinned, the scheduler hoists every tile's loads (spills)
         }
 #pragma unroll
@@ -1303,6 +1336,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         flush_lsum(m);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+      };
+      // two chunks per trip, so that the two Gram tiles swap roles without register copies; an odd T runs one dummy chunk
+      for (int k = 0; k < T; k += 2) {
+        iteration(k, Sa, Sb);
+        iteration(k + 1, Sb, Sa);
       }
     } else {
       // loss only (y-row blocks, or no gradient asked for): Gram + lookups per chunk
@@ -1310,10 +1348,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         const int64_t t = t0 + k;
         if (k + 2 < T) issue_z8(t + 2, k & 1);
         const ChunkMeta m = chunk_meta(t + 1, true);
-        const i32x16 S = gram((k + 1) & 1);
-        const i32x4* tb4 = tab_s + (m.cols_x ? 0 : TABN);
+        i32x16 S = gram((k + 1) & 1);
+        if (m.fix) fixup(S, m);
+        const unsigned char* tb = table_base(m);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb4, m), r, Bw);
+        for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb), r, Bw);
         flush_lsum(m);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

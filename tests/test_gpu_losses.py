@@ -65,7 +65,7 @@ def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
         assert err <= max(1e-5 * abs(float(want)), 2e-7, 2 * abs(float(w32) - float(want))), (flag, lv, float(want))
         assert (g - gwant).abs().max() <= 2e-5 * gwant.abs().max() + 1e-9, flag
     assert abs(out["1"][0] - out["0"][0]) <= 2e-6 * abs(out["0"][0]) + 1e-9
-    assert (out["1"][1] - out["0"][1]).abs().max() <= 4e-6 * gwant.abs().max() + 1e-10
+    assert (out["1"][1] - out["0"][1]).abs().max() <= 1e-5 * gwant.abs().max() + 1e-10
 
 
 def test_mmd_128_row_block_kernel_loss_only_and_float_rows(monkeypatch):
