@@ -19,9 +19,12 @@ import torch
 
 
 def execute_training(model, n_epochs: int, qpu: Optional[str] = None, n_latents: Optional[int] = None,
-                     set_progress: Optional[Callable] = None, details_path: Optional[str] = None, verbose: bool = True):
+                     set_progress: Optional[Callable] = None, details_path: Optional[str] = None, verbose: bool = True,
+                     on_epoch_end: Optional[Callable] = None):
     """Runs ``n_epochs`` over ``model._dataloader``; ``model.train_init(n_epochs)`` must have been called.
-    Returns a list with one dict per epoch (the fields the reference prints / dumps)."""
+    Returns a list with one dict per epoch (the fields the reference prints / dumps).  ``on_epoch_end(epoch, report)``
+    is called after each epoch with the reference's seven report fields (callback_helpers.execute_training hangs the
+    per-epoch figure generation there)."""
     reports = []
     for epoch in range(n_epochs):
         start = time.perf_counter()
@@ -52,6 +55,8 @@ def execute_training(model, n_epochs: int, qpu: Optional[str] = None, n_latents:
         if details_path:
             with open(details_path, "w") as f:
                 json.dump(report, f)
+        if on_epoch_end is not None:
+            on_epoch_end(epoch, dict(report))
         reports.append(dict(report, minutes=minutes))
     return reports
 

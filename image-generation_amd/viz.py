@@ -32,6 +32,7 @@ def sharpen(images: torch.Tensor, lower: float = LOWER_THRESHOLD, upper: float =
     return (over + (1 - over) * images) * under
 
 
+@torch.no_grad()  # (as torchvision's: the reference hands it tensors that still require grad, model_wrapper.py:467)
 def make_grid(images: torch.Tensor, nrow: int = 8, padding: int = 2, pad_value: float = 0.0) -> torch.Tensor:
     """(N, C, H, W) -> (3, rows * (H + padding) + padding, cols * (W + padding) + padding): ``nrow`` images per row,
     single-channel images replicated to three channels, cells separated (and framed) by ``padding`` pixels of

@@ -81,3 +81,20 @@ def make_masks(N, seed, keep=0.8):
 
 def subsample(a, stride=97):
     return np.ascontiguousarray(a.reshape(-1)[::stride])
+
+
+def figure_image(fig):
+    """The picture inside a ``px.imshow`` figure as a uint8 (H, W, 3) array: plotly stores RGB pictures as a PNG data URI
+    (``source``), small ones as an array (``z``)."""
+    import base64
+    import io
+
+    tr = fig.data[0] if hasattr(fig, "data") else fig["data"][0]
+    get = (lambda k: getattr(tr, k, None)) if hasattr(tr, "type") else (lambda k: tr.get(k))
+    if get("z") is not None:
+        z = np.asarray(get("z"), dtype=np.float64)
+        return np.clip(np.rint(z * (255.0 if z.max() <= 1.0 else 1.0)), 0, 255).astype(np.uint8)
+    from PIL import Image
+
+    raw = base64.b64decode(get("source").split(",", 1)[1])
+    return np.asarray(Image.open(io.BytesIO(raw)).convert("RGB"), dtype=np.uint8)
