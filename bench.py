@@ -361,9 +361,9 @@ def main():
         # largest total time; achieved = its executed FLOPs (2*rows*Cin*Cout*taps per launch -- the folded-upsample
         # layers are credited their 4 or 16 folded taps, not the 9 they replace -- summed by the library over the
         # timed launches) / its HIP-event time over the timed region.
-        # The MMD pair kernel serves +-1 spin rows ("mmd_pm1") on two matrix pipes rates at once: the Gram of every
-        # visited pair on the int8 MFMA (2x the bf16 rate) and the gradient GEMM as 3 exact bf16 terms on the bf16
-        # MFMA.  It is priced per type: the library reports its work in bf16-equivalent FLOPs (int8 FLOPs x 0.5 +
+        # The MMD pair kernel serves +-1 spin rows ("mmd_pm1") at two matrix-pipe rates at once: the Gram of every
+        # visited pair on the int8 MFMA (2x the bf16 rate) and the gradient GEMM as 2 (large problems) or 3 bf16 terms per
+        # weight on the bf16 MFMA.  It is priced per type: the library reports its work in bf16-equivalent FLOPs (int8 FLOPs x 0.5 +
         # bf16 FLOPs), i.e. frac = (int8 FLOPs / 5 PF + bf16 FLOPs / 2.5 PF) / measured time; `pricing` spells the two
         # parts out.  General rows run on the f32 MFMA ("mmd_main").  A candidate whose rate exceeds its peak is a
         # mislabelled launch and is dropped.
@@ -382,14 +382,15 @@ def main():
             e["traffic"], e["traffic_source"] = pmc_traffic(k, args.config, lib_hash)
             e["mfma_busy_pmc"] = pmc_mfma_busy(k, args.config, lib_hash) if args.precision == "f32" else None
             if k == "mmd_pm1":
+                i8, b16, terms = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+                _lib.check(L.dvg_mmd_spin_flops(cfg["B"] * cfg["R"], cfg["C"], cfg["n"], ctypes.byref(i8), ctypes.byref(b16),
+                                                ctypes.byref(terms)), "dvg_mmd_spin_flops")
                 nx, ny, d = cfg["B"] * cfg["R"], cfg["C"], cfg["n"]
-                i8 = 2.0 * (nx * (nx + ny) + ny * ny) * d
-                b16 = 3 * 2.0 * nx * (nx + ny) * d
                 e["unit"] = "TFLOP/s (bf16-equivalent: int8 FLOPs x 0.5 + bf16 FLOPs)"
-                e["pricing"] = {"int8_gram_tflop_per_launch": i8 / 1e12, "int8_peak_tflops": 2 * PEAK_BF16_MFMA_TFLOPS,
-                                "bf16_gradient_tflop_per_launch": b16 / 1e12, "bf16_terms": 3,
+                e["pricing"] = {"int8_gram_tflop_per_launch": i8.value / 1e12, "int8_peak_tflops": 2 * PEAK_BF16_MFMA_TFLOPS,
+                                "bf16_gradient_tflop_per_launch": b16.value / 1e12, "bf16_terms": terms.value,
                                 "bf16_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
-                                "time_at_peak_us": (i8 / (2 * PEAK_BF16_MFMA_TFLOPS) + b16 / PEAK_BF16_MFMA_TFLOPS) / 1e6,
+                                "time_at_peak_us": (i8.value / (2 * PEAK_BF16_MFMA_TFLOPS) + b16.value / PEAK_BF16_MFMA_TFLOPS) / 1e6,
                                 "algorithmic_tflop_per_launch": (2.0 * (nx + ny) ** 2 * d + 2.0 * nx * (nx + ny) * d) / 1e12}
             return e
 

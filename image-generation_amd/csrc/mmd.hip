@@ -1062,7 +1062,6 @@ template <int NST, int NFT>
 __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned char* smem) {
   using L = W128<NST, NFT>;
   constexpr int D = L::D;
-  const i32x4* tab_s = reinterpret_cast<const i32x4*>(smem);
   double* red = reinterpret_cast<double*>(smem + L::OFF_RED);
   unsigned char* z8buf = smem + L::OFF_Z8;
   unsigned char* ztbuf = smem + L::OFF_ZT;
@@ -1098,6 +1097,18 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (h <= D) v = a.tab[which * (D + 1) + h];
     else if (h == D + 2) { v = a.tab[which * (D + 1)]; v.x = 0u; }
+    // This kernel multiplies with TWO bf16 terms, both rounded to nearest: hi = bf16(w), lo = bf16(w - hi), so
+    // |w - (hi + lo)| <= 2^-18 |w|, unbiased.  (The 32-row kernels' third, truncation-split term is below half an ulp
+    // of a float32 accumulator that already holds a few hundred weights, i.e. it is rounded away add by add -- a
+    // systematic loss of ~2^-17 of the sum -- and costs a third of the gradient GEMM)
+    {
+      const float w = __uint_as_float(v.y);
+      auto rn_bf16 = [](float f) { const uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; };
+      const uint32_t hi = rn_bf16(w);
+      const uint32_t lo = rn_bf16(w - __uint_as_float(hi));
+      v.z = hi | (lo >> 16);
+      v.w = 0u;
+    }
     reinterpret_cast<uint4*>(smem)[e] = v;
   }
   i32x4 xb[NST];
@@ -1214,21 +1225,21 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // of the Gram accumulator: see the comment on the spin path above).  Split in two so that a row's table read is issued
   // a feature tile -- six MFMAs -- ahead of its use.
   float lsum = 0.f;
-  uint32_t hm_prev = 0, lo_prev = 0;
+  uint32_t hm_prev = 0;
+  constexpr int NTERM = 2;  // bf16 terms of a weight
   auto look_issue = [&](const i32x16& S, int r, const unsigned char* tb) -> i32x4 {
     return *reinterpret_cast<const i32x4*>(tb + __mul24(S[r], -8));
   };
-  auto look_use = [&](const i32x4& e, int r, i32x4 (&Bn)[2][3]) {
+  auto look_use = [&](const i32x4& e, int r, i32x4 (&Bn)[2][NTERM]) {
     lsum += __int_as_float(e[0]);
     rowsum += __int_as_float(e[1]);
-    const uint32_t hm = (uint32_t)e[2], lw = (uint32_t)e[3];
+    const uint32_t hm = (uint32_t)e[2];
     if (r & 1) {
       const int s2 = r >> 3, q = (r & 7) >> 1;
       Bn[s2][0][q] = (int)__builtin_amdgcn_perm(hm, hm_prev, 0x07060302u);
       Bn[s2][1][q] = (int)__builtin_amdgcn_perm(hm, hm_prev, 0x05040100u);
-      Bn[s2][2][q] = (int)__builtin_amdgcn_perm(lw, lo_prev, 0x05040100u);
     } else {
-      hm_prev = hm; lo_prev = lw;
+      hm_prev = hm;
     }
   };
   // (tb = table base + 8 D: the byte offset of Gram value S is then -8 S)
@@ -1243,7 +1254,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     lsum = 0.f;
   };
 
-  i32x4 Bw[2][3];
+  i32x4 Bw[2][NTERM];
   if (T > 0) {
     // ---- prologue: images of chunks t0 and t0+1, Gram + lookups of chunk t0, Gram of chunk t0+1
     issue_z8(t0, 0);
@@ -1283,7 +1294,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         const unsigned char* tb = table_base(m);
         const unsigned char* zt0 = ztbuf + (k & 1) * L::ZT_BYTES;
         const unsigned char* zrow = z8buf + (k & 1) * L::Z8_BYTES + c * D;
-        i32x4 Bn[2][3];
+        i32x4 Bn[2][NTERM];
         i32x4 ent[RMAX];   // table entries requested beside tile ft, consumed beside tile ft + 1
         i32x4 an[2], ac[2], zn[GPT], zc[GPT];
         ac[0] = *reinterpret_cast<const i32x4*>(zt0 + aoff0);
@@ -1293,6 +1304,18 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         Snext = (i32x16){0};
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
+          // Everything this tile consumes was requested a tile ago: wait for it HERE, before the next tile's requests go
+          // out (the compiler waits with lgkmcnt(0) at the first use; placed behind fresh requests that wait would sit
+          // out their whole latency every tile).  The empty asm is that first use.
+#pragma unroll
+          for (int u = 0; u < GPT; ++u) asm volatile("" ::"v"(zc[u]));
+          asm volatile("" ::"v"(ac[0]), "v"(ac[1]));
+          if (ft > 0) {
+#pragma unroll
+            for (int u = 0; u < RMAX; ++u)
+              if (rb(ft - 1) + u < rb(ft)) asm volatile("" ::"v"(ent[u]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
           if (ft + 1 < NFT) {
             an[0] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff0);
             an[1] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff1);
@@ -1304,8 +1327,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 #pragma unroll
           for (int u = 0; u < RMAX; ++u)
             if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(Scur, rb(ft) + u, tb);
+          // the loads above serve the NEXT tile: they must be issued before this tile's MFMAs, not after them (left to
+          // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency)
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int term = 0; term < 3; ++term) {
+          for (int term = 0; term < NTERM; ++term) {
             G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[0]),
                                                             __builtin_bit_cast(bf16x8, Bw[0][term]), G[ft], 0, 0, 0);
             G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[1]),
@@ -1332,7 +1358,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int term = 0; term < 3; ++term) Bw[s2][term] = Bn[s2][term];
+          for (int term = 0; term < NTERM; ++term) Bw[s2][term] = Bn[s2][term];
         flush_lsum(m);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1558,9 +1584,16 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
 // Executed matrix work of a spin-path pair launch in bf16-MFMA-equivalent FLOPs (what bench.py prices against the
 // 2.5 PFLOP/s dense bf16 peak): the int8 Gram of every visited pair (x rows against all rows, y rows against y rows)
 // runs at twice the bf16 rate, hence the 0.5; the gradient GEMM runs `terms` bf16 products per pair and feature.
-static double mmd_pm1_work(const MmdArgs& a, int terms) {
-  const double nx = (double)a.nx, ny = (double)a.ny, d = (double)a.d;
-  return 0.5 * 2.0 * (nx * (nx + ny) + ny * ny) * d + (a.grad_part ? terms * 2.0 * nx * (nx + ny) * d : 0.0);
+// `gram_passes`: how often the x-row Gram is computed (the 128-row-block kernel recomputes it per feature slice).
+static void mmd_pm1_flops(int64_t nx_, int64_t ny_, int d_, bool grad, int terms, int gram_passes, double* i8, double* b16) {
+  const double nx = (double)nx_, ny = (double)ny_, d = (double)d_;
+  *i8 = 2.0 * (gram_passes * nx * (nx + ny) + ny * ny) * d;
+  *b16 = grad ? terms * 2.0 * nx * (nx + ny) * d : 0.0;
+}
+static double mmd_pm1_work(const MmdArgs& a, int terms, int gram_passes = 1) {
+  double i8, b16;
+  mmd_pm1_flops(a.nx, a.ny, a.d, a.grad_part != nullptr, terms, gram_passes, &i8, &b16);
+  return 0.5 * i8 + b16;
 }
 
 template <int NFBW>
@@ -1588,7 +1621,7 @@ static int launch_pair_w128(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   constexpr int lds = W128<NST, NFT>::LDS_BYTES;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 3), kern, dim3((unsigned)(p.rb128x + p.rb128y), (unsigned)p.S2, NST / NFT),
+  DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 2, NST / NFT), kern, dim3((unsigned)(p.rb128x + p.rb128y), (unsigned)p.S2, NST / NFT),
                   dim3(256), (size_t)lds, s, a);
   return DVG_OK;
 }
@@ -1613,6 +1646,16 @@ static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
 }  // namespace dvg
 
 using namespace dvg;
+
+extern "C" int dvg_mmd_spin_flops(int64_t nx, int64_t ny, int dim, double* int8_flops, double* bf16_flops, int* bf16_terms) {
+  DVG_REQUIRE(nx >= 2 && ny >= 2 && dim >= 32 && dim % 32 == 0 && int8_flops && bf16_flops && bf16_terms, "mmd_spin_flops: bad argument");
+  const MmdPlan p = mmd_plan(nx, ny, dim);
+  if (!p.pm1_ok) { *int8_flops = 0.0; *bf16_flops = 0.0; *bf16_terms = 0; return DVG_OK; }  // f32 kernels only
+  const int passes = p.w128 ? (dim > 256 ? 2 : 1) : 1;
+  *bf16_terms = p.w128 ? 2 : 3;
+  mmd_pm1_flops(nx, ny, dim, true, *bf16_terms, passes, int8_flops, bf16_flops);
+  return DVG_OK;
+}
 
 extern "C" size_t dvg_mmd_workspace_bytes(int64_t nx, int64_t ny, int dim) {
   if (nx <= 0 || ny <= 0 || dim <= 0 || dim % 32) return 0;

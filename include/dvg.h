@@ -151,6 +151,10 @@ typedef struct {
   int32_t biased;      /* 0: unbiased estimator (default), 1: biased (plain means) */
 } dvg_mmd_cfg_t;
 size_t dvg_mmd_workspace_bytes(int64_t nx, int64_t ny, int dim);
+/* Executed matrix work of one dvg_mmd_fwd_bwd call with gradient on +-1 (spin) rows of this shape, by MFMA type: int8
+ * FLOPs of the Gram tiles, bf16 FLOPs of the gradient GEMM and the number of bf16 terms a weight is split into (0 / 0 / 0
+ * when the shape is served by the f32 kernels).  For roofline pricing (bench.py); launches nothing. */
+int dvg_mmd_spin_flops(int64_t nx, int64_t ny, int dim, double *int8_flops, double *bf16_flops, int *bf16_terms);
 int dvg_mmd_fwd_bwd(const float *x, int64_t nx, const float *y, int64_t ny, int dim,
                     const dvg_mmd_cfg_t *cfg, float *loss_out /* device scalar */,
                     float *grad_x /* (nx, dim) or NULL */, void *ws, size_t ws_bytes,

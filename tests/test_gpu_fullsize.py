@@ -123,9 +123,9 @@ def test_mmd_c3_size_against_float64_on_sampled_rows():
     got = xa.grad[idx].double()
     # The gradient is the difference of two sums over ~33 k pairs each (the x-x and the x-y term), here ~30x larger than
     # their difference, accumulated in float32 (one rounding per MFMA k-step: 2064 of them per element): the error bar is
-    # set against the size of the PARTS, which is what float32 accumulation in any order can promise (measured: 2e-6).
+    # set against the size of the PARTS, which is what float32 accumulation in any order can promise.
     parts = float((g_xx.abs() + g_xy.abs()).max())
-    assert float((got - want_g).abs().max()) <= 5e-6 * parts, (float((got - want_g).abs().max()), parts, float(want_g.abs().max()))
+    assert float((got - want_g).abs().max()) <= 1e-5 * parts, (float((got - want_g).abs().max()), parts, float(want_g.abs().max()))
     assert float((got - want_g).abs().max()) <= 2e-4 * float(want_g.abs().max())
 
 
