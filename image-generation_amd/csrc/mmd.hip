@@ -1230,14 +1230,19 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   auto look_issue = [&](const i32x16& S, int r, const unsigned char* tb) -> i32x4 {
     return *reinterpret_cast<const i32x4*>(tb + __mul24(S[r], -8));
   };
+  // (the empty asm statements pin each row's arithmetic to the tile it is written in: its results are only needed by the
+  // NEXT iteration, and left alone the compiler sinks all of it behind the barrier, into a VALU-only stretch of ~150
+  // instructions during which the matrix pipe idles -- with one wave per SIMD nothing else would fill it)
   auto look_use = [&](const i32x4& e, int r, i32x4 (&Bn)[2][NTERM]) {
     lsum += __int_as_float(e[0]);
     rowsum += __int_as_float(e[1]);
+    asm volatile("" ::"v"(lsum), "v"(rowsum));
     const uint32_t hm = (uint32_t)e[2];
     if (r & 1) {
       const int s2 = r >> 3, q = (r & 7) >> 1;
       Bn[s2][0][q] = (int)__builtin_amdgcn_perm(hm, hm_prev, 0x07060302u);
       Bn[s2][1][q] = (int)__builtin_amdgcn_perm(hm, hm_prev, 0x05040100u);
+      asm volatile("" ::"v"(Bn[s2][0][q]), "v"(Bn[s2][1][q]));
     } else {
       hm_prev = hm;
     }
@@ -1350,6 +1355,13 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
           ac[0] = an[0]; ac[1] = an[1];
 #pragma unroll
           for (int u = 0; u < GPT; ++u) zc[u] = zn[u];
+          // wanted order inside the tile: an MFMA, two vector instructions of the lookups, an MFMA, ... (an MFMA keeps the
+          // SIMD's issue port for 8 of its 32 cycles: a few VALU instructions per MFMA are free, a block of them is not)
+#pragma unroll
+          for (int i = 0; i < 2 * NTERM + GPT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);  // pin the tile order: unpinned, the scheduler hoists every tile's loads (spills)
         }
 #pragma unroll
