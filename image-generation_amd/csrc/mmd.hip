@@ -1089,6 +1089,9 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     t0 = ncx; t1 = ncx + ncy;
   }
   const int T = t1 > t0 ? (int)(t1 - t0) : 0;
+  // (32-bit copies for the block-uniform per-chunk arithmetic of the loop: chunk and row counts are far below 2^31)
+  const int ncx_i = (int)ncx, ncy_i = (int)ncy, nx_i = (int)a.nx, ny_i = (int)a.ny, gi_i = (int)gi, base_i_i = (int)base_i;
+  (void)ncy_i;
 
   // ---- one-time staging: pair table (+ the two masking entries per table) -> LDS, this wave's 32 rows -> B fragments
   constexpr int TABN = L::TABN;
@@ -1125,7 +1128,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // Per-lane pieces are constant over the kernel: (row, swizzled slot) -> a 32-bit source offset inside the chunk and the
   // LDS piece; per chunk only a wave-uniform base pointer changes (scalar registers), plus a clamp on the last,
   // partial chunk of x or y.
-  int z8off[NST / 4], z8row[NST / 4], ztoff[NFT / 2];
+  int z8off[NST / 4], z8row[NST / 4], z8col[NST / 4], ztoff[NFT / 2];
 #pragma unroll
   for (int q = 0; q < NST / 4; ++q) {
     const int byte = (wave * (NST / 4) + q) * 1024 + lane * 16;  // position in the [32][D] image
@@ -1133,6 +1136,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     const int fz = (D % 256 == 0) ? (r & 15) : ((r >> 1) & 7);
     z8row[q] = r;
     z8off[q] = r * D + ((sl ^ fz) << 4);
+    z8col[q] = (sl ^ fz) << 4;
   }
 #pragma unroll
   for (int q = 0; q < NFT / 2; ++q) {
@@ -1154,6 +1158,32 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         const int r = z8row[q] < last ? z8row[q] : last;
         dma16(base + (z8off[q] - z8row[q] * D + r * D), dst + q * 1024);
       }
+    }
+  };
+  // The same transfers one 1 KiB piece at a time and without branches, for issue from inside the MFMA stream of the
+  // steady-state loop: `i` < NZ8 is a piece of the int8 rows of chunk tz8 (rows clamped to `last8`), the others are
+  // pieces of the transposed copy of chunk tzt.  The bases are wave-uniform and computed once per iteration.
+  constexpr int NZ8 = NST / 4, NZT = NFT / 2;
+  struct DmaPlan { const int8_t* z8base; int last8; unsigned char* z8dst; const unsigned char* ztbase; unsigned char* ztdst; };
+  auto dma_plan = [&](int tz8, int buf8, int tzt, int buft) -> DmaPlan {
+    DmaPlan pl;
+    const bool cx8 = tz8 < ncx_i;
+    const int jrow0 = (cx8 ? tz8 : tz8 - ncx_i) * 32, cnt_j = cx8 ? nx_i : ny_i;
+    pl.z8base = a.zi8 + ((int64_t)(cx8 ? 0 : nx_i) + jrow0) * D;
+    pl.last8 = cnt_j - 1 - jrow0;  // (>= 31 for a whole chunk: no row is clamped)
+    pl.z8dst = z8buf + buf8 * L::Z8_BYTES + wave * NZ8 * 1024;
+    const bool cxt = tzt < ncx_i;
+    pl.ztbase = reinterpret_cast<const unsigned char*>(a.zt) +
+                (((cxt ? 0 : a.ztb_y) + (int64_t)(cxt ? tzt : tzt - ncx_i)) * (int64_t)D + f0) * 64;
+    pl.ztdst = ztbuf + buft * L::ZT_BYTES + wave * NZT * 1024;
+    return pl;
+  };
+  auto dma_piece = [&](const DmaPlan& pl, int i) {
+    if (i < NZ8) {
+      const int r = z8row[i] < pl.last8 ? z8row[i] : pl.last8;
+      dma16(pl.z8base + (r * D + z8col[i]), pl.z8dst + i * 1024);
+    } else {
+      dma16(pl.ztbase + ztoff[i - NZ8], pl.ztdst + (i - NZ8) * 1024);
     }
   };
   auto issue_zt = [&](int64_t t, int buf) {
@@ -1198,14 +1228,15 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   //     block-uniform branch outside the MFMA stream: an invalid pair becomes S = -(D+2), i.e. "Hamming distance" D+1,
   //     whose table entry is all zero; the diagonal pair becomes S = -(D+4), entry D+2 = entry 0 with a zero kernel sum.
   struct ChunkMeta { bool cols_x, fix; int nj, dloc; };
-  auto chunk_meta = [&](int64_t t, bool exists) -> ChunkMeta {
+  const bool diag_kind = !a.biased;
+  auto chunk_meta = [&](int t, bool exists) -> ChunkMeta {
     ChunkMeta m;
-    m.cols_x = t < ncx;
-    const int64_t jrow0 = (m.cols_x ? t : t - ncx) * 32, cnt_j = m.cols_x ? a.nx : a.ny;
-    m.nj = exists ? (int)(cnt_j - jrow0 < 32 ? cnt_j - jrow0 : 32) : 0;
-    const bool same = rows_x == m.cols_x;
-    const bool diag_here = exists && same && !a.biased && jrow0 + 32 > base_i && jrow0 < base_i + 128;  // block-uniform
-    m.dloc = diag_here ? (int)(gi - jrow0) : -1;  // (outside [0, 32) for the waves / lanes the chunk does not cross)
+    m.cols_x = t < ncx_i;
+    const int jrow0 = (m.cols_x ? t : t - ncx_i) * 32, cnt_j = m.cols_x ? nx_i : ny_i;
+    const int left = cnt_j - jrow0;
+    m.nj = exists ? (left < 32 ? left : 32) : 0;
+    const bool diag_here = exists && diag_kind && rows_x == m.cols_x && jrow0 + 32 > base_i_i && jrow0 < base_i_i + 128;
+    m.dloc = diag_here ? gi_i - jrow0 : -1;  // (outside [0, 32) for the waves / lanes the chunk does not cross)
     m.fix = m.nj < 32 || diag_here;
     return m;
   };
@@ -1268,7 +1299,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // also publishes the pair table
     {
-      const ChunkMeta m = chunk_meta(t0, true);
+      const ChunkMeta m = chunk_meta((int)t0, true);
       i32x16 S = gram(0);
       if (m.fix) fixup(S, m);
       const unsigned char* tb = table_base(m);
@@ -1290,9 +1321,12 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       // (its Gram tile Scur, fixed up first if need be) -> next weights || Gram of chunk t+2 (int8 rows in z8buf[k&1])
       // -> Snext.  Chunks past t1 are dummies: no DMA, every pair masked, zero weights.
       auto iteration = [&](int k, i32x16& Scur, i32x16& Snext) {
-        const int64_t t = t0 + k;
-        if (k + 1 < T) issue_zt(t + 1, (k + 1) & 1);  // (that buffer's last reader was iteration k-1)
-        if (k + 3 < T) issue_z8(t + 3, (k + 1) & 1);  // (ditto: the Gram of chunk t+1 ran in iteration k-1)
+        const int t = (int)t0 + k, tl = (int)t1 - 1;
+        // next transfers: transposed copy of chunk t+1 -> ztbuf[(k+1)&1] (last read in iteration k-1), int8 rows of chunk
+        // t+3 -> z8buf[(k+1)&1] (ditto: the Gram of chunk t+1 ran in iteration k-1).  Past the last chunk the last one
+        // is fetched again (harmless, and it keeps the issue free of branches): the pieces go out from inside the first
+        // tiles of the MFMA stream below.
+        const DmaPlan pl = dma_plan(t + 3 < tl ? t + 3 : tl, (k + 1) & 1, t + 1 < tl ? t + 1 : tl, (k + 1) & 1);
         const bool more = k + 1 < T;
         const ChunkMeta m = chunk_meta(more ? t + 1 : t, more);
         if (m.fix) fixup(Scur, m);
@@ -1332,6 +1366,12 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 #pragma unroll
           for (int u = 0; u < RMAX; ++u)
             if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(Scur, rb(ft) + u, tb);
+          {  // this tile's share of the DMA pieces (all of them go out in the first half of the tiles: time to land)
+            constexpr int PPT = (NZ8 + NZT + NFT / 2 - 1) / (NFT / 2);
+#pragma unroll
+            for (int u = 0; u < PPT; ++u)
+              if (ft * PPT + u < NZ8 + NZT) dma_piece(pl, ft * PPT + u);
+          }
           // the loads above serve the NEXT tile: they must be issued before this tile's MFMAs, not after them (left to
           // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency)
           __builtin_amdgcn_sched_barrier(0);
@@ -1385,7 +1425,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       for (int k = 0; k + 1 < T; ++k) {
         const int64_t t = t0 + k;
         if (k + 2 < T) issue_z8(t + 2, k & 1);
-        const ChunkMeta m = chunk_meta(t + 1, true);
+        const ChunkMeta m = chunk_meta((int)t + 1, true);
         i32x16 S = gram((k + 1) & 1);
         if (m.fix) fixup(S, m);
         const unsigned char* tb = table_base(m);
