@@ -109,6 +109,8 @@ SIGNATURES = {
     ),
     "dvg_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvg_heaviside_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "dvg_resize_binarise": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "dvg_gather_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "dvg_mmd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "dvg_mmd_spin_flops": (c_int, [c_int64, c_int64, c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "dvg_mmd_fwd_bwd": (

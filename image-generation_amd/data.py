@@ -3,9 +3,11 @@
 The reference trains on MNIST resized to 32x32 and rounded to {0,1}
 (/root/reference/src/model_wrapper.py:70-103: ``Resize((32,32))``, ``ToTensor()``, ``round``;
 ``DataLoader(shuffle=True, drop_last=True)``).  This module provides the same batches from
-(a) MNIST IDX files when they are present locally (no network here), resized on the host with
-the same antialiased bilinear rule torchvision applies, or (b) a synthetic stand-in of the same
-shape and ink fraction, resident on the device.
+(a) MNIST IDX files when they are present locally (no network here): the raw uint8 images go to the
+device once and ``dvg_resize_binarise`` applies the reference's transform there, bit for bit what
+torchvision's Resize does to the PIL images (Pillow's two-pass fixed-point BILINEAR; oracle/resize.py
+is pinned against Pillow); or (b) a synthetic stand-in of the same shape and ink fraction.  The data
+set stays resident in HBM and every shuffled mini-batch is one ``dvg_gather_rows`` launch.
 """
 from __future__ import annotations
 
@@ -40,7 +42,38 @@ class TensorBatches:
         order = order.to(self.images.device)
         for k in range(len(self)):
             idx = order[k * self.batch_size: (k + 1) * self.batch_size]
-            yield self.images[idx], self.labels[idx]
+            yield gather_rows(self.images, idx), self.labels[idx]
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``table[idx]`` along dim 0.  Device-resident float32 tables take the library's gather kernel (one launch, 16-byte
+    copies); anything else (CPU-side construction in tests) plain indexing."""
+    if not (table.is_cuda and table.dtype == torch.float32 and table.is_contiguous()):
+        return table[idx]
+    from . import _lib
+
+    idx = idx.to(device=table.device, dtype=torch.int64).contiguous()
+    out = torch.empty((idx.numel(),) + tuple(table.shape[1:]), dtype=torch.float32, device=table.device)
+    row = int(table[0].numel()) if table.shape[0] else 0
+    if idx.numel() and row:
+        with torch.cuda.device(table.device):
+            _lib.check(_lib.lib().dvg_gather_rows(table.data_ptr(), table.shape[0], row, idx.data_ptr(), idx.numel(),
+                                                  out.data_ptr(), None, _lib.stream_ptr(table.device)), "dvg_gather_rows")
+    return out
+
+
+def resize_binarise(raw: torch.Tensor, image_size: int) -> torch.Tensor:
+    """(N, H, H) uint8 on the device -> (N, 1, S, S) float32 in {0, 1}: the reference's Resize -> ToTensor -> round."""
+    from . import _lib
+
+    if not raw.is_cuda or raw.dtype != torch.uint8 or raw.dim() != 3 or raw.shape[1] != raw.shape[2]:
+        raise _lib.DvgError("resize_binarise needs a (N, H, H) uint8 CUDA tensor; there is no CPU fallback")
+    raw = raw.contiguous()
+    out = torch.empty((raw.shape[0], 1, image_size, image_size), dtype=torch.float32, device=raw.device)
+    with torch.cuda.device(raw.device):
+        _lib.check(_lib.lib().dvg_resize_binarise(raw.data_ptr(), raw.shape[0], raw.shape[1], image_size, out.data_ptr(),
+                                                  _lib.stream_ptr(raw.device)), "dvg_resize_binarise")
+    return out
 
 
 def synthetic_images(count: int, seed: int, ink: float = 0.13, device="cpu") -> torch.Tensor:
@@ -58,24 +91,26 @@ def _read_idx_images(path: str) -> np.ndarray:
         return np.frombuffer(f.read(), dtype=np.uint8).reshape(n, h, w)
 
 
-def load_mnist(root: str = "data", image_size: int = 32) -> Optional[torch.Tensor]:
-    """MNIST train images -> (60000,1,S,S) float {0,1}, or None when the files are not on disk."""
+def load_mnist_raw(root: str = "data") -> Optional[torch.Tensor]:
+    """MNIST train images as stored: (60000, 28, 28) uint8, or None when the IDX files are not on disk."""
     for name in ("train-images-idx3-ubyte", "train-images-idx3-ubyte.gz"):
         for sub in ("MNIST/raw", ""):
             path = os.path.join(root, sub, name)
             if os.path.exists(path):
-                raw = torch.from_numpy(_read_idx_images(path).copy()).unsqueeze(1)  # uint8, as PIL would hold it
-                # torchvision Resize on a PIL image = antialiased bilinear on uint8, then ToTensor (/255), then round
-                up = torch.nn.functional.interpolate(raw.float(), size=(image_size, image_size), mode="bilinear",
-                                                     antialias=True, align_corners=False)
-                return torch.round(up.round().clamp(0, 255) / 255.0)
+                return torch.from_numpy(_read_idx_images(path).copy())
     return None
+
+
+def load_mnist(root: str = "data", image_size: int = 32, device="cuda") -> Optional[torch.Tensor]:
+    """MNIST train images -> (60000, 1, S, S) float32 {0, 1} on ``device`` (the transform runs there), or None."""
+    raw = load_mnist_raw(root)
+    return None if raw is None else resize_binarise(raw.to(device), image_size)
 
 
 def get_dataloader(image_size: int, batch_size: int, dataset_size: Optional[int] = None, seed: int = 0,
                    device=None, root: str = "data", rank: int = 0, world_size: int = 1) -> TensorBatches:
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
-    images = load_mnist(root, image_size)
+    images = load_mnist(root, image_size, device) if torch.device(device).type == "cuda" else None
     if images is None:
         images = synthetic_images(dataset_size or 60000, seed)
     if dataset_size:

@@ -116,6 +116,20 @@ int dvg_grbm_suffstats(const dvg_graph_t *g, const float *x, int64_t rows, const
                        float scale, float *acc_linear, float *acc_quadratic, int accumulate,
                        void *ws, size_t ws_bytes, dvg_stream_t stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * The reference's per-image transform Resize((S,S)) -> ToTensor() -> round
+ * (/root/reference/src/model_wrapper.py:70-77) over a whole data set: src (n_images, in, in) uint8 ->
+ * out (n_images, 1, out, out) float32 in {0, 1}.  Bit-exact restatement of PIL's two-pass BILINEAR
+ * resampling (8-bit intermediate, 22-bit fixed-point coefficients), which is what torchvision's Resize
+ * applies to the PIL images MNIST yields; sides up to 64. */
+int dvg_resize_binarise(const uint8_t *src, int64_t n_images, int in_size, int out_size, float *out,
+                        dvg_stream_t stream);
+/* out[r] = table[idx[r]], rows of row_floats floats (the shuffled mini-batch of a device-resident data
+ * set: DataLoader(shuffle=True), /root/reference/src/model_wrapper.py:103).  idx: DEVICE int64.  An index
+ * outside [0, rows) is not dereferenced; *bad_index_flag (DEVICE int, may be NULL) is set to 1. */
+int dvg_gather_rows(const float *table, int64_t rows, int64_t row_floats, const int64_t *idx, int64_t n,
+                    float *out, int *bad_index_flag, dvg_stream_t stream);
+
 /* ------------------------------------------------------------------ latent -> discrete
  * Default latent_to_discrete of DiscreteVariationalAutoencoder
  * (/root/reference/src/model_wrapper.py:184-188 passes None -> plugin default):

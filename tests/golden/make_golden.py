@@ -435,6 +435,25 @@ def epoch_fixture(n=64, n_epochs=2, steps_per_epoch=3):
     print("wrote epoch fixture:", {k: getattr(v, "shape", v) for k, v in out.items()}, meta["details"], meta["files"])
 
 
+def resize_fixture():
+    """Pillow's own BILINEAR 28 -> 32 resize (what torchvision's Resize applies to the PIL images of MNIST,
+    /root/reference/src/model_wrapper.py:71-77) of committed uint8 inputs: uniform noise and saturated digit-like
+    strokes.  Needs Pillow only (present in the build image), not the reference."""
+    from PIL import Image
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(0)
+    strokes = np.zeros((40, 28, 28), np.uint8)
+    for i in range(40):
+        b = gaussian_filter(rng.random((28, 28)), sigma=1.5)
+        b = (b - b.min()) / (b.max() - b.min())
+        strokes[i] = np.clip((b - 0.45) * 6 * 255, 0, 255).astype(np.uint8)
+    imgs = np.concatenate([rng.integers(0, 256, (24, 28, 28), dtype=np.uint8), strokes])
+    pil = np.stack([np.asarray(Image.fromarray(im, mode="L").resize((32, 32), Image.BILINEAR)) for im in imgs])
+    np.savez_compressed(os.path.join(HERE, "resize_pil.npz"), src=imgs, pil32=pil)
+    print("wrote resize_pil.npz", imgs.shape, pil.shape)
+
+
 def _load_module(name, path):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
@@ -454,3 +473,5 @@ if __name__ == "__main__":
         step_fixture()
     if "epoch" in which:
         epoch_fixture()
+    if "resize" in which:
+        resize_fixture()
