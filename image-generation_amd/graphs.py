@@ -95,6 +95,46 @@ def zephyr_graph(m: int = 12, t: int = 4) -> nx.Graph:
     return g
 
 
+# ----------------------------------------------------------------------------
+# layouts (for the UI's topology picture: /root/reference/src/utils/callback_helpers.py:344-381)
+# ----------------------------------------------------------------------------
+# ``dwave_networkx.drawing.{pegasus,zephyr}_layout`` are not available offline; these place every qubit at the midpoint
+# of its wire segment in the lattice the topology papers draw (unit square, y pointing down), which is what those
+# layouts depict.  Coordinates are a picture, not arithmetic: nothing on the training path reads them.
+
+
+def pegasus_layout(m: int = 16, crosses: bool = True) -> dict:
+    """node -> (x, y) for Pegasus P_m with the linear labels of :func:`pegasus_graph`.  A vertical qubit (u = 0) with
+    tile offset w, wire k and segment z spans rows 12 z + shift .. 12 z + shift + 12 at column 12 w + k; horizontal
+    qubits the same with the axes swapped.  ``crosses``: draw the two qubits of an odd-coupler pair slightly apart so
+    that K4,4 crossings show as crosses (the reference asks for that look)."""
+    m1 = m - 1
+    off0, off1 = _PEGASUS_OFFSETS
+    span = 12.0 * m
+    pos = {}
+    for u, w, k, z in product((0, 1), range(m), range(12), range(m1)):
+        shift = (off0 if u == 0 else off1)[k]
+        across = 12 * w + k + (0.25 * (1 if k % 2 else -1) if crosses else 0.0) + 0.5
+        along = 12 * z + shift + 6.0
+        x, y = (across, along) if u == 0 else (along, across)
+        pos[((u * m + w) * 12 + k) * m1 + z] = (x / span, 1.0 - y / span)
+    return pos
+
+
+def zephyr_layout(m: int = 12, t: int = 4) -> dict:
+    """node -> (x, y) for Zephyr Z_{m,t} with the linear labels of :func:`zephyr_graph`: a vertical qubit
+    (u, w, k, j, z) = (0, ...) sits at column (2 t) w / 2-ish + k and spans two unit cells starting at 2 z + j."""
+    M = 2 * m + 1
+    span = float(M * t)
+    pos = {}
+    for u, w, k, j, z in product((0, 1), range(M), range(t), (0, 1), range(m)):
+        across = w * t + k + 0.5
+        along = (2 * z + j + 1) * t
+        x, y = (across, along) if u == 0 else (along, across)
+        pos[(((u * M + w) * t + k) * 2 + j) * m + z] = (x / span, 1.0 - y / span)
+    return pos
+
+
 # solver name -> (generator, h_range, j_range); the ranges are the published
 # QPU properties the reference reads at /root/reference/src/utils/common.py:129
 LOCAL_SOLVERS = {

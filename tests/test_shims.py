@@ -76,3 +76,33 @@ def test_reference_sampler_construction_runs_on_the_local_solver(shim_path):
     assert built.plan.n == 64 and built.plan.n_edges == ours.plan.n_edges
     pairs = lambda p: sorted(zip(np.asarray(p.edge_i).tolist(), np.asarray(p.edge_j).tolist()))  # noqa: E731
     assert pairs(built.plan) == pairs(ours.plan)  # (edge ORDER is a per-sampler detail: couplers are looked up by key)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference checkout not present")
+def test_reference_generate_model_fig_runs_on_the_layout_shim(shim_path, tmp_path, monkeypatch):
+    """The reference's own ``generate_model_fig`` (/root/reference/src/utils/callback_helpers.py:344-381: local solver ->
+    sub-graph -> ``dnx.drawing.pegasus_layout`` / ``zephyr_layout`` -> two plotly figures) over the ``dwave_networkx``
+    shim: every sub-graph node gets a coordinate, couplers join nearby points."""
+    pytest.importorskip("plotly")
+    for mod in ("torchvision", "torchvision.datasets", "torchvision.transforms", "torchvision.utils"):
+        if mod not in sys.modules:
+            sys.modules[mod] = types.ModuleType(mod)
+    tv = sys.modules
+    tv["torchvision.datasets"].MNIST = object
+    for name in ("Compose", "Resize", "ToTensor"):
+        setattr(tv["torchvision.transforms"], name, object)
+    tv["torchvision.utils"].make_grid = tv["torchvision.utils"].save_image = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("assets/model_diagram")
+    from src.utils import callback_helpers as ref_ch  # the reference's own file, unmodified
+
+    for qpu, n in (("Advantage_system4", 64), ("Advantage2_system1", 128)):
+        fig_qpu, fig_not_qpu, latent_mapping = ref_ch.generate_model_fig(qpu, n, 1234)
+        assert sorted(latent_mapping) == list(range(n))
+        edges, nodes = fig_qpu.data[0], fig_qpu.data[1]
+        assert len(nodes.x) == n and len(fig_not_qpu.data) == 1 and len(fig_not_qpu.data[0].x) == n
+        xs = np.asarray([v for v in edges.x if v is not None]).reshape(-1, 2)
+        ys = np.asarray([v for v in edges.y if v is not None]).reshape(-1, 2)
+        assert len(xs) > n and float(np.hypot(xs[:, 0] - xs[:, 1], ys[:, 0] - ys[:, 1]).max()) < 0.1
+        assert len({(round(a, 6), round(b, 6)) for a, b in zip(nodes.x, nodes.y)}) == n
