@@ -1283,11 +1283,18 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     return smem + (m.cols_x ? 0 : TABN * 16) + 8 * D;
   };
   double l_cx = 0.0, l_cy = 0.0;  // kernel sums against x columns / y columns
+  // Per chunk the two float32 running sums of a lane (16 pairs each) move into double accumulators.  For the row sums
+  // this is an accuracy matter, not a nicety: a lane adds ~N/2 table values -- a few dozen DISTINCT values, so the
+  // rounding errors of a float32 chain do not average out -- and x_i * rowsum_i - G_i subtracts two nearly equal
+  // numbers (measured at c3's size against float64: 1.3e-5 of the parts with a float32 chain of 16 k terms per lane).
+  double rowsum_d = 0.0;
   auto flush_lsum = [&](const ChunkMeta& m) {
     const double dl = vi ? (double)lsum : 0.0;
     l_cx += m.cols_x ? dl : 0.0;
     l_cy += m.cols_x ? 0.0 : dl;
     lsum = 0.f;
+    rowsum_d += (double)rowsum;
+    rowsum = 0.f;
   };
 
   i32x4 Bw[2][NTERM];
@@ -1451,7 +1458,9 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 
   // ---- grad[i][f] = x[i][f] * rowsum_i - G^T[f][i]; a lane holds features 32 ft + 8 q + 4 hh + (0..3) of its row in
   // accumulator registers 4 q .. 4 q + 3: one 16-byte store each.  x is +-1: its sign comes from the int8 copy.
-  rowsum += __shfl_xor(rowsum, 32, 64);
+  rowsum_d += (double)rowsum;
+  rowsum_d += __shfl_xor(rowsum_d, 32, 64);
+  rowsum = (float)rowsum_d;
   if (vi) {
     float* out = a.grad_part + (size_t)sp * a.nx * D + gi * D + f0;
     const int8_t* xs = a.zi8 + gi * D + f0;

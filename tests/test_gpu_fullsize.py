@@ -29,8 +29,13 @@ def _rel_l2(got, want):
     return float((got - want).norm() / (want.norm() + 1e-300))
 
 
-def test_decoder_c2_size_matches_float64_oracle_on_device():
-    n, B, R = 128, 256, 8
+# c2's shape; c3's networks (n = 512) at a batch whose launches reach the 128 x 128 tile on their own (B R = 8192 rows);
+# c5's networks (n = 1024)
+NET_SHAPES = [(128, 256, 8), (512, 1024, 8), (1024, 64, 8)]
+
+
+@pytest.mark.parametrize("n,B,R", NET_SHAPES)
+def test_decoder_full_size_matches_float64_oracle_on_device(n, B, R):
     params = gen.make_params(n, "decoder", 77)
     dec = _load(Decoder(n), params).train()
     p = _p64(params)
@@ -57,8 +62,8 @@ def test_decoder_c2_size_matches_float64_oracle_on_device():
         assert _rel_l2(prm.grad, p[name].grad) < 2e-3, name
 
 
-def test_encoder_c2_size_matches_float64_oracle_on_device():
-    n, B = 128, 256
+@pytest.mark.parametrize("n,B,R", NET_SHAPES)
+def test_encoder_full_size_matches_float64_oracle_on_device(n, B, R):
     params = gen.make_params(n, "encoder", 78)
     enc = _load(Encoder(n), params).train()
     p = _p64(params)
@@ -155,9 +160,12 @@ def test_mmd_full_size_properties(nx, ny, d):
         assert float((xa.grad.double() - x64.grad).abs().max()) <= 2e-5 * float(x64.grad.abs().max())
 
 
-def test_gibbs_full_c3_size_bit_exact():
-    """512-spin Zephyr sub-graph, 256 chains, 200 sweeps per draw (BASELINE.json configs[2]) against the C restatement."""
-    seed, n, C, sweeps = 775321899904, 512, 256, 200
+@pytest.mark.parametrize("n,C,sweeps,calls", [(512, 256, 200, 2), (1024, 2048, 50, 1)])
+def test_gibbs_full_size_bit_exact(n, C, sweeps, calls):
+    """c3's draw (512-spin Zephyr sub-graph, 256 chains, 200 sweeps, BASELINE.json configs[2]: twice, persistent chains)
+    and c5's per-GPU slice (1024 spins, 2048 chains, 50 sweeps, configs[4]: the 16-wave workgroup form) against the C
+    restatement, every spin."""
+    seed = 775321899904
     mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(n, seed, graphs.zephyr_graph(12)))
     nodes, ei, ej = graphs.edges_of(mg)
     plan = graphs.build_plan(n, ei, ej)
@@ -170,7 +178,7 @@ def test_gibbs_full_c3_size_bit_exact():
     hs, Js = gibbs.scaled_fields(h, J, 0.05, (-4, 4), (-1, 1))
     ids = np.arange(C, dtype=np.uint32)
     want = cref.init_state(ids, n, seed)
-    for call in range(2):
+    for call in range(calls):
         got = s.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
         want = cref.gibbs_sweeps(want, ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
                                  plan.adj_eid, seed, call * sweeps, sweeps)
