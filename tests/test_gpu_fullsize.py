@@ -128,12 +128,14 @@ def test_mmd_c3_size_against_float64_on_sampled_rows():
     g_xy, = torch.autograd.grad(part_xy, xs)
     want_g = g_xx + g_xy
     got = xa.grad[idx].double()
-    # The gradient is the difference of two sums over ~33 k pairs each (the x-x and the x-y term), here ~30x larger than
-    # their difference, accumulated in float32 (one rounding per MFMA k-step: 2064 of them per element): the error bar is
-    # set against the size of the PARTS, which is what float32 accumulation in any order can promise.
+    # The gradient is the difference of two sums over ~33 k pairs each (the x-x and the x-y term, here ~4x larger than
+    # their difference), accumulated in float32 by the MFMA (one rounding per 16-deep k-step): the bar is set against
+    # the size of the parts.  Measured (tools/mmd_accuracy.py): 4.7e-7 of the parts = 2e-6 of the largest gradient entry
+    # for this kernel (row sums leave float32 once per chunk); the 32-row-block kernels and the general float32 kernel,
+    # whose row sums are float32 chains of thousands of terms, sit at 2-3e-6 of the parts.
     parts = float((g_xx.abs() + g_xy.abs()).max())
-    assert float((got - want_g).abs().max()) <= 1e-5 * parts, (float((got - want_g).abs().max()), parts, float(want_g.abs().max()))
-    assert float((got - want_g).abs().max()) <= 2e-4 * float(want_g.abs().max())
+    assert float((got - want_g).abs().max()) <= 2e-6 * parts, (float((got - want_g).abs().max()), parts, float(want_g.abs().max()))
+    assert float((got - want_g).abs().max()) <= 1e-5 * float(want_g.abs().max())
 
 
 @pytest.mark.parametrize("nx,ny,d", [(2048, 256, 128), (32768, 256, 512)])
