@@ -303,6 +303,9 @@ class ModelWrapper:
                                         weight_decay=self.AUTOENCODER_WEIGHT_DECAY, grad_buffer=self._joint_grad[:nd])
         self._grbm_optimizer = FlatAdam(self._grbm.parameters(), lr=self.BM_INITIAL_LR, weight_decay=self.BM_WEIGHT_DECAY,
                                         grad_buffer=self._joint_grad[nd:])
+        # the networks' backward kernels write their parameter gradients straight into the joint buffer
+        for net in (self._dvae.encoder, self._dvae.decoder):
+            net._grad_sink = [self._dvae_optimizer.grad_view(p) for p in net._trainable()]
 
     def set_dataloader(self, dataloader) -> None:
         """Any iterable of ``(images (B,1,32,32) in {0,1}, labels)`` with ``len()``."""

@@ -37,6 +37,26 @@ def _check_param(t: torch.Tensor, name: str):
 # ------------------------------------------------------------------------------------ encoder
 
 
+def _grad_targets(module, params):
+    """Where the backward kernels write the parameter gradients.  Normally fresh tensors handed back to autograd.  When
+    the module has a gradient sink (``ModelWrapper`` points it at the views of the optimizer's flat gradient buffer) and
+    no parameter holds a gradient yet, the kernels write straight into those views: the flat buffer is then already
+    packed when the backward pass ends -- no per-tensor allocations, no concatenation launch in front of Adam / the
+    all-reduce."""
+    sink = getattr(module, "_grad_sink", None)
+    if sink is not None and len(sink) == len(params) and all(p.grad is None for p in module._trainable()):
+        return sink, True
+    return [torch.empty_like(p) for p in params], False
+
+
+def _grad_returns(module, grads, direct):
+    if not direct:
+        return grads
+    for p, g in zip(module._trainable(), grads):
+        p.grad = g  # (a leaf's .grad may be set directly; autograd is handed None for these inputs)
+    return [None] * len(grads)
+
+
 class _EncoderFn(torch.autograd.Function):
     """args: images, module, then the 18 trainable tensors in registration order."""
 
@@ -66,7 +86,7 @@ class _EncoderFn(torch.autograd.Function):
         x, ws, *params = ctx.saved_tensors
         module = ctx.module
         st = module._native_struct(params)
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = _grad_targets(module, params)
         gs = EncoderGrads()
         for l in range(4):
             gs.conv_w[l], gs.conv_b[l] = grads[4 * l].data_ptr(), grads[4 * l + 1].data_ptr()
@@ -76,7 +96,7 @@ class _EncoderFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(L.dvg_encoder_bwd(ctypes.byref(st), module.n_latents, x.data_ptr(), ctx.B, gl.data_ptr(),
                                     ctypes.byref(gs), ws.data_ptr(), ws.numel(), stream_ptr(x.device)), "dvg_encoder_bwd")
-        return (None, None, *grads)
+        return (None, None, *_grad_returns(module, grads, direct))
 
 
 class Encoder(torch.nn.Module):
@@ -169,7 +189,7 @@ class _DecoderFn(torch.autograd.Function):
         module = ctx.module
         B, R, n = ctx.shape
         st = module._native_struct(params)
-        grads = [torch.empty_like(p) for p in params]
+        grads, direct = _grad_targets(module, params)
         gs = DecoderGrads()
         gs.lin_w, gs.lin_b = grads[0].data_ptr(), grads[1].data_ptr()
         for l in range(4):
@@ -181,7 +201,7 @@ class _DecoderFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(L.dvg_decoder_bwd(ctypes.byref(st), n, x.data_ptr(), B * R, go.data_ptr(), ctypes.byref(gs),
                                     _lib.ptr(gx), ws.data_ptr(), ws.numel(), stream_ptr(x.device)), "dvg_decoder_bwd")
-        return (gx, None, None, None, None, *grads)
+        return (gx, None, None, None, None, *_grad_returns(module, grads, direct))
 
 
 class Decoder(torch.nn.Module):

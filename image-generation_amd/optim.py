@@ -52,8 +52,20 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
+    def grad_view(self, param: torch.nn.Parameter) -> torch.Tensor:
+        """The slice of ``flat_grad`` that holds ``param``'s gradient, shaped like it."""
+        for p, off in zip(self.params, self.offsets):
+            if p is param:
+                return self.flat_grad[off: off + p.numel()].view(p.shape)
+        raise KeyError("parameter does not belong to this optimizer")
+
     def gather_grads(self) -> torch.Tensor:
-        """Pack the per-tensor gradients into ``flat_grad`` (missing gradients count as zero)."""
+        """Pack the per-tensor gradients into ``flat_grad`` (missing gradients count as zero).  Gradients that already
+        live in their slice of the buffer (the modules' backward wrote them there: modules._grad_targets) cost nothing."""
+        base, esz = self.flat_grad.data_ptr(), self.flat_grad.element_size()
+        if all(p.grad is not None and p.grad.data_ptr() == base + off * esz and p.grad.is_contiguous()
+               for p, off in zip(self.params, self.offsets)):
+            return self.flat_grad
         views = []
         for p, off in zip(self.params, self.offsets):
             views.append(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=self.flat.device))

@@ -445,3 +445,40 @@ def test_captured_graph_is_dropped_when_its_tensors_are_replaced(tmp_path, golde
     assert eager == graphed
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+def test_backward_writes_parameter_gradients_into_the_flat_buffer(golden_dir):
+    """The networks' backward kernels write their parameter gradients straight into the optimizer's flat gradient buffer
+    (no per-tensor tensors, no concatenation launch); turning the sink off gives the same gradients and the same step bit
+    for bit; gradients that are already there when a backward runs fall back to autograd's accumulation."""
+    def run(sink):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 2, seed=21)).reshape(2, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(2)])
+        m.train_init(1)
+        if not sink:
+            m._dvae.encoder._grad_sink = m._dvae.decoder._grad_sink = None
+        m.step((imgs[0], None), epoch=0)
+        opt = m._dvae_optimizer
+        base = opt.flat_grad.data_ptr()
+        in_place = [p.grad is not None and p.grad.data_ptr() == base + 4 * off for p, off in zip(opt.params, opt.offsets)]
+        torch.cuda.synchronize()
+        return m, all(in_place), opt.flat_grad.clone(), opt.flat.clone()
+
+    m1, in_place1, g1, p1 = run(True)
+    m0, in_place0, g0, p0 = run(False)
+    assert in_place1 and not in_place0
+    assert torch.equal(g1, g0) and torch.equal(p1, p0)
+    # a second backward without zero_grad: PyTorch semantics (accumulate) through the ordinary autograd path
+    enc = m1._dvae.encoder
+    x = torch.rand(4, 1, 32, 32).cuda()
+    for p in enc.parameters():
+        p.grad = None
+    enc.train()
+    enc(x).sum().backward()
+    once = [p.grad.clone() for p in enc.parameters()]
+    enc(x).sum().backward()
+    for p, g in zip(enc.parameters(), once):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
