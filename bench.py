@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--child", action="store_true", help="(internal) a child run of another configuration: no extras")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay: every step launches its kernels one by one")
     ap.add_argument("--breakdown", default="", help="write the per-kernel HIP-event breakdown (JSON) to this path")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="operands of the forward / data-gradient convolution GEMMs: f32 (the 1e-5 loss parity; the bench "
                          "line) or bf16 inputs with f32 accumulate (BASELINE.json configs[1] names bf16; reported beside it)")
     args = ap.parse_args()
@@ -301,7 +301,7 @@ def main():
     model.keep_step_losses = False  # ... and no per-step copies of the loss scalars into the history lists
 
     L = _lib.lib()
-    _lib.check(L.dvg_set_conv_precision(1 if args.precision == "bf16" else 0), "dvg_set_conv_precision")
+    _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
     is_gemm = lambda nm: nm.startswith("conv_igemm_kernel") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm) or nm == "gibbs_sweeps") if not args.breakdown else (1 << len(names)) - 1

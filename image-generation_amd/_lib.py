@@ -233,16 +233,17 @@ class StepState:
 
 def set_conv_precision(mode: str) -> None:
     """Operands of the forward / data-gradient convolution GEMMs, process-wide (include/dvg.h, dvg_set_conv_precision):
-    ``"f32"`` (default; the 1e-5 loss parity) or ``"bf16"`` (bf16 inputs, f32 accumulate; weight gradients stay f32).
-    A forward pass and its backward pass must run in the same mode."""
-    modes = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+    ``"f32"`` (default: float32 operands on the f32 MFMA), ``"f32x3"`` (float32 operands as three bf16 pieces, six piece
+    products on the bf16 MFMA, float32 accumulation: float32-class results) or ``"bf16"`` (bf16 inputs, f32 accumulate;
+    weight gradients stay f32).  A forward pass and its backward pass must run in the same mode."""
+    modes = {"f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f32x3": 2, "split3": 2}
     if mode not in modes:
         raise ValueError(f"conv precision must be one of {sorted(modes)}, got {mode!r}")
     check(lib().dvg_set_conv_precision(modes[mode]), "dvg_set_conv_precision")
 
 
 def get_conv_precision() -> str:
-    return "bf16" if lib().dvg_get_conv_precision() == 1 else "f32"
+    return {0: "f32", 1: "bf16", 2: "f32x3"}[lib().dvg_get_conv_precision()]
 
 
 def check(rc: int, what: str = "") -> None:

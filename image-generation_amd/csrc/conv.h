@@ -99,14 +99,19 @@ struct ConvArgs {
   int fold = 0;
   float* splitk_ws;   // scratch of conv_splitk_floats() floats, or null: never split K
   int ksplit;         // set by launch_conv_igemm
-  // bf16 = 1: "bf16 GEMM inputs, f32 accumulate" (conv_precision_bf16()): `wp` then points at the bf16 K-major pack
-  // Wp16[tap][b][a] (PackJob.bf16t) and the activations are rounded to bf16 (RNE) on their way into LDS
+  // bf16 = 1: "bf16 GEMM inputs, f32 accumulate" (conv_precision_mode() == 1): `wp` then points at the bf16 K-major pack
+  // Wp16[tap][b][a] (PackJob.bf16t) and the activations are rounded to bf16 (RNE) on their way into LDS.
+  // bf16 = 2: float32 operands as three bf16 pieces (conv_precision_mode() == 2): `wp` points at three such K-major planes
+  // (hi, mid, lo; PackJob.bf16t = 2) and the activations are split into their three pieces on the way into LDS.
   int bf16 = 0;
   // bias_perm = n > 0: column j = p*n + c takes bias[c*4 + p] (the decoder's Linear(n, 4n) bias in checkpoint order)
   int bias_perm = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();
+int conv_precision_mode();  // 0 f32, 1 bf16 inputs, 2 f32 as three bf16 pieces
+// packed-weight buffers are sized for the largest format: three bf16 planes = 6 bytes per entry
+static inline size_t conv_pack_floats(size_t entries) { return (entries * 3 + 1) / 2; }
 void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
 bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
@@ -139,7 +144,8 @@ int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, fl
 // Wp[tap][a][b] <- checkpoint-layout weight
 int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t = 0);
 // several packs in ONE launch (forward and data-gradient packs of a whole network)
-// bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer)
+// bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer);
+// bf16t = 2: three such planes back to back (hi, mid, lo pieces of every weight: hi + mid + lo == w)
 struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; };
 constexpr int MAX_PACK_JOBS = 8;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);

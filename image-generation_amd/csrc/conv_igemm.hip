@@ -25,13 +25,19 @@ namespace dvg {
 // BF = true: bf16 operands in LDS (activations rounded on the way in, weights pre-packed K-major as bf16),
 // v_mfma_f32_32x32x16_bf16, f32 accumulators: same tiles, loaders of A, neighbour table and epilogues.
 // (K depth per iteration measured for the bf16 form: 64 as in the f32 form; 32 and 128 both cost c3 +19 %, c2 +2 %.)
-template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
+// PM = 2: float32 operands as three bf16 pieces each (f32_split3), six piece products per k-step (everything down to
+// 2^-16 of a product; the three dropped ones are below 2^-23): float32-class results on the bf16 MFMA at 6/16 of the f32
+// MFMA's matrix time.  One 32-channel chunk per iteration (three bf16 images of a 32-deep slab fill the LDS a 64-deep
+// float32 slab does: two blocks per CU stay resident), six times the MFMA work of the bf16 form per staged byte.
+template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a) {
-  static_assert(!BF || WK == 1, "bf16 form: no K wave groups");
+  constexpr bool BF = PM != 0;           // operands live in LDS as bf16
+  constexpr int NP = PM == 2 ? 3 : 1;    // bf16 pieces per operand
+  static_assert(!BF || WK == 1, "bf16 forms: no K wave groups");
   constexpr int NT = WM * WN * WK * 64, NTG = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int BK = 64;                 // K per wave group and iteration: two 32-channel chunks (possibly of different taps)
-  constexpr int KH = 2 * WK, BKT = BK * WK;  // chunks / K extent staged per iteration by the whole block
+  constexpr int BK = PM == 2 ? 32 : 64;  // K per wave group and iteration: 32-channel chunks (possibly of different taps)
+  constexpr int KH = (BK / 32) * WK, BKT = BK * WK;  // chunks / K extent staged per iteration by the whole block
   // A rows are 16-byte aligned so the staging stores are ds_write_b128; the MFMA A-operand reads (one float per lane,
   // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
   constexpr int AP = BKT + 4, BP = BN + 4;
@@ -45,9 +51,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   extern __shared__ __align__(16) unsigned char igemm_smem[];  // conv_igemm_lds_bytes<...>() bytes
   float* As = reinterpret_cast<float*>(igemm_smem);            // [BM][AP]
   float* Bs = As + BM * AP;                                    // [BKT][BP]
-  uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 form: [BM][AP16], then Bs16 [BN][AP16] (K-major)
-  uint16_t* Bs16 = As16 + BM * AP16;
-  float* red = BF ? reinterpret_cast<float*>(Bs16 + BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
+  uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 forms: [NP][BM][AP16], then Bs16 [NP][BN][AP16] (K-major)
+  uint16_t* Bs16 = As16 + NP * BM * AP16;
+  float* red = BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
   int* nbr = reinterpret_cast<int*>(red + WM * BN * 2);        // [BM][NBS] source row of every (tile row, tap), -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,6 +95,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   const char* in_bytes = reinterpret_cast<const char*>(a.in);
   const char* wp_bytes = reinterpret_cast<const char*>(a.wp);
   const uint32_t row_bytes = (uint32_t)a.Cin * 4u, wrow_bytes = (uint32_t)a.Cout * 4u;
+  // split mode: byte distance between the piece planes of the packed weights ([taps][Cout][Cin] bf16 each)
+  const uint32_t plane_bytes = (uint32_t)((a.fold == 1 ? 16 : a.ntaps) * a.Cin * a.Cout) * 2u;
   const int nci = a.Cin >> 5, nchunk = a.ntaps * nci, niter = (nchunk + KH - 1) / KH;
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -129,11 +137,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
           (uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;             \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
         const int idx = BPART ? (tid < NB16 ? tid : NB16 - 1) : tid + NT * q;  /* clamped: spare threads re-read */   \
-        if constexpr (BF) {  /* Wp16[tap][col][ci]: 4 x 16 bytes per column and chunk */                              \
+        if constexpr (BF) {  /* Wp16[piece][tap][col][ci]: 4 x 16 bytes per column, chunk and piece */                \
           const int col = idx >> 2, q4 = idx & 3;                                                                     \
           const uint32_t off = ((uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cout + n0 + col) * (uint32_t)a.Cin +  \
                                 (uint32_t)(cc * 32 + q4 * 8)) * 2u;                                                   \
-          BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + off);                                               \
+          _Pragma("unroll") for (int pc = 0; pc < NP; ++pc)                                                           \
+            BREG[h][q * NP + pc] = *reinterpret_cast<const f32x4*>(wp_bytes + (off + (uint32_t)pc * plane_bytes));    \
         } else {                                                                                                      \
           const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
           BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u)); \
@@ -150,7 +159,17 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
         const int row = (tid + NT * q) >> 3;                                                                          \
         const float mk = AMASK[h][q];                                                                                 \
         const f32x4 v = AREG[h][q] * mk;                                                                              \
-        if constexpr (BF) {                                                                                           \
+        if constexpr (PM == 2) {                                                                                      \
+          uint16_t ph[4], pm[4], pl[4];                                                                               \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) f32_split3(v[u], ph[u], pm[u], pl[u]);                        \
+          uint16_t* dst = As16 + row * AP16 + h * 32 + ac4 * 4;                                                       \
+          *reinterpret_cast<uint2*>(dst) =                                                                            \
+              make_uint2((uint32_t)ph[0] | ((uint32_t)ph[1] << 16), (uint32_t)ph[2] | ((uint32_t)ph[3] << 16));       \
+          *reinterpret_cast<uint2*>(dst + BM * AP16) =                                                                \
+              make_uint2((uint32_t)pm[0] | ((uint32_t)pm[1] << 16), (uint32_t)pm[2] | ((uint32_t)pm[3] << 16));       \
+          *reinterpret_cast<uint2*>(dst + 2 * BM * AP16) =                                                            \
+              make_uint2((uint32_t)pl[0] | ((uint32_t)pl[1] << 16), (uint32_t)pl[2] | ((uint32_t)pl[3] << 16));       \
+        } else if constexpr (BF) {                                                                                    \
           uint2 pk;                                                                                                   \
           pk.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);                           \
           pk.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);                           \
@@ -162,8 +181,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
         const int idx = tid + NT * q;                                                                                 \
         if constexpr (BF) {                                                                                           \
-          if (!BPART || idx < NB16)                                                                                   \
-            *reinterpret_cast<f32x4*>(Bs16 + (idx >> 2) * AP16 + h * 32 + (idx & 3) * 8) = BREG[h][q];                \
+          if (!BPART || idx < NB16) {                                                                                 \
+            _Pragma("unroll") for (int pc = 0; pc < NP; ++pc)                                                         \
+              *reinterpret_cast<f32x4*>(Bs16 + pc * BN * AP16 + (idx >> 2) * AP16 + h * 32 + (idx & 3) * 8) =         \
+                  BREG[h][q * NP + pc];                                                                               \
+          }                                                                                                           \
         } else {                                                                                                      \
           const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
           if (!BPART || idx < NB16) *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];      \
@@ -197,12 +219,38 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   } while (0)
 
   {
-    f32x4 aA[KH][RA], bA[KH][RB];
+    f32x4 aA[KH][RA], bA[KH][RB * NP];
     float mA[KH][RA];
     for (int it = it_beg; it <= it_end; ++it) {
       if (it < it_end) IGEMM_LOAD(aA, bA, mA, it);
       if (it > it_beg) {
-        if constexpr (BF) {
+        if constexpr (PM == 2) {
+          // two 16-deep k-steps per 32-deep slab; per step the three pieces of every A row / B column fragment, then
+          // the six piece products, smallest first (lo hi, hi lo, mid mid, mid hi, hi mid, hi hi) into ONE accumulator
+          const uint16_t* ap = As16 + (wm * TM * 32 + c) * AP16 + 8 * hh;
+          const uint16_t* bp = Bs16 + (wn * TN * 32 + c) * AP16 + 8 * hh;
+#pragma unroll
+          for (int s = 0; s < BK / 16; ++s) {
+            bf16x8v av[3][TM], bv[3][TN];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+                av[pc][i] = *reinterpret_cast<const bf16x8v*>(ap + pc * BM * AP16 + i * 32 * AP16 + 16 * s);
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                bv[pc][j] = *reinterpret_cast<const bf16x8v*>(bp + pc * BN * AP16 + j * 32 * AP16 + 16 * s);
+            }
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t]][i], bv[PB[t]][j], acc[i][j], 0, 0, 0);
+          }
+        } else if constexpr (BF) {
           // four 16-deep k-steps per 64-deep slab; operands are 16-byte LDS reads (8 bf16 of this lane's row / column)
           const uint16_t* ap = As16 + (wm * TM * 32 + c) * AP16 + 8 * hh;
           const uint16_t* bp = Bs16 + (wn * TN * 32 + c) * AP16 + 8 * hh;
@@ -389,16 +437,17 @@ static int igemm_cfg(int64_t M, int Cout) {
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;
 }
-template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
+template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static constexpr size_t conv_igemm_lds_bytes() {
-  if (BF) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
+  if (PM == 2) return sizeof(uint16_t) * (size_t)(3 * (BM + BN) * (32 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
+  if (PM == 1) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
 }
 
-template <int BM, int BN, int WM, int WN, int WK, bool BF = false>
+template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, BF>();
-  auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, BF>;
+  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>();
+  auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, PM>;
   static bool attr_set = false;  // one instantiation = one static
   if (lds > 64 * 1024 && !attr_set) {
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -436,7 +485,7 @@ size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) 
 
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
-  if (conv_precision_bf16()) a.bf16 = 1;  // the packs were written in the matching format (launch_weight_pack*)
+  a.bf16 = conv_precision_mode();  // the packs were written in the matching format (launch_weight_pack*)
   const bool taps_ok = a.fold == 1 ? a.ntaps == 4 : a.fold == 2 ? a.ntaps == 16 : (a.ntaps == 9 || a.ntaps == 1);
   if (a.fold && (a.ups || a.poolsum || !conv_fold_ok(a.M))) {
     set_error("conv_igemm: fold=%d needs ups=poolsum=0 and whole 128-row blocks (M=%lld)", a.fold, (long long)a.M);
@@ -462,13 +511,21 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
   int rc;
-  if (a.bf16) {
+  if (a.bf16 == 2) {
     switch (cfg) {
-      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, true>(K_IGEMM_128x64, flops, grid, a, s); break;
-      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, true>(K_IGEMM_64x64, flops, grid, a, s); break;
-      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, true>(K_IGEMM_32x64, flops, grid, a, s); break;
-      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, true>(K_IGEMM_128x128, flops, grid, a, s); break;
-      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, true>(K_IGEMM_128x32, flops, grid, a, s); break;
+      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 2>(K_IGEMM_128x64, flops, grid, a, s); break;
+      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 2>(K_IGEMM_64x64, flops, grid, a, s); break;
+      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 2>(K_IGEMM_32x64, flops, grid, a, s); break;
+      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 2>(K_IGEMM_128x128, flops, grid, a, s); break;
+      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 2>(K_IGEMM_128x32, flops, grid, a, s); break;
+    }
+  } else if (a.bf16) {
+    switch (cfg) {
+      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
+      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 1>(K_IGEMM_64x64, flops, grid, a, s); break;
+      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 1>(K_IGEMM_32x64, flops, grid, a, s); break;
+      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 1>(K_IGEMM_128x128, flops, grid, a, s); break;
+      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 1>(K_IGEMM_128x32, flops, grid, a, s); break;
     }
   } else
   switch (cfg) {

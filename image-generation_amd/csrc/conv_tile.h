@@ -17,6 +17,17 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float v) {
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// x = hi + mid + lo with three bf16 pieces (round to nearest even each): exact for every finite float32 whose low pieces
+// do not underflow (3 x 8 significand bits).  The operand format of the split mode (conv_precision_mode() == 2).
+__device__ __forceinline__ void f32_split3(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+  hi = f32_to_bf16_rne(x);
+  const float r1 = x - bf16_to_f32(hi);
+  mid = f32_to_bf16_rne(r1);
+  lo = f32_to_bf16_rne(r1 - bf16_to_f32(mid));
+}
+
 // Diagnostic build only (-DDVG_STAMP): per-phase cycle sums of the main loop, written to ConvArgs.stats
 // (which the diagnostic harness points at a debug buffer: 8 uint64 per block).  Never in the product build.
 #ifdef DVG_STAMP

@@ -472,6 +472,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// one packed entry in the format `fmt`: 0 = f32 [tap][a][b] (index e); 1 = bf16 K-major [tap][b][a] (index kmaj);
+// 2 = three bf16 K-major planes, the exact pieces hi + mid + lo of the weight
+__device__ __forceinline__ void pack_store(float* wp, int64_t total, int64_t kmaj, int64_t e, float v, int fmt) {
+  if (fmt == 0) { wp[e] = v; return; }
+  uint16_t* w16 = reinterpret_cast<uint16_t*>(wp);
+  const uint16_t hi = f32_to_bf16_rne(v);
+  w16[kmaj] = hi;
+  if (fmt == 2) {
+    const float r1 = v - bf16_to_f32(hi);
+    const uint16_t mid = f32_to_bf16_rne(r1);
+    w16[total + kmaj] = mid;
+    w16[2 * total + kmaj] = f32_to_bf16_rne(r1 - bf16_to_f32(mid));
+  }
+}
+
 __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ wp,
                                                           int bf16t) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
@@ -480,8 +495,7 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restric
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
     const float v = packed_weight(w, map, tap, a, b);
-    if (bf16t) reinterpret_cast<uint16_t*>(wp)[((int64_t)tap * map.Cb + b) * map.Ca + a] = f32_to_bf16_rne(v);
-    else wp[e] = v;
+    pack_store(wp, total, ((int64_t)tap * map.Cb + b) * map.Ca + a, e, v, bf16t);
   }
 }
 
@@ -496,8 +510,7 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
     const int a = (int)((e / map.Cb) % map.Ca);
     const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
     const float v = packed_weight(j.w, map, tap, a, b);
-    if (j.bf16t) reinterpret_cast<uint16_t*>(j.wp)[((int64_t)tap * map.Cb + b) * map.Ca + a] = f32_to_bf16_rne(v);
-    else j.wp[e] = v;
+    pack_store(j.wp, total, ((int64_t)tap * map.Cb + b) * map.Ca + a, e, v, j.bf16t);
   }
 }
 
@@ -507,7 +520,7 @@ int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s) {
   int64_t biggest = 0;
   for (int k = 0; k < njobs; ++k) {
     pj.job[k] = jobs[k];
-    if (conv_precision_bf16()) pj.job[k].bf16t = 1;  // every pack feeds launch_conv_igemm
+    pj.job[k].bf16t = conv_precision_mode();  // every pack feeds launch_conv_igemm
     const int64_t t = (int64_t)jobs[k].map.ntaps * jobs[k].map.Ca * jobs[k].map.Cb;
     if (t > biggest) biggest = t;
   }
@@ -536,7 +549,7 @@ int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, 
 }
 
 int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t) {
-  if (conv_precision_bf16()) bf16t = 1;
+  if (conv_precision_mode()) bf16t = conv_precision_mode();
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
   DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w, map, wp, bf16t);
   return DVG_OK;

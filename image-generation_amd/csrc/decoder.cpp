@@ -47,8 +47,8 @@ DecPlan dec_plan(int64_t N, int n) {
   for (int i = 0; i < 5; ++i) p.ch[i] = ch[i];
   size_t o = 0;
   p.X0 = bump(o, (size_t)N * 4 * n);
-  p.wp_lin = bump(o, (size_t)n * 4 * n);
-  p.wpd_lin = bump(o, (size_t)n * 4 * n);
+  p.wp_lin = bump(o, conv_pack_floats((size_t)n * 4 * n));
+  p.wpd_lin = bump(o, conv_pack_floats((size_t)n * 4 * n));
   p.bias_lin = bump(o, (size_t)4 * n);
   p.ksplit_lin = wgrad_ksplit(N, n, 4 * n, 1);
   size_t max_slab = (size_t)p.ksplit_lin * n * 4 * n;
@@ -69,8 +69,8 @@ DecPlan dec_plan(int64_t N, int n) {
     p.stats[l] = bump(o, (size_t)(p.nblk[l] + BN_FOLD_ROWS) * C * 2);  // + scratch rows of launch_bn_finalize
     p.mask[l] = bump(o, (size_t)N * C);
     if (l < 3) {
-      p.wp[l] = bump(o, (size_t)16 * ch[l] * C);   // 9 taps, or 16 folded (class, tap) pairs
-      p.wpd[l] = bump(o, (size_t)16 * ch[l] * C);
+      p.wp[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));   // 9 taps, or 16 folded (class, tap) pairs
+      p.wpd[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));
       p.ksplit[l] = p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * (p.fold[l] ? 16 : 9) * ch[l] * C;
       if (slab > max_slab) max_slab = slab;

@@ -52,8 +52,8 @@ EncPlan enc_plan(int64_t B, int n) {
     p.wp[l] = p.wpd[l] = 0;
     p.ksplit[l] = 0;
     if (l > 0) {
-      p.wp[l] = bump(o, (size_t)9 * ch[l] * C);
-      p.wpd[l] = bump(o, (size_t)9 * ch[l] * C);
+      p.wp[l] = bump(o, conv_pack_floats((size_t)9 * ch[l] * C));
+      p.wpd[l] = bump(o, conv_pack_floats((size_t)9 * ch[l] * C));
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;

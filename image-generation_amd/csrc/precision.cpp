@@ -3,6 +3,10 @@
 //   1            "bf16 GEMM inputs, f32 accumulate" (BASELINE.json configs[1]): activations and weights
 //                are rounded to bf16 (round to nearest even) on their way into LDS, products and sums stay f32
 //                (v_mfma_f32_32x32x16_bf16).  Weight gradients, BatchNorm, losses, Adam stay float32.
+//   2            float32 operands carried as THREE bf16 pieces each (x = hi + mid + lo exactly: 3 x 8 significand bits),
+//                multiplied as the six piece products down to 2^-16 (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid) on
+//                v_mfma_f32_32x32x16_bf16 with f32 accumulation: every piece product is exact, what is dropped is below
+//                2^-23 of a product -- float32-class arithmetic at 6/16 of the f32 MFMA's matrix time.
 // A forward call and its backward call must run in the same mode (the backward reuses the forward's weight packs).
 #include <atomic>
 #include <cstdlib>
@@ -13,6 +17,7 @@
 
 namespace dvg {
 bool conv_precision_bf16();
+int conv_precision_mode();
 namespace {
 std::atomic<int> g_mode{-1};
 std::mutex g_ws_mutex;
@@ -24,27 +29,30 @@ std::unordered_map<const void*, int> g_ws_mode;  // mode of the last forward cal
 void conv_precision_note_forward(const void* ws) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   if (g_ws_mode.size() > 4096) g_ws_mode.clear();
-  g_ws_mode[ws] = conv_precision_bf16() ? 1 : 0;
+  g_ws_mode[ws] = conv_precision_mode();
 }
 bool conv_precision_matches_forward(const void* ws) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   auto it = g_ws_mode.find(ws);
-  return it == g_ws_mode.end() || it->second == (conv_precision_bf16() ? 1 : 0);
+  return it == g_ws_mode.end() || it->second == conv_precision_mode();
 }
 
-bool conv_precision_bf16() {
+int conv_precision_mode() {
   int m = g_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = getenv("DVG_CONV_BF16");
+    const char* e2 = getenv("DVG_CONV_MODE");  // 0 / 1 / 2
     m = (e && e[0] == '1') ? 1 : 0;
+    if (e2 && e2[0] >= '0' && e2[0] <= '2') m = e2[0] - '0';
     g_mode.store(m, std::memory_order_relaxed);
   }
-  return m == 1;
+  return m;
 }
+bool conv_precision_bf16() { return conv_precision_mode() == 1; }
 }  // namespace dvg
 
 extern "C" int dvg_set_conv_precision(int mode) {
-  if (mode != DVG_PRECISION_F32 && mode != DVG_PRECISION_BF16_INPUTS) {
+  if (mode != DVG_PRECISION_F32 && mode != DVG_PRECISION_BF16_INPUTS && mode != DVG_PRECISION_F32_SPLIT3) {
     dvg::set_error("dvg_set_conv_precision: unknown mode %d", mode);
     return DVG_E_INVALID;
   }
@@ -52,4 +60,4 @@ extern "C" int dvg_set_conv_precision(int mode) {
   return DVG_OK;
 }
 
-extern "C" int dvg_get_conv_precision(void) { return dvg::conv_precision_bf16() ? DVG_PRECISION_BF16_INPUTS : DVG_PRECISION_F32; }
+extern "C" int dvg_get_conv_precision(void) { return dvg::conv_precision_mode(); }

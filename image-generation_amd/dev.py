@@ -60,7 +60,7 @@ def conv_igemm(x_m, w, mode, M, Cin, Cout, L, ntaps=9, ups=0, poolsum=0, bias=No
                splitk=True):
     Lb = lib()
     dev = x_m.device
-    wp = wp if wp is not None else torch.empty(ntaps * Cin * Cout, device=dev)
+    wp = wp if wp is not None else torch.empty((ntaps * Cin * Cout * 3 + 1) // 2, device=dev)  # (up to three bf16 planes)
     out = torch.empty(((M // 4) if poolsum else M, Cout), device=dev)
     st = torch.empty((Lb.dvg_dev_conv_stats_blocks(M, Cout), Cout, 2), device=dev) if stats else None
     nsk = Lb.dvg_dev_conv_splitk_floats(M, Cin, Cout, ntaps, poolsum) if splitk else 0

@@ -265,10 +265,15 @@ int dvg_stream_anchor(dvg_stream_t stream);
  * reference's CPU path.  DVG_PRECISION_BF16_INPUTS: "bf16 GEMM inputs, f32 accumulate" for the forward and
  * data-gradient GEMMs of encoder and decoder -- what a `torch.autocast(bfloat16)` run of src/encoder.py:28-30 /
  * src/decoder.py:28,34-38 would feed its convolutions; weight gradients, BatchNorm, losses and Adam stay float32.
- * Environment DVG_CONV_BF16=1 selects the bf16 mode at first use.
+ * DVG_PRECISION_F32_SPLIT3: float32 operands of the same GEMMs carried as three bf16 pieces each (x = hi + mid + lo,
+ * exact) and multiplied as the six piece products down to 2^-16 on the bf16 MFMA with float32 accumulation: what is
+ * dropped is below 2^-23 of a product, i.e. float32-class results (same parity bars as DVG_PRECISION_F32) at 6/16 of
+ * the f32 MFMA's matrix time.
+ * Environment DVG_CONV_BF16=1 / DVG_CONV_MODE=0|1|2 select the mode at first use.
  */
 #define DVG_PRECISION_F32 0
 #define DVG_PRECISION_BF16_INPUTS 1
+#define DVG_PRECISION_F32_SPLIT3 2
 int dvg_set_conv_precision(int mode);
 int dvg_get_conv_precision(void);
 

@@ -34,8 +34,18 @@ def _rel_l2(got, want):
 NET_SHAPES = [(128, 256, 8), (512, 1024, 8), (1024, 64, 8)]
 
 
+@pytest.fixture(params=["f32", "f32x3"])
+def conv_mode(request):
+    """Both float32-class arithmetic modes of the forward / data-gradient GEMMs meet the same bars: float32 operands on
+    the f32 MFMA, and float32 operands as three bf16 pieces (six piece products) on the bf16 MFMA."""
+    from image_generation_amd import _lib
+    _lib.set_conv_precision(request.param)
+    yield request.param
+    _lib.set_conv_precision("f32")
+
+
 @pytest.mark.parametrize("n,B,R", NET_SHAPES)
-def test_decoder_full_size_matches_float64_oracle_on_device(n, B, R):
+def test_decoder_full_size_matches_float64_oracle_on_device(conv_mode, n, B, R):
     params = gen.make_params(n, "decoder", 77)
     dec = _load(Decoder(n), params).train()
     p = _p64(params)
@@ -65,7 +75,7 @@ def test_decoder_full_size_matches_float64_oracle_on_device(n, B, R):
 
 
 @pytest.mark.parametrize("n,B,R", NET_SHAPES)
-def test_encoder_full_size_matches_float64_oracle_on_device(n, B, R):
+def test_encoder_full_size_matches_float64_oracle_on_device(conv_mode, n, B, R):
     params = gen.make_params(n, "encoder", 78)
     enc = _load(Encoder(n), params).train()
     p = _p64(params)

@@ -143,3 +143,72 @@ def test_bf16_inputs_linear_as_one_tap_gemm():
         dx = dev.conv_igemm(gyp.cuda(), w.cuda(), 5, N, 4 * n, n, 0, ntaps=1)
     assert _rel(out.cpu(), y_r.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n)) < 3e-6
     assert _rel(dx.cpu(), dx_r) < 3e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# DVG_PRECISION_F32_SPLIT3: float32 operands as three bf16 pieces, six piece products on the bf16 MFMA, float32
+# accumulation.  The bar is the float32 kernel's own: against float64 it must be as close as the f32-MFMA form is.
+
+class _split3:
+    def __enter__(self):
+        from image_generation_amd import _lib
+        self.lib = _lib.lib()
+        assert self.lib.dvg_set_conv_precision(2) == 0 and self.lib.dvg_get_conv_precision() == 2
+
+    def __exit__(self, *exc):
+        assert self.lib.dvg_set_conv_precision(0) == 0
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8),
+                                             (256, 128, 128, 4), (64, 128, 128, 4), (40, 128, 128, 8), (512, 128, 256, 8)])
+def test_split3_conv2d_fwd_dgrad_is_float32_class(N, Cin, Cout, side):
+    torch.manual_seed(N)
+    x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    L, M = side.bit_length() - 1, N * side * side
+    xm, gm = dev.nchw_to_morton(x).cuda(), dev.nchw_to_morton(gy).cuda()
+    out_f, st_f = dev.conv_igemm(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+    dx_f = dev.conv_igemm(gm, w.cuda(), 1, M, Cout, Cin, L)
+    with _split3():
+        out, st = dev.conv_igemm(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+        dx = dev.conv_igemm(gm, w.cuda(), 1, M, Cout, Cin, L)
+    e_s = _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side).double(), y64)
+    e_f = _rel(dev.morton_to_nchw(out_f.cpu(), N, Cout, side).double(), y64)
+    assert e_s < 3e-7 and e_s < 3 * e_f + 1e-8, (e_s, e_f)   # float32-class: within a small factor of the f32 MFMA's own error
+    d_s = _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side).double(), dx64)
+    d_f = _rel(dev.morton_to_nchw(dx_f.cpu(), N, Cin, side).double(), dx64)
+    assert d_s < 3e-7 and d_s < 3 * d_f + 1e-8, (d_s, d_f)
+    s = st.sum(0).cpu()
+    assert _rel(s[:, 0].double(), y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1].double(), (y64 ** 2).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(4, 128, 64, 4), (3, 64, 32, 8), (2, 96, 128, 2), (128, 128, 64, 8)])
+def test_split3_convtranspose_with_fused_upsample_and_fold(N, Cin, Cout, side):
+    torch.manual_seed(side)
+    xs = torch.randn(N, Cin, side // 2, side // 2); w = torch.randn(Cin, Cout, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    x64 = xs.double().requires_grad_(True)
+    y64 = F.conv_transpose2d(F.interpolate(x64, scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    y64.backward(gy.double())
+    L, M = side.bit_length() - 1, N * side * side
+    with _split3():
+        out = dev.conv_igemm(dev.nchw_to_morton(xs).cuda(), w.cuda(), 2, M, Cin, Cout, L, ups=1, bias=b.cuda())
+        dx = dev.conv_igemm(dev.nchw_to_morton(gy).cuda(), w.cuda(), 3, M, Cout, Cin, L, poolsum=1)
+    assert _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side).double(), y64.detach()) < 3e-7
+    assert _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side // 2).double(), x64.grad) < 5e-7
+
+
+def test_split3_linear_as_one_tap_gemm():
+    torch.manual_seed(0)
+    N, n = 37, 64
+    x = torch.randn(N, n); w = torch.randn(4 * n, n) / n**0.5
+    gy = torch.randn(N, 4 * n)
+    y64 = F.linear(x.double(), w.double())
+    gyp = gy.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n).contiguous()
+    with _split3():
+        out = dev.conv_igemm(x.cuda(), w.cuda(), 4, N, n, 4 * n, 0, ntaps=1)
+        dx = dev.conv_igemm(gyp.cuda(), w.cuda(), 5, N, 4 * n, n, 0, ntaps=1)
+    assert _rel(out.cpu().double(), y64.reshape(N, n, 4).permute(0, 2, 1).reshape(N, 4 * n)) < 3e-7
+    assert _rel(dx.cpu().double(), gy.double() @ w.double()) < 3e-7

@@ -482,3 +482,19 @@ def test_backward_writes_parameter_gradients_into_the_flat_buffer(golden_dir):
     enc(x).sum().backward()
     for p, g in zip(enc.parameters(), once):
         assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
+
+
+def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
+    """The 12-step fixture of the reference's own ``ModelWrapper.step`` under DVG_PRECISION_F32_SPLIT3 (float32 operands
+    as three bf16 pieces on the bf16 MFMA): the north star's 1e-5 relative on every loss of every step, as in float32."""
+    import __graft_entry__ as entry
+    from image_generation_amd import _lib
+
+    _lib.set_conv_precision("f32x3")
+    try:
+        r = entry.parity_check(steps=12)
+    finally:
+        _lib.set_conv_precision("f32")
+    assert r["gibbs_spin_mismatches"] == 0
+    for name, dev_ in r["max_rel_dev"].items():
+        assert dev_ <= 1e-5, (name, dev_)
