@@ -146,7 +146,12 @@ int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStrea
 // several packs in ONE launch (forward and data-gradient packs of a whole network)
 // bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer);
 // bf16t = 2: three such planes back to back (hi, mid, lo pieces of every weight: hi + mid + lo == w)
-struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; };
+// rows: GEMM rows of the launch this pack feeds (launch_conv_igemm's M over all classes): together with map.Cb it
+// decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
+struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; };
+// operand format of one forward / data-gradient launch: the process-wide mode, except that the split mode (2) only
+// serves launches large enough for the 128 x 128 tile (smaller ones are latency-bound: the float32 kernel is faster)
+int conv_launch_mode(int64_t gemm_rows, int Cout);
 constexpr int MAX_PACK_JOBS = 8;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);
 

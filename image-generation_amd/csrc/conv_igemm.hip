@@ -160,15 +160,13 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
         const float mk = AMASK[h][q];                                                                                 \
         const f32x4 v = AREG[h][q] * mk;                                                                              \
         if constexpr (PM == 2) {                                                                                      \
-          uint16_t ph[4], pm[4], pl[4];                                                                               \
-          _Pragma("unroll") for (int u = 0; u < 4; ++u) f32_split3(v[u], ph[u], pm[u], pl[u]);                        \
+          /* truncation split: 5 VALU per element, exact (hi + mid + lo == v bit for bit) */                        \
+          uint32_t ph[4], pm[4], pl[4];                                                                               \
+          _Pragma("unroll") for (int u = 0; u < 4; ++u) f32_split3_trunc(v[u], ph[u], pm[u], pl[u]);                  \
           uint16_t* dst = As16 + row * AP16 + h * 32 + ac4 * 4;                                                       \
-          *reinterpret_cast<uint2*>(dst) =                                                                            \
-              make_uint2((uint32_t)ph[0] | ((uint32_t)ph[1] << 16), (uint32_t)ph[2] | ((uint32_t)ph[3] << 16));       \
-          *reinterpret_cast<uint2*>(dst + BM * AP16) =                                                                \
-              make_uint2((uint32_t)pm[0] | ((uint32_t)pm[1] << 16), (uint32_t)pm[2] | ((uint32_t)pm[3] << 16));       \
-          *reinterpret_cast<uint2*>(dst + 2 * BM * AP16) =                                                            \
-              make_uint2((uint32_t)pl[0] | ((uint32_t)pl[1] << 16), (uint32_t)pl[2] | ((uint32_t)pl[3] << 16));       \
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]));             \
+          *reinterpret_cast<uint2*>(dst + BM * AP16) = make_uint2(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3])); \
+          *reinterpret_cast<uint2*>(dst + 2 * BM * AP16) = make_uint2(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3])); \
         } else if constexpr (BF) {                                                                                    \
           uint2 pk;                                                                                                   \
           pk.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);                           \
@@ -457,6 +455,14 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
   return DVG_OK;
 }
 
+// DVG_SPLIT3_ALL=1: the split form for every tile configuration (tests, A/B runs)
+int conv_launch_mode(int64_t gemm_rows, int Cout) {
+  const int mode = conv_precision_mode();
+  if (mode != 2) return mode;
+  static const bool all = [] { const char* e = getenv("DVG_SPLIT3_ALL"); return e && e[0] == '1'; }();
+  return (all || igemm_cfg(gemm_rows, Cout) == 4) ? 2 : 0;
+}
+
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
 static int igemm_bn(int cfg) { return cfg == 2 ? 32 : cfg == 4 ? 128 : 64; }
 
@@ -485,7 +491,8 @@ size_t conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) 
 
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
-  a.bf16 = conv_precision_mode();  // the packs were written in the matching format (launch_weight_pack*)
+  // (the packs were written in the matching format: launch_weight_pack_multi makes the same decision per job)
+  a.bf16 = conv_launch_mode(a.fold == 1 ? a.M * 4 : a.M, a.Cout);
   const bool taps_ok = a.fold == 1 ? a.ntaps == 4 : a.fold == 2 ? a.ntaps == 16 : (a.ntaps == 9 || a.ntaps == 1);
   if (a.fold && (a.ups || a.poolsum || !conv_fold_ok(a.M))) {
     set_error("conv_igemm: fold=%d needs ups=poolsum=0 and whole 128-row blocks (M=%lld)", a.fold, (long long)a.M);

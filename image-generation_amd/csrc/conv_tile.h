@@ -28,6 +28,17 @@ __device__ __forceinline__ void f32_split3(float x, uint16_t& hi, uint16_t& mid,
   lo = f32_to_bf16_rne(r1 - bf16_to_f32(mid));
 }
 
+// The same decomposition by truncation, on the float's bits (hi = top 8 significand bits, mid = next 8, lo = last 8: hi + mid
+// + lo == x bit for bit, all three of x's sign): five VALU instructions per element, what the GEMM kernels can afford for
+// every activation they stage.  Returned as float32 bit patterns whose low 16 bits are zero.
+__device__ __forceinline__ void f32_split3_trunc(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  hi = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  lo = __float_as_uint(r1 - __uint_as_float(mid)) & 0xffff0000u;  // (at most 8 significant bits are left: exact)
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
 // Diagnostic build only (-DDVG_STAMP): per-phase cycle sums of the main loop, written to ConvArgs.stats
 // (which the diagnostic harness points at a debug buffer: 8 uint64 per block).  Never in the product build.
 #ifdef DVG_STAMP

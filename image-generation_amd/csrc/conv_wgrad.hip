@@ -520,7 +520,8 @@ int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s) {
   int64_t biggest = 0;
   for (int k = 0; k < njobs; ++k) {
     pj.job[k] = jobs[k];
-    pj.job[k].bf16t = conv_precision_mode();  // every pack feeds launch_conv_igemm
+    // every pack feeds launch_conv_igemm: same format decision as that launch will make
+    pj.job[k].bf16t = jobs[k].rows > 0 ? conv_launch_mode(jobs[k].rows, jobs[k].map.Cb) : conv_precision_mode();
     const int64_t t = (int64_t)jobs[k].map.ntaps * jobs[k].map.Ca * jobs[k].map.Cb;
     if (t > biggest) biggest = t;
   }

@@ -134,16 +134,17 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
   // Linear(n, 4n) -> X0 (N, 2x2 Morton, n)
   {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
     PackJob jobs[8];
-    jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}};
-    jobs[1] = PackJob{p->lin_w, W + pl.wpd_lin, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}};
+    jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, 0, N};
+    jobs[1] = PackJob{p->lin_w, W + pl.wpd_lin, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}, 0, N};
     for (int l = 0; l < 3; ++l) {
       if (pl.fold[l]) {
-        jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FOLD_FWD, pl.ch[l], pl.ch[l + 1], 16}};
-        jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_FOLD_DGRAD, pl.ch[l + 1], pl.ch[l], 16}};
+        // (forward: 4 classes x M/4 source rows = M GEMM rows; data gradient: M/4 source rows)
+        jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FOLD_FWD, pl.ch[l], pl.ch[l + 1], 16}, 0, pl.M[l]};
+        jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_FOLD_DGRAD, pl.ch[l + 1], pl.ch[l], 16}, 0, pl.M[l] / 4};
         continue;
       }
-      jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}};
-      jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}};
+      jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l]};
+      jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l]};
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
   }

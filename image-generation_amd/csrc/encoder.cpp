@@ -115,8 +115,8 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
     PackJob jobs[6];
     for (int l = 1; l < 4; ++l) {
-      jobs[2 * (l - 1)] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}};
-      jobs[2 * (l - 1) + 1] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9}};
+      jobs[2 * (l - 1)] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l]};
+      jobs[2 * (l - 1) + 1] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l]};
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 6, s));
   }
