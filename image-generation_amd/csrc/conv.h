@@ -142,7 +142,7 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);
 // Wp[tap][a][b] <- checkpoint-layout weight
-int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t = 0);
+int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t = -1);  // -1: the process-wide mode
 // several packs in ONE launch (forward and data-gradient packs of a whole network)
 // bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer);
 // bf16t = 2: three such planes back to back (hi, mid, lo pieces of every weight: hi + mid + lo == w)

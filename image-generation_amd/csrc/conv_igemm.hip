@@ -459,8 +459,8 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
 int conv_launch_mode(int64_t gemm_rows, int Cout) {
   const int mode = conv_precision_mode();
   if (mode != 2) return mode;
-  static const bool all = [] { const char* e = getenv("DVG_SPLIT3_ALL"); return e && e[0] == '1'; }();
-  return (all || igemm_cfg(gemm_rows, Cout) == 4) ? 2 : 0;
+  const char* e = getenv("DVG_SPLIT3_ALL");  // (read per call: the tests flip it inside one process)
+  return ((e && e[0] == '1') || igemm_cfg(gemm_rows, Cout) == 4) ? 2 : 0;
 }
 
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }

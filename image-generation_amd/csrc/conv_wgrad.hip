@@ -550,7 +550,7 @@ int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, 
 }
 
 int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t) {
-  if (conv_precision_mode()) bf16t = conv_precision_mode();
+  if (bf16t < 0) bf16t = conv_precision_mode();
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
   DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_kernel, dim3(ew_grid(total)), dim3(256), 0, s, w, map, wp, bf16t);
   return DVG_OK;

@@ -8,7 +8,7 @@ extern "C" int dvg_dev_conv_igemm(const float* in, const float* w, int mode, flo
                                   int repack, float* splitk_ws, dvg_stream_t stream) {
   DVG_REQUIRE(in && w && wp && out, "dev_conv_igemm: null argument");
   hipStream_t s = (hipStream_t)stream;
-  if (repack) DVG_TRY(launch_weight_pack(w, WeightMap{mode, Cin, Cout, ntaps}, wp, s));
+  if (repack) DVG_TRY(launch_weight_pack(w, WeightMap{mode, Cin, Cout, ntaps}, wp, s, conv_launch_mode(M, Cout)));
   ConvArgs a;
   a.in = in; a.wp = wp; a.bias = bias; a.out = out; a.stats = stats;
   a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.ntaps = ntaps; a.ups = ups; a.poolsum = poolsum;
