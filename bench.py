@@ -210,6 +210,27 @@ def bf16_inputs_run(args):
         return {"error": repr(exc)}
 
 
+def split3_run(args):
+    """The same workload with the operands of the LARGE forward / data-gradient launches carried as three bf16 pieces each
+    (DVG_PRECISION_F32_SPLIT3: six exact piece products per k-step on the bf16 MFMA, float32 accumulation -- float32-class
+    results, see `loss_parity` inside), timed by a child run of this script.  Reported BESIDE the headline, which stays on
+    the f32 MFMA."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--precision", "f32x3", "--no-cpu-baseline", "--child", "--parity"] + (["--eager"] if args.eager else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        d = json.loads(lines[-1])
+        rf = d["roofline"]
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                "dominant_kernel": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "pricing")},
+                "conv_all": rf.get("conv_all"), "loss_parity": d.get("loss_parity")}
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def extra_config_run(args, config):
     """The other single-GPU configurations (c2 = configs[1], c1 = configs[0]), timed by a child run of this script after
     the headline line is complete; reported under `extra`, never as `value`."""
@@ -266,6 +287,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--child", action="store_true", help="(internal) a child run of another configuration: no extras")
+    ap.add_argument("--parity", action="store_true", help="(internal) run the 12-step loss-parity check in this arithmetic mode")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay: every step launches its kernels one by one")
     ap.add_argument("--breakdown", default="", help="write the per-kernel HIP-event breakdown (JSON) to this path")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3"],
@@ -368,7 +390,15 @@ def main():
         # parts out.  General rows run on the f32 MFMA ("mmd_main").  A candidate whose rate exceeds its peak is a
         # mislabelled launch and is dropped.
         lib_hash = L.dvg_source_hash().decode()
-        bf16_gemm = lambda nm: nm == "mmd_pm1" or (args.precision == "bf16" and nm.startswith("conv_igemm_kernel"))  # noqa: E731
+        # --precision f32x3: the launches of the two large tile configurations run their float32 operands as three bf16 pieces,
+        # i.e. they EXECUTE six bf16 products per algorithmic multiply-add: priced as 6 x the algorithmic FLOPs against the
+        # bf16 peak (the library's work counter holds the algorithmic count; `algorithmic_f32_tflops` keeps it visible)
+        split_gemm = lambda nm: args.precision == "f32x3" and nm in ("conv_igemm_kernel<128,128,2,2,1>", "conv_igemm_kernel<128,64,2,2,1>")  # noqa: E731
+        for k, v in per_kernel.items():
+            if split_gemm(k):
+                v["algorithmic_work"] = v["work"]
+                v["work"] = 6.0 * v["work"]
+        bf16_gemm = lambda nm: nm == "mmd_pm1" or split_gemm(nm) or (args.precision == "bf16" and nm.startswith("conv_igemm_kernel"))  # noqa: E731
         peak_of = lambda nm: PEAK_BF16_MFMA_TFLOPS if bf16_gemm(nm) else PEAK_F32_MFMA_TFLOPS  # noqa: E731
         cands = {k: v for k, v in per_kernel.items() if is_gemm(k) and v["work"] > 0
                  and v["work"] / (v["total_ms"] * 1e-3) / 1e12 <= peak_of(k)}
@@ -379,6 +409,9 @@ def main():
             e = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak_of(k), "unit": "TFLOP/s",
                  "frac": ach / peak_of(k), "avg_launch_us": v["total_ms"] * 1e3 / v["launches"], "launches": v["launches"],
                  "gflop_per_launch": v["work"] / v["launches"] / 1e9, "ms_per_step": v["total_ms"] / prof_steps}
+            if "algorithmic_work" in v:
+                e["unit"] = "TFLOP/s (bf16 products executed: 6 per algorithmic float32 multiply-add)"
+                e["algorithmic_f32_tflops"] = v["algorithmic_work"] / (v["total_ms"] * 1e-3) / 1e12
             e["traffic"], e["traffic_source"] = pmc_traffic(k, args.config, lib_hash)
             e["mfma_busy_pmc"] = pmc_mfma_busy(k, args.config, lib_hash) if args.precision == "f32" else None
             if k == "mmd_pm1":
@@ -404,8 +437,9 @@ def main():
         conv = {k: v for k, v in cands.items() if k.startswith("conv_")}
         if conv:  # the convolution GEMM beside it (north star: >= 40 % MFMA utilisation on the encoder/decoder GEMMs)
             roofline["conv"] = entry(max(conv, key=lambda k: conv[k]["total_ms"]))
-            tw, tt = sum(v["work"] for v in conv.values()), sum(v["total_ms"] for v in conv.values())
-            roofline["conv_all"] = {"tflops": tw / (tt * 1e-3) / 1e12, "frac": tw / (tt * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
+            tw, tt = sum(v.get("algorithmic_work", v["work"]) for v in conv.values()), sum(v["total_ms"] for v in conv.values())
+            roofline["conv_all"] = {"tflops": tw / (tt * 1e-3) / 1e12, "note": "algorithmic float32 FLOPs of all convolution GEMM kernels / their summed time; frac against the f32 MFMA peak (bf16 peak in --precision bf16)",
+                                    "frac": tw / (tt * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
                                     "ms_per_step": tt / prof_steps, "gflop_per_step": tw / prof_steps / 1e9}
         if "mmd_pm1" in cands and dom != "mmd_pm1":
             roofline["mmd_pair"] = entry("mmd_pm1")
@@ -419,7 +453,9 @@ def main():
             "unit": "images/s", "n_gpus": args.gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16 GEMM inputs, f32 accumulate (weight gradients f32)",
+            "dtype": {"f32": "f32", "bf16": "bf16 GEMM inputs, f32 accumulate (weight gradients f32)",
+                      "f32x3": "f32 (operands of the large forward / data-gradient GEMM launches as three bf16 pieces, six piece "
+                               "products per k-step on the bf16 MFMA, f32 accumulate; everything else f32)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}", "global_batch": cfg["B"] * args.gpus,
                        "n_latents": cfg["n"], "n_replicas": cfg["R"], "num_reads_per_gpu": cfg["C"],
@@ -432,7 +468,13 @@ def main():
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["loss_parity"] = loss_parity()
+        if args.parity and args.gpus == 1:
+            # (the fixture's launches are small: force the split kernels onto every tile configuration for the check)
+            os.environ["DVG_SPLIT3_ALL"] = "1"
+            out["loss_parity"] = dict(loss_parity(), note="12 fixture steps with the split kernels forced onto every launch")
+            os.environ.pop("DVG_SPLIT3_ALL", None)
         if args.gpus == 1 and not args.child and not args.no_cpu_baseline and args.precision == "f32":
+            out["f32x3"] = split3_run(args)
             out["bf16_inputs"] = bf16_inputs_run(args)
             if args.config == "c3":
                 out["extra"] = {c: extra_config_run(args, c) for c in ("c2", "c1")}

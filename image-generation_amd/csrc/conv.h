@@ -150,7 +150,7 @@ int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStrea
 // decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
 struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; };
 // operand format of one forward / data-gradient launch: the process-wide mode, except that the split mode (2) only
-// serves launches large enough for the 128 x 128 tile (smaller ones are latency-bound: the float32 kernel is faster)
+// serves launches large enough for the 128 x 128 / 128 x 64 tiles (smaller ones are latency-bound: the float32 kernel is faster)
 int conv_launch_mode(int64_t gemm_rows, int Cout);
 constexpr int MAX_PACK_JOBS = 8;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);

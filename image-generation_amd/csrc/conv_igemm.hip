@@ -460,7 +460,10 @@ int conv_launch_mode(int64_t gemm_rows, int Cout) {
   const int mode = conv_precision_mode();
   if (mode != 2) return mode;
   const char* e = getenv("DVG_SPLIT3_ALL");  // (read per call: the tests flip it inside one process)
-  return ((e && e[0] == '1') || igemm_cfg(gemm_rows, Cout) == 4) ? 2 : 0;
+  // measured at c3 (in-situ, per launch): 128x128 tile 1046 -> 778 us, 128x64 728 -> 609, 128x32 852 -> 972 (wave tile
+  // 32x32: six MFMAs per six operand reads -- not enough matrix work per staged byte), small launches (c2) slower
+  const int cfg = igemm_cfg(gemm_rows, Cout);
+  return ((e && e[0] == '1') || cfg == 4 || cfg == 0) ? 2 : 0;
 }
 
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
