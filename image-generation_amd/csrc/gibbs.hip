@@ -373,7 +373,12 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   // draw overlapped with the encoder forward: 4 -> 1.237 ms, 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for
   // issue slots, fatter workgroups do not pay for the CUs they free.
   static const int waves_env = [] { const char* e = getenv("DVG_GIBBS_WAVES"); return e ? atoi(e) : 0; }();
-  const int waves = waves_env ? waves_env : 4;
+  // Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one wave per
+  // workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger
+  // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
+  // encoder's convolutions that run beside the draw (c3: 19.15 ms with four waves, 19.4 with two, 19.7 with one).
+  const bool small = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
+  const int waves = waves_env ? waves_env : (small ? 1 : 4);
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
   // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw)
