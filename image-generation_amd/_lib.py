@@ -137,6 +137,12 @@ SIGNATURES = {
         [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p,
          c_size_t, c_void_p],
     ),
+    "dvg_decoder_bwd_ex": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p,
+         c_size_t, c_int, c_void_p],
+    ),
+    "dvg_stream_join_side": (c_int, [c_void_p]),
     "dvg_mse_workspace_bytes": (c_size_t, []),
     "dvg_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dvg_adam_step": (

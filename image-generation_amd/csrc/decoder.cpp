@@ -197,6 +197,18 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
 extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
                                const float* grad_out, const dvg_decoder_grads_t* g, float* grad_spins, void* ws,
                                size_t ws_bytes, dvg_stream_t stream) {
+  return dvg_decoder_bwd_ex(p, n, spins, N, grad_out, g, grad_spins, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int dvg_stream_join_side(dvg_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream, s2 = side_stream(s);
+  if (s2 != s) DVG_TRY(stream_order_after(s, s2));
+  return DVG_OK;
+}
+
+extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
+                                  const float* grad_out, const dvg_decoder_grads_t* g, float* grad_spins, void* ws,
+                                  size_t ws_bytes, int defer_join, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "decoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
@@ -286,7 +298,7 @@ extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float
     wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;
     DVG_TRY(launch_conv_wgrad(wa, s2));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, g->lin_w, s2));
-    DVG_TRY(stream_order_after(s, s2));  // join
+    if (!defer_join) DVG_TRY(stream_order_after(s, s2));  // join (deferred: dvg_stream_join_side / the next backward call)
   }
   return DVG_OK;
 }

@@ -148,7 +148,33 @@ __global__ __launch_bounds__(256) void rowsum_partial_kernel(const float* __rest
   }
 }
 
+// The same with a thread owning four consecutive columns (16-byte loads, a wavefront covers 1 KiB of a row) and four
+// rows in flight per thread: the one-float form above walked a 2048-column matrix in 64 passes of 128-byte row pieces
+// (c3's decoder Linear bias gradient: 268 MB in 454 us = 0.6 TB/s, on the tail of the decoder's backward).
+__global__ __launch_bounds__(256) void rowsum_partial_v4_kernel(const float* __restrict__ mat, int64_t rows, int cols,
+                                                                float* __restrict__ part) {
+  __shared__ float red[4 * 256];
+  const Chan4 cm(cols);
+  for (int c0 = 0; c0 < cols; c0 += 4 * cm.CQ) {
+    f32x4v acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    const int64_t stride = (int64_t)gridDim.x * cm.RL;
+    int64_t r = (int64_t)blockIdx.x * cm.RL + cm.rl;
+    const float* p = mat + c0 + 4 * cm.cq;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+      const f32x4v v0 = ld4(p + r * cols), v1 = ld4(p + (r + stride) * cols), v2 = ld4(p + (r + 2 * stride) * cols),
+                   v3 = ld4(p + (r + 3 * stride) * cols);
+      acc[0] += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < rows; r += stride) acc[0] += ld4(p + r * cols);
+    block_reduce_store4<1>(acc, cm, red, part, cols, c0);
+  }
+}
+
 int launch_rowsum_partial(const float* mat, int64_t rows, int cols, float* part, hipStream_t s) {
+  if (cols % 4 == 0 && ((cols >> 2) <= 256 ? 256 % (cols >> 2) == 0 : (cols >> 2) % 256 == 0)) {
+    DVG_LAUNCH(K_MISC, rowsum_partial_v4_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, mat, rows, cols, part);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_MISC, rowsum_partial_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, mat, rows, cols, part);
   return DVG_OK;
 }

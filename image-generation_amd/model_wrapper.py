@@ -402,6 +402,7 @@ class ModelWrapper:
         # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
         # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
         samples = self._draw_overlapped() if self.overlap_sampler else None
+        self._dvae.decoder._defer_join = True  # (this step always runs the encoder's backward behind the decoder's)
         if samples is not None and self.overlap_mmd:
             # The MMD needs only the spins and the draw, so it follows the draw on the side stream and runs under
             # the decoder forward and the MSE; the streams join before the two losses are added.
@@ -601,6 +602,12 @@ class ModelWrapper:
         return self.dist is not None and (self.dist.world_size > 1 or getattr(self.dist, "force", False))
 
     def _reduce_and_step(self, opt):
+        if opt is self._dvae_optimizer and self._device.type == "cuda":
+            # the decoder's backward ran with its weight-gradient join deferred (see _dvae_half): the encoder's backward
+            # behind it joined the shared side stream already; this makes the ordering explicit whatever ran in between
+            from . import _lib
+            _lib.check(_lib.lib().dvg_stream_join_side(_lib.stream_ptr(self._device)), "dvg_stream_join_side")
+            self._dvae.decoder._defer_join = False  # (only this step's own backward runs deferred)
         if self._dist_active():
             opt.gather_grads()  # packed into this optimizer's part of the joint buffer; see _flush_dist
             if not self._capturing_split:  # (under capture the replay re-registers it: _step_graphed)

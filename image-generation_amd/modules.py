@@ -199,8 +199,11 @@ class _DecoderFn(torch.autograd.Function):
         go = grad_out.contiguous().float()
         gx = torch.empty_like(x) if ctx.need_input_grad else None
         with torch.cuda.device(x.device):
-            check(L.dvg_decoder_bwd(ctypes.byref(st), n, x.data_ptr(), B * R, go.data_ptr(), ctypes.byref(gs),
-                                    _lib.ptr(gx), ws.data_ptr(), ws.numel(), stream_ptr(x.device)), "dvg_decoder_bwd")
+            # defer_join (set by ModelWrapper around its own step, where the encoder's backward always follows on the same
+            # stream): the tail of the weight-gradient chain overlaps the head of the encoder's data-gradient chain
+            check(L.dvg_decoder_bwd_ex(ctypes.byref(st), n, x.data_ptr(), B * R, go.data_ptr(), ctypes.byref(gs),
+                                       _lib.ptr(gx), ws.data_ptr(), ws.numel(), int(bool(getattr(module, "_defer_join", False))),
+                                       stream_ptr(x.device)), "dvg_decoder_bwd_ex")
         return (gx, None, None, None, None, *_grad_returns(module, grads, direct))
 
 

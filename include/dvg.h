@@ -229,6 +229,18 @@ int dvg_decoder_bwd(const dvg_decoder_params_t *p, int n_latents, const float *s
                     const float *grad_out, const dvg_decoder_grads_t *grads,
                     float *grad_spins /* (N,n) or NULL */, void *ws, size_t ws_bytes,
                     dvg_stream_t stream);
+/* The same with the join of the weight-gradient chain left to the caller: grad_spins is complete in `stream` order when
+ * the call returns, the PARAMETER gradients only after dvg_stream_join_side(stream) or after the next dvg_encoder_bwd /
+ * dvg_decoder_bwd call on `stream` has returned (their weight-gradient chains run on the same library side stream, in
+ * order, and their own join covers what was queued before).  A training step whose decoder backward is followed by the
+ * encoder backward overlaps the tail of the decoder's weight-gradient chain (the Linear layer's, ~1 ms at B R = 32768)
+ * with the head of the encoder's data-gradient chain this way.  defer_join = 0 is dvg_decoder_bwd. */
+int dvg_decoder_bwd_ex(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                       const float *grad_out, const dvg_decoder_grads_t *grads, float *grad_spins, void *ws,
+                       size_t ws_bytes, int defer_join, dvg_stream_t stream);
+/* Orders `stream` behind everything queued so far on the library's side stream of the current device (no-op when the
+ * side stream is disabled). */
+int dvg_stream_join_side(dvg_stream_t stream);
 
 /* ------------------------------------------------------------------ MSE
  * torch.nn.functional.mse_loss(reconstructed, images.unsqueeze(1).repeat(1,R,...))
