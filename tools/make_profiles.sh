@@ -35,5 +35,8 @@ python bench.py --breakdown $OUT/${R}_hip_event_breakdown_c3.json > $OUT/c3.log 
 python bench.py --config c2 --no-cpu-baseline --steps 30 --breakdown $OUT/${R}_hip_event_breakdown_c2.json > $OUT/c2.log 2>&1; last $OUT/c2.log $OUT/${R}_bench_c2.json
 python bench.py --config c5 --no-cpu-baseline --steps 20 > $OUT/c5.log 2>&1; last $OUT/c5.log $OUT/${R}_bench_c5.json
 python bench.py --config c3 --precision bf16 --no-cpu-baseline --steps 10 > $OUT/c3b.log 2>&1; last $OUT/c3b.log $OUT/${R}_bench_c3_bf16_inputs.json
+python bench.py --config c3 --precision f32x3 --no-cpu-baseline --parity --steps 20 > $OUT/c3x.log 2>&1; last $OUT/c3x.log $OUT/${R}_bench_c3_f32x3.json
+python tools/mmd_accuracy.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_accuracy_c3.txt
+python tools/mmd_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_kernels_c3.txt
 rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/*.log
 ls -la $OUT
