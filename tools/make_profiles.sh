@@ -10,6 +10,9 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 last() { grep '^{"metric"' "$1" | tail -1 > "$2"; }
+# `bash tools/make_profiles.sh r02 bench`: only the bench lines of step 3 (the PMC files already in profiles/ must be of
+# this build of the kernels: bench.py checks their hash)
+if [ "${2:-all}" != "bench" ]; then
 # 1. rocprofv3 kernel stats of the headline command (c3) and of c2
 cd /tmp && export TMPDIR=/tmp
 for C in c3 c2; do
@@ -29,8 +32,10 @@ for C in c3 c2; do
   python profiles/aggregate_mfma.py $(ls $OUT/pmc_m_$C/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_mfma_busy_$C.json
   python profiles/aggregate_pmc.py $(ls $OUT/pmc_f_$C/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_w_$C/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_traffic_$C.json $(ls $OUT/pmc_w_$C/*/*kernel_trace.csv | head -1)
 done
-# 3. bench lines LAST (they read the PMC files of this build from profiles/: copy them in first)
 cp $OUT/${R}_pmc_*.json $ROOT/profiles/
+fi
+# 3. bench lines LAST (they read the PMC files of this build from profiles/)
+cd $ROOT
 python bench.py --breakdown $OUT/${R}_hip_event_breakdown_c3.json > $OUT/c3.log 2>&1; last $OUT/c3.log $OUT/${R}_bench_c3.json
 python bench.py --config c2 --no-cpu-baseline --steps 30 --breakdown $OUT/${R}_hip_event_breakdown_c2.json > $OUT/c2.log 2>&1; last $OUT/c2.log $OUT/${R}_bench_c2.json
 python bench.py --config c5 --no-cpu-baseline --steps 20 > $OUT/c5.log 2>&1; last $OUT/c5.log $OUT/${R}_bench_c5.json
