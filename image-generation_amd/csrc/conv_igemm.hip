@@ -29,14 +29,23 @@ namespace dvg {
 // 2^-16 of a product; the three dropped ones are below 2^-23): float32-class results on the bf16 MFMA at 6/16 of the f32
 // MFMA's matrix time.  One 32-channel chunk per iteration (three bf16 images of a 32-deep slab fill the LDS a 64-deep
 // float32 slab does: two blocks per CU stay resident), six times the MFMA work of the bf16 form per staged byte.
+// PM = 3: the float32 form with LDS-DMA staging (global_load_lds_dwordx4: no staging registers, no ds_write pass, no
+// mask multiply).  One 32-channel chunk per iteration, two LDS stages, ONE barrier per iteration; both operands sit in
+// LDS as [row][32 floats] (weights packed K-major, PackJob.bf16t = 3), 16-byte slots XOR-swizzled on the per-lane SOURCE
+// address, and the MFMA's two k-lanes take k = s and k = 16 + s at step s, so a lane's 16 operands of a chunk are
+// four ds_read_b128 instead of sixteen ds_read_b32.  The transfers are raw buffer loads: padding rows carry an
+// out-of-range offset, for which the hardware writes zeros.
+
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a) {
-  constexpr bool BF = PM != 0;           // operands live in LDS as bf16
+  constexpr bool BF = PM == 1 || PM == 2;  // operands live in LDS as bf16
+  constexpr bool DMA = PM == 3;
+  static_assert(!DMA || WK == 1, "LDS-DMA form: no K wave groups");
   constexpr int NP = PM == 2 ? 3 : 1;    // bf16 pieces per operand
   static_assert(!BF || WK == 1, "bf16 forms: no K wave groups");
   constexpr int NT = WM * WN * WK * 64, NTG = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int BK = PM == 2 ? 32 : 64;  // K per wave group and iteration: 32-channel chunks (possibly of different taps)
+  constexpr int BK = (PM == 2 || PM == 3) ? 32 : 64;  // K per wave group and iteration: 32-channel chunks (possibly of different taps)
   constexpr int KH = (BK / 32) * WK, BKT = BK * WK;  // chunks / K extent staged per iteration by the whole block
   // A rows are 16-byte aligned so the staging stores are ds_write_b128; the MFMA A-operand reads (one float per lane,
   // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
@@ -53,7 +62,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   float* Bs = As + BM * AP;                                    // [BKT][BP]
   uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 forms: [NP][BM][AP16], then Bs16 [NP][BN][AP16] (K-major)
   uint16_t* Bs16 = As16 + NP * BM * AP16;
-  float* red = BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
+  constexpr int STAGE = (BM + BN) * 128;  // LDS-DMA form: one stage = A [BM][32 f32] then B [BN][32 f32]
+  float* red = DMA ? reinterpret_cast<float*>(igemm_smem + 2 * STAGE)
+               : BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
   int* nbr = reinterpret_cast<int*>(red + WM * BN * 2);        // [BM][NBS] source row of every (tile row, tap), -1 = padding
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,7 +98,10 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
     if (a.ups) src >>= 2;
     const int64_t img = m >> logHW;
-    nbr[row * NBS + tap] = !ok ? -1 : a.fold == 2 ? (int)(img * (HWin << 2) + 4 * src + cq) : (int)(img * HWin + src);
+    const int srow = a.fold == 2 ? (int)(img * (HWin << 2) + 4 * src + cq) : (int)(img * HWin + src);
+    // (LDS-DMA form: byte offsets; padding = an offset past the buffer descriptor's range, which loads zeros)
+    if constexpr (DMA) nbr[row * NBS + tap] = !ok ? (int)0xFFFF0000u : (int)((uint32_t)srow * ((uint32_t)a.Cin * 4u));
+    else nbr[row * NBS + tap] = !ok ? -1 : srow;
   }
   __syncthreads();
 
@@ -216,7 +230,99 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     }                                                                                                                 \
   } while (0)
 
-  {
+  if constexpr (DMA) {
+    constexpr int NW = NT / 64, PAW = BM / 8 / NW, PBW = BN / 8 / NW;  // 1 KiB pieces (8 rows) per wave and stage
+    static_assert(PAW * NW * 8 == BM && PBW * NW * 8 == BN, "LDS-DMA pieces must divide the tile");
+    typedef __attribute__((address_space(3))) void lds_void;
+    unsigned char* stg = igemm_smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // buffer descriptors (raw, 32-bit byte offsets): a lane whose offset is past num_records writes ZEROS to LDS --
+    // that is the zero padding of the im2col rows (checked on the MI355X: scratch/buflds_test.hip)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)0xFFFF0000u, 0x00020000);
+    // per-lane pieces, constant over the kernel: lane l of piece e writes LDS slot (row = e*8 + l/8, slot l%8) and
+    // therefore fetches the logical slot (l%8) ^ f(row), f(row) = (row >> 1) & 7 (128-byte rows: conflict-free b128 reads)
+    int arow[PAW];
+    uint32_t acol[PAW], bcol[PBW];
+#pragma unroll
+    for (int q = 0; q < PAW; ++q) {
+      const int e = (wave * PAW + q) * 64 + lane, row = e >> 3, ps = e & 7;
+      arow[q] = row * NBS;
+      acol[q] = (uint32_t)((ps ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int q = 0; q < PBW; ++q) {
+      const int e = (wave * PBW + q) * 64 + lane, n = e >> 3, ps = e & 7;
+      bcol[q] = (uint32_t)(n0 + n) * row_bytes + (uint32_t)((ps ^ ((n >> 1) & 7)) << 4);  // Wk[tap][col][ci] f32
+    }
+    const uint32_t tap_bytes = (uint32_t)a.Cout * row_bytes;
+    const uint32_t cls_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)((a.fold == 1 ? (uint32_t)cls * 4u : 0u) * tap_bytes));
+    // chunk counters: `f*` runs over the chunk whose neighbour rows are fetched next, `i*` over the chunk issued next
+    int ftap = it_beg / nci, fcc = it_beg - ftap * nci, itap = ftap, icc = fcc;
+    uint32_t srcn[PAW];  // per-lane byte offsets of the next chunk's A pieces (without the channel-chunk offset)
+    auto fetch_nbr = [&]() {
+#pragma unroll
+      for (int q = 0; q < PAW; ++q) srcn[q] = (uint32_t)nbr[arow[q] + ftap];  // (used a whole chunk later: no wait here)
+      if (++fcc == nci) { fcc = 0; ++ftap; }
+    };
+    auto issue = [&](int buf) {
+      unsigned char* dstA = stg + buf * STAGE + wave_u * PAW * 1024;
+      const int ccb = icc * 128;  // wave-uniform: the instruction's scalar offset
+#pragma unroll
+      for (int q = 0; q < PAW; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dstA + q * 1024), 16, (int)(srcn[q] + acol[q]), ccb, 0, 0);
+      unsigned char* dstB = stg + buf * STAGE + BM * 128 + wave_u * PBW * 1024;
+      const int boff = (int)(cls_off + (uint32_t)itap * tap_bytes) + ccb;
+#pragma unroll
+      for (int q = 0; q < PBW; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(dstB + q * 1024), 16, (int)bcol[q], boff, 0, 0);
+      if (++icc == nci) { icc = 0; ++itap; }
+    };
+    // operand reads: lane (c, hh) owns floats 16 hh .. 16 hh + 15 of row / column c: logical slots 4 hh + j
+    int offl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) offl[j] = c * 128 + (((4 * hh + j) ^ ((c >> 1) & 7)) << 4);
+    if (it_beg < it_end) {
+      fetch_nbr();
+      issue(0);
+      if (it_beg + 1 < it_end) fetch_nbr();
+    }
+    for (int it = it_beg; it < it_end; ++it) {
+      const int buf = (it - it_beg) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it` have landed ...
+      __syncthreads();                                    // ... everyone's have, and stage buf^1 is free again
+      if (it + 1 < it_end) issue(buf ^ 1);
+      if (it + 2 < it_end) fetch_nbr();
+      const unsigned char* Ab = stg + buf * STAGE + wm * TM * 32 * 128;
+      const unsigned char* Bb = stg + buf * STAGE + BM * 128 + wn * TN * 32 * 128;
+      f32x4 av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offl[0]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 4096 + offl[0]);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      // [reads of quarter j4+1] then [MFMAs of quarter j4]: the LDS latency elapses under the matrix pipe
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const int cur = j4 & 1, nxt = cur ^ 1;
+        if (j4 < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offl[j4 + 1]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bv[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 4096 + offl[j4 + 1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bv[cur][j][e], acc[i][j], 0, 0, 0);
+        if (j4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      }
+    }
+  } else {
     f32x4 aA[KH][RA], bA[KH][RB * NP];
     float mA[KH][RA];
     for (int it = it_beg; it <= it_end; ++it) {
@@ -437,6 +543,7 @@ static int igemm_cfg(int64_t M, int Cout) {
 }
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static constexpr size_t conv_igemm_lds_bytes() {
+  if (PM == 3) return (size_t)(2 * (BM + BN) * 128) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   if (PM == 2) return sizeof(uint16_t) * (size_t)(3 * (BM + BN) * (32 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   if (PM == 1) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
@@ -456,8 +563,16 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
 }
 
 // DVG_SPLIT3_ALL=1: the split form for every tile configuration (tests, A/B runs)
+// DVG_IGEMM_DMA = 0: the register-staged form of the float32 kernel instead of the LDS-DMA form (tests, A/B runs)
+static int igemm_dma_env() {
+  const char* e = getenv("DVG_IGEMM_DMA");  // (read per call: the tests flip it inside one process)
+  return !e ? -1 : (e[0] == '1' ? 1 : 0);
+}
 int conv_launch_mode(int64_t gemm_rows, int Cout) {
   const int mode = conv_precision_mode();
+  if (mode == 0) {
+    return igemm_dma_env() != 0 ? 3 : 0;  // (measured faster for every tile configuration and launch size: tools/igemm_ab.py)
+  }
   if (mode != 2) return mode;
   const char* e = getenv("DVG_SPLIT3_ALL");  // (read per call: the tests flip it inside one process)
   // measured at c3 (in-situ, per launch): 128x128 tile 1046 -> 778 us, 128x64 728 -> 609, 128x32 852 -> 972 (wave tile
@@ -507,7 +622,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   }
   // the kernel addresses its input and weights with 32-bit byte offsets
   const double in_bytes = (double)(a.ups ? a.M / 4 : (a.fold == 2 ? a.M * 4 : a.M)) * a.Cin * 4.0;
-  if (in_bytes >= 4294967296.0 || a.M >= 2147483647LL) {
+  if (in_bytes >= 4294901760.0 || a.M >= 2147483647LL) {  // (0xFFFF0000: offsets from there up mean "padding")
     set_error("conv_igemm: input tensor of %.0f bytes exceeds the 4 GiB addressing range of this kernel", in_bytes);
     return DVG_E_UNSUPPORTED;
   }
@@ -521,7 +636,15 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
   int rc;
-  if (a.bf16 == 2) {
+  if (a.bf16 == 3) {
+    switch (cfg) {
+      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 3>(K_IGEMM_128x64, flops, grid, a, s); break;
+      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 3>(K_IGEMM_64x64, flops, grid, a, s); break;
+      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 3>(K_IGEMM_32x64, flops, grid, a, s); break;
+      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 3>(K_IGEMM_128x128, flops, grid, a, s); break;
+      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 3>(K_IGEMM_128x32, flops, grid, a, s); break;
+    }
+  } else if (a.bf16 == 2) {
     switch (cfg) {
       case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 2>(K_IGEMM_128x64, flops, grid, a, s); break;
       case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 2>(K_IGEMM_64x64, flops, grid, a, s); break;

@@ -8,6 +8,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));  // operand of v_mfma_f32_32x32x16_bf16  // register-resident (a float4 array can end up in scratch)
 
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to LDS at wave-uniform base + 16 lane (global_load_lds_dwordx4)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ __forceinline__ int crow16(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // float32 -> bfloat16, round to nearest even (NaN stays NaN): the bf16-input mode of the forward / data-gradient GEMMs

@@ -473,9 +473,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // one packed entry in the format `fmt`: 0 = f32 [tap][a][b] (index e); 1 = bf16 K-major [tap][b][a] (index kmaj);
-// 2 = three bf16 K-major planes, the exact pieces hi + mid + lo of the weight
+// 2 = three bf16 K-major planes, the exact pieces hi + mid + lo of the weight; 3 = f32 K-major
 __device__ __forceinline__ void pack_store(float* wp, int64_t total, int64_t kmaj, int64_t e, float v, int fmt) {
   if (fmt == 0) { wp[e] = v; return; }
+  if (fmt == 3) { wp[kmaj] = v; return; }  // f32 K-major [tap][b][a]: the LDS-DMA form of the float32 GEMM kernel
   uint16_t* w16 = reinterpret_cast<uint16_t*>(wp);
   const uint16_t hi = f32_to_bf16_rne(v);
   w16[kmaj] = hi;

@@ -13,9 +13,20 @@ def _rel(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
 
 
+@pytest.fixture(params=["reg", "dma"])
+def staging(request):
+    """Both staging forms of the float32 GEMM kernel for EVERY tile configuration (DVG_IGEMM_DMA: the product picks
+    per launch size): register-staged with ds_write, and LDS-DMA with K-major packed weights."""
+    import os
+    os.environ["DVG_IGEMM_DMA"] = "1" if request.param == "dma" else "0"
+    yield request.param
+    os.environ.pop("DVG_IGEMM_DMA", None)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4),
-                                             (256, 128, 128, 4), (64, 128, 128, 4)])  # the last two take the split-K path
-def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side):
+                                             (256, 128, 128, 4), (64, 128, 128, 4),  # these two take the split-K path
+                                             (1024, 128, 128, 8), (600, 64, 64, 16)])  # 128x128 and 128x64 tiles
+def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side, staging):
     torch.manual_seed(N)
     x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
     x.requires_grad_(True); w.requires_grad_(True)
@@ -36,7 +47,7 @@ def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,side", [(4, 128, 64, 4), (3, 64, 32, 8), (2, 96, 128, 2)])
-def test_convtranspose_with_fused_upsample(N, Cin, Cout, side):
+def test_convtranspose_with_fused_upsample(N, Cin, Cout, side, staging):
     """side = OUTPUT resolution; the input lives at side/2 and is nearest-upsampled inside the gather;
     the data-gradient sums each 2x2 quad in the epilogue."""
     torch.manual_seed(side)
@@ -57,7 +68,7 @@ def test_convtranspose_with_fused_upsample(N, Cin, Cout, side):
     assert _rel(gw.cpu(), w.grad) < 3e-6
 
 
-def test_linear_as_one_tap_gemm():
+def test_linear_as_one_tap_gemm(staging):
     torch.manual_seed(0)
     N, n = 37, 64
     x = torch.randn(N, n, requires_grad=True); w = (torch.randn(4 * n, n) / n**0.5).requires_grad_(True)
