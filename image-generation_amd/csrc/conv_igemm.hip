@@ -536,7 +536,8 @@ static int igemm_cfg(int64_t M, int Cout) {
   // better, c2 has no such launch.  (DVG_IGEMM_THR128 overrides: tuning runs.)
   static const int64_t thr128 = [] { const char* e = getenv("DVG_IGEMM_THR128"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
   if (Cout % 128 == 0 && ceil_div(M, 128) * (Cout / 128) >= thr128) return 4;
-  if (ceil_div(M, 128) * (Cout / 64) >= 512) return 0;
+  static const int64_t thr64 = [] { const char* e = getenv("DVG_IGEMM_THR64"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+  if (ceil_div(M, 128) * (Cout / 64) >= thr64) return 0;
   static const int64_t thr32 = [] { const char* e = getenv("DVG_IGEMM_THR32"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;

@@ -3,6 +3,7 @@
 // (/root/reference/src/encoder.py:28-30, /root/reference/src/decoder.py:28, :34-38).
 // Separate translation unit from conv_igemm.hip so the two can carry different code-generation options (Makefile).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_tile.h"
 
@@ -242,6 +243,285 @@ __global__ __launch_bounds__(WA* WB* WT * 64) void conv_wgrad9_kernel(WgradArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, 3x3, LDS-DMA
+// conv_wgrad9_kernel with the staging done by `buffer_load ... lds` (as the LDS-DMA form of the forward kernel,
+// conv_igemm.hip): no staging registers, no ds_write pass, no mask multiply (slots outside the image and rows past the
+// slab carry an out-of-range offset: the hardware writes zeros), two LDS stages and ONE barrier per 32-pixel chunk.  The
+// per-lane source offsets of chunk t+2 are computed in Morton space (masked adds from the chunk's origin, no
+// decode / re-encode) between the MFMAs of chunk t.  Needs both tensors below 0xFFFF0000 bytes (32-bit offsets).
+// FOLD = true: the folded Upsample(x2) + 3x3 layer (conv_wgrad_fold_kernel's job: <1, 1, 4>, one wave per output
+// parity class, 4 shifted rows of the SOURCE map per class, the chunk's 128 contiguous dY rows staged with it).
+template <int WA, int WB, int WT, bool FOLD = false>
+__global__ __launch_bounds__(WA* WB* WT * 64) void conv_wgrad9_dma_kernel(WgradArgs a) {
+  static_assert(!FOLD || (WA == 1 && WB == 1 && WT == 4), "folded form: one 32x32 channel tile, one wave per class");
+  constexpr int NT = WA * WB * WT * 64, NW = NT / 64, BA = 32 * WA, BB = 32 * WB;
+  constexpr int NACC = FOLD ? 4 : (9 + WT - 1) / WT;
+  constexpr int SMAX = 128;                              // slots per chunk: 60 (H >= 8), 72 (H = 4), 128 (H = 2)
+  constexpr int YROWS = FOLD ? 128 : 32;                 // dY rows per chunk (folded: 4 output pixels per source pixel)
+  constexpr int XB = SMAX * BA * 4, YB = YROWS * BB * 4, STAGE = XB + YB;
+  constexpr int RXD = SMAX * (BA / 4) / 64 / NW;         // 1 KiB pieces of the patch per wave (worst case)
+  constexpr int NYI = YROWS * (BB / 4) / 64;             // 1 KiB pieces of the dY rows
+  constexpr int RYD = (NYI + NW - 1) / NW;               // ... per wave (piece wv + NW q, if < NYI)
+  static_assert(RXD * NW * 64 == SMAX * (BA / 4), "LDS-DMA pieces must divide the stage");
+  typedef __attribute__((address_space(3))) void lds_void;
+  extern __shared__ __align__(16) unsigned char wg_smem[];  // 2 * STAGE bytes
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wv / (WA * WB), wa = (wv / WB) % WA, wb = wv % WB, hh = lane >> 5, c = lane & 31;
+  const int tiles_b = a.Cout / BB;
+  const int a0 = (blockIdx.x / tiles_b) * BA, b0 = (blockIdx.x % tiles_b) * BB;
+  const int z = blockIdx.y;
+  const int L = a.L, H = 1 << L, logHW = 2 * L, HW = 1 << logHW;
+  const uint32_t HWin = a.ups ? (uint32_t)(HW >> 2) : (uint32_t)HW;
+  const int ph = H < 4 ? H : 4, pw = H < 8 ? H : 8;
+  const int SW = pw + 2, SP = (ph + 2) * SW;
+  const int pix_per_img = HW < 32 ? HW : 32;
+  const int nimg = 32 / pix_per_img;
+  const int S = nimg * SP;
+  int64_t per = (a.M + a.ksplit - 1) / a.ksplit;
+  per = (per + 31) & ~(int64_t)31;
+  const int64_t mbeg = (int64_t)z * per;
+  const int64_t mend = mbeg + per < a.M ? mbeg + per : a.M;
+  const int nchunks = mbeg < mend ? (int)((mend - mbeg + 31) / 32) : 0;
+
+  int base_slot[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = 2 * s + hh;
+    const uint32_t p = (uint32_t)(k & (pix_per_img - 1));
+    base_slot[s] = ((k / pix_per_img) * SP + ((int)morton_y(p) + 1) * SW + (int)morton_x(p) + 1) * BA;
+  }
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) acc[j] = (f32x16){0};
+
+  const uint32_t row_bytes = (uint32_t)a.Cin * 4u, yrow_bytes = (uint32_t)a.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)0xFFFF0000u, 0x00020000);
+  constexpr uint32_t XM = 0x55555555u, YM = 0xAAAAAAAAu, PAD = 0xFFFF0000u;
+  // per-lane piece constants: piece q of this wave is 1 KiB piece j = wv + NW q of the patch image [slot][BA floats];
+  // its lane covers 16-byte element e = 64 j + lane: slot e / (BA/4), channels 4 (e % (BA/4)) ...
+  const int nxi = (S * (BA / 4) + 63) / 64;  // pieces in use (wave-uniform)
+  uint32_t q_dxm[RXD], q_dym[RXD], q_const[RXD];  // Morton-space deltas from (y0-1, x0-1); image + channel byte offset
+  int q_il[RXD];
+  bool q_live[RXD];
+#pragma unroll
+  for (int q = 0; q < RXD; ++q) {
+    const int e = (wv + NW * q) * 64 + lane;
+    const int slot = e / (BA / 4), c4 = e % (BA / 4);
+    const int il = slot / SP, r = slot - il * SP;
+    q_il[q] = il;
+    q_dym[q] = part1by1((uint32_t)(r / SW)) << 1;
+    q_dxm[q] = part1by1((uint32_t)(r % SW));
+    q_const[q] = (uint32_t)il * HWin * row_bytes + (uint32_t)(a0 + c4 * 4) * 4u;
+    q_live[q] = slot < S;
+  }
+  int ypx[RYD];       // dY pieces: row and channel bytes of this lane
+  uint32_t ycol[RYD];
+#pragma unroll
+  for (int q = 0; q < RYD; ++q) {
+    const int e = (wv + NW * q) * 64 + lane;
+    ypx[q] = e / (BB / 4);
+    ycol[q] = (uint32_t)(b0 + (e % (BB / 4)) * 4) * 4u;
+  }
+
+  uint32_t xoff[RXD], yoff[RYD];  // offsets of the chunk to be issued next
+  // scalar part of a chunk's addressing
+  const int n_img = (int)((a.M + HW - 1) >> logHW);  // images (whole or partial) in the tensor
+  struct Org { uint32_t bx, by, img_bytes; int64_t img0; };
+  auto origin = [&](int t) -> Org {
+    const int64_t m1 = mbeg + (int64_t)t * 32;
+    const uint32_t p0 = (uint32_t)(m1 & (HW - 1));
+    Org o;
+    o.img0 = m1 >> logHW;
+    // Morton images of x0 - 1 and y0 - 1 in two's complement over the masked bit lanes (-1 = all lanes set)
+    o.bx = ((p0 & XM) - 1u) & XM;
+    o.by = ((p0 & YM) - 2u) & YM;
+    o.img_bytes = (uint32_t)o.img0 * HWin * row_bytes;
+    return o;
+  };
+  auto calc_x = [&](const Org& o, int q) {
+    const uint32_t nx = ((o.bx | YM) + q_dxm[q]) & XM, ny = ((o.by | XM) + q_dym[q]) & YM;
+    const uint32_t pm = nx | ny;  // Morton index of the slot's pixel; bits at or above HW: outside the image
+    // (bitwise, not short-circuit: no branches inside the MFMA stream)
+    const bool ok = q_live[q] & ((pm >> logHW) == 0u) & ((int)o.img0 + q_il[q] < n_img);
+    const uint32_t src = a.ups ? pm >> 2 : pm;
+    xoff[q] = ok ? o.img_bytes + q_const[q] + src * row_bytes : PAD;
+  };
+  auto calc_y = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < RYD; ++q) {
+      const int64_t m = (mbeg + (int64_t)t * 32) * (FOLD ? 4 : 1) + ypx[q];  // (folded: output pixel 4 q + class)
+      yoff[q] = m < mend * (FOLD ? 4 : 1) ? (uint32_t)m * yrow_bytes + ycol[q] : PAD;
+    }
+  };
+  auto issue = [&](int buf) {
+    unsigned char* dx = wg_smem + buf * STAGE;
+#pragma unroll
+    for (int q = 0; q < RXD; ++q)
+      if (wv + NW * q < nxi)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void*)(dx + (wv + NW * q) * 1024), 16, (int)xoff[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < RYD; ++q)
+      if (wv + NW * q < NYI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void*)(dx + XB + (wv + NW * q) * 1024), 16, (int)yoff[q], 0, 0, 0);
+  };
+  auto calc_all = [&](int t) {
+    const Org o = origin(t);
+#pragma unroll
+    for (int q = 0; q < RXD; ++q) calc_x(o, q);
+    calc_y(t);
+  };
+
+  if (nchunks > 0) {
+    calc_all(0);
+    issue(0);
+    if (nchunks > 1) calc_all(1);
+  }
+  int shiftw[NACC];  // LDS float offset of tap t's shifted row (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const int t = wt + WT * j;
+    // folded: class (pa, pb) = wave, tap j = (dr, dc) reads source pixel (i - 1 + pa + dr, j - 1 + pb + dc)
+    shiftw[j] = FOLD ? (((wt >> 1) - 1 + (j >> 1)) * SW + ((wt & 1) - 1 + (j & 1))) * BA : ((t / 3 - 1) * SW + (t % 3 - 1)) * BA;
+  }
+  // The chunk loop, instantiated for the two tap counts a wave can have (its last tap may not exist: t = 9): a
+  // wave-uniform choice made ONCE, so that the 16 k-steps are one straight line the reads can be pipelined through
+  auto run = [&](auto nc) {
+    constexpr int NA = decltype(nc)::value;
+    for (int it = 0; it < nchunks; ++it) {
+      const int buf = it & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (it + 1 < nchunks) issue(buf ^ 1);
+      const Org o2 = origin(it + 2 < nchunks ? it + 2 : it);
+      const float* xp = reinterpret_cast<const float*>(wg_smem + buf * STAGE) + wa * 32 + c;
+      constexpr int YS = FOLD ? 8 * BB : 2 * BB;  // floats between the dY rows of consecutive k-steps
+      const float* yp = reinterpret_cast<const float*>(wg_smem + buf * STAGE + XB) +
+                        (FOLD ? (4 * hh + wt) * BB : hh * BB + wb * 32) + c;
+      float bv[2], xv[2][NA];
+      bv[0] = yp[0];
+#pragma unroll
+      for (int j = 0; j < NA; ++j) xv[0][j] = xp[base_slot[0] + shiftw[j]];
+      __builtin_amdgcn_sched_group_barrier(0x100, NA + 1, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < 16) {  // operands of k-step s+1: their LDS latency elapses under the MFMAs of step s
+          bv[nxt] = yp[(s + 1) * YS];
+#pragma unroll
+          for (int j = 0; j < NA; ++j) xv[nxt][j] = xp[base_slot[s + 1] + shiftw[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[cur][j], bv[cur], acc[j], 0, 0, 0);
+        if (s + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, NA + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+        // the address arithmetic of chunk it+2 rides between the k-steps (the matrix pipe is busy for NA x 64 cycles)
+        if (s >= 2 && s < 2 + RXD) calc_x(o2, s - 2);
+        if (s == 2 + RXD) calc_y(it + 2);
+      }
+    }
+  };
+  if (FOLD || wt + WT * (NACC - 1) < 9) run(std::integral_constant<int, NACC>{});
+  else run(std::integral_constant<int, NACC - 1>{});
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const int t = FOLD ? j : wt + WT * j;
+    if (t < 9) {
+      float* dst = FOLD ? a.slabs + (((size_t)z * 16 + wt * 4 + j) * a.Cin + a0) * a.Cout + b0 + c
+                        : a.slabs + (((size_t)z * 9 + t) * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[j][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, 1 tap, LDS-DMA
+// dW[ci][co] = sum_m X[m][ci] dY[m][co] (the decoder's Linear layer): a plain TN GEMM over the rows.  128 x 128 channel
+// tile per block, 4 waves with a 64 x 64 wave tile (4 accumulator tiles), 32 rows per stage by LDS-DMA, two stages, one
+// barrier per stage; rows past the slab carry an out-of-range offset (zeros).
+__global__ __launch_bounds__(256) void conv_wgrad1_dma_kernel(WgradArgs a) {
+  constexpr int BA = 128, BB = 128, XB = 32 * BA * 4, STAGE = 2 * XB;  // X rows then dY rows, 16 KB each
+  typedef __attribute__((address_space(3))) void lds_void;
+  extern __shared__ __align__(16) unsigned char wg_smem[];  // 2 * STAGE bytes
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), wa = wv >> 1, wb = wv & 1;
+  const int tiles_b = a.Cout / BB;
+  const int a0 = (blockIdx.x / tiles_b) * BA, b0 = (blockIdx.x % tiles_b) * BB;
+  const int z = blockIdx.y;
+  int64_t per = (a.M + a.ksplit - 1) / a.ksplit;
+  per = (per + 31) & ~(int64_t)31;
+  const int64_t mbeg = (int64_t)z * per;
+  const int64_t mend = mbeg + per < a.M ? mbeg + per : a.M;
+  const int nchunks = mbeg < mend ? (int)((mend - mbeg + 31) / 32) : 0;
+  const uint32_t xrow_bytes = (uint32_t)a.Cin * 4u, yrow_bytes = (uint32_t)a.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)0xFFFF0000u, 0x00020000);
+  constexpr uint32_t PAD = 0xFFFF0000u;
+  // stage image [32 rows][128 floats]: 16 pieces of 1 KiB (2 rows each), 4 per wave and operand
+  int prow[4];
+  uint32_t pcol[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = (wv * 4 + q) * 64 + lane;
+    prow[q] = e >> 5;
+    pcol[q] = (uint32_t)(e & 31) * 16u;
+  }
+  auto issue = [&](int t, int buf) {
+    unsigned char* dst = wg_smem + buf * STAGE + wv * 4096;
+    const int64_t m1 = mbeg + (int64_t)t * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t m = m1 + prow[q];
+      const bool ok = m < mend;
+      const uint32_t xo = ok ? (uint32_t)m * xrow_bytes + (uint32_t)a0 * 4u + pcol[q] : PAD;
+      const uint32_t yo = ok ? (uint32_t)m * yrow_bytes + (uint32_t)b0 * 4u + pcol[q] : PAD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void*)(dst + q * 1024), 16, (int)xo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (lds_void*)(dst + XB + q * 1024), 16, (int)yo, 0, 0, 0);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  if (nchunks > 0) issue(0, 0);
+  for (int it = 0; it < nchunks; ++it) {
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < nchunks) issue(it + 1, buf ^ 1);
+    const float* xp = reinterpret_cast<const float*>(wg_smem + buf * STAGE) + hh * BA + wa * 64 + c;
+    const float* yp = reinterpret_cast<const float*>(wg_smem + buf * STAGE + XB) + hh * BB + wb * 64 + c;
+    float av[2][2], bv[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { av[0][i] = xp[i * 32]; bv[0][i] = yp[i * 32]; }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { av[nxt][i] = xp[2 * (s + 1) * BA + i * 32]; bv[nxt][i] = yp[2 * (s + 1) * BB + i * 32]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+      if (s + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* dst = a.slabs + ((size_t)z * a.Cin + a0 + wa * 64 + i * 32) * a.Cout + b0 + wb * 64 + j * 32 + c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[i][j][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad, folded upsample
 // Weight gradient of Upsample(x2) + ConvTranspose 3x3 in the folded form (conv.h: ConvArgs.fold):
 //     dWf[cls][t][ci][co] = sum_q X[q + off(cls, t)][ci] * dY[4q + cls][co],   off = (pa-1+dr, pb-1+dc)
@@ -392,6 +672,17 @@ __global__ __launch_bounds__(256) void wgrad_fold_reduce_kernel(const float* __r
   }
 }
 
+static bool wgrad_dma_on() {
+  const char* e = getenv("DVG_WGRAD_DMA");  // (read per call: the tests flip it inside one process)
+  return !(e && e[0] == '0');
+}
+// the 1-tap form: 128 x 128 channel tiles (DMA kernel) when both channel counts allow and the tensors fit 32-bit offsets
+static bool wgrad1_dma_ok(int64_t M, int Cin, int Cout) {
+  // (and enough rows that the 128 x 128 tiles still fill the chip: c2's Linear layer has 2048 rows -- 32 such blocks)
+  return wgrad_dma_on() && Cin % 128 == 0 && Cout % 128 == 0 && (double)M * Cin * 4.0 < 4294901760.0 &&
+         (double)M * Cout * 4.0 < 4294901760.0 && (int64_t)(Cin / 128) * (Cout / 128) * ceil_div(M, 256) >= 256;
+}
+
 int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   const int ba = (Cin % 64 == 0) ? 64 : 32, bb = (Cout % 64 == 0) ? 64 : 32;
   const int64_t tiles = (int64_t)(Cin / ba) * (Cout / bb);
@@ -406,6 +697,10 @@ int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
     k = resident / tiles;
     const int64_t kmax = ceil_div(M, 64);
     if (k > kmax) k = kmax;
+  } else if (ntaps == 1 && wgrad1_dma_ok(M, Cin, Cout)) {
+    k = ceil_div(512, (int64_t)(Cin / 128) * (Cout / 128));  // two 4-wave blocks of 128 x 128 are resident per CU
+    const int64_t kmax = ceil_div(M, 256);
+    if (k > kmax) k = kmax;
   } else {
     k = ceil_div(1024, tiles * ntaps);
     const int64_t kmax = ceil_div(M, 256);
@@ -416,6 +711,19 @@ int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   return (int)k;
 }
 
+template <int WA, int WB, int WT, bool FOLD = false>
+static int launch_wgrad9_dma(int id, double flops, dim3 grid, const WgradArgs& a, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(128 * 32 * WA * 4 + (FOLD ? 128 : 32) * 32 * WB * 4);
+  auto kern = conv_wgrad9_dma_kernel<WA, WB, WT, FOLD>;
+  static bool attr_set = false;  // one instantiation = one static
+  if (lds > 64 * 1024 && !attr_set) {
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  DVG_LAUNCH_WORK(id, flops, kern, grid, dim3(WA * WB * WT * 64), lds, s, a);
+  return DVG_OK;
+}
+
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.Cin % 32 || a.Cout % 32 || a.M <= 0 || a.ksplit < 1) {
     set_error("conv_wgrad: unsupported shape Cin=%d Cout=%d M=%lld", a.Cin, a.Cout, (long long)a.M);
@@ -424,6 +732,8 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   if (a.fold) {
     if (a.ntaps != 16 || a.ups) { set_error("conv_wgrad: fold needs ntaps=16, ups=0"); return DVG_E_INVALID; }
     const double fl = 2.0 * (double)a.M * a.Cin * a.Cout * 16;  // executed FLOPs (4/9 of the 9-tap form)
+    if (wgrad_dma_on() && (double)a.M * a.Cin * 4.0 < 4294901760.0 && (double)a.M * 4.0 * a.Cout * 4.0 < 4294901760.0)
+      return launch_wgrad9_dma<1, 1, 4, true>(K_WGRAD_FOLD, fl, dim3((unsigned)((a.Cin / 32) * (a.Cout / 32)), (unsigned)a.ksplit), a, s);
     DVG_LAUNCH_WORK(K_WGRAD_FOLD, fl, conv_wgrad_fold_kernel, dim3((unsigned)((a.Cin / 32) * (a.Cout / 32)), (unsigned)a.ksplit),
                     dim3(256), 0, s, a);
     return DVG_OK;
@@ -437,11 +747,29 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     // (4 waves x 9 tiles, one per SIMD): +10 % on the kernel in-situ (c3 53 -> 59, c2 41 -> 45 TFLOP/s), steps neutral
     // to -1 %.  DVG_WGRAD9_WT2=0 restores the 4-wave form (A/B runs).
     static const bool wt2 = [] { const char* e = getenv("DVG_WGRAD9_WT2"); return !e || e[0] != '0'; }();
+    // LDS-DMA form (32-bit offsets: both tensors below 0xFFFF0000 bytes); DVG_WGRAD_DMA=0: the register-staged form
+    const double xbytes = (double)(a.ups ? a.M / 4 : a.M) * a.Cin * 4.0, ybytes = (double)a.M * a.Cout * 4.0;
+    if (wgrad_dma_on() && xbytes < 4294901760.0 && ybytes < 4294901760.0) {
+      if (a64 && b64) return launch_wgrad9_dma<2, 2, 2>(K_WGRAD_2x2, flops, g9, a, s);
+      if (a64) return launch_wgrad9_dma<2, 1, 2>(K_WGRAD_2x1, flops, g9, a, s);
+      if (b64) return launch_wgrad9_dma<1, 2, 2>(K_WGRAD_1x2, flops, g9, a, s);
+      return launch_wgrad9_dma<1, 1, 4>(K_WGRAD_1x1, flops, g9, a, s);
+    }
     if (a64 && b64 && wt2) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad9_kernel<2, 2, 2>), g9, dim3(512), 0, s, a);
     else if (a64 && b64) DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, (conv_wgrad9_kernel<2, 2, 1>), g9, dim3(256), 0, s, a);
     else if (a64) DVG_LAUNCH_WORK(K_WGRAD_2x1, flops, (conv_wgrad9_kernel<2, 1, 2>), g9, dim3(256), 0, s, a);
     else if (b64) DVG_LAUNCH_WORK(K_WGRAD_1x2, flops, (conv_wgrad9_kernel<1, 2, 2>), g9, dim3(256), 0, s, a);
     else DVG_LAUNCH_WORK(K_WGRAD_1x1, flops, (conv_wgrad9_kernel<1, 1, 4>), g9, dim3(256), 0, s, a);
+    return DVG_OK;
+  }
+  if (a.ntaps == 1 && wgrad1_dma_ok(a.M, a.Cin, a.Cout)) {
+    auto kern = conv_wgrad1_dma_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+      DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+      attr_set = true;
+    }
+    DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, kern, dim3((unsigned)((a.Cin / 128) * (a.Cout / 128)), (unsigned)a.ksplit), dim3(256), 65536, s, a);
     return DVG_OK;
   }
   const dim3 grid((unsigned)((a.Cin / ba) * (a.Cout / bb)), (unsigned)a.ntaps, (unsigned)a.ksplit);

@@ -15,12 +15,12 @@ def _rel(a, b):
 
 @pytest.fixture(params=["reg", "dma"])
 def staging(request):
-    """Both staging forms of the float32 GEMM kernel for EVERY tile configuration (DVG_IGEMM_DMA: the product picks
-    per launch size): register-staged with ds_write, and LDS-DMA with K-major packed weights."""
+    """Both staging forms of the float32 GEMM kernels (DVG_IGEMM_DMA, DVG_WGRAD_DMA; the product runs the LDS-DMA forms):
+    register-staged with ds_write, and LDS-DMA (forward / data-gradient with K-major packed weights; 3x3 weight gradient)."""
     import os
-    os.environ["DVG_IGEMM_DMA"] = "1" if request.param == "dma" else "0"
+    os.environ["DVG_IGEMM_DMA"] = os.environ["DVG_WGRAD_DMA"] = "1" if request.param == "dma" else "0"
     yield request.param
-    os.environ.pop("DVG_IGEMM_DMA", None)
+    os.environ.pop("DVG_IGEMM_DMA", None); os.environ.pop("DVG_WGRAD_DMA", None)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4),
@@ -68,9 +68,9 @@ def test_convtranspose_with_fused_upsample(N, Cin, Cout, side, staging):
     assert _rel(gw.cpu(), w.grad) < 3e-6
 
 
-def test_linear_as_one_tap_gemm(staging):
+@pytest.mark.parametrize("N,n", [(37, 64), (700, 128), (16384, 128)])  # (n = 128: the 128 x 128-tile 1-tap weight-gradient kernel)
+def test_linear_as_one_tap_gemm(N, n, staging):
     torch.manual_seed(0)
-    N, n = 37, 64
     x = torch.randn(N, n, requires_grad=True); w = (torch.randn(4 * n, n) / n**0.5).requires_grad_(True)
     y = F.linear(x, w)  # (N, 4n), column c*4+p
     gy = torch.randn_like(y)

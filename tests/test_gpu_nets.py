@@ -188,6 +188,33 @@ def test_decoder_matches_oracle_full_gradients(n, B, R):
             _close(dec.state_dict()[f"convtrans.{5*l+1}.{stat}"].cpu(), p[f"convtrans.{5*l+1}.{stat}"], 1e-5, stat)
 
 
+@pytest.mark.parametrize("n,B,R", [(128, 8, 8), (256, 40, 4)])
+def test_decoder_gradients_do_not_depend_on_the_staging_form(n, B, R):
+    """The LDS-DMA forms of the weight-gradient kernels (3x3, folded upsample + 3x3) keep the register-staged forms'
+    accumulation order: bit-identical gradients.  (The Linear layer's 1-tap form uses another tile and K split: float32
+    rounding apart; the forward / data-gradient kernels' two forms order their sums differently: 1e-5.)"""
+    params = gen.make_params(n, "decoder", 5 + n)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 11)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 9)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    grads = {}
+    for form in ("0", "1"):
+        os.environ["DVG_WGRAD_DMA"] = form
+        try:
+            dec = _load(Decoder(n), params).train()
+            dec.inject_dropout_masks(masks)
+            sg = spins.clone().requires_grad_(True)
+            (dec(sg) * go).sum().backward()
+            grads[form] = {k: v.grad.clone() for k, v in dec.named_parameters()}
+        finally:
+            os.environ.pop("DVG_WGRAD_DMA", None)
+    for k in grads["0"]:
+        if k == "increase_latent_dim.weight" and n % 128 == 0:
+            _close(grads["1"][k].cpu(), grads["0"][k].cpu(), 2e-6, k)
+        else:
+            assert torch.equal(grads["0"][k], grads["1"][k]), k
+
+
 def test_decoder_device_dropout_is_per_sample_channel_and_reproducible():
     n, B, R = 64, 16, 4
     dec = _load(Decoder(n), gen.make_params(n, "decoder", 3)).train()
