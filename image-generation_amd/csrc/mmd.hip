@@ -389,6 +389,121 @@ __device__ __forceinline__ void mmd_distsum_generic(const MmdArgs& a, unsigned c
   if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
+// Spin rows, d = 128 .. 512 in steps of 128, many rows (c3): 256 rows per block, 64 per wave, resident in registers as
+// int8 MFMA B fragments; the rows of x and y are ONE contiguous int8 array (x then y), walked as a triangle of
+// 256-row blocks x 32-row column chunks (block b takes row blocks b and T-1-b; the chunks of a row block are dealt to
+// gridDim.y blocks).  The kernel is bound by the L2 -> LDS traffic of the column rows, which this shape halves against
+// the 128-row form; the chunks [32][d] arrive by LDS-DMA (buffer_load ... lds, double-buffered, 16-byte slots swizzled
+// on the source address, rows past the end read zeros and are masked), one barrier per chunk.  A pair's distance is
+// symmetric and zero on the diagonal: chunks inside the row block's own range count once (the square holds both
+// orders), chunks to its right twice.
+template <int NST>
+__device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned char* dsm) {
+  constexpr int D = 32 * NST, CH = 32 * D, NPW = NST / 4;  // chunk bytes; 1 KiB DMA pieces per wave and chunk
+  typedef __attribute__((address_space(3))) void lds_void;
+  double* red = reinterpret_cast<double*>(dsm);                  // [256]
+  float* Dtab = reinterpret_cast<float*>(dsm + 2048);            // [D + 1]
+  unsigned char* zbuf = dsm + 2048 + ((D + 1) * 4 + 1023) / 1024 * 1024;  // [2][32][D]
+  for (int h = threadIdx.x; h <= D; h += 256) {
+    const float d2 = (float)(4 * h);  // |a|^2 + |b|^2 - 2ab with |.|^2 = d: exact
+    Dtab[h] = a.squared ? d2 : sqrtf(d2);
+  }
+  const int N = (int)(a.nx + a.ny);
+  const int T = (N + 255) >> 8, TC = (N + 31) >> 5;  // 256-row blocks, 32-row chunks
+  const int lane = threadIdx.x & 63, hh = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.zi8), 0, N * D, 0x00020000);
+  // DMA pieces: piece q of this wave covers bytes 1024 (NPW wave + q) + 16 lane of the chunk image: row r, physical slot
+  // sl; it fetches logical slot sl ^ f(r)
+  int poff[NPW];
+#pragma unroll
+  for (int q = 0; q < NPW; ++q) {
+    const int byte = (wave * NPW + q) * 1024 + lane * 16;
+    const int r = byte / D, sl = (byte % D) >> 4;
+    const int f = (D % 256 == 0) ? (r & 15) : ((r >> 1) & 7);
+    poff[q] = r * D + ((sl ^ f) << 4);
+  }
+  auto issue = [&](int t, int buf) {
+    unsigned char* dst = zbuf + buf * CH + wave * NPW * 1024;
+#pragma unroll
+    for (int q = 0; q < NPW; ++q)  // (rows past N: offset past num_records: zeros)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + q * 1024), 16, poff[q], t * CH, 0, 0);
+  };
+  const int fc = (D % 256 == 0) ? (c & 15) : ((c >> 1) & 7);
+  const int tb2 = 2048 + 2 * D;  // LDS byte address of Dtab[h] for Gram value S: tb2 - 2 S  (h = (D - S) / 2)
+  double total = 0.0;
+  __syncthreads();
+  for (int seg = 0; seg < 2; ++seg) {
+    const int g = seg == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x;
+    if (g >= T || (seg == 1 && g <= (int)blockIdx.x)) break;  // (block-uniform)
+    i32x4 xb[2][NST];
+    bool vi[2];
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+      const int gi = g * 256 + wave * 64 + rs * 32 + c;
+      vi[rs] = gi < N;
+      const int8_t* xrow = a.zi8 + (int64_t)(vi[rs] ? gi : N - 1) * D + hh * 16;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) xb[rs][s] = *reinterpret_cast<const i32x4*>(xrow + s * 32);
+    }
+    const int t0 = g * 8 + (int)blockIdx.y, t_own_end = g * 8 + 8;
+    float part[2] = {0.f, 0.f};  // this segment's sums of the two row sets, flushed to double below
+    double segsum[2] = {0.0, 0.0};
+    if (t0 < TC) issue(t0, 0);
+    int buf = 0;
+    for (int t = t0; t < TC; t += (int)gridDim.y, buf ^= 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + (int)gridDim.y < TC) issue(t + (int)gridDim.y, buf ^ 1);
+      const unsigned char* zrow = zbuf + buf * CH + c * D;
+      i32x16 acc[2];
+      acc[0] = (i32x16){0}; acc[1] = (i32x16){0};
+#pragma unroll
+      for (int s = 0; s < NST; ++s) {
+        const i32x4 za = *reinterpret_cast<const i32x4*>(zrow + (((2 * s + hh) ^ fc) << 4));
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[0][s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[1][s], acc[1], 0, 0, 0);
+      }
+      const float wgt = t < t_own_end ? 1.0f : 2.0f;
+      float p0 = 0.f, p1 = 0.f;
+      if (t * 32 + 32 <= N) {  // whole chunk valid (block-uniform): no masks
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          p0 += *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[0][r]));
+          p1 += *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[1][r]));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool vj = t * 32 + crow(r, hh) < N;
+          const float d0 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[0][r]));
+          const float d1 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[1][r]));
+          p0 += vj ? d0 : 0.f;
+          p1 += vj ? d1 : 0.f;
+        }
+      }
+      part[0] = fmaf(p0, wgt, part[0]);
+      part[1] = fmaf(p1, wgt, part[1]);
+      if (((t - t0) / (int)gridDim.y & 15) == 15) {  // keep the float32 running sums short
+        segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
+        part[0] = 0.f; part[1] = 0.f;
+      }
+    }
+    segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
+    total += (vi[0] ? segsum[0] : 0.0) + (vi[1] ? segsum[1] : 0.0);
+    __syncthreads();  // (the next segment's first DMA must not overtake a straggler's reads of stage 0)
+  }
+  const double sum = block_sum(total, red);
+  if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sum;
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void mmd_distsum_spin256_kernel(MmdArgs a) {
+  extern __shared__ __align__(16) unsigned char dsm[];
+  if (*a.not_pm1 == 0) mmd_distsum_spin256<NST>(a, dsm);
+  else mmd_distsum_generic(a, dsm, false);
+}
+
 // One launch serves both kinds of input (device flag written by mmd_prep_kernel: exact int8 Gram for +-1 rows).
 template <int NS>
 __global__ __launch_bounds__(256, NS <= 16 ? 2 : 1) void mmd_distsum_spin_kernel(MmdArgs a) {
@@ -616,7 +731,12 @@ __global__ __launch_bounds__(256) void mmd_bandwidth_table_kernel(MmdArgs a, con
 
 // bf16 transposed copy: zt[(jb * d + f) * 32 + 16 s + 8 h + e] = row[32 jb + 16 s + 8 (e>>2) + 4 h + (e&3)][f]
 // (zero beyond the last row).  One thread per (jb, f): 32 strided reads, coalesced over f, one 64-byte write.
-__global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* __restrict__ zt) {
+__global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* __restrict__ zt, int zero_loss_parts) {
+  // (the loss partials the pair kernels of this call will NOT write must read as zero in the final sum: cleared here
+  // rather than by a memset node of its own)
+  for (int64_t e = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; e < 3 * (int64_t)zero_loss_parts;
+       e += (int64_t)gridDim.x * gridDim.y * 256)
+    a.loss_part[e] = 0.0;
   if (*a.not_pm1 != 0) return;
   const int64_t jb = blockIdx.y;
   const int f = blockIdx.x * 256 + threadIdx.x;
@@ -1538,6 +1658,7 @@ __global__ __launch_bounds__(256) void mmd_final_kernel(const double* __restrict
 
 struct MmdPlan {
   int nfb, zslices, S, S1;
+  bool d256;  // pass 1 by the 256-row-block spin kernel
   int64_t rbx, rby, GX1;
   size_t off_sq, off_coef, off_dist, off_loss, off_grad, off_flag, off_zi8, off_zt, off_tab, total;
   int pm1_ok;
@@ -1592,7 +1713,17 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   // pass 1 (distance sum): spin-capable shapes launch the folded 128-row form, ceil(T/2) x S1 blocks of about
   // (T+1)/S1 tiles each, two blocks per CU wanted; other shapes one block per 32-row block
   int64_t S1;
-  if (p.pm1_ok) {
+  {
+    const char* e = getenv("DVG_MMD_D256");  // 0: never, 1: whenever the shape allows (tests); read per call
+    const int env = !e ? -1 : (e[0] == '1' ? 1 : 0);
+    const int64_t t256 = ceil_div(nx + ny, 256);
+    p.d256 = p.pm1_ok && env != 0 && d % 128 == 0 && d <= 512 && (t256 >= 32 || env == 1) && (nx + ny) * (int64_t)d < 2147483647LL;
+  }
+  if (p.d256) {  // 256-row blocks: ceil(T/2) x S1 blocks, two resident per CU
+    p.GX1 = (ceil_div(nx + ny, 256) + 1) / 2;
+    S1 = ceil_div(512, p.GX1);
+    if (S1 > 32) S1 = 32;
+  } else if (p.pm1_ok) {
     p.GX1 = (tiles + 1) / 2;
     S1 = ceil_div(512, p.GX1);
     if (S1 > tiles + 1) S1 = tiles + 1;
@@ -1758,9 +1889,16 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   DVG_CHECK_HIP(hipMemsetAsync(w + p.off_flag, 0, sizeof(int), s));
   DVG_LAUNCH(K_MMD_PREP, mmd_prep_kernel, dim3((unsigned)ceil_div(nx + ny, 4)), dim3(256), 0, s, x, nx, y, ny, dim,
              (float*)(w + p.off_sq), (int8_t*)(w + p.off_zi8), (int*)(w + p.off_flag));
+  int loss_parts = (int)(p.S * (p.rbx + p.rby));
+  if (p.w128) {
+    // (the 128-row-block pair kernel and the float32 kernel behind it number their loss partials by their own grids and
+    // exactly one of them runs: the slots the other layout would have filled must read as zero in the final sum)
+    if ((int)(p.S2 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * (p.rb128x + p.rb128y));
+    if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
+  }
   if (p.pm1_ok)
     DVG_LAUNCH(K_MMD_PREP, mmd_prep_zt_kernel, dim3((unsigned)ceil_div(dim, 256), (unsigned)(p.ztb_x + p.ztb_y)),
-               dim3(256), 0, s, a, (uint16_t*)(w + p.off_zt));
+               dim3(256), 0, s, a, (uint16_t*)(w + p.off_zt), p.w128 ? loss_parts : 0);
   int ndist = 0;
   if (!(cfg->bandwidth > 0.f)) {
     ndist = (int)(p.S1 * p.GX1);
@@ -1776,6 +1914,18 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
         DVG_LAUNCH(K_MMD_DISTSUM, kern, grid, dim3(256), lds_d, s, a);
         return DVG_OK;
       };
+      if (p.d256) {
+        const size_t lds_2 = 2048 + ((size_t)(dim + 1) * 4 + 1023) / 1024 * 1024 + 2 * (size_t)32 * dim;
+        const size_t lds_256 = lds_f > lds_2 ? lds_f : lds_2;
+        auto launch256 = [&](auto kern) -> int {
+          DVG_LAUNCH(K_MMD_DISTSUM, kern, grid, dim3(256), lds_256, s, a);
+          return DVG_OK;
+        };
+        if (dim == 128) DVG_TRY(launch256(mmd_distsum_spin256_kernel<4>));
+        else if (dim == 256) DVG_TRY(launch256(mmd_distsum_spin256_kernel<8>));
+        else if (dim == 384) DVG_TRY(launch256(mmd_distsum_spin256_kernel<12>));
+        else DVG_TRY(launch256(mmd_distsum_spin256_kernel<16>));
+      } else
       if (dim <= 128) DVG_TRY(launch(mmd_distsum_spin_kernel<4>));
       else if (dim <= 512) DVG_TRY(launch(mmd_distsum_spin_kernel<16>));
       else DVG_TRY(launch(mmd_distsum_spin_kernel<32>));
@@ -1791,13 +1941,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
              (double)(nx + ny), cfg->bandwidth, cfg->factor, (float*)(w + p.off_coef),
              p.pm1_ok ? (uint4*)(w + p.off_tab) : (uint4*)nullptr);
   int rc;
-  int loss_parts = (int)(p.S * (p.rbx + p.rby));
   if (p.w128) {
-    // (the two kernels below number their loss partials by their own grids and exactly one of them runs: the slots the
-    // other layout would have filled must read as zero in the final sum)
-    if ((int)(p.S2 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * (p.rb128x + p.rb128y));
-    if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
-    DVG_CHECK_HIP(hipMemsetAsync(w + p.off_loss, 0, sizeof(double) * 3 * (size_t)loss_parts, s));
     // Large spin problems: 128-row blocks.  General (not +-1) rows cannot be known on the host without a sync, so the
     // f32 kernel is launched behind it with the same split count and stands down on the device flag (its blocks exit at
     // once; it writes the same loss_part / grad_part slots when it does run).

@@ -56,6 +56,7 @@ def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
     out = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("DVG_MMD_W128", flag)
+        monkeypatch.setenv("DVG_MMD_D256", flag)  # (and the 256-row-block distance-sum kernel with it)
         xg = x.cuda().requires_grad_(True)
         loss = F.mmd_loss(xg, y.cuda(), **kw)
         loss.backward()
