@@ -73,8 +73,9 @@ def net_flops_per_image(n, R):
     return 3 * (f_enc + R * f_dec)
 
 
-# (rocprof spells out the kernels' trailing arithmetic-form template argument; the float32 instantiation, 0, is the one priced)
-_NORM = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").replace("dvg::", "").split("(")[0].replace(",false>", ">").replace(",1,0>", ",1>")  # noqa: E731
+# (rocprof spells out the kernels' trailing arithmetic-form template argument; the float32 instantiations -- 3, the LDS-DMA
+# form the library launches, or 0, the register-staged one -- are the ones priced)
+_NORM = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").replace("dvg::", "").split("(")[0].replace(",false>", ">").replace(",1,0>", ",1>").replace(",1,3>", ",1>")  # noqa: E731
 # name of the rocprof kernel behind a library profiler id that is not itself a kernel name
 PROF_TO_ROCPROF = {"mmd_pm1": "mmd_pair", "gibbs_sweeps": "gibbs_"}
 

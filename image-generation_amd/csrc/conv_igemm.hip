@@ -56,16 +56,20 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   constexpr bool BPART = RB * NT != NB16;     // fewer B loads than threads (32-column tile, 512 threads)
   constexpr int AP16 = BKT + 8;               // bf16 form: row pitch of both tiles in bf16 elements (144 bytes)
   static_assert(RA * NT == 8 * BM && (!BPART || RB == 1), "tile loaders must divide evenly");
-  constexpr int NBS = 16;                // taps per row in the neighbour table (9, 4 or 16 used)
+  // taps per row in the neighbour table: 16 for the folded data gradient, else 9 (a 128-row table is 4.5 KB instead of
+  // 8: with it three blocks of the 128x64 LDS-DMA form fit a CU's 160 KB)
+  const int NBS = a.ntaps > 9 ? 16 : 9;
   extern __shared__ __align__(16) unsigned char igemm_smem[];  // conv_igemm_lds_bytes<...>() bytes
   float* As = reinterpret_cast<float*>(igemm_smem);            // [BM][AP]
   float* Bs = As + BM * AP;                                    // [BKT][BP]
   uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 forms: [NP][BM][AP16], then Bs16 [NP][BN][AP16] (K-major)
   uint16_t* Bs16 = As16 + NP * BM * AP16;
   constexpr int STAGE = (BM + BN) * 128;  // LDS-DMA form: one stage = A [BM][32 f32] then B [BN][32 f32]
-  float* red = DMA ? reinterpret_cast<float*>(igemm_smem + 2 * STAGE)
-               : BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;  // [WM][BN][2]
-  int* nbr = reinterpret_cast<int*>(red + WM * BN * 2);        // [BM][NBS] source row of every (tile row, tap), -1 = padding
+  // [WM][BN][2] BatchNorm partials of the epilogue (LDS-DMA form: on top of the then-dead stage 0, behind a barrier)
+  float* red = DMA ? reinterpret_cast<float*>(igemm_smem)
+               : BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;
+  // [BM][NBS] source row of every (tile row, tap), -1 = padding
+  int* nbr = DMA ? reinterpret_cast<int*>(igemm_smem + 2 * STAGE) : reinterpret_cast<int*>(red + WM * BN * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kg = wave / (WM * WN), wv = wave - kg * (WM * WN);  // K group, wave within the (WM x WN) tile grid
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       }
     }
   if (a.stats) {
+    if constexpr (DMA) __syncthreads();  // every wave is done reading the stages `red` overlays
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       s1[j] += __shfl_xor(s1[j], 32, 64);
@@ -544,7 +549,7 @@ static int igemm_cfg(int64_t M, int Cout) {
 }
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static constexpr size_t conv_igemm_lds_bytes() {
-  if (PM == 3) return (size_t)(2 * (BM + BN) * 128) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
+  if (PM == 3) return (size_t)(2 * (BM + BN) * 128);  // + the neighbour table (launch_igemm_cfg); the BN partials overlay a stage
   if (PM == 2) return sizeof(uint16_t) * (size_t)(3 * (BM + BN) * (32 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   if (PM == 1) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
   return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
@@ -552,11 +557,13 @@ static constexpr size_t conv_igemm_lds_bytes() {
 
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, hipStream_t s) {
-  constexpr size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>();
+  // (LDS-DMA form: the neighbour table is sized by the launch's tap count; the other forms always carry 16 per row)
+  const size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM == 3 ? sizeof(int) * (size_t)BM * (a.ntaps > 9 ? 16 : 9) : 0);
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, PM>;
   static bool attr_set = false;  // one instantiation = one static
-  if (lds > 64 * 1024 && !attr_set) {
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  constexpr size_t lds_max = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM == 3 ? sizeof(int) * (size_t)BM * 16 : 0);
+  if (lds_max > 64 * 1024 && !attr_set) {
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   DVG_LAUNCH_WORK(id, flops, kern, grid, dim3(WM * WN * WK * 64), lds, s, a);

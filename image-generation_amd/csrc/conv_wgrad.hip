@@ -787,7 +787,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int sub = threadIdx.x & 7;
   for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += ((int64_t)gridDim.x * 256) >> 3) {
     float s = 0.f;
-    for (int k = sub; k < ksplit; k += 8) s += slabs[(size_t)k * total + e];
+    for (int k0 = sub; k0 < ksplit; k0 += 64) {  // eight loads in flight, summed in the same order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = k0 + 8 * u < ksplit ? slabs[(size_t)(k0 + 8 * u) * total + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (k0 + 8 * u < ksplit) s += v[u];
+    }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);

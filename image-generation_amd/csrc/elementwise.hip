@@ -93,13 +93,27 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Sum of part[g * stride] over g = lane, lane + 64, ... < G in that order (double), with eight loads in flight: the
+// partials were written by another kernel's blocks on other XCDs, so every dependent load is a trip past the L2
+// (~1 us each; the finalizer kernels are a few dependent trips long and sit on the step's critical chain at c2).
+__device__ __forceinline__ double strided_sum8(const float* __restrict__ p, int lane, int G, size_t stride) {
+  double s = 0.0;
+  for (int g0 = lane; g0 < G; g0 += 512) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = g0 + 64 * u < G ? p[(size_t)(g0 + 64 * u) * stride] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (g0 + 64 * u < G) s += (double)v[u];
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int G, int stride, int count,
                                                      float scale, float* __restrict__ out, int permA, int permB) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (w >= count) return;
-  double s = 0.0;
-  for (int g = lane; g < G; g += 64) s += (double)part[(size_t)g * stride + w];
+  double s = strided_sum8(part + w, lane, G, (size_t)stride);
   s = wave_sum(s);
   if (lane == 0) {
     const int o = permA > 0 ? (w % permA) * permB + w / permA : w;
@@ -119,8 +133,7 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (w >= count_a + count_b) return;
-  double s = 0.0;
-  for (int g = lane; g < G; g += 64) s += (double)part[(size_t)g * stride + w];
+  double s = strided_sum8(part + w, lane, G, (size_t)stride);
   s = wave_sum(s);
   if (lane == 0) {
     if (w < count_a) out_a[w] = (float)s;
@@ -207,11 +220,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     return;
   }
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = lane; k < nblk; k += 64) {
-    s1 += (double)part[((size_t)k * C + c) * 2];
-    s2 += (double)part[((size_t)k * C + c) * 2 + 1];
-  }
+  double s1 = strided_sum8(part + (size_t)c * 2, lane, nblk, (size_t)C * 2);
+  double s2 = strided_sum8(part + (size_t)c * 2 + 1, lane, nblk, (size_t)C * 2);
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane != 0) return;

@@ -43,5 +43,7 @@ python bench.py --config c3 --precision bf16 --no-cpu-baseline --steps 10 > $OUT
 python bench.py --config c3 --precision f32x3 --no-cpu-baseline --parity --steps 20 > $OUT/c3x.log 2>&1; last $OUT/c3x.log $OUT/${R}_bench_c3_f32x3.json
 python tools/mmd_accuracy.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_accuracy_c3.txt
 python tools/mmd_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_kernels_c3.txt
+python tools/igemm_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_igemm_staging_ab.txt
+python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
 rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/*.log
 ls -la $OUT
