@@ -40,7 +40,12 @@ enum WeightMode : int {
   // ConvTranspose2d behind a nearest Upsample(x2), folded (see ConvArgs.fold): 16 "taps" = 4 output parity classes
   // x 2x2 source pixels; each packed entry is the SUM of the 1, 2 or 4 original taps that read that source pixel
   WM_CONVT_FOLD_FWD,  // tap = cls*4 + t: a = ci, b = co
-  WM_CONVT_FOLD_DGRAD // tap = cls*4 + t: a = co, b = ci
+  WM_CONVT_FOLD_DGRAD,// tap = cls*4 + t: a = co, b = ci
+  // ConvTranspose2d 3x3 (padding 1) on 2x2 images as ONE dense map per image: of the 9 taps of an output pixel only the
+  // 4 that land inside the image multiply anything but padding, and input pixel p_in reaches output pixel p_out through
+  // exactly one tap.  1-tap GEMM over images: Ca = 4 Cin, Cb = 4 Cout, ntaps = 1; 16/36 of the 9-tap form's FLOPs.
+  WM_CONVT_D22_FWD,   // a = p_in*Cin + ci, b = p_out*Cout + co   (p = Morton index of the pixel: x | y << 1)
+  WM_CONVT_D22_DGRAD  // a = p_out*Cout + co, b = p_in*Cin + ci
 };
 
 // Folding a 3x3 kernel over a x2-upsampled input: output pixel (2i+pa, 2j+pb) reads source rows i-1+pa+dr, dr in
@@ -58,6 +63,15 @@ __host__ __device__ __forceinline__ int64_t torch_weight_offset(const WeightMap&
     case WM_CONVT_FWD: return ((int64_t)a * w.Cb + b) * 9 + (8 - tap);
     case WM_CONVT_DGRAD: return ((int64_t)b * w.Ca + a) * 9 + tap;
     case WM_LIN_FWD: { const int c = b % w.Ca, p = b / w.Ca; return (int64_t)(c * 4 + p) * w.Ca + a; }
+    case WM_CONVT_D22_FWD:
+    case WM_CONVT_D22_DGRAD: {
+      const bool fwd = w.mode == WM_CONVT_D22_FWD;
+      const int Cin = (fwd ? w.Ca : w.Cb) / 4, Cout = (fwd ? w.Cb : w.Ca) / 4;
+      const int ai = fwd ? a : b, bo = fwd ? b : a;  // (p_in, ci) index, (p_out, co) index
+      const int p_in = ai / Cin, ci = ai % Cin, p_out = bo / Cout, co = bo % Cout;
+      const int t = ((p_in >> 1) - (p_out >> 1) + 1) * 3 + ((p_in & 1) - (p_out & 1) + 1);  // forward-GEMM tap
+      return ((int64_t)ci * Cout + co) * 9 + (8 - t);  // ConvTranspose2d (Cin,Cout,3,3), taps flipped
+    }
     default: { const int c = a % w.Cb, p = a / w.Cb; return (int64_t)(c * 4 + p) * w.Cb + b; }
   }
 }
@@ -106,6 +120,8 @@ struct ConvArgs {
   int bf16 = 0;
   // bias_perm = n > 0: column j = p*n + c takes bias[c*4 + p] (the decoder's Linear(n, 4n) bias in checkpoint order)
   int bias_perm = 0;
+  // bias_mod = C > 0: column j = p*C + c takes bias[c] (the dense 2x2 form: one bias per channel, four pixels per row)
+  int bias_mod = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();
@@ -138,6 +154,9 @@ struct WgradArgs {
 int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps);
 int wgrad_fold_ksplit(int64_t Msrc, int Cin, int Cout);
 int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s);
+// dense 2x2 form (WM_CONVT_D22_FWD): slabs [ksplit][4 Cin][4 Cout] -> ConvTranspose2d gradient (Cin,Cout,3,3): every tap
+// sums the (p_in, p_out) blocks that use it (4 for the centre tap, 2 for an edge, 1 for a corner), slabs in order
+int launch_wgrad_d22_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);

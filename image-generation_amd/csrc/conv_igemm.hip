@@ -462,7 +462,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * TN * 32 + j * 32 + c;
-      const float bias = a.bias ? a.bias[a.bias_perm ? (col % a.bias_perm) * 4 + col / a.bias_perm : col] : 0.f;
+      const float bias = a.bias ? a.bias[a.bias_perm ? (col % a.bias_perm) * 4 + col / a.bias_perm
+                                                : a.bias_mod ? col % a.bias_mod : col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
@@ -500,14 +501,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
 // partials in the layout of the unsplit kernel: stats[row_block][Cout][2], row blocks of `bm` OUTPUT pixels.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int64_t rows, int C,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            float* __restrict__ stats, int bm, int bias_perm) {
+                                                            float* __restrict__ stats, int bm, int bias_perm, int bias_mod) {
   __shared__ float red[2 * 256];
   // block = (row block of `bm` rows) x (32 channels); thread = (channel, one of 8 row lanes)
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int64_t r0 = (int64_t)blockIdx.x * bm;
   const int64_t r1 = r0 + bm < rows ? r0 + bm : rows;
   const int c = blockIdx.y * 32 + cl;
-  const float b = bias ? bias[bias_perm ? (c % bias_perm) * 4 + c / bias_perm : c] : 0.f;
+  const float b = bias ? bias[bias_perm ? (c % bias_perm) * 4 + c / bias_perm : bias_mod ? c % bias_mod : c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   for (int64_t r = r0 + rl; r < r1; r += 8) {
     float v = b;
@@ -682,7 +683,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const int64_t rows_out = a.poolsum ? a.M / 4 : Mg;
     const int bm = igemm_bm(cfg) / (a.poolsum ? 4 : 1);
     DVG_LAUNCH(K_MISC, splitk_reduce_kernel, dim3((unsigned)ceil_div(rows_out, bm), a.Cout / 32), dim3(256), 0, s, a.splitk_ws, a.ksplit,
-               rows_out, a.Cout, a.bias, a.out, a.poolsum ? nullptr : a.stats, bm, a.bias_perm);
+               rows_out, a.Cout, a.bias, a.out, a.poolsum ? nullptr : a.stats, bm, a.bias_perm, a.bias_mod);
   }
   return DVG_OK;
 }

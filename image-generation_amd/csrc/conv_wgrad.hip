@@ -683,6 +683,33 @@ static bool wgrad1_dma_ok(int64_t M, int Cin, int Cout) {
          (double)M * Cout * 4.0 < 4294901760.0 && (int64_t)(Cin / 128) * (Cout / 128) * ceil_div(M, 256) >= 256;
 }
 
+// Dense 2x2 form: slabs [ksplit][4 Cin][4 Cout]; grad_w (Cin,Cout,3,3)[ci][co][8 - t] = sum over the slabs (in order, 8
+// lanes per element, fixed shuffle tree) of the blocks (p_in, p_out) whose displacement is forward tap t.
+__global__ __launch_bounds__(256) void wgrad_d22_reduce_kernel(const float* __restrict__ slabs, int ksplit, int Cin, int Cout,
+                                                              float* __restrict__ grad_w) {
+  const int64_t plane = (int64_t)Cin * Cout, total = 9 * plane, srow = 4 * (int64_t)Cout, slab = 4 * (int64_t)Cin * srow;
+  const int sub = threadIdx.x & 7;
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += ((int64_t)gridDim.x * 256) >> 3) {
+    const int t = (int)(e / plane);
+    const int64_t ab = e - (int64_t)t * plane;
+    const int ci = (int)(ab / Cout), co = (int)(ab - (int64_t)ci * Cout);
+    const int dy = t / 3 - 1, dx = t % 3 - 1;  // p_in = p_out + (dy, dx)
+    float s = 0.f;
+    for (int k = sub; k < ksplit; k += 8) {
+      const float* sl = slabs + (size_t)k * slab;
+#pragma unroll
+      for (int po = 0; po < 4; ++po) {
+        const int yi = (po >> 1) + dy, xi = (po & 1) + dx;
+        if (yi >= 0 && yi < 2 && xi >= 0 && xi < 2) s += sl[((int64_t)((yi << 1 | xi) * Cin + ci)) * srow + po * Cout + co];
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) grad_w[ab * 9 + (8 - t)] = s;
+  }
+}
+
 int wgrad_ksplit(int64_t M, int Cin, int Cout, int ntaps) {
   const int ba = (Cin % 64 == 0) ? 64 : 32, bb = (Cout % 64 == 0) ? 64 : 32;
   const int64_t tiles = (int64_t)(Cin / ba) * (Cout / bb);
@@ -880,6 +907,12 @@ int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, fl
 
 int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s) {
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_fold_reduce_kernel, dim3(ew_grid((int64_t)9 * Cin * Cout * 8)), dim3(256), 0, s, slabs, ksplit,
+             Cin, Cout, grad_w);
+  return DVG_OK;
+}
+
+int launch_wgrad_d22_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s) {
+  DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_d22_reduce_kernel, dim3(ew_grid((int64_t)9 * Cin * Cout * 8)), dim3(256), 0, s, slabs, ksplit,
              Cin, Cout, grad_w);
   return DVG_OK;
 }

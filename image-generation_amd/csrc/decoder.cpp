@@ -25,6 +25,7 @@ struct DecPlan {
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partL, partW, partF, splitk;
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
+  bool d22;      // layer 0 (3x3 on 2x2 images) runs as the dense per-image map (conv.h: WM_CONVT_D22_FWD)
   size_t total_floats;
 };
 
@@ -32,6 +33,12 @@ struct DecPlan {
 bool fold_enabled() {
   static const bool off = [] { const char* e = getenv("DVG_NO_FOLD"); return e && e[0] == '1'; }();
   return !off;
+}
+
+// DVG_NO_D22=1 keeps the 9-tap form for the first ConvTranspose layer (A/B runs, tests)
+bool d22_enabled() {
+  const char* e = getenv("DVG_NO_D22");  // (read per call: the tests flip it inside one process)
+  return !(e && e[0] == '1');
 }
 
 size_t bump(size_t& o, size_t count) {
@@ -56,12 +63,15 @@ DecPlan dec_plan(int64_t N, int n) {
   size_t max_split = conv_splitk_floats(N, n, 4 * n, 1, 0);
   { const size_t sd = conv_splitk_floats(N, 4 * n, n, 1, 0); if (sd > max_split) max_split = sd; }
   int cmax = 4 * n;
+  p.d22 = d22_enabled();
   for (int l = 0; l < 4; ++l) {
     p.L[l] = l + 1;
     p.M[l] = N * ((int64_t)4 << (2 * l));
     const int C = ch[l + 1];
     p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
     p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
+    // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]
+    if (l == 0 && p.d22) p.nblk[l] = 4 * conv_stats_blocks(N, 4 * C);
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xs[l] = bump(o, (size_t)p.M[l] * C);
     p.mean[l] = bump(o, C);
@@ -71,11 +81,15 @@ DecPlan dec_plan(int64_t N, int n) {
     if (l < 3) {
       p.wp[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));   // 9 taps, or 16 folded (class, tap) pairs
       p.wpd[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));
-      p.ksplit[l] = p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
-      const size_t slab = (size_t)p.ksplit[l] * (p.fold[l] ? 16 : 9) * ch[l] * C;
+      const bool d22 = l == 0 && p.d22;
+      p.ksplit[l] = d22 ? wgrad_ksplit(N, 4 * ch[l], 4 * C, 1)
+                        : p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
+      const size_t slab = (size_t)p.ksplit[l] * (p.fold[l] || d22 ? 16 : 9) * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
-      const size_t sk_f = p.fold[l] ? conv_splitk_floats(p.M[l], ch[l], C, 4, 0) : conv_splitk_floats(p.M[l], ch[l], C, 9, 0);
-      const size_t sk_d = p.fold[l] ? conv_splitk_floats(p.M[l] / 4, C, ch[l], 16, 0) : conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
+      const size_t sk_f = d22 ? conv_splitk_floats(N, 4 * ch[l], 4 * C, 1, 0)
+                              : p.fold[l] ? conv_splitk_floats(p.M[l], ch[l], C, 4, 0) : conv_splitk_floats(p.M[l], ch[l], C, 9, 0);
+      const size_t sk_d = d22 ? conv_splitk_floats(N, 4 * C, 4 * ch[l], 1, 0)
+                              : p.fold[l] ? conv_splitk_floats(p.M[l] / 4, C, ch[l], 16, 0) : conv_splitk_floats(p.M[l], C, ch[l], 9, l > 0);
       if (sk_f > max_split) max_split = sk_f;
       if (sk_d > max_split) max_split = sk_d;
     }
@@ -137,6 +151,11 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, 0, N};
     jobs[1] = PackJob{p->lin_w, W + pl.wpd_lin, WeightMap{WM_LIN_DGRAD, 4 * n, n, 1}, 0, N};
     for (int l = 0; l < 3; ++l) {
+      if (l == 0 && pl.d22) {  // dense 2x2 form: 1-tap GEMMs over the N images
+        jobs[2] = PackJob{p->conv_w[0], W + pl.wp[0], WeightMap{WM_CONVT_D22_FWD, 4 * pl.ch[0], 4 * pl.ch[1], 1}, 0, N};
+        jobs[3] = PackJob{p->conv_w[0], W + pl.wpd[0], WeightMap{WM_CONVT_D22_DGRAD, 4 * pl.ch[1], 4 * pl.ch[0], 1}, 0, N};
+        continue;
+      }
       if (pl.fold[l]) {
         // (forward: 4 classes x M/4 source rows = M GEMM rows; data gradient: M/4 source rows)
         jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FOLD_FWD, pl.ch[l], pl.ch[l + 1], 16}, 0, pl.M[l]};
@@ -178,6 +197,9 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = l > 0; a.poolsum = 0;
       if (pl.fold[l]) { a.M = pl.M[l] / 4; a.L = pl.L[l] - 1; a.ntaps = 4; a.ups = 0; a.fold = 1; }
+      if (l == 0 && pl.d22) {  // rows = images, columns = (pixel, channel): the same memory as [4 N][C]
+        a.M = N; a.Cin = 4 * Cin; a.Cout = 4 * C; a.L = 0; a.ntaps = 1; a.bias_mod = C;
+      }
       a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
     } else {
@@ -263,6 +285,8 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = l > 0;
     if (pl.fold[l]) { a.M = pl.M[l] / 4; a.L = pl.L[l] - 1; a.ntaps = 16; a.poolsum = 0; a.fold = 2; }
+    const bool d22 = l == 0 && pl.d22;
+    if (d22) { a.M = N; a.Cin = 4 * C; a.Cout = 4 * Cin; a.L = 0; a.ntaps = 1; a.poolsum = 0; }
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
@@ -270,7 +294,11 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
-    if (pl.fold[l]) {
+    if (d22) {
+      wa.M = N; wa.Cin = 4 * Cin; wa.Cout = 4 * C; wa.L = 0; wa.ntaps = 1; wa.ups = 0;
+      DVG_TRY(launch_conv_wgrad(wa, s2));
+      DVG_TRY(launch_wgrad_d22_reduce(W + pl.slabs, pl.ksplit[l], Cin, C, g->conv_w[l], s2));
+    } else if (pl.fold[l]) {
       wa.M = pl.M[l] / 4; wa.L = pl.L[l] - 1; wa.ntaps = 16; wa.ups = 0; wa.fold = 1;
       DVG_TRY(launch_conv_wgrad(wa, s2));
       DVG_TRY(launch_wgrad_fold_reduce(W + pl.slabs, pl.ksplit[l], Cin, C, g->conv_w[l], s2));

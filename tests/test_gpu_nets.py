@@ -215,6 +215,38 @@ def test_decoder_gradients_do_not_depend_on_the_staging_form(n, B, R):
             assert torch.equal(grads["0"][k], grads["1"][k]), k
 
 
+@pytest.mark.parametrize("n,B,R", [(64, 5, 3), (128, 64, 8)])
+def test_decoder_first_layer_dense_2x2_form_equals_the_9_tap_form(n, B, R):
+    """ConvTranspose2d 3x3 on the 2x2 images behind the Linear layer runs as one dense map per image (only the 4 of 9
+    taps that land inside the image: 16/36 of the FLOPs); DVG_NO_D22=1 keeps the 9-tap implicit GEMM.  Same output, same
+    gradients (summation order apart), same BatchNorm statistics."""
+    params = gen.make_params(n, "decoder", 77 + n)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 13)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 10)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(6)).cuda()
+    res = {}
+    for form in ("1", "0"):
+        os.environ["DVG_NO_D22"] = form
+        try:
+            dec = _load(Decoder(n), params).train()
+            dec.inject_dropout_masks(masks)
+            sg = spins.clone().requires_grad_(True)
+            out = dec(sg)
+            (out * go).sum().backward()
+            res[form] = (out.detach().cpu(), sg.grad.cpu(), {k: v.grad.cpu() for k, v in dec.named_parameters()},
+                         {k: v.cpu() for k, v in dec.state_dict().items() if "running" in k})
+        finally:
+            os.environ.pop("DVG_NO_D22", None)
+    _close(res["0"][0], res["1"][0], 1e-5, "output")
+    _close(res["0"][1], res["1"][1], 2e-5, "grad spins")
+    for k in res["0"][2]:
+        if k.startswith("convtrans") and k.endswith("bias") and k.split(".")[1] in ("0", "5", "10", "15"):
+            continue  # (zero true gradient in front of a BatchNorm: rounding noise only)
+        _close(res["0"][2][k], res["1"][2][k], 2e-5, k)
+    for k in res["0"][3]:
+        _close(res["0"][3][k], res["1"][3][k], 1e-6, k)
+
+
 def test_decoder_device_dropout_is_per_sample_channel_and_reproducible():
     n, B, R = 64, 16, 4
     dec = _load(Decoder(n), gen.make_params(n, "decoder", 3)).train()
