@@ -252,6 +252,26 @@ def extra_config_run(args, config):
         return {"error": repr(exc)}
 
 
+def layerwise_run(args):
+    """The same workload with the decoder's first two layers run one by one as the reference writes them -- Linear(n, 4n),
+    then the 9-tap ConvTranspose GEMM over the 2x2 images -- instead of the library's default (ONE composed linear map
+    per image, padding taps never multiplied: DESIGN.md 3).  Same function, same gradients of every parameter; reported
+    beside the headline so that the gain of the reformulation stays visible."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--no-cpu-baseline", "--child"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, DVG_NO_LC0="1", DVG_NO_D22="1"))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        d = json.loads(lines[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "net_gflop_per_step": d["config"].get("net_gflop_per_step"),
+                "note": "DVG_NO_LC0=1 DVG_NO_D22=1: Linear and the first ConvTranspose layer as two layer-by-layer GEMMs (9 taps)"}
+    except Exception as exc:  # the headline line must not depend on the extra runs
+        return {"error": repr(exc)}
+
+
 def sampler_roofline(per_kernel, cfg, plan, prof_steps):
     """SURVEY.md 8d for the block-Gibbs draw: spin updates/s, the fraction of the VALU / LDS issue bound that the op
     count of one update implies, and the algorithmic HBM bytes per draw against its duration (the chain state lives in
@@ -480,6 +500,7 @@ def main():
             out["bf16_inputs"] = bf16_inputs_run(args)
             if args.config == "c3":
                 out["extra"] = {c: extra_config_run(args, c) for c in ("c2", "c1")}
+                out["layerwise_first_layers"] = layerwise_run(args)
         if args.breakdown:
             with open(args.breakdown, "w") as f:
                 json.dump({"ms_per_step": elapsed / args.steps * 1e3, "profiled_steps": prof_steps, "kernels": per_kernel}, f, indent=1)

@@ -157,6 +157,17 @@ int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, 
 // dense 2x2 form (WM_CONVT_D22_FWD): slabs [ksplit][4 Cin][4 Cout] -> ConvTranspose2d gradient (Cin,Cout,3,3): every tap
 // sums the (p_in, p_out) blocks that use it (4 for the centre tap, 2 for an edge, 1 for a corner), slabs in order
 int launch_wgrad_d22_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s);
+// Helpers of the composed Linear + dense-2x2 form of the decoder's first two layers (decoder.cpp):
+// out[r][c] = sum of the slabs [ksplit][rows][cols] in order (8 lanes per element), and its transpose outT[c][r]
+int launch_slab_sum(const float* slabs, int ksplit, int rows, int cols, float* out, float* outT, hipStream_t s);
+// bc[o] = sum_j lin_b[c*4 + p] * WkEff[o][j] + conv_b[o % C]   (j = p*n + c; WkEff = the K-major dense-2x2 forward pack)
+int launch_lc0_bias(const float* lin_b, const float* wk_eff, const float* conv_b, int n, int C, float* bc, hipStream_t s);
+// grad_lin_b[c*4 + p] = sum_o dbc[o] * WkD[j][o]   (WkD = the K-major dense-2x2 data-gradient pack, rows j = p*n + c)
+int launch_lc0_lin_bias_grad(const float* dbc, const float* wk_d, int n, int C, float* grad_lin_b, hipStream_t s);
+// dWeff[(p*n + c)][o] += lin_b[c*4 + p] * dbc[o]   (dWeff: [4n][4C])
+int launch_lc0_rank1_add(float* dweff, const float* lin_b, const float* dbc, int n, int C, hipStream_t s);
+// grad_lin_w[(c*4 + p)][i] = t[(p*n + c)][i]   (rows of the [4n][n] product back into the Linear weight's row order)
+int launch_lc0_rows_to_linear(const float* t, int n, float* grad_lin_w, hipStream_t s);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // sums the slabs in order and scatters into the checkpoint layout (grad_w is overwritten)
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s);

@@ -911,6 +911,100 @@ int launch_wgrad_fold_reduce(const float* slabs, int ksplit, int Cin, int Cout, 
   return DVG_OK;
 }
 
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int ksplit, int rows, int cols,
+                                                      float* __restrict__ out, float* __restrict__ outT) {
+  const int64_t total = (int64_t)rows * cols;
+  const int sub = threadIdx.x & 7;
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += ((int64_t)gridDim.x * 256) >> 3) {
+    float s = 0.f;
+    for (int k0 = sub; k0 < ksplit; k0 += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = k0 + 8 * u < ksplit ? slabs[(size_t)(k0 + 8 * u) * total + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (k0 + 8 * u < ksplit) s += v[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) {
+      out[e] = s;
+      if (outT) outT[(e % cols) * rows + e / cols] = s;
+    }
+  }
+}
+
+int launch_slab_sum(const float* slabs, int ksplit, int rows, int cols, float* out, float* outT, hipStream_t s) {
+  DVG_LAUNCH(K_WGRAD_REDUCE, slab_sum_kernel, dim3(ew_grid((int64_t)rows * cols * 8)), dim3(256), 0, s, slabs, ksplit, rows, cols,
+             out, outT);
+  return DVG_OK;
+}
+
+// one wavefront per output: a dot product of length `len` in double, fixed lane partition and shuffle tree
+__device__ __forceinline__ double lc0_wave_dot(const float* __restrict__ a_vec, const float* __restrict__ row, int len, int lane,
+                                               int perm_n) {
+  double s = 0.0;
+  for (int j = lane; j < len; j += 64) {
+    // perm_n > 0: element j = p*n + c of the vector lives at a_vec[c*4 + p] (the Linear bias in checkpoint order)
+    const float av = perm_n ? a_vec[(j % perm_n) * 4 + j / perm_n] : a_vec[j];
+    s += (double)av * (double)row[j];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void lc0_bias_kernel(const float* __restrict__ lin_b, const float* __restrict__ wk_eff,
+                                                      const float* __restrict__ conv_b, int n, int C, float* __restrict__ bc) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= 4 * C) return;
+  const double s = lc0_wave_dot(lin_b, wk_eff + (size_t)o * 4 * n, 4 * n, lane, n);
+  if (lane == 0) bc[o] = (float)(s + (double)conv_b[o % C]);
+}
+
+__global__ __launch_bounds__(256) void lc0_lin_bias_grad_kernel(const float* __restrict__ dbc, const float* __restrict__ wk_d,
+                                                               int n, int C, float* __restrict__ grad_lin_b) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= 4 * n) return;
+  const double s = lc0_wave_dot(dbc, wk_d + (size_t)j * 4 * C, 4 * C, lane, 0);
+  if (lane == 0) grad_lin_b[(j % n) * 4 + j / n] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void lc0_rows_to_linear_kernel(const float* __restrict__ t, int n, float* __restrict__ grad_lin_w) {
+  const int64_t total = (int64_t)4 * n * n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e / n), i = (int)(e - (int64_t)j * n);
+    grad_lin_w[(int64_t)((j % n) * 4 + j / n) * n + i] = t[e];
+  }
+}
+
+// dWeff[j][o] += lin_b[c*4 + p] * dbc[o]  (j = p*n + c): the Linear bias reaches the dense map's weight gradient too
+__global__ __launch_bounds__(256) void lc0_rank1_add_kernel(float* __restrict__ dweff, const float* __restrict__ lin_b,
+                                                           const float* __restrict__ dbc, int n, int C4) {
+  const int64_t total = (int64_t)4 * n * C4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = (int)(e / C4), o = (int)(e - (int64_t)j * C4);
+    dweff[e] = fmaf(lin_b[(j % n) * 4 + j / n], dbc[o], dweff[e]);
+  }
+}
+int launch_lc0_rank1_add(float* dweff, const float* lin_b, const float* dbc, int n, int C, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, lc0_rank1_add_kernel, dim3(ew_grid((int64_t)4 * n * 4 * C)), dim3(256), 0, s, dweff, lin_b, dbc, n, 4 * C);
+  return DVG_OK;
+}
+
+int launch_lc0_bias(const float* lin_b, const float* wk_eff, const float* conv_b, int n, int C, float* bc, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, lc0_bias_kernel, dim3((unsigned)C), dim3(256), 0, s, lin_b, wk_eff, conv_b, n, C, bc);
+  return DVG_OK;
+}
+int launch_lc0_lin_bias_grad(const float* dbc, const float* wk_d, int n, int C, float* grad_lin_b, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, lc0_lin_bias_grad_kernel, dim3((unsigned)n), dim3(256), 0, s, dbc, wk_d, n, C, grad_lin_b);
+  return DVG_OK;
+}
+int launch_lc0_rows_to_linear(const float* t, int n, float* grad_lin_w, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, lc0_rows_to_linear_kernel, dim3(ew_grid((int64_t)4 * n * n)), dim3(256), 0, s, t, n, grad_lin_w);
+  return DVG_OK;
+}
+
 int launch_wgrad_d22_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s) {
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_d22_reduce_kernel, dim3(ew_grid((int64_t)9 * Cin * Cout * 8)), dim3(256), 0, s, slabs, ksplit,
              Cin, Cout, grad_w);

@@ -26,6 +26,14 @@ struct DecPlan {
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   bool d22;      // layer 0 (3x3 on 2x2 images) runs as the dense per-image map (conv.h: WM_CONVT_D22_FWD)
+  // Large batches: Linear(n, 4n) and layer 0 have nothing but a reshape between them, so the pair is ONE linear map per
+  // image, spins (n) -> the 4 x 128 pre-BatchNorm values, with the composed weight Wc = Wlin . Weff (a 2 n x 4n x 512
+  // weight-space product per step).  Forward, data gradient and weight gradient then cost 3 x 2 N n 512 FLOPs instead of
+  // 3 x 2 N (n 4n + 4n 512); the gradients of BOTH original parameter tensors follow by the chain rule in weight space
+  // (dWlin = dWc . Weff^T, dWeff = Wlin^T . dWc + blin (x) dbc).  X0 is never materialised.
+  bool lc0;
+  size_t WcT, Wc, bc, dbc, dWc, dWcT, T1, dWeff, partC;
+  int ksplit_c;
   size_t total_floats;
 };
 
@@ -39,6 +47,14 @@ bool fold_enabled() {
 bool d22_enabled() {
   const char* e = getenv("DVG_NO_D22");  // (read per call: the tests flip it inside one process)
   return !(e && e[0] == '1');
+}
+
+// DVG_NO_LC0=1: never compose the Linear layer with layer 0 (A/B runs, tests); DVG_LC0=1: also for small batches (tests)
+int lc0_env() {
+  const char* off = getenv("DVG_NO_LC0");  // (read per call: the tests flip it inside one process)
+  if (off && off[0] == '1') return 0;
+  const char* on = getenv("DVG_LC0");
+  return on && on[0] == '1' ? 1 : -1;
 }
 
 size_t bump(size_t& o, size_t count) {
@@ -95,6 +111,32 @@ DecPlan dec_plan(int64_t N, int n) {
     }
     const size_t act = (size_t)p.M[l] * C;
     if (act > max_dx) max_dx = act;  // dXs[l] has the shape of Xs[l]
+  }
+  {
+    // composed form: float32 LDS-DMA GEMMs only (their K-major float32 packs double as plain row-major matrices)
+    const int C = ch[1], env = lc0_env();
+    p.lc0 = p.d22 && env != 0 && (N >= 4096 || env == 1) && conv_launch_mode(N, 4 * C) == 3 && conv_launch_mode(N, n) == 3 &&
+            conv_launch_mode(N, 4 * n) == 3 && conv_launch_mode(4 * C, n) == 3 && conv_launch_mode(n, 4 * C) == 3 &&
+            conv_launch_mode(4 * n, n) == 3 && conv_launch_mode(4 * n, 4 * C) == 3;
+    if (p.lc0) {
+      p.WcT = bump(o, (size_t)4 * C * n);
+      p.Wc = bump(o, (size_t)n * 4 * C);
+      p.bc = bump(o, (size_t)4 * C);
+      p.dbc = bump(o, (size_t)4 * C);
+      p.dWc = bump(o, (size_t)n * 4 * C);
+      p.dWcT = bump(o, (size_t)4 * C * n);
+      p.T1 = bump(o, (size_t)4 * n * n);
+      p.dWeff = bump(o, (size_t)4 * n * 4 * C);
+      p.partC = bump(o, (size_t)EW_BLOCKS * 4 * C);
+      p.ksplit_c = wgrad_ksplit(N, n, 4 * C, 1);
+      const size_t slab = (size_t)p.ksplit_c * n * 4 * C;
+      if (slab > max_slab) max_slab = slab;
+      // (the composed forward GEMM: N rows, n -> 4 C; its BatchNorm partials as in the dense form)
+      p.nblk[0] = 4 * conv_stats_blocks(N, 4 * C);
+      const size_t sk = conv_splitk_floats(N, n, 4 * C, 1, 0), sk2 = conv_splitk_floats(N, 4 * C, n, 1, 0);
+      if (sk > max_split) max_split = sk;
+      if (sk2 > max_split) max_split = sk2;
+    }
   }
   p.dXbuf = bump(o, max_dx);
   // one dY buffer per layer: a layer's weight gradient (side stream) may still be reading its dY when the data-gradient
@@ -167,7 +209,19 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
   }
-  {
+  if (pl.lc0) {
+    // composed weight, both orientations (K-major operands of the forward and of the data-gradient GEMM), and bias:
+    //   WcT[o][i] = sum_j Weff[j][o] Wlin[i][j]   rows of the dense-2x2 forward pack [o][j]  x  the Linear dgrad pack [i][j]
+    //   Wc[i][o]                                    rows of the Linear dgrad pack [i][j]       x  the dense-2x2 forward pack
+    const int C = pl.ch[1];
+    ConvArgs a;
+    a.bias = nullptr; a.stats = nullptr; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0; a.splitk_ws = nullptr;
+    a.in = W + pl.wp[0]; a.wp = W + pl.wpd_lin; a.out = W + pl.WcT; a.M = 4 * C; a.Cin = 4 * n; a.Cout = n;
+    DVG_TRY(launch_conv_igemm(a, s));
+    a.in = W + pl.wpd_lin; a.wp = W + pl.wp[0]; a.out = W + pl.Wc; a.M = n; a.Cin = 4 * n; a.Cout = 4 * C;
+    DVG_TRY(launch_conv_igemm(a, s));
+    DVG_TRY(launch_lc0_bias(p->lin_b, W + pl.wp[0], p->conv_b[0], n, C, W + pl.bc, s));
+  } else {
     ConvArgs a;
     a.in = spins; a.wp = W + pl.wp_lin; a.bias = p->lin_b; a.bias_perm = n; a.out = W + pl.X0; a.stats = nullptr;  // bias'[p*n + c] = b[c*4 + p]
     a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
@@ -199,6 +253,9 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       if (pl.fold[l]) { a.M = pl.M[l] / 4; a.L = pl.L[l] - 1; a.ntaps = 4; a.ups = 0; a.fold = 1; }
       if (l == 0 && pl.d22) {  // rows = images, columns = (pixel, channel): the same memory as [4 N][C]
         a.M = N; a.Cin = 4 * Cin; a.Cout = 4 * C; a.L = 0; a.ntaps = 1; a.bias_mod = C;
+      }
+      if (l == 0 && pl.lc0) {  // ... straight from the spins through the composed weight
+        a.in = spins; a.wp = W + pl.WcT; a.bias = W + pl.bc; a.bias_mod = 0; a.Cin = n;
       }
       a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
@@ -273,6 +330,42 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     hipEvent_t dy_ready = nullptr;
     if (s2 != s) DVG_TRY(stream_mark(s, &dy_ready));
     const float* xin = l == 0 ? W + pl.X0 : W + pl.Xs[l - 1];
+    if (l == 0 && pl.lc0) {
+      // Composed Linear + layer 0: one data-gradient GEMM straight to the spins, one weight-gradient GEMM for dWc, and the
+      // gradients of the two original weights / biases by the chain rule in weight space (side stream).
+      const int n4 = 4 * n, C4 = 4 * C;
+      if (grad_spins) {
+        ConvArgs a;
+        a.in = dY; a.wp = W + pl.Wc; a.bias = nullptr; a.out = grad_spins; a.stats = nullptr;
+        a.M = N; a.Cin = C4; a.Cout = n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+        a.splitk_ws = W + pl.splitk;
+        DVG_TRY(launch_conv_igemm(a, s));
+      }
+      if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+      DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
+      // dbc[o] = column sums of dY seen as [N][4 C]
+      DVG_TRY(launch_rowsum_partial(dY, N, C4, W + pl.partC, s2));
+      DVG_TRY(launch_colsum(W + pl.partC, EW_BLOCKS, C4, C4, 1.0f, W + pl.dbc, 0, 0, s2));
+      DVG_TRY(launch_lc0_lin_bias_grad(W + pl.dbc, W + pl.wpd[0], n, C, g->lin_b, s2));
+      // dWc[i][o] = sum_images spins[i] dY[o]  (and its transpose)
+      WgradArgs wa;
+      wa.in = spins; wa.dy = dY; wa.slabs = W + pl.slabs;
+      wa.M = N; wa.Cin = n; wa.Cout = C4; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_c;
+      DVG_TRY(launch_conv_wgrad(wa, s2));
+      DVG_TRY(launch_slab_sum(W + pl.slabs, pl.ksplit_c, n, C4, W + pl.dWc, W + pl.dWcT, s2));
+      ConvArgs b;
+      b.bias = nullptr; b.stats = nullptr; b.L = 0; b.ntaps = 1; b.ups = 0; b.poolsum = 0; b.splitk_ws = nullptr;
+      // T1[j][i] = sum_o Weff[j][o] dWc[i][o]: rows of the dense-2x2 data-gradient pack [j][o] x dWc as the K-major operand
+      b.in = W + pl.wpd[0]; b.wp = W + pl.dWc; b.out = W + pl.T1; b.M = n4; b.Cin = C4; b.Cout = n;
+      DVG_TRY(launch_conv_igemm(b, s2));
+      DVG_TRY(launch_lc0_rows_to_linear(W + pl.T1, n, g->lin_w, s2));
+      // dWeff[j][o] = sum_i Wlin[i][j] dWc[i][o]: rows of the Linear forward pack [j][i] x dWc^T [o][i]
+      b.in = W + pl.wp_lin; b.wp = W + pl.dWcT; b.out = W + pl.dWeff; b.M = n4; b.Cin = n; b.Cout = C4;
+      DVG_TRY(launch_conv_igemm(b, s2));
+      DVG_TRY(launch_lc0_rank1_add(W + pl.dWeff, p->lin_b, W + pl.dbc, n, C, s2));  // (+ the Linear bias' share of X0)
+      DVG_TRY(launch_wgrad_d22_reduce(W + pl.dWeff, 1, Cin, C, g->conv_w[l], s2));
+      continue;
+    }
     if (l == 3) {
       DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
       if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
@@ -307,8 +400,10 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONVT_FWD, Cin, C, 9}, g->conv_w[l], s2));
     }
   }
-  // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward:
-  {
+  // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward (composed form: done with layer 0 above):
+  if (pl.lc0) {
+    if (!defer_join) DVG_TRY(stream_order_after(s, s2));
+  } else {
     hipEvent_t dx_ready = nullptr;  // dX is final
     if (s2 != s) DVG_TRY(stream_mark(s, &dx_ready));
     if (grad_spins) {
