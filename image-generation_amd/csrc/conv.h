@@ -122,6 +122,11 @@ struct ConvArgs {
   int bias_perm = 0;
   // bias_mod = C > 0: column j = p*C + c takes bias[c] (the dense 2x2 form: one bias per channel, four pixels per row)
   int bias_mod = 0;
+  // posmajor (set by launch_conv_igemm): the rows of a block tile are ONE pixel position of BM consecutive images instead
+  // of BM consecutive pixels, so every row of the tile has the same taps inside the image and the K loop runs over those
+  // only: the padding taps of the image border ((3H-2)^2 of 9 H^2 (pixel, tap) pairs are real: 69 % at 4x4, 84 % at 8x8)
+  // are never staged or multiplied.  Same outputs, same number of BatchNorm partial rows.
+  int posmajor = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();

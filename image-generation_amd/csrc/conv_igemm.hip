@@ -82,11 +82,32 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   const int n0 = blockIdx.y * BN;
   const int L = a.L, H = 1 << L, logHW = 2 * L;
   const int64_t HWin = a.ups ? ((int64_t)1 << logHW) >> 2 : ((int64_t)1 << logHW);
+  // position-major tiles (ConvArgs.posmajor): block = (pixel position `pos`, BM consecutive images from pm_img0)
+  const bool PMJ = DMA && a.posmajor;
+  // The blocks of one image group (all positions of the same BM images) read the same input rows: the hardware deals
+  // consecutive workgroups round-robin to the 8 XCDs, so logical block (b % 8) * (n / 8) + b / 8 puts a group's blocks on
+  // ONE XCD, next to each other in time, and the group's rows are fetched into that XCD's L2 once instead of 8 times.
+  const uint32_t pm_nb = gridDim.x;
+  const uint32_t pm_b = (PMJ && pm_nb % 8 == 0) ? (blockIdx.x % 8) * (pm_nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int pm_pos = PMJ ? (int)(pm_b & ((1u << logHW) - 1u)) : 0;
+  const int64_t pm_img0 = PMJ ? (int64_t)(pm_b >> logHW) * BM : 0;
+  auto grow = [&](int row) -> int64_t { return PMJ ? ((pm_img0 + row) << logHW) + pm_pos : m0 + row; };  // GEMM row of a tile row
+  // the taps of this block's K loop: all of them, or (position-major) those inside the image, 4 bits each
+  uint64_t tap_list = 0;
+  int ntv = a.ntaps;
+  if (PMJ) {
+    ntv = 0;
+    const int py = (int)morton_y((uint32_t)pm_pos), px = (int)morton_x((uint32_t)pm_pos);
+    for (int t = 0; t < 9; ++t) {
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < H) { tap_list |= (uint64_t)t << (4 * ntv); ++ntv; }
+    }
+  }
 
   // neighbour table: the Morton decode / re-encode happens once per (row, tap), not once per K-chunk
   for (int e = tid; e < BM * a.ntaps; e += NT) {
     const int row = e / a.ntaps, tap = e - row * a.ntaps;
-    const int64_t m = m0 + row;
+    const int64_t m = grow(row);
     const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
     int dy, dx, cq = 0;
     if (a.fold == 1) {         // source pixel (i-1+pa+dr, j-1+pb+dc) of output class (pa, pb)
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   const uint32_t row_bytes = (uint32_t)a.Cin * 4u, wrow_bytes = (uint32_t)a.Cout * 4u;
   // split mode: byte distance between the piece planes of the packed weights ([taps][Cout][Cin] bf16 each)
   const uint32_t plane_bytes = (uint32_t)((a.fold == 1 ? 16 : a.ntaps) * a.Cin * a.Cout) * 2u;
-  const int nci = a.Cin >> 5, nchunk = a.ntaps * nci, niter = (nchunk + KH - 1) / KH;
+  const int nci = a.Cin >> 5, nchunk = ntv * nci, niter = (nchunk + KH - 1) / KH;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -265,8 +286,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     int ftap = it_beg / nci, fcc = it_beg - ftap * nci, itap = ftap, icc = fcc;
     uint32_t srcn[PAW];  // per-lane byte offsets of the next chunk's A pieces (without the channel-chunk offset)
     auto fetch_nbr = [&]() {
+      const int tf = PMJ ? (int)((tap_list >> (4 * ftap)) & 15) : ftap;
 #pragma unroll
-      for (int q = 0; q < PAW; ++q) srcn[q] = (uint32_t)nbr[arow[q] + ftap];  // (used a whole chunk later: no wait here)
+      for (int q = 0; q < PAW; ++q) srcn[q] = (uint32_t)nbr[arow[q] + tf];  // (used a whole chunk later: no wait here)
       if (++fcc == nci) { fcc = 0; ++ftap; }
     };
     auto issue = [&](int buf) {
@@ -276,7 +298,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       for (int q = 0; q < PAW; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dstA + q * 1024), 16, (int)(srcn[q] + acol[q]), ccb, 0, 0);
       unsigned char* dstB = stg + buf * STAGE + BM * 128 + wave_u * PBW * 1024;
-      const int boff = (int)(cls_off + (uint32_t)itap * tap_bytes) + ccb;
+      const int ti = PMJ ? (int)((tap_list >> (4 * itap)) & 15) : itap;
+      const int boff = (int)(cls_off + (uint32_t)ti * tap_bytes) + ccb;
 #pragma unroll
       for (int q = 0; q < PBW; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(dstB + q * 1024), 16, (int)bcol[q], boff, 0, 0);
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
                                                 : a.bias_mod ? col % a.bias_mod : col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * TM * 32 + i * 32 + crow16(r, hh);
+        const int64_t m = grow(wm * TM * 32 + i * 32 + crow16(r, hh));
         if (active && m < a.M) {
           const float v = acc[i][j][r] + bias;
           a.out[(a.fold == 1 ? 4 * m + cls : m) * a.Cout + col] = v;
@@ -639,6 +662,20 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int64_t Mg = a.fold == 1 ? a.M * 4 : a.M;  // GEMM rows over all classes
   const double flops = 2.0 * (double)Mg * a.Cin * a.Cout * a.ntaps;
   a.ksplit = a.splitk_ws ? conv_igemm_ksplit(Mg, a.Cin, a.Cout, a.ntaps) : 1;
+  double flops_exec = flops;
+  {
+    // position-major tiles: plain 3x3 launches of the LDS-DMA form whose images fill whole row blocks (then the grid and
+    // the BatchNorm partial rows are what they were).  DVG_NO_POSMAJOR=1: pixel-major tiles everywhere (A/B runs, tests)
+    const char* e = getenv("DVG_NO_POSMAJOR");  // (read per call: the tests flip it inside one process)
+    const int bm_ = igemm_bm(igemm_cfg(Mg, a.Cout));
+    const int64_t nimg = a.L >= 1 ? a.M >> (2 * a.L) : 0;
+    a.posmajor = !(e && e[0] == '1') && a.bf16 == 3 && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.ksplit == 1 &&
+                 a.L >= 1 && a.L <= 15 && nimg > 0 && (nimg << (2 * a.L)) == a.M && nimg % bm_ == 0;
+    if (a.posmajor) {
+      const double side = (double)(3 * (1 << a.L) - 2);
+      flops_exec = 2.0 * (double)nimg * side * side * a.Cin * a.Cout;  // the (pixel, tap) pairs inside the image
+    }
+  }
   const unsigned kz = (unsigned)a.ksplit;
   const int cfg = igemm_cfg(Mg, a.Cout);
   const unsigned cm = a.fold == 1 ? 4u : 1u;
@@ -647,11 +684,11 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   int rc;
   if (a.bf16 == 3) {
     switch (cfg) {
-      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 3>(K_IGEMM_128x64, flops, grid, a, s); break;
-      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 3>(K_IGEMM_64x64, flops, grid, a, s); break;
-      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 3>(K_IGEMM_32x64, flops, grid, a, s); break;
-      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 3>(K_IGEMM_128x128, flops, grid, a, s); break;
-      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 3>(K_IGEMM_128x32, flops, grid, a, s); break;
+      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 3>(K_IGEMM_128x64, flops_exec, grid, a, s); break;
+      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 3>(K_IGEMM_64x64, flops_exec, grid, a, s); break;
+      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 3>(K_IGEMM_32x64, flops_exec, grid, a, s); break;
+      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 3>(K_IGEMM_128x128, flops_exec, grid, a, s); break;
+      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 3>(K_IGEMM_128x32, flops_exec, grid, a, s); break;
     }
   } else if (a.bf16 == 2) {
     switch (cfg) {

@@ -25,7 +25,9 @@ def staging(request):
 
 @pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4),
                                              (256, 128, 128, 4), (64, 128, 128, 4),  # these two take the split-K path
-                                             (1024, 128, 128, 8), (600, 64, 64, 16)])  # 128x128 and 128x64 tiles
+                                             (1024, 128, 128, 8), (600, 64, 64, 16),  # 128x128 and 128x64 tiles
+                                             # position-major tiles (whole row blocks of images, no split-K): 8x8 above, 4x4, 2x2
+                                             (1024, 32, 64, 4), (8192, 32, 64, 2)])
 def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side, staging):
     torch.manual_seed(N)
     x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
