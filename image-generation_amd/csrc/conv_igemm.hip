@@ -87,19 +87,35 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   // The blocks of one image group (all positions of the same BM images) read the same input rows: the hardware deals
   // consecutive workgroups round-robin to the 8 XCDs, so logical block (b % 8) * (n / 8) + b / 8 puts a group's blocks on
   // ONE XCD, next to each other in time, and the group's rows are fetched into that XCD's L2 once instead of 8 times.
-  const uint32_t pm_nb = gridDim.x;
-  const uint32_t pm_b = (PMJ && pm_nb % 8 == 0) ? (blockIdx.x % 8) * (pm_nb / 8) + blockIdx.x / 8 : blockIdx.x;
+  // (fold = 1: the grid spans 4 output classes x row blocks; the mapping works inside a class)
+  const uint32_t pm_nb = a.fold == 1 ? (uint32_t)mblocks : gridDim.x;
+  const uint32_t pm_bx = a.fold == 1 ? blockIdx.x - (uint32_t)cls * (uint32_t)mblocks : blockIdx.x;
+  const uint32_t pm_b = (PMJ && pm_nb % 8 == 0) ? (pm_bx % 8) * (pm_nb / 8) + pm_bx / 8 : pm_bx;
   const int pm_pos = PMJ ? (int)(pm_b & ((1u << logHW) - 1u)) : 0;
   const int64_t pm_img0 = PMJ ? (int64_t)(pm_b >> logHW) * BM : 0;
   auto grow = [&](int row) -> int64_t { return PMJ ? ((pm_img0 + row) << logHW) + pm_pos : m0 + row; };  // GEMM row of a tile row
   // the taps of this block's K loop: all of them, or (position-major) those inside the image, 4 bits each
+  // displacement (and, for the folded data gradient, output class) behind tap index `tap` of this launch
+  auto tap_delta = [&](int tap, int& dy, int& dx, int& cq) {
+    cq = 0;
+    if (a.fold == 1) {         // source pixel (i-1+pa+dr, j-1+pb+dc) of output class (pa, pb)
+      dy = (cls >> 1) - 1 + (tap >> 1); dx = (cls & 1) - 1 + (tap & 1);
+    } else if (a.fold == 2) {  // adjoint: the output pixel of class cq whose tap (dr, dc) read this source pixel
+      cq = tap >> 2;
+      dy = -((cq >> 1) - 1 + ((tap >> 1) & 1)); dx = -((cq & 1) - 1 + (tap & 1));
+    } else {
+      dy = a.ntaps == 9 ? tap / 3 - 1 : 0; dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
+    }
+  };
   uint64_t tap_list = 0;
   int ntv = a.ntaps;
   if (PMJ) {
     ntv = 0;
     const int py = (int)morton_y((uint32_t)pm_pos), px = (int)morton_x((uint32_t)pm_pos);
-    for (int t = 0; t < 9; ++t) {
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+    for (int t = 0; t < a.ntaps; ++t) {
+      int dy, dx, cq;
+      tap_delta(t, dy, dx, cq);
+      const int yy = py + dy, xx = px + dx;
       if (yy >= 0 && yy < H && xx >= 0 && xx < H) { tap_list |= (uint64_t)t << (4 * ntv); ++ntv; }
     }
   }
@@ -109,15 +125,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     const int row = e / a.ntaps, tap = e - row * a.ntaps;
     const int64_t m = grow(row);
     const uint32_t p = (uint32_t)(m & (((int64_t)1 << logHW) - 1));
-    int dy, dx, cq = 0;
-    if (a.fold == 1) {         // source pixel (i-1+pa+dr, j-1+pb+dc) of output class (pa, pb)
-      dy = (cls >> 1) - 1 + (tap >> 1); dx = (cls & 1) - 1 + (tap & 1);
-    } else if (a.fold == 2) {  // adjoint: the output pixel of class cq whose tap (dr, dc) read this source pixel
-      cq = tap >> 2;
-      dy = -((cq >> 1) - 1 + ((tap >> 1) & 1)); dx = -((cq & 1) - 1 + (tap & 1));
-    } else {
-      dy = a.ntaps == 9 ? tap / 3 - 1 : 0; dx = a.ntaps == 9 ? tap % 3 - 1 : 0;
-    }
+    int dy, dx, cq;
+    tap_delta(tap, dy, dx, cq);
     const int yy = (int)morton_y(p) + dy, xx = (int)morton_x(p) + dx;
     const bool ok = m < a.M && yy >= 0 && yy < H && xx >= 0 && xx < H;
     uint32_t src = morton((uint32_t)yy, (uint32_t)xx);
@@ -669,11 +678,24 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const char* e = getenv("DVG_NO_POSMAJOR");  // (read per call: the tests flip it inside one process)
     const int bm_ = igemm_bm(igemm_cfg(Mg, a.Cout));
     const int64_t nimg = a.L >= 1 ? a.M >> (2 * a.L) : 0;
-    a.posmajor = !(e && e[0] == '1') && a.bf16 == 3 && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.ksplit == 1 &&
-                 a.L >= 1 && a.L <= 15 && nimg > 0 && (nimg << (2 * a.L)) == a.M && nimg % bm_ == 0;
+    const bool taps9 = !a.fold && a.ntaps == 9;
+    a.posmajor = !(e && e[0] == '1') && a.bf16 == 3 && (taps9 || a.fold) && !a.ups && !a.poolsum && a.ksplit == 1 &&
+                 a.L >= 1 && a.L <= 5 && nimg > 0 && (nimg << (2 * a.L)) == a.M && nimg % bm_ == 0;
     if (a.posmajor) {
-      const double side = (double)(3 * (1 << a.L) - 2);
-      flops_exec = 2.0 * (double)nimg * side * side * a.Cin * a.Cout;  // the (pixel, tap) pairs inside the image
+      // executed FLOPs: the (pixel, [class,] tap) combinations whose displacement stays inside the image
+      const int H = 1 << a.L;
+      int64_t pairs = 0;
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < H; ++x)
+          for (int c4 = 0; c4 < (a.fold == 1 ? 4 : 1); ++c4)
+            for (int t = 0; t < a.ntaps; ++t) {
+              int dy, dx;
+              if (a.fold == 1) { dy = (c4 >> 1) - 1 + (t >> 1); dx = (c4 & 1) - 1 + (t & 1); }
+              else if (a.fold == 2) { const int cq = t >> 2; dy = -((cq >> 1) - 1 + ((t >> 1) & 1)); dx = -((cq & 1) - 1 + (t & 1)); }
+              else { dy = t / 3 - 1; dx = t % 3 - 1; }
+              pairs += (y + dy >= 0 && y + dy < H && x + dx >= 0 && x + dx < H) ? 1 : 0;
+            }
+      flops_exec = 2.0 * (double)nimg * (double)pairs * a.Cin * a.Cout;
     }
   }
   const unsigned kz = (unsigned)a.ksplit;

@@ -259,6 +259,44 @@ def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B
             _close(res[name][3][k], res["9tap"][3][k], 1e-6, name + " " + k)
 
 
+def test_position_major_tiles_equal_pixel_major_tiles():
+    """Launches whose images fill whole row blocks run position-major tiles (a tile = one pixel position of 64..128
+    images; the K loop skips the taps that fall outside the image: conv_igemm.hip) -- plain 3x3 and both folded forms.
+    DVG_NO_POSMAJOR=1 keeps pixel-major tiles.  Same networks, 1024 images: outputs to 1e-5 (the BatchNorm partial sums
+    group other rows), gradients to 2e-3 (LeakyReLU kink, see the composed-form test)."""
+    n, B, R = 64, 128, 8
+    dparams, eparams = gen.make_params(n, "decoder", 9), gen.make_params(n, "encoder", 10)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 3)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 4)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(8)).cuda()
+    imgs = torch.from_numpy(gen.make_images(1024, 5)).cuda()
+    gl = torch.randn(1024, n, generator=torch.Generator().manual_seed(9)).cuda()
+    res = {}
+    for flag in ("1", "0"):
+        os.environ["DVG_NO_POSMAJOR"] = flag
+        try:
+            dec = _load(Decoder(n), dparams).train()
+            dec.inject_dropout_masks(masks)
+            sg = spins.clone().requires_grad_(True)
+            out = dec(sg)
+            (out * go).sum().backward()
+            enc = _load(Encoder(n), eparams).train()
+            logits = enc(imgs)
+            (logits * gl).sum().backward()
+            res[flag] = (out.detach().cpu(), logits.detach().cpu(), sg.grad.cpu(),
+                         {"dec." + k: v.grad.cpu() for k, v in dec.named_parameters()} |
+                         {"enc." + k: v.grad.cpu() for k, v in enc.named_parameters()})
+        finally:
+            os.environ.pop("DVG_NO_POSMAJOR", None)
+    _close(res["0"][0], res["1"][0], 1e-5, "decoder output")
+    _close(res["0"][1], res["1"][1], 1e-5, "encoder logits")
+    _close(res["0"][2], res["1"][2], 2e-3, "grad spins")
+    for k in res["0"][3]:
+        if k.endswith("bias") and ("convtrans" in k or "conv." in k) and not k.endswith("16.bias") and "increase" not in k:
+            continue  # (conv biases in front of a BatchNorm: zero true gradient)
+        _close(res["0"][3][k], res["1"][3][k], 2e-3, k)
+
+
 def test_decoder_device_dropout_is_per_sample_channel_and_reproducible():
     n, B, R = 64, 16, 4
     dec = _load(Decoder(n), gen.make_params(n, "decoder", 3)).train()
