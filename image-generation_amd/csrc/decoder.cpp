@@ -313,6 +313,13 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     DVG_TRY(launch_colsum2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4], s2));
   }
 
+  bool conv3_sums_pending = false;
+  auto conv3_sums = [&]() -> int {  // column sums of layer 3's bias / weight-gradient partials (side stream)
+    if (!conv3_sums_pending) return DVG_OK;
+    conv3_sums_pending = false;
+    DVG_TRY(launch_colsum(W + pl.partB[3], EW_BLOCKS, pl.ch[4], pl.ch[4], 1.0f, g->conv_b[3], 0, 0, s2));
+    return launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2);  // [tap][ci] -> [ci][tap]
+  };
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     const float* Y = W + pl.Y[l];
@@ -367,11 +374,20 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       continue;
     }
     if (l == 3) {
-      DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
-      if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-      DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
-      DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
-      DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
+      // data gradient and weight-gradient partials in ONE pass over the images on the caller's stream (special.hip); only
+      // the column sums go to the side stream.  DVG_CONV3_SPLIT=1: the two separate kernels (A/B runs, tests)
+      const char* e3 = getenv("DVG_CONV3_SPLIT");
+      if (e3 && e3[0] == '1') {
+        DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
+        if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+        DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
+        DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
+        DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
+      } else {
+        // (no fork here: the two column sums join the side work of layer 2's fork, behind that layer's main-chain kernel)
+        DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
+        conv3_sums_pending = true;
+      }
       continue;
     }
     ConvArgs a;
@@ -383,6 +399,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
+    DVG_TRY(conv3_sums());
     DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
   constexpr int XP = 36;  // row pitch in floats: 16-byte aligned rows, conflict-free b128 reads across source rows
   __shared__ __align__(16) float xs[64 * XP];
   __shared__ float w9[288];    // w[ci*9 + kh*3 + kw]
-  __shared__ float wfs[512];
+  __shared__ __align__(16) float wfs[512];
   __shared__ float outs[256];
   __shared__ float red[2 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -245,11 +245,10 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
     wfs[e] = acc;
   }
   __syncthreads();
-  float wf[4][32];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int ci = 0; ci < 32; ++ci) wf[t][ci] = wfs[(cls * 4 + t) * 32 + ci];
+  // The class's 4 x 32 folded weights stay in LDS and are read as wave-uniform (broadcast) float4s: in registers they
+  // made this a 168-VGPR kernel, 8 more than an MMD pair-kernel wave (352 of a SIMD's 512) leaves -- at c3 the kernel
+  // then sat behind the pair kernel for 1.4 ms of the step's critical chain instead of running beside it.
+  const float* wcls = wfs + cls * 128;
   const float b0 = bias[0];
   const int ys = (int)morton_y((uint32_t)lane), xq = (int)morton_x((uint32_t)lane);
   int src[4];
@@ -275,11 +274,12 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
     for (int t = 0; t < 4; ++t) {
       if (src[t] >= 0) {
         const float4* row = reinterpret_cast<const float4*>(xs + src[t] * XP);
+        const float4* wr = reinterpret_cast<const float4*>(wcls + t * 32);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float4 a = row[k];
-          acc = fmaf(a.x, wf[t][4 * k], acc); acc = fmaf(a.y, wf[t][4 * k + 1], acc);
-          acc = fmaf(a.z, wf[t][4 * k + 2], acc); acc = fmaf(a.w, wf[t][4 * k + 3], acc);
+          const float4 a = row[k], wv = wr[k];
+          acc = fmaf(a.x, wv.x, acc); acc = fmaf(a.y, wv.y, acc);
+          acc = fmaf(a.z, wv.z, acc); acc = fmaf(a.w, wv.w, acc);
         }
       }
     }
@@ -391,6 +391,78 @@ __global__ __launch_bounds__(288) void dec_conv3_wgrad_kernel(const float* __res
     for (int q = 0; q < 64; ++q) acc = fmaf(G[q * 9 + tap], xb[q * 32], acc);
   }
   part[(size_t)blockIdx.x * 288 + tid] = acc;
+}
+
+// Data gradient AND weight gradient in one pass over the images.  Both are products with the same small matrix
+//   G[q][tap] = sum of dY over the (<= 4) output pixels whose tap reads source pixel q        (64 x 9 per image):
+//   dX[q][ci] = sum_tap G[q][tap] Wt[ci][tap]          dWt[ci][tap] += sum_q G[q][tap] X[q][ci]
+// so an image costs one read of its dY row (1 KB) and X tile (8 KB), one write of dX (8 KB) and 2 x 18 k FMAs -- the
+// separate kernels gathered dY 36 times per source pixel (74 k FMAs) and read X / wrote dX in passes of their own
+// (0.47 + 0.44 ms alone at c3 for 0.57 GB of traffic).  288 threads: (tap, ci) for the weight gradient; the first 256 are
+// (source pixel, 8-channel group) for the data gradient.  part[blk][tap*32 + ci] as dec_conv3_wgrad_kernel.
+__global__ __launch_bounds__(288) void dec_conv3_bwd_kernel(const float* __restrict__ X, int64_t N,
+                                                            const float* __restrict__ dY, const float* __restrict__ w,
+                                                            float* __restrict__ dX, float* __restrict__ part) {
+  __shared__ float dys[256];
+  __shared__ float G[64 * 9];
+  __shared__ __align__(16) float xs[64 * 32];
+  __shared__ float ws[9 * 32];  // [tap][ci]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += 288) ws[(i % 9) * 32 + i / 9] = w[i];
+  // the (<= 4) dY elements behind this thread's two G entries: fixed for the whole kernel
+  int gsrc[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 288 * k, q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
+    const int ys = (int)morton_y((uint32_t)q), xq = (int)morton_x((uint32_t)q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int y = 2 * ys + (u >> 1) - 1 + kh, x = 2 * xq + (u & 1) - 1 + kw;
+      gsrc[k][u] = (y >= 0 && y < 16 && x >= 0 && x < 16) ? (int)morton((uint32_t)y, (uint32_t)x) : -1;
+    }
+  }
+  const int tap = tid >> 5, ci = tid & 31;      // weight-gradient role
+  const int q = tid >> 2, cg = (tid & 3) * 8;   // data-gradient role (tid < 256)
+  float acc = 0.f;
+  __syncthreads();
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();  // the previous image's readers of dys / G / xs are done
+    if (tid < 256) dys[tid] = dY[img * 256 + tid];
+    {
+      const float4* g4 = reinterpret_cast<const float4*>(X + img * 64 * 32);
+      for (int e = tid; e < 512; e += 288) reinterpret_cast<float4*>(xs)[e] = g4[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float g = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g += gsrc[k][u] >= 0 ? dys[gsrc[k][u]] : 0.f;
+      G[tid + 288 * k] = g;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float g = G[q * 9 + t];
+        const float* wr = ws + t * 32 + cg;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaf(g, wr[k], o[k]);
+      }
+      float4* dst = reinterpret_cast<float4*>(dX + (img * 64 + q) * 32 + cg);
+      dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+#pragma unroll 8
+    for (int qq = 0; qq < 64; ++qq) acc = fmaf(G[qq * 9 + tap], xs[qq * 32 + ci], acc);
+  }
+  part[(size_t)blockIdx.x * 288 + tid] = acc;
+}
+
+int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float* w, float* dX, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_kernel, dim3(EW_BLOCKS), dim3(288), 0, s, X, N, dY, w, dX, part);
+  return DVG_OK;
 }
 
 int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* part, hipStream_t s) {
