@@ -32,6 +32,7 @@ struct MmdArgs {
   int n_kernels, squared, reduce_mean, biased;
   int pow2;             // factor == 2: exp(c_k D) by repeated squaring
   double* loss_part;    // [nblocks][3]  (xx, xy, yy)
+  int vgx = 0, vgy = 0, vgz = 0;  // logical grid of the gated float32 launch (mmd_main_kernel)
   float* grad_part;     // [S][nx][d] (or grad_x itself when S == 1)
   int S;                // column splits
   double* dist_part;    // distsum mode: [nblocks]
@@ -524,8 +525,10 @@ __device__ __forceinline__ double mmd_wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------ pass 2: loss sums + gradient
+// (vbx, vby, vbz, vgx, vgy): the block's place in the LOGICAL grid (rbx + rby, column splits, feature slices) -- the
+// hardware grid, or a virtual block of the capped 1-D grid of the gated launch behind the 128-row spin kernel
 template <int NFB>
-__device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
+__device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem, int vbx, int vby, int vbz, int vgx, int vgy) {
   float* Zs = smem;                           // [128][33]
   float* Xs = Zs + MMD_BJ * MMD_PITCH;        // [32][33]
   float* Gs = Xs + MMD_BI * MMD_PITCH;        // [NFB*32][33] cross-wave reduction of G^T
@@ -533,9 +536,9 @@ __device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
   double* red = reinterpret_cast<double*>(rs_s + 4 * 32 + 2);  // [256] (8-byte aligned: offsets are even)
 
   const int64_t rbx = (a.nx + MMD_BI - 1) / MMD_BI;
-  const int64_t rb = blockIdx.x;
+  const int64_t rb = vbx;
   const bool rows_x = rb < rbx;
-  const int zslice = blockIdx.z;
+  const int zslice = vbz;
   if (!rows_x && zslice > 0) return;  // y-row blocks only feed the loss; count them once
   const float* src_i = rows_x ? a.x : a.y;
   const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * MMD_BI;
@@ -564,7 +567,7 @@ __device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
 
   // x-row blocks visit x- and y-column tiles; y-row blocks only y-column tiles (the yy term)
   const int64_t t_begin = rows_x ? 0 : tx;
-  for (int64_t t = t_begin + blockIdx.y; t < tx + ty; t += gridDim.y) {
+  for (int64_t t = t_begin + vby; t < tx + ty; t += vgy) {
     const bool cols_x = t < tx;
     const float* src_j = cols_x ? a.x : a.y;
     const int64_t cnt_j = cols_x ? a.nx : a.ny, base_j = (cols_x ? t : t - tx) * MMD_BJ;
@@ -620,7 +623,7 @@ __device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
   // ---- loss partial sums (feature slice 0 only, so each pair is counted once)
   const double sxx = block_sum(l_xx, red), sxy = block_sum(l_xy, red), syy = block_sum(l_yy, red);
   if (tid == 0 && zslice == 0) {
-    double* lp = a.loss_part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+    double* lp = a.loss_part + ((size_t)vby * vgx + vbx) * 3;
     lp[0] = sxx; lp[1] = sxy; lp[2] = syy;
   }
   if (!rows_x || !a.grad_part) return;
@@ -641,7 +644,7 @@ __device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem) {
     __syncthreads();
   }
   // grad[i][f] = x[i][f] * rowsum_i - G^T[f][i]
-  float* out = a.grad_part + (size_t)blockIdx.y * a.nx * a.d;
+  float* out = a.grad_part + (size_t)vby * a.nx * a.d;
   for (int e = tid; e < MMD_BI * NFB * 32; e += 256) {
     const int i = e / (NFB * 32), fl = e % (NFB * 32);
     const int64_t gr = base_i + i;
@@ -1611,15 +1614,26 @@ __global__ __launch_bounds__(256, 1) void mmd_pair_w128_kernel(MmdArgs a) {
 template <int NFB>
 __global__ __launch_bounds__(256, 1) void mmd_main_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char main_smem[];
-  if (a.gate_main && *a.not_pm1 == 0) return;  // +-1 rows: the spin kernel in front of this launch has done the work
-  mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem));
+  if (a.gate_main) {
+    // Launched behind the 128-row spin kernel for the rows that are not +-1 (known on the device only): a capped 1-D grid
+    // whose blocks walk the logical grid, so that the usual case -- nothing to do -- is a few hundred empty workgroups,
+    // not the thousands of the logical grid queueing for LDS (0.35 ms at c3) behind the kernels that do have work.
+    if (*a.not_pm1 == 0) return;
+    const int gx = a.vgx, gy = a.vgy, total = gx * gy * a.vgz;
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+      mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem), vb % gx, (vb / gx) % gy, vb / (gx * gy), gx, gy);
+      __syncthreads();
+    }
+    return;
+  }
+  mmd_main_body<NFB>(a, reinterpret_cast<float*>(main_smem), blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 template <int NFBW>
 __global__ __launch_bounds__(256, 1) void mmd_pair_fq_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char fq_smem[];
   if (*a.not_pm1 == 0) mmd_pm1_fq_body<NFBW>(a, fq_smem);
-  else mmd_main_body<(NFBW * 4 > 8 ? 8 : NFBW * 4)>(a, reinterpret_cast<float*>(fq_smem));
+  else mmd_main_body<(NFBW * 4 > 8 ? 8 : NFBW * 4)>(a, reinterpret_cast<float*>(fq_smem), blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 // One launch serves both kinds of input: the prep kernel's device flag picks the body (no host synchronisation, and
@@ -1628,7 +1642,7 @@ template <int NFB>
 __global__ __launch_bounds__(256, 1) void mmd_pair_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char pair_smem[];
   if (a.pm1_ok && *a.not_pm1 == 0) mmd_pm1_body<NFB>(a, pair_smem);
-  else mmd_main_body<NFB>(a, reinterpret_cast<float*>(pair_smem));
+  else mmd_main_body<NFB>(a, reinterpret_cast<float*>(pair_smem), blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 // ------------------------------------------------------------------ finalize
@@ -1769,6 +1783,13 @@ static int launch_main(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const double N = (double)(a.nx + a.ny);
   const double flops = 2.0 * N * N * a.d + 2.0 * (double)a.nx * N * a.d;  // Gram + gradient GEMM
+  if (a.gate_main) {
+    MmdArgs g = a;
+    g.vgx = (int)(p.rbx + p.rby); g.vgy = p.S; g.vgz = p.zslices;
+    const int64_t total = (int64_t)g.vgx * g.vgy * g.vgz;
+    DVG_LAUNCH_WORK(K_MMD_MAIN, flops, kern, dim3((unsigned)(total < 512 ? total : 512)), dim3(256), lds, s, g);
+    return DVG_OK;
+  }
   DVG_LAUNCH_WORK(K_MMD_MAIN, flops, kern, dim3((unsigned)(p.rbx + p.rby), (unsigned)p.S, (unsigned)p.zslices), dim3(256), lds, s, a);
   return DVG_OK;
 }
