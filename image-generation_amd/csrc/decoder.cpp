@@ -297,6 +297,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
   for (int l = 0; l < 4; ++l) DVG_REQUIRE(g->bn_g[l] && g->bn_b[l], "decoder_bwd: null BN gradient buffer %d", l);
   hipStream_t s = (hipStream_t)stream;
   hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
+  ColsumBatch sums;  // the bias / small-weight column sums of the whole call: ONE launch at the end of the side chain
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
   float* partA = W + pl.partA;
@@ -310,16 +311,10 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, start));
     DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
-    DVG_TRY(launch_colsum2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4], s2));
+    DVG_REQUIRE(sums.add2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4]), "decoder_bwd: column-sum batch full");
   }
 
-  bool conv3_sums_pending = false;
-  auto conv3_sums = [&]() -> int {  // column sums of layer 3's bias / weight-gradient partials (side stream)
-    if (!conv3_sums_pending) return DVG_OK;
-    conv3_sums_pending = false;
-    DVG_TRY(launch_colsum(W + pl.partB[3], EW_BLOCKS, pl.ch[4], pl.ch[4], 1.0f, g->conv_b[3], 0, 0, s2));
-    return launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2);  // [tap][ci] -> [ci][tap]
-  };
+  // (the fused conv3 backward leaves its two column sums to the batch below)
   for (int l = 3; l >= 0; --l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     const float* Y = W + pl.Y[l];
@@ -349,7 +344,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
         DVG_TRY(launch_conv_igemm(a, s));
       }
       if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-      DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
+      DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0), "decoder_bwd: column-sum batch full");
       // dbc[o] = column sums of dY seen as [N][4 C]
       DVG_TRY(launch_rowsum_partial(dY, N, C4, W + pl.partC, s2));
       DVG_TRY(launch_colsum(W + pl.partC, EW_BLOCKS, C4, C4, 1.0f, W + pl.dbc, 0, 0, s2));
@@ -380,14 +375,14 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       if (e3 && e3[0] == '1') {
         DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
         if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-        DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
         DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
-        DVG_TRY(launch_colsum(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9, s2));  // [tap][ci] -> [ci][tap]
       } else {
-        // (no fork here: the two column sums join the side work of layer 2's fork, behind that layer's main-chain kernel)
+        // (no fork here: the column sums of this layer are in the batch at the end of the side chain)
         DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
-        conv3_sums_pending = true;
       }
+      DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
+                  sums.add(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
+                  "decoder_bwd: column-sum batch full");
       continue;
     }
     ConvArgs a;
@@ -399,8 +394,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-    DVG_TRY(conv3_sums());
-    DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
+    DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0), "decoder_bwd: column-sum batch full");
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];
@@ -419,6 +413,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
   }
   // dX now holds the gradient wrt X0 (N, 4n) in (p, c) order.  Linear backward (composed form: done with layer 0 above):
   if (pl.lc0) {
+    DVG_TRY(launch_colsum_batch(sums, s2));
     if (!defer_join) DVG_TRY(stream_order_after(s, s2));
   } else {
     hipEvent_t dx_ready = nullptr;  // dX is final
@@ -432,12 +427,13 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dx_ready));
     DVG_TRY(launch_rowsum_partial(dX, N, 4 * n, W + pl.partL, s2));
-    DVG_TRY(launch_colsum(W + pl.partL, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4, s2));  // j' = p*n+c -> c*4+p
+    DVG_REQUIRE(sums.add(W + pl.partL, EW_BLOCKS, 4 * n, 4 * n, 1.0f, g->lin_b, n, 4), "decoder_bwd: column-sum batch full");  // j' = p*n+c -> c*4+p
     WgradArgs wa;
     wa.in = spins; wa.dy = dX; wa.slabs = W + pl.slabs;
     wa.M = N; wa.Cin = n; wa.Cout = 4 * n; wa.L = 0; wa.ntaps = 1; wa.ups = 0; wa.ksplit = pl.ksplit_lin;
     DVG_TRY(launch_conv_wgrad(wa, s2));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, g->lin_w, s2));
+    DVG_TRY(launch_colsum_batch(sums, s2));
     if (!defer_join) DVG_TRY(stream_order_after(s, s2));  // join (deferred: dvg_stream_join_side / the next backward call)
   }
   return DVG_OK;

@@ -128,6 +128,27 @@ int launch_colsum(const float* part, int G, int stride, int count, float scale, 
   return DVG_OK;
 }
 
+__global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumBatch b) {
+  const ColsumJob& j = b.job[blockIdx.y];
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= j.count) return;
+  double s = strided_sum8(j.part + w, lane, j.G, (size_t)j.stride);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int o = j.permA > 0 ? (w % j.permA) * j.permB + w / j.permA : w;
+    j.out[o] = (float)(s * (double)j.scale);
+  }
+}
+
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t s) {
+  if (b.n == 0) return DVG_OK;
+  int most = 1;
+  for (int k = 0; k < b.n; ++k) most = b.job[k].count > most ? b.job[k].count : most;
+  DVG_LAUNCH(K_MISC, colsum_batch_kernel, dim3((unsigned)ceil_div(most, 4), (unsigned)b.n), dim3(256), 0, s, b);
+  return DVG_OK;
+}
+
 __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ part, int G, int stride, int count_a,
                                                       float* __restrict__ out_a, int count_b, float* __restrict__ out_b) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -154,6 +154,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   DVG_REQUIRE(g->proj_w && g->proj_b, "encoder_bwd: null projection gradient buffer");
   hipStream_t s = (hipStream_t)stream;
   hipStream_t s2 = side_stream(s);  // weight-gradient chain (streams.cpp); the data-gradient chain stays on `s`
+  ColsumBatch sums;  // the bias / projection column sums of the whole call: ONE launch at the end of the side chain
   float* W = (float*)ws;
   float* dX = W + pl.dXbuf;
   float* partA = W + pl.partA;
@@ -189,10 +190,10 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
     if (proj_pending) {
-      DVG_TRY(launch_colsum2(W + pl.partP, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b, s2));
+      DVG_REQUIRE(sums.add2(W + pl.partP, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b), "encoder_bwd: column-sum batch full");
       proj_pending = false;
     }
-    DVG_TRY(launch_colsum(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0, s2));
+    DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0), "encoder_bwd: column-sum batch full");
     // weight gradient
     WgradArgs wa;
     wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
@@ -200,6 +201,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     DVG_TRY(launch_conv_wgrad(wa, s2));
     DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
   }
+  DVG_TRY(launch_colsum_batch(sums, s2));
   DVG_TRY(stream_order_after(s, s2));  // join
   return DVG_OK;
 }

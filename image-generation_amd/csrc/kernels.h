@@ -13,6 +13,24 @@ constexpr float DROPOUT_KEEP = 0.8f;  // Dropout2d(0.2) (/root/reference/src/dec
 
 // out[perm(w)] = scale * sum_g part[g*stride + w], w < count, accumulated in double in fixed order.
 // permA > 0: perm(w) = (w % permA) * permB + w / permA, else identity.
+// Several column sums in ONE launch (the bias / small-weight gradient finalisers of a whole backward call: each is a
+// ~5 us kernel, and a dozen of them strung along the side stream were a tenth of c2's step).  Same arithmetic per job as
+// launch_colsum; launch_colsum2's two outputs are two jobs over the same partials.
+struct ColsumJob { const float* part; int G, stride, count; float scale; float* out; int permA, permB; };
+constexpr int MAX_COLSUM_JOBS = 12;
+struct ColsumBatch {
+  ColsumJob job[MAX_COLSUM_JOBS];
+  int n = 0;
+  bool add(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB) {
+    if (n >= MAX_COLSUM_JOBS) return false;
+    job[n++] = ColsumJob{part, G, stride, count, scale, out, permA, permB};
+    return true;
+  }
+  bool add2(const float* part, int G, int stride, int count_a, float* out_a, int count_b, float* out_b) {  // as launch_colsum2
+    return add(part, G, stride, count_a, 1.0f, out_a, 0, 0) && add(part + count_a, G, stride, count_b, 1.0f, out_b, 0, 0);
+  }
+};
+int launch_colsum_batch(const ColsumBatch& b, hipStream_t s);
 int launch_colsum(const float* part, int G, int stride, int count, float scale, float* out, int permA, int permB,
                   hipStream_t s);
 
