@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
     unsigned char* stg = igemm_smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // buffer descriptors (raw, 32-bit byte offsets): a lane whose offset is past num_records writes ZEROS to LDS --
-    // that is the zero padding of the im2col rows (checked on the MI355X: scratch/buflds_test.hip)
+    // that is the zero padding of the im2col rows (checked on the MI355X: tools/buflds_oob_test.hip)
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)0xFFFF0000u, 0x00020000);
     // per-lane pieces, constant over the kernel: lane l of piece e writes LDS slot (row = e*8 + l/8, slot l%8) and
