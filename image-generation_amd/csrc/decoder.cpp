@@ -148,7 +148,7 @@ DecPlan dec_plan(int64_t N, int n) {
   for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);
   p.partL = bump(o, (size_t)EW_BLOCKS * cmax);
   p.partF = bump(o, (size_t)EW_BLOCKS * 10);
-  p.partW = bump(o, (size_t)EW_BLOCKS * 288);
+  p.partW = bump(o, (size_t)STREAM_BLOCKS * 288);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -372,16 +372,18 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       // data gradient and weight-gradient partials in ONE pass over the images on the caller's stream (special.hip); only
       // the column sums go to the side stream.  DVG_CONV3_SPLIT=1: the two separate kernels (A/B runs, tests)
       const char* e3 = getenv("DVG_CONV3_SPLIT");
+      int w3_blocks = stream_blocks(N);  // partial rows of the weight gradient
       if (e3 && e3[0] == '1') {
         DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
         if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
         DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
+        w3_blocks = EW_BLOCKS;
       } else {
         // (no fork here: the column sums of this layer are in the batch at the end of the side chain)
         DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
       }
       DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
-                  sums.add(partW, EW_BLOCKS, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
+                  sums.add(partW, w3_blocks, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
                   "decoder_bwd: column-sum batch full");
       continue;
     }

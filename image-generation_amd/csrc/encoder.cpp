@@ -74,7 +74,7 @@ EncPlan enc_plan(int64_t B, int n) {
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);  // per layer: reduced on the side stream
   p.partP = bump(o, (size_t)EW_BLOCKS * 8);
-  p.part320 = bump(o, (size_t)EW_BLOCKS * 320);
+  p.part320 = bump(o, (size_t)STREAM_BLOCKS * 320);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -175,7 +175,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
                                          dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     if (l == 0) {
       DVG_TRY(launch_enc_conv0_wgrad(images, B, dY, W + pl.part320, s));
-      DVG_TRY(launch_colsum2(W + pl.part320, EW_BLOCKS, 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
+      DVG_TRY(launch_colsum2(W + pl.part320, stream_blocks(8 * B), 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
       break;
     }
     // fork: dY is ready; the caller's-stream kernel goes first (see decoder.cpp: queue inheritance under capture)

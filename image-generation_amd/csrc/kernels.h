@@ -5,6 +5,14 @@
 namespace dvg {
 
 constexpr int EW_BLOCKS = 512;       // fixed grid of the reducing elementwise kernels (partials per block)
+// Streaming kernels that keep one image or pixel range per iteration in flight want more resident waves than 2 blocks per
+// CU give them (enc_conv0_wgrad ran at 2.3 TB/s, dec_conv3_bwd at 2.6 TB/s with EW_BLOCKS blocks): their own, larger
+// grids for large batches, partials per block as before
+constexpr int STREAM_BLOCKS = 2048;
+static inline int stream_blocks(int64_t images) {  // >= 8 images per block, between EW_BLOCKS and STREAM_BLOCKS blocks
+  const int64_t b = images / 8;
+  return (int)(b < EW_BLOCKS ? EW_BLOCKS : (b > STREAM_BLOCKS ? STREAM_BLOCKS : b));
+}
 constexpr int BN_FOLD_ROWS = 256;    // scratch rows behind the BN partials: launch_bn_finalize folds long lists first
 constexpr float BN_EPS = 1e-5f;      // torch.nn.BatchNorm2d defaults (/root/reference/src/encoder.py:32)
 constexpr float BN_MOMENTUM = 0.1f;

@@ -450,8 +450,25 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
     const int t0 = g * 8 + (int)blockIdx.y, t_own_end = g * 8 + 8;
     float part[2] = {0.f, 0.f};  // this segment's sums of the two row sets, flushed to double below
     double segsum[2] = {0.0, 0.0};
+    // distances of one chunk's two Gram tiles (`masked`: the last chunk of the array may hold rows past the end)
+    auto lookups = [&](const i32x16& g0, const i32x16& g1, int t, bool masked) {
+      float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d0 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * g0[r]));
+        const float d1 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * g1[r]));
+        const bool vj = !masked || t * 32 + crow(r, hh) < N;
+        p0 += vj ? d0 : 0.f;
+        p1 += vj ? d1 : 0.f;
+      }
+      const float wgt = t < t_own_end ? 1.0f : 2.0f;
+      part[0] = fmaf(p0, wgt, part[0]);
+      part[1] = fmaf(p1, wgt, part[1]);
+    };
     if (t0 < TC) issue(t0, 0);
-    int buf = 0;
+    int buf = 0, tp = -1, since_flush = 0;
+    i32x16 accp[2];  // the previous chunk's Gram tiles: their lookups run under this chunk's MFMAs
+    accp[0] = (i32x16){0}; accp[1] = (i32x16){0};
     for (int t = t0; t < TC; t += (int)gridDim.y, buf ^= 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -465,31 +482,17 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
         acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[0][s], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[1][s], acc[1], 0, 0, 0);
       }
-      const float wgt = t < t_own_end ? 1.0f : 2.0f;
-      float p0 = 0.f, p1 = 0.f;
-      if (t * 32 + 32 <= N) {  // whole chunk valid (block-uniform): no masks
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p0 += *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[0][r]));
-          p1 += *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[1][r]));
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool vj = t * 32 + crow(r, hh) < N;
-          const float d0 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[0][r]));
-          const float d1 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * acc[1][r]));
-          p0 += vj ? d0 : 0.f;
-          p1 += vj ? d1 : 0.f;
-        }
-      }
-      part[0] = fmaf(p0, wgt, part[0]);
-      part[1] = fmaf(p1, wgt, part[1]);
-      if (((t - t0) / (int)gridDim.y & 15) == 15) {  // keep the float32 running sums short
+      // (a chunk that is looked up here is never the array's last one: that one is always some block's final chunk)
+      if (tp >= 0) lookups(accp[0], accp[1], tp, false);
+      accp[0] = acc[0]; accp[1] = acc[1];
+      tp = t;
+      if (++since_flush == 16) {  // keep the float32 running sums short
         segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
         part[0] = 0.f; part[1] = 0.f;
+        since_flush = 0;
       }
     }
+    if (tp >= 0) lookups(accp[0], accp[1], tp, tp * 32 + 32 > N);
     segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
     total += (vi[0] ? segsum[0] : 0.0) + (vi[1] ? segsum[1] : 0.0);
     __syncthreads();  // (the next segment's first DMA must not overtake a straggler's reads of stage 0)

@@ -95,7 +95,7 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
   return DVG_OK;
 }
 
-// dW[co][t] = sum_m dY[m][co] * in_t[m];  db[co] = sum_m dY[m][co];  part [EW_BLOCKS][320]
+// dW[co][t] = sum_m dY[m][co] * in_t[m];  db[co] = sum_m dY[m][co];  part [stream_blocks(B)][320]
 // A (32 x K) x (K x 10) GEMM with K = B*1024 pixels: one f32 MFMA per two pixels.  The A operand (dY rows, 32
 // channels = 128 B) and the B operand (the 9 shifted input pixels + a column of ones for the bias, rest zero) go
 // straight from global memory to the MFMA: no LDS, no staging.
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void enc_conv0_wgrad_kernel(const float* __res
 }
 
 int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_conv0_wgrad_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, images, B, dY, part);
+  DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_conv0_wgrad_kernel, dim3((unsigned)stream_blocks(8 * B)), dim3(256), 0, s, images, B, dY, part);  // (pixel ranges, not images)
   return DVG_OK;
 }
 
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_kernel(const float* __restr
 }
 
 int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float* w, float* dX, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_kernel, dim3(EW_BLOCKS), dim3(288), 0, s, X, N, dY, w, dX, part);
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_kernel, dim3((unsigned)stream_blocks(N)), dim3(288), 0, s, X, N, dY, w, dX, part);
   return DVG_OK;
 }
 
