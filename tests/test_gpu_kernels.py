@@ -48,6 +48,26 @@ def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side, staging):
     assert _rel(gw.cpu(), w.grad) < 3e-6
 
 
+@pytest.mark.parametrize("N,Cin,Cout,side", [(1024, 32, 64, 4), (8192, 32, 64, 2), (1024, 128, 128, 8)])
+def test_position_major_tiles_are_bit_identical_to_pixel_major_tiles(N, Cin, Cout, side):
+    """Position-major tiles (conv.h: ConvArgs.posmajor) skip the taps that fall outside the image -- multiplications by
+    zero padding -- and keep the order of the rest: the same bits as pixel-major tiles (DVG_NO_POSMAJOR=1)."""
+    import os
+    torch.manual_seed(N + side)
+    L, M = side.bit_length() - 1, N * side * side
+    x = torch.randn(M, Cin, device="cuda"); w = (torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5)).cuda(); b = torch.randn(Cout).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["DVG_NO_POSMAJOR"] = flag
+        try:
+            outs[flag] = dev.conv_igemm(x, w, 0, M, Cin, Cout, L, bias=b, stats=True)
+        finally:
+            os.environ.pop("DVG_NO_POSMAJOR", None)
+    assert torch.equal(outs["0"][0], outs["1"][0])
+    # (the BatchNorm partial rows group other pixels: their totals agree to float32 rounding)
+    assert _rel(outs["0"][1].sum(0), outs["1"][1].sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side", [(4, 128, 64, 4), (3, 64, 32, 8), (2, 96, 128, 2)])
 def test_convtranspose_with_fused_upsample(N, Cin, Cout, side, staging):
     """side = OUTPUT resolution; the input lives at side/2 and is nearest-upsampled inside the gather;
