@@ -84,7 +84,7 @@ def _profile(kind, config, lib_hash):
     """A committed profiles/ JSON of this round, or None when it was measured on a different build of the kernels:
     every file carries `kernels_hash` = dvg_source_hash() of the library it was measured on (tools/make_profiles.sh),
     and a number from another build would survive a kernel regression unchanged."""
-    for rnd in ("r02",):
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{kind}_{config}.json")
         if os.path.exists(path):
             d = json.load(open(path))
@@ -138,8 +138,9 @@ def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle (a port: stock PyTorch CPU ops + the C Gibbs restatement) on this box's host cores, on a BOUNDED
     sample of the workload: the same model, sampler and replica count at a batch of at most 512 images per step (a c3
     step is 4096; the oracle's MMD materialises the (B R + C)^2 kernel matrix as the reference does, 4.4 GB per
-    temporary at c3), >= 3 warm-up steps unless one step alone exceeds the budget, then >= 3 timed steps for about
-    `seconds`; median step time."""
+    temporary at c3), 3 warm-up steps, then >= 10 timed steps for about `seconds`; median step time.
+    The sample's batch is NOT the GPU line's batch: the oracle's MMD is quadratic in B R, so images/s at B = 512 flatters
+    the CPU against the same model at B = 4096 -- `batch` and `comparable_to_value` say so in the line."""
     from image_generation_amd import graphs
     from oracle.step import OracleTrainer
 
@@ -160,19 +161,20 @@ def cpu_baseline(cfg, seconds=20.0):
     tr.step(batch(), force_grbm=False)  # first step: allocator / thread-pool warm-up
     first = time.perf_counter() - t0
     warm = 1
-    while warm < 3 and first * (warm + 4) < seconds:
+    while warm < 3:
         tr.step(batch(), force_grbm=False)
         warm += 1
     times = []
     t_all = time.perf_counter()
-    while len(times) < 3 or (time.perf_counter() - t_all < seconds - first * warm and len(times) < 40):
+    while len(times) < 10 or (time.perf_counter() - t_all < seconds - first * warm and len(times) < 40):
         t0 = time.perf_counter()
         tr.step(batch())  # GRBM branch at its natural duty (step 10k)
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
     return {"value": Bc / med, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-            "host_cores": os.cpu_count(),
+            "host_cores": os.cpu_count(), "batch": Bc, "workload_batch": cfg["B"], "timed_steps": len(times),
+            "comparable_to_value": bool(Bc == cfg["B"]),
             "sample": f"{len(times)} train steps of the {cfg['B']}-image workload's model (n={cfg['n']}, R={cfg['R']}, "
                       f"{cfg['C']} chains x {cfg['sweeps']} sweeps) at B={Bc} images per step on the CPU oracle after {warm} "
                       f"warm-up steps; median {med * 1e3:.0f} ms/step, min {times[0] * 1e3:.0f} ms",
@@ -326,6 +328,11 @@ def main():
     dp = DataParallel()
     if dp.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world_size}: launch with torch.distributed.run")
+    if dp.active:
+        import torch.distributed as tdist
+
+        if tdist.get_world_size() != args.gpus and not (dp.force and args.gpus == 1):
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {tdist.get_world_size()} ranks")
     dev = torch.device("cuda", dp.local_rank)
     torch.cuda.set_device(dev)
 
@@ -377,6 +384,17 @@ def main():
     elapsed = time.perf_counter() - t0
     L.dvg_prof_enable(0)
     elapsed = dp.max_over_ranks(elapsed)
+    # What the timed region computed: the last timed step's losses (device scalars the step left in model.last) and the
+    # parameters it produced.  A run whose numbers are not finite is not a measurement.
+    last_mse, last_mmd = float(model.last["mse"]), float(model.last["mmd"])
+    params_finite = bool(torch.isfinite(model._dvae_optimizer.flat).all()) and bool(torch.isfinite(model._grbm_optimizer.flat).all())
+    workload_losses = {"mse": last_mse, "mmd": last_mmd, "mse+mmd": last_mse + last_mmd,
+                       "nll": float(model.last["nll"]) if "nll" in model.last else None,
+                       "params_finite": params_finite, "step": step_idx - 1,
+                       "note": "losses of the LAST timed step and finiteness of every parameter after the timed region"}
+    if not (params_finite and all(v == v and abs(v) != float("inf") for v in (last_mse, last_mmd))):
+        raise SystemExit(f"bench: rank {dp.rank}: the timed steps produced non-finite numbers: {workload_losses}")
+    per_rank = dp.gather_objects({"rank": dp.rank, "dist": dp.describe(), "mse": last_mse, "mmd": last_mmd})
     prof_steps = args.steps
     if model.use_graph:
         # hipGraph replays cannot carry per-kernel event records, so the per-kernel HIP-event timing behind
@@ -485,6 +503,13 @@ def main():
                        "launch": ("hipGraph replay of the autoencoder half (GRBM update of every 10th step eager behind it)"
                                   if model.use_graph else "eager"),
                        "net_gflop_per_step": net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9},
+            "workload_losses": workload_losses,
+            # what the process group looked like from inside (not what --gpus claimed): backend, world size RCCL reports,
+            # every rank's device
+            "dist": dict(dp.describe(), ranks=[{"rank": r["rank"], "device": r["dist"].get("device"),
+                                                "device_name": r["dist"].get("device_name"),
+                                                "world_size_seen": r["dist"].get("world_size_seen"),
+                                                "mse": r["mse"], "mmd": r["mmd"]} for r in per_rank]),
             "roofline": roofline,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -41,9 +41,16 @@ def _sharpen_output() -> bool:
         return False
 
 
+def _is_main(model) -> bool:
+    is_main = getattr(model, "is_main_rank", None)
+    return True if is_main is None else bool(is_main())
+
+
 def create_model_files(model, file_name: str, qpu: str, n_latents: int, n_epochs: int, loss_data: dict) -> None:
     """/root/reference/src/utils/callback_helpers.py:70-108: ``models/<file_name>/{dvae.pth, grbm.pth, parameters.json,
     losses.json}``, ``loss_data`` written as given."""
+    if not _is_main(model):  # data-parallel: one writer (save() is rank-local; every rank holds the same model)
+        return
     model.save(file_path=MODEL_PATH / file_name)
     with open(MODEL_PATH / file_name / "parameters.json", "w") as f:
         json.dump({"n_latents": n_latents, "n_epochs": n_epochs, "prefactor": model.PREFACTOR, "qpu": qpu,
@@ -62,6 +69,8 @@ def execute_training(set_progress: Optional[Callable], model, n_epochs: int, qpu
     figs = [None]
 
     def end_of_epoch(epoch: int, report: dict) -> None:
+        if not _is_main(model):  # data-parallel: rank 0 writes the side files and draws the figures (rank-local calls)
+            return
         with open(PROBLEM_DETAILS_PATH, "w") as f:
             json.dump(report, f)
         fig_output = model.generate_output(latent_qpu_file=LATENT_QPU_FILE, sharpen=sharpen,

@@ -1859,6 +1859,12 @@ static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
+// DVG_MMD_SLICES=2: the two-feature-slice form of the 128-row-block pair kernel at d > 256 (A/B runs; read per call)
+static bool mmd_two_slices() {
+  const char* esl = getenv("DVG_MMD_SLICES");
+  return esl && esl[0] == '2';
+}
+
 }  // namespace dvg
 
 using namespace dvg;
@@ -1867,7 +1873,9 @@ extern "C" int dvg_mmd_spin_flops(int64_t nx, int64_t ny, int dim, double* int8_
   DVG_REQUIRE(nx >= 2 && ny >= 2 && dim >= 32 && dim % 32 == 0 && int8_flops && bf16_flops && bf16_terms, "mmd_spin_flops: bad argument");
   const MmdPlan p = mmd_plan(nx, ny, dim);
   if (!p.pm1_ok) { *int8_flops = 0.0; *bf16_flops = 0.0; *bf16_terms = 0; return DVG_OK; }  // f32 kernels only
-  const int passes = p.w128 ? (dim > 256 ? 2 : 1) : 1;
+  // the form dvg_mmd_fwd_bwd launches: ONE feature slice per block (the Gram and the lookups computed once) unless the
+  // two-slice form is asked for (mmd_two_slices(), d > 256 only)
+  const int passes = (p.w128 && dim > 256 && mmd_two_slices()) ? 2 : 1;
   *bf16_terms = p.w128 ? 2 : 3;
   mmd_pm1_flops(nx, ny, dim, true, *bf16_terms, passes, int8_flops, bf16_flops);
   return DVG_OK;
@@ -1969,8 +1977,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     // Large spin problems: 128-row blocks.  General (not +-1) rows cannot be known on the host without a sync, so the
     // f32 kernel is launched behind it with the same split count and stands down on the device flag (its blocks exit at
     // once; it writes the same loss_part / grad_part slots when it does run).
-    const char* esl = getenv("DVG_MMD_SLICES");  // (read per call)
-    const bool two_slices = esl && esl[0] == '2';
+    const bool two_slices = mmd_two_slices();
     switch (dim / 128) {
       case 1: rc = launch_pair_w128<4, 4>(a, p, s); break;
       case 2: rc = launch_pair_w128<8, 8>(a, p, s); break;

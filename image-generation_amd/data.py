@@ -107,14 +107,28 @@ def load_mnist(root: str = "data", image_size: int = 32, device="cuda") -> Optio
     return None if raw is None else resize_binarise(raw.to(device), image_size)
 
 
+def random_subset_indices(n: int, k: int, seed: Optional[int] = None) -> torch.Tensor:
+    """``DATASET_SIZE`` as the reference applies it (/root/reference/src/model_wrapper.py:96-100):
+    ``torch.utils.data.random_split(dataset, [k, n - k])[0]`` -- the first ``k`` entries of ONE ``randperm(n)``, a random
+    subset, not the first ``k`` images.  ``seed=None`` draws from torch's global generator exactly as the reference does
+    (the same call, so the same subset after the same seeding); data-parallel runs pass the run's seed so that every
+    rank holds the same subset whatever its generator has consumed."""
+    if not 0 < k <= n:
+        raise ValueError(f"DATASET_SIZE={k} must be in 1..{n}")
+    gen = None if seed is None else torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    subset = torch.utils.data.random_split(range(n), [k, n - k], generator=gen) if gen is not None else \
+        torch.utils.data.random_split(range(n), [k, n - k])
+    return torch.tensor(subset[0].indices, dtype=torch.int64)
+
+
 def get_dataloader(image_size: int, batch_size: int, dataset_size: Optional[int] = None, seed: int = 0,
                    device=None, root: str = "data", rank: int = 0, world_size: int = 1) -> TensorBatches:
     device = device or ("cuda" if torch.cuda.is_available() else "cpu")
     images = load_mnist(root, image_size, device) if torch.device(device).type == "cuda" else None
     if images is None:
-        images = synthetic_images(dataset_size or 60000, seed)
+        images = synthetic_images(60000, seed)
     if dataset_size:
-        images = images[:dataset_size]
+        images = images[random_subset_indices(images.shape[0], int(dataset_size), seed if world_size > 1 else None)]
     labels = torch.zeros(images.shape[0], dtype=torch.int64)
     return TensorBatches(images.to(device), labels.to(device), batch_size, shuffle=True, seed=seed, rank=rank,
                          world_size=world_size)

@@ -116,10 +116,13 @@ class ModelWrapper:
 
     # ------------------------------------------------------------------ checkpoints
     def save(self, file_path) -> None:
-        """Two ``state_dict`` files, as /root/reference/src/model_wrapper.py:148-162."""
+        """Two ``state_dict`` files, as /root/reference/src/model_wrapper.py:148-162.
+
+        Rank-local (no collective): ``if rank == 0: model.save(...)`` is safe.  In a data-parallel run the BatchNorm
+        running statistics differ per rank until :meth:`sync_buffers` -- a collective every rank must reach; the epoch
+        driver (training.execute_training) calls it at the end of every epoch -- has made them rank 0's."""
         file_path = Path(file_path)
         file_path.mkdir(exist_ok=True, parents=True)
-        self.sync_buffers()
         torch.save({k: v.detach().cpu().clone() for k, v in self._dvae.state_dict().items()}, file_path / "dvae.pth")
         torch.save({k: v.detach().cpu().clone() for k, v in self._grbm.state_dict().items()}, file_path / "grbm.pth")
 
@@ -275,11 +278,25 @@ class ModelWrapper:
 
     def sync_buffers(self) -> None:
         """BatchNorm running statistics are rank 0's (they are read only in eval mode; each rank's training-mode
-        batch statistics stay local, DDP semantics): broadcast before a checkpoint or an eval-mode entry point."""
+        batch statistics stay local, DDP semantics).  A COLLECTIVE: every rank must call it (the epoch driver does, at
+        the end of each epoch); ``save`` / ``generate_*`` / ``reconstruct_images`` are rank-local and never call it."""
         if not self._dist_active():
             return
-        for b in self._bn_buffers():
-            self.dist.broadcast_(b)
+        bufs = self._bn_buffers()
+        if not bufs:
+            return
+        # ONE broadcast: float32 statistics and the int64 batch counters travel as float64 (exact for both)
+        flat = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])
+        self.dist.broadcast_(flat)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flat[off: off + b.numel()].view(b.shape).to(b.dtype))
+                off += b.numel()
+
+    def is_main_rank(self) -> bool:
+        """True on the rank that writes checkpoints / figures / side files (rank 0; always without a process group)."""
+        return self.dist is None or self.dist.rank == 0
 
     def local_num_reads(self) -> int:
         """Chains per rank.  Data parallelism is weak-scaled: every rank keeps the full per-GPU
@@ -398,6 +415,31 @@ class ModelWrapper:
 
     def _dvae_half(self, images):
         """Forward, MSE + MMD, backward and Adam for the autoencoder (/root/reference/src/model_wrapper.py:297-327)."""
+        try:
+            return self._dvae_half_impl(images)
+        except BaseException:
+            # the decoder's backward may have returned with the library's side stream still forked (deferred join): close
+            # the fork, release what it pinned and clear the flag, so that neither a later standalone decoder backward nor
+            # the end of a failed hipGraph capture sees a half-open step
+            try:
+                self._join_deferred()
+            except Exception:
+                pass
+            raise
+
+    def _join_deferred(self):
+        """Joins the library's side stream into the current stream (the decoder's deferred weight-gradient chain), then
+        drops the tensors the decoder's backward pinned for that chain and clears the deferral flag."""
+        dec = self._dvae.decoder
+        try:
+            if self._device is not None and self._device.type == "cuda":
+                from . import _lib
+                _lib.check(_lib.lib().dvg_stream_join_side(_lib.stream_ptr(self._device)), "dvg_stream_join_side")
+        finally:
+            dec._defer_join = False  # (only this step's own backward runs deferred)
+            dec._deferred_keep = None
+
+    def _dvae_half_impl(self, images):
         # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
         # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
         # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
@@ -604,10 +646,9 @@ class ModelWrapper:
     def _reduce_and_step(self, opt):
         if opt is self._dvae_optimizer and self._device.type == "cuda":
             # the decoder's backward ran with its weight-gradient join deferred (see _dvae_half): the encoder's backward
-            # behind it joined the shared side stream already; this makes the ordering explicit whatever ran in between
-            from . import _lib
-            _lib.check(_lib.lib().dvg_stream_join_side(_lib.stream_ptr(self._device)), "dvg_stream_join_side")
-            self._dvae.decoder._defer_join = False  # (only this step's own backward runs deferred)
+            # behind it joined the shared side stream already; this makes the ordering explicit whatever ran in between,
+            # and only now are the decoder's workspace / gradient tensors handed back to the allocator
+            self._join_deferred()
         if self._dist_active():
             opt.gather_grads()  # packed into this optimizer's part of the joint buffer; see _flush_dist
             if not self._capturing_split:  # (under capture the replay re-registers it: _step_graphed)
@@ -642,7 +683,7 @@ class ModelWrapper:
 
     @torch.no_grad()
     def _generate(self, sharpen: bool, lower: float, upper: float):
-        self.sync_buffers()
+        # (rank-local, like save(): data-parallel callers run sync_buffers() on every rank first)
         self._dvae.eval()
         self._grbm.eval()
         samples = self._grbm.sample(self.sampler, prefactor=self.PREFACTOR, device=self._device,
@@ -667,7 +708,6 @@ class ModelWrapper:
                 self._load_dataset(batch_size=self.BATCH_SIZE, dataset_size=self.DATASET_SIZE)
             batch = next(iter(self._dataloader))[0]
         batch = batch.to(self._device)
-        self.sync_buffers()
         self._dvae.eval()
         self._grbm.eval()
         _, _, reconstructed = self._dvae(batch)

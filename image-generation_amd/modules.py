@@ -198,12 +198,19 @@ class _DecoderFn(torch.autograd.Function):
         gs.conv_w[4], gs.conv_b[4] = grads[18].data_ptr(), grads[19].data_ptr()
         go = grad_out.contiguous().float()
         gx = torch.empty_like(x) if ctx.need_input_grad else None
+        defer = bool(getattr(module, "_defer_join", False))
         with torch.cuda.device(x.device):
             # defer_join (set by ModelWrapper around its own step, where the encoder's backward always follows on the same
             # stream): the tail of the weight-gradient chain overlaps the head of the encoder's data-gradient chain
             check(L.dvg_decoder_bwd_ex(ctypes.byref(st), n, x.data_ptr(), B * R, go.data_ptr(), ctypes.byref(gs),
-                                       _lib.ptr(gx), ws.data_ptr(), ws.numel(), int(bool(getattr(module, "_defer_join", False))),
+                                       _lib.ptr(gx), ws.data_ptr(), ws.numel(), int(defer),
                                        stream_ptr(x.device)), "dvg_decoder_bwd_ex")
+        if defer:
+            # The library's side stream is still reading ws / go / x (and writing the slabs in ws and the gradients) when
+            # this call returns, and torch's caching allocator knows nothing of that raw stream: autograd would release
+            # ws the moment this node is done, and a main-stream allocation made before the join could be carved out of
+            # it.  The owner of the deferral (ModelWrapper) drops these references AFTER dvg_stream_join_side.
+            module._deferred_keep = (ws, go, x, gx, tuple(grads))
         return (gx, None, None, None, None, *_grad_returns(module, grads, direct))
 
 
@@ -232,6 +239,8 @@ class Decoder(torch.nn.Module):
         self._injected_masks: Optional[List[torch.Tensor]] = None
         self.dropout_seed = 0
         self._dropout_calls = 0
+        self._defer_join = False     # see _DecoderFn.backward; set and cleared by ModelWrapper around its own step
+        self._deferred_keep = None   # tensors the library's side stream may still touch until the deferred join
 
     def inject_dropout_masks(self, masks: Optional[List[torch.Tensor]]):
         """Use these keep-masks for the next training forward instead of the device RNG."""

@@ -28,6 +28,13 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.owns_group = False
         self.force = os.environ.get("DVG_FORCE_DIST") == "1"  # exercise the collective path with a single rank
+        if self.rank < 0 or self.rank >= self.world_size:
+            raise RuntimeError(f"DataParallel: RANK={self.rank} outside WORLD_SIZE={self.world_size}")
+        # one process per GPU of ONE node: a launcher that hands out more local ranks than the node has devices would
+        # otherwise surface as an opaque HIP 'invalid device ordinal' (or, worse, as two ranks on one device inside RCCL)
+        if torch.cuda.is_available() and device is None and self.local_rank >= torch.cuda.device_count():
+            raise RuntimeError(f"DataParallel: LOCAL_RANK={self.local_rank} but this node exposes "
+                               f"{torch.cuda.device_count()} GPU(s); launch one process per visible device")
         if (self.world_size > 1 or self.force) and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -85,6 +92,26 @@ class DataParallel:
         t = torch.tensor([value], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def describe(self) -> dict:
+        """What the process group actually looks like from this rank (bench.py prints it: the line then says what RCCL
+        saw, not what the command line claimed)."""
+        info = {"backend": None, "world_size_seen": 1, "rank": self.rank, "local_rank": self.local_rank,
+                "env_world_size": self.world_size, "forced_single_rank_group": bool(self.force and self.world_size == 1)}
+        if dist.is_available() and dist.is_initialized():
+            info.update(backend=dist.get_backend(), world_size_seen=dist.get_world_size(), rank=dist.get_rank())
+        if torch.cuda.is_available():
+            idx = self.device.index if self.device.type == "cuda" and self.device.index is not None else torch.cuda.current_device()
+            info.update(device=f"cuda:{idx}", device_name=torch.cuda.get_device_name(idx), devices_visible=torch.cuda.device_count())
+        return info
+
+    def gather_objects(self, obj):
+        """Every rank's ``obj`` on every rank (small Python objects: the bench's per-rank records)."""
+        if not (self.world_size > 1 or self.force) or not dist.is_initialized():
+            return [obj]
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
 
     def shutdown(self):
         if self.owns_group and dist.is_initialized():

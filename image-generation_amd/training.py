@@ -36,6 +36,10 @@ def execute_training(model, n_epochs: int, qpu: Optional[str] = None, n_latents:
             mse_loss = model.step(batch, epoch)
         if model._device.type == "cuda":
             torch.cuda.synchronize(model._device)
+        # data-parallel: the one point of an epoch every rank reaches outside the step -- BatchNorm running statistics
+        # become rank 0's here, so that the rank-local save() / generate_*() behind it see one model on every rank
+        if hasattr(model, "sync_buffers"):
+            model.sync_buffers()
         lr_dvae = float(model._tpar["dvae_lr_schedule"][model._tpar["opt_step"]])
         lr_grbm = float(model._tpar["grbm_lr_schedule"][model._tpar["opt_step"]])
         minutes = (time.perf_counter() - start) / 60
@@ -52,7 +56,8 @@ def execute_training(model, n_epochs: int, qpu: Optional[str] = None, n_latents:
             print(f"Epoch {epoch + 1}/{n_epochs} - MSE Loss: {float(mse_loss):.4f} - Learning rate DVAE: {lr_dvae:.3E} "
                   f"Learning rate GRBM: {lr_grbm:.3E} Time: {minutes:.2f} mins. "
                   f"({total * model.BATCH_SIZE / (minutes * 60):.0f} images/s)")
-        if details_path:
+        is_main = getattr(model, "is_main_rank", None)
+        if details_path and (is_main is None or is_main()):
             with open(details_path, "w") as f:
                 json.dump(report, f)
         if on_epoch_end is not None:
@@ -65,6 +70,9 @@ def create_model_files(model, model_dir, n_epochs: int, loss_data: Optional[dict
     """``dvae.pth`` + ``grbm.pth`` + ``parameters.json`` + ``losses.json`` in the reference's format
     (/root/reference/src/utils/callback_helpers.py:70-108)."""
     model_dir = Path(model_dir)
+    is_main = getattr(model, "is_main_rank", None)
+    if is_main is not None and not is_main():  # data-parallel: one writer
+        return
     model.save(model_dir)
     with open(model_dir / "parameters.json", "w") as f:
         json.dump(

@@ -12,6 +12,8 @@ Fixtures:
                        deterministic inputs from gen.py.
   epoch_n64.npz/.json  the reference's verbatim execute_training (callback_helpers.py) over its verbatim
                        ModelWrapper on the CPU oracle: losses, progress calls, side files, figure contents.
+  ckpt_adv2_40.npz     a shipped checkpoint (models/Advantage2_system1_40_epochs/dvae.pth) as float32 arrays plus the
+                       reference modules' eval-mode outputs on fixed inputs (``checkpoint`` target).
   common.json          reference greedy_get_subgraph / get_graph_mapping /
                        heaviside latent_to_discrete / train_grbm / push_to_deque
                        (imported from /root/reference/src/utils/*.py and
@@ -454,6 +456,42 @@ def resize_fixture():
     print("wrote resize_pil.npz", imgs.shape, pil.shape)
 
 
+def checkpoint_fixture(model="Advantage2_system1_40_epochs", B=32, R=2):
+    """A SHIPPED checkpoint through the reference's own modules: ``models/<model>/dvae.pth`` (trained weights, trained
+    BatchNorm running statistics: ``num_batches_tracked`` = 18720) loaded into the reference's ``Encoder`` / ``Decoder``
+    (/root/reference/src/model_wrapper.py:164-175 does the same through the DVAE container), eval-mode forward of both on
+    fixed inputs (/root/reference/demo_callbacks.py:757-758 -> generate_output / generate_reconstucted_samples), and the
+    encoder's training-mode forward (batch statistics on trained weight ranges).  The weights themselves are committed as
+    DATA next to the outputs (ckpt_*.npz holds float32 arrays only), so the GPU box needs neither the reference nor the
+    28 MB models/ directory."""
+    Encoder, Decoder = import_reference()
+    sd = torch.load(os.path.join(REF, "models", model, "dvae.pth"), weights_only=True)
+    n = sd["_decoder.increase_latent_dim.weight"].shape[1]
+    enc, dec = Encoder(n), Decoder(n)
+    enc.load_state_dict({k[len("_encoder."):]: v for k, v in sd.items() if k.startswith("_encoder.")}, strict=True)
+    dec.load_state_dict({k[len("_decoder."):]: v for k, v in sd.items() if k.startswith("_decoder.")}, strict=True)
+    x = torch.from_numpy(gen.make_images(B, seed=2024))
+    spins = torch.from_numpy(gen.make_spins(B, R, n, seed=2025))
+    out = {"n": n, "B": B, "R": R}
+    with torch.no_grad():
+        enc.eval(); dec.eval()
+        out["enc_eval_logits"] = enc(x).numpy()
+        out["dec_eval_out"] = dec(spins).numpy()
+        # generation as the reference wires it: decoder(samples.unsqueeze(1)) (/root/reference/src/model_wrapper.py:378)
+        out["dec_eval_out_r1"] = dec(spins[:, :1]).numpy()
+        enc.train()
+        out["enc_train_logits"] = enc(x).numpy()
+        after = enc.state_dict()
+        for name in after:
+            if "running" in name or "num_batches" in name:
+                out[f"enc_after/{name}"] = after[name].numpy()
+    for k, v in sd.items():
+        out[f"sd/{k}"] = v.numpy()
+    path = os.path.join(HERE, "ckpt_adv2_40.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; n =", n)
+
+
 def _load_module(name, path):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
@@ -475,3 +513,5 @@ if __name__ == "__main__":
         epoch_fixture()
     if "resize" in which:
         resize_fixture()
+    if "checkpoint" in which:
+        checkpoint_fixture()

@@ -64,6 +64,12 @@ def test_idx_files_go_through_the_device_transform(tmp_path):
     os.makedirs(tmp_path / "MNIST" / "raw")
     with gzip.open(tmp_path / "MNIST" / "raw" / "train-images-idx3-ubyte.gz", "wb") as f:
         f.write(struct.pack(">IIII", 2051, 200, 28, 28) + raw.tobytes())
+    # DATASET_SIZE is the reference's random_split subset (/root/reference/src/model_wrapper.py:96-100): the first 128
+    # entries of one randperm(200) from torch's global generator
+    torch.manual_seed(77)
+    want_idx = torch.utils.data.random_split(range(200), [128, 72])[0].indices
+    torch.manual_seed(77)
     dl = data.get_dataloader(32, 16, dataset_size=128, seed=1, device="cuda", root=str(tmp_path))
     assert len(dl) == 8 and dl.images.is_cuda and dl.images.shape == (128, 1, 32, 32)
-    assert np.array_equal(dl.images.cpu().numpy(), resize.resize_binarise(raw[:128], 32))
+    assert sorted(want_idx) != list(range(128))
+    assert np.array_equal(dl.images.cpu().numpy(), resize.resize_binarise(raw[want_idx], 32))

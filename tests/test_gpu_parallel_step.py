@@ -7,7 +7,8 @@ rank-keyed noise); (2) a GRBM step issues ONE all-reduce (encoder/decoder gradie
 differences in one buffer); (3) after every step the replicas are bit-identical; (4) the first update equals the Adam
 update of the MEAN of the two shards' gradients; (5) graph replay (two graphs + the collective between them) is
 bit-identical to the eager data-parallel run; (6) replicas that were built from different seeds are equalised by the
-broadcast in ``setup``."""
+broadcast in ``setup``; (7) rank r's losses equal the CPU oracle on shard r and the exchanged gradient the sum of
+the oracle's per-shard gradients."""
 import os
 import socket
 import subprocess
@@ -22,7 +23,7 @@ pytestmark = pytest.mark.gpu
 WORKER = r'''
 import os, sys, numpy as np, torch
 repo = os.environ["DVG_REPO"]
-sys.path.insert(0, repo); sys.path.insert(0, os.path.join(repo, "tests", "golden"))
+sys.path.insert(0, repo); sys.path.insert(0, os.path.join(repo, "tests", "golden")); sys.path.insert(0, os.path.join(repo, "tests"))
 import gen
 import torch.distributed as tdist
 from image_generation_amd.model_wrapper import ModelWrapper
@@ -38,7 +39,7 @@ class Shard:  # a single-rank stand-in that carries a rank (seeds, chain numberi
 def images(rank, B):
     return torch.from_numpy(gen.make_images(B * steps, seed=40 + rank)).reshape(steps, B, 1, 32, 32).cuda()
 
-def run(dist, rank, use_graph=False, seed=None):
+def run(dist, rank, use_graph=False, seed=None, oracle=False):
     m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=params, dist=dist)
     imgs = images(rank, 8)
     m.set_dataloader([(imgs[k], None) for k in range(steps)])
@@ -49,6 +50,22 @@ def run(dist, rank, use_graph=False, seed=None):
     m.sync_losses = False
     m.use_graph = use_graph
     rec = {"mse": [], "mmd": [], "flat": [], "gflat": []}
+    if oracle:
+        # SURVEY.md 8e: "rank r's losses equal the CPU oracle on shard r with the same noise; gradients equal the mean over
+        # shards" -- the CPU oracle (float32, stock torch + the C sampler) steps from this rank's snapshot on this rank's
+        # shard with this rank's injected Gumbel noise / dropout masks and this rank's globally numbered chains
+        import halfstep_oracle as ho
+        g = torch.Generator().manual_seed(900 + rank)
+        B, R, n = 8, int(m.N_REPLICAS), 64
+        gumbels = -torch.log(torch.empty(B, R, n, 2).exponential_(generator=g))
+        masks = [(torch.rand(B * R, c, generator=g) < 0.8).float() for c in (128, 64, 32, 1)]
+        m.noise_hook = lambda step: {"gumbels": gumbels, "dropout_masks": masks} if step == 0 else {}
+        w = ho.oracle_step(ho.meta_of(m), ho.snapshot(m), imgs[0].cpu(), gumbels, masks, ho.oracle_sampler_like(m),
+                           dtype=torch.float32, device="cpu", grbm_branch=True)
+        names = [k for k, _ in m._dvae.named_parameters()]
+        rec["oracle_losses"] = np.array([w["mse"], w["mmd"], w["nll"]])
+        rec["oracle_grad"] = np.concatenate([w["grads"][k].reshape(-1).numpy() for k in names]
+                                            + [w["grad_linear"].numpy(), w["grad_quadratic"].numpy()])
     rec["p0"] = np.concatenate([m._dvae_optimizer.flat.detach().cpu().numpy(), m._grbm_optimizer.flat.detach().cpu().numpy()])
     calls = {"n": 0}
     if dist is not None and getattr(dist, "active", False):
@@ -81,7 +98,8 @@ if mode == "single":          # one process: the two shards one after the other,
 else:
     dp = DataParallel(backend="gloo", device=torch.device("cuda", 0))
     assert dp.world_size == 2 and tdist.get_backend() == "gloo"
-    rec, m = run(dp, dp.rank, use_graph=(mode == "graph"), seed=(100 + dp.rank if mode == "seeds" else None))
+    rec, m = run(dp, dp.rank, use_graph=(mode == "graph"), seed=(100 + dp.rank if mode == "seeds" else None),
+                 oracle=(mode == "oracle"))
     np.savez(os.path.join(out_dir, f"{mode}{dp.rank}.npz"), **{k: np.asarray(v) for k, v in rec.items()})
     dp.barrier()
     dp.shutdown()
@@ -169,3 +187,21 @@ def test_replicas_built_from_different_seeds_are_equalised(tmp_path):
     a, b = _load(tmp_path, "seeds0.npz"), _load(tmp_path, "seeds1.npz")
     for k in range(3):
         assert np.array_equal(a["flat"][k], b["flat"][k]) and np.array_equal(a["gflat"][k], b["gflat"][k])
+
+
+def test_two_rank_losses_equal_cpu_oracle_on_each_shard(tmp_path):
+    """SURVEY.md 8e's parity statement, literally: rank r's step-0 losses == the CPU oracle on shard r (1e-5 relative,
+    identical injected noise, the rank's own chains), and the ONE all-reduced gradient buffer == the SUM over ranks of the
+    oracle's gradients (the 1/world_size of the mean is Adam's grad_scale)."""
+    _launch("oracle", tmp_path, 1, 2)
+    d = [_load(tmp_path, f"oracle{r}.npz") for r in range(2)]
+    for r in range(2):
+        got = np.array([d[r]["mse"][0], d[r]["mse"][0] + d[r]["mmd"][0], d[r]["nll0"]])
+        o = d[r]["oracle_losses"]
+        np.testing.assert_allclose(got, [o[0], o[0] + o[1], o[2]], rtol=1e-5, err_msg=f"rank {r}")  # mse, mse + mmd, nll
+        assert abs(d[r]["mmd"][0] - o[1]) <= 1e-4 * abs(o[1]), r
+    assert d[0]["oracle_losses"][0] != d[1]["oracle_losses"][0]
+    want = d[0]["oracle_grad"].astype(np.float64) + d[1]["oracle_grad"]
+    got = d[0]["grad0"].astype(np.float64)
+    assert np.array_equal(d[0]["grad0"], d[1]["grad0"])
+    assert np.linalg.norm(got - want) <= 2e-4 * np.linalg.norm(want)

@@ -71,3 +71,20 @@ def test_generate_loss_plot_figures_and_side_files(tmp_path, golden_dir):
     assert list(f_tot.data[0].x) == [0, 1, 2] and f_mse.layout.xaxis.title.text == "Batch" and f_mse.layout.yaxis.title.text == "Loss"
     d = json.load(open(tmp_path / "tot.json"))
     assert d["data"][0]["type"] == "scatter" and d["layout"]["margin"] == {"t": 0, "l": 0, "b": 0, "r": 0}
+
+
+def test_dataset_size_is_the_references_random_split_subset():
+    """/root/reference/src/model_wrapper.py:96-100: ``random_split(dataset, [k, n - k])[0]`` -- a random subset drawn from
+    torch's global generator, not the first k images; data-parallel ranks (seeded form) agree among themselves."""
+    torch.manual_seed(5)
+    want = torch.utils.data.random_split(range(1000), [100, 900])[0].indices
+    torch.manual_seed(5)
+    got = data.random_subset_indices(1000, 100)
+    assert got.tolist() == want and sorted(want) != list(range(100)) and len(set(want)) == 100
+    a, b = data.random_subset_indices(1000, 100, seed=3), data.random_subset_indices(1000, 100, seed=3)
+    assert torch.equal(a, b) and not torch.equal(a, got)
+    with pytest.raises(ValueError):
+        data.random_subset_indices(10, 11)
+    torch.manual_seed(5)
+    dl = data.get_dataloader(32, 10, dataset_size=100, seed=1, device="cpu")
+    assert len(dl) == 10 and dl.images.shape == (100, 1, 32, 32)

@@ -124,3 +124,23 @@ def test_mmd_properties():
     kxx, kyy, kxy = K[:96, :96], K[96:, 96:], K[:96, 96:]
     want = (kxx.sum() - kxx.trace()) / (96 * 95) + (kyy.sum() - kyy.trace()) / (64 * 63) - 2 * kxy.mean()
     assert abs(float(v - want)) < 1e-5
+
+
+def test_chunked_mmd_of_the_full_size_checker_equals_the_plain_estimator():
+    """tests/halfstep_oracle.py evaluates oracle/plugin.py's MMD in row chunks for BASELINE.json's full sizes (the
+    reference's N x N kernel matrix would be 8.7 GB in float64 at c3): same loss, same gradient as ``plugin.mmd_loss``."""
+    import torch
+
+    import halfstep_oracle as ho
+    from oracle import plugin
+
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(300, 64, generator=g) < 0.4).double() * 2 - 1
+    x[7] = x[3]
+    y = (torch.rand(70, 64, generator=g) < 0.5).double() * 2 - 1
+    xa = x.clone().requires_grad_(True)
+    want = plugin.mmd_loss(xa, y)
+    want.backward()
+    got, grad = ho.chunked_mmd(x, y, chunk=128)
+    assert abs(float(got) - float(want.detach())) <= 1e-13 * abs(float(want.detach()))
+    assert float((grad - xa.grad).abs().max()) <= 1e-12 * float(xa.grad.abs().max())
