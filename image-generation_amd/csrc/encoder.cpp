@@ -4,6 +4,7 @@
 //   each followed by BN(batch stats) -> MaxPool2d(2) -> LeakyReLU (none after the last); then Linear(4,1).
 #include "conv.h"
 #include "kernels.h"
+#include "../../include/dvg_dev.h"
 
 using namespace dvg;
 
@@ -96,6 +97,13 @@ int check_common(const dvg_encoder_params_t* p, int n, int64_t B, const void* ws
 }
 
 }  // namespace
+
+extern "C" int dvg_dev_encoder_layout(int64_t B, int n_latents, size_t out[16]) {
+  DVG_REQUIRE(out && B >= 1 && n_latents >= 32 && n_latents % 32 == 0, "dev_encoder_layout: bad argument");
+  const EncPlan pl = enc_plan(B, n_latents);
+  for (int l = 0; l < 4; ++l) { out[l] = pl.Y[l]; out[4 + l] = pl.Xp[l]; out[8 + l] = pl.mean[l]; out[12 + l] = pl.invstd[l]; }
+  return DVG_OK;
+}
 
 extern "C" size_t dvg_encoder_workspace_bytes(int64_t B, int n_latents) {
   dvg::side_stream_warm();  // the backward's fork/join context exists before any step is captured

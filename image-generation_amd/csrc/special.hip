@@ -17,7 +17,7 @@ typedef float f32x16c __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restrict__ img, int64_t B,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ Y, float* __restrict__ stats_part) {
-  __shared__ float red[2 * 4 * 32];
+  __shared__ double red[2 * 4 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
   // B operand of MFMA j: B[k = 2j + hh][co = c]
   float bw[5];
@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restr
     dx[j] = t < 9 ? t % 3 - 1 : 0;
   }
   const int64_t tiles = B * 32;  // 32 pixels each (B * 1024 pixels, Morton order within an image)
-  float s1 = 0.f, s2 = 0.f;
+  // BatchNorm partials in double: a lane adds up to ~700 values at c3, and the variance is E[y^2] - E[y]^2 of a map that is
+  // mostly one constant (the background of a binary image): float32 running sums put 2e-5 on 1/sigma, enough to re-route
+  // dozens of near-tie pooling windows further down (measured against float64).  The kernel is bound by its stores.
+  double s1 = 0.0, s2 = 0.0;
   constexpr int TU = 2;
   for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
     float av[TU][5];
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
           const float v = acc[r];
           dst[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32] = v;
-          s1 += v;
-          s2 = fmaf(v, v, s2);
+          s1 += (double)v;
+          s2 = fma((double)v, (double)v, s2);
         }
       }
     }
@@ -74,9 +77,9 @@ __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restr
   if (hh == 0) { red[wave * 32 + c] = s1; red[128 + wave * 32 + c] = s2; }
   __syncthreads();
   if (tid < 32) {
-    stats_part[((size_t)blockIdx.x * 32 + tid) * 2] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    stats_part[((size_t)blockIdx.x * 32 + tid) * 2] = (float)((red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]));
     stats_part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] =
-        (red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid]);
+        (float)((red[128 + tid] + red[160 + tid]) + (red[192 + tid] + red[224 + tid]));
   }
 }
 
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
   __shared__ float w9[288];    // w[ci*9 + kh*3 + kw]
   __shared__ __align__(16) float wfs[512];
   __shared__ float outs[256];
-  __shared__ float red[2 * 4];
+  __shared__ double red[2 * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int cls = __builtin_amdgcn_readfirstlane(tid >> 6), pa = cls >> 1, pb = cls & 1;
   for (int i = tid; i < 288; i += 256) w9[i] = w[i];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
     const int yy = ys - 1 + pa + (t >> 1), xx = xq - 1 + pb + (t & 1);
     src[t] = (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) ? (int)morton((uint32_t)yy, (uint32_t)xx) : -1;
   }
-  float s1 = 0.f, s2 = 0.f;
+  double s1 = 0.0, s2 = 0.0;  // (BatchNorm partials in double: see enc_conv0_fwd_kernel)
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();  // previous image's xs / outs readers are done
     {  // 64 rows x 32 floats = 512 float4: two per thread, coalesced
@@ -284,8 +287,8 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
       }
     }
     outs[4 * lane + cls] = acc;  // Morton: output pixel = 4 * source pixel + class
-    s1 += acc;
-    s2 = fmaf(acc, acc, s2);
+    s1 += (double)acc;
+    s2 = fma((double)acc, (double)acc, s2);
     __syncthreads();
     Y[img * 256 + tid] = outs[tid];
   }
@@ -295,8 +298,8 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
   if (lane == 0) { red[cls] = s1; red[4 + cls] = s2; }
   __syncthreads();
   if (tid == 0) {
-    stats_part[(size_t)blockIdx.x * 2] = (red[0] + red[1]) + (red[2] + red[3]);
-    stats_part[(size_t)blockIdx.x * 2 + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    stats_part[(size_t)blockIdx.x * 2] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+    stats_part[(size_t)blockIdx.x * 2 + 1] = (float)((red[4] + red[5]) + (red[6] + red[7]));
   }
 }
 

@@ -15,6 +15,7 @@ _SIGS = {
     "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 5 +
                            [ctypes.c_void_p]),
+    "dvg_dev_encoder_layout": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
 }
 _bound = False
 
@@ -79,3 +80,18 @@ def conv_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ntaps=9, ups=0):
     _lib.check(Lb.dvg_dev_conv_wgrad(x_m.data_ptr(), dy.data_ptr(), slabs.data_ptr(), gw.data_ptr(), mode, M, Cin, Cout, L,
                                      ntaps, ups, _lib.stream_ptr(dev)))
     return gw
+
+
+def encoder_saved(ws: torch.Tensor, B: int, n: int):
+    """Views into an encoder workspace after a forward call: per layer the pre-BatchNorm convolution output as NCHW, the
+    batch mean and the batch inverse standard deviation (diagnostics)."""
+    off = (ctypes.c_size_t * 16)()
+    _lib.check(lib().dvg_dev_encoder_layout(B, n, off), "dvg_dev_encoder_layout")
+    f = ws.view(torch.float32)
+    ch = [32, 64, 128, n]
+    out = []
+    for l in range(4):
+        side, C = 32 >> l, ch[l]
+        y = f[off[l]: off[l] + B * side * side * C]
+        out.append(dict(Y=morton_to_nchw(y, B, C, side), mean=f[off[8 + l]: off[8 + l] + C], invstd=f[off[12 + l]: off[12 + l] + C]))
+    return out

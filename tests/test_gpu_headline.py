@@ -89,8 +89,9 @@ def _check_step_against_float64(tmp_path, cfg, grad_bar):
     # 1-2e-2 from float64 on the early encoder layers (measured; the HIP path: 3-7e-3).  So: relative L2 <= 5e-3 against
     # float64, or -- where stock float32 itself is farther than that -- at least as close to float64 as stock float32 is.
     osampler32 = ho.oracle_sampler_like_snapshot(osampler_start)
-    w32 = ho.oracle_step(meta, snap, imgs[0], gumbels, masks, osampler32, dtype=torch.float32, device="cuda",
-                         grbm_branch=False, mmd_chunk=1024)
+    with torch.backends.cudnn.flags(enabled=False):  # (ATen's own float32 convolutions: MIOpen's first-call search takes minutes)
+        w32 = ho.oracle_step(meta, snap, imgs[0], gumbels, masks, osampler32, dtype=torch.float32, device="cuda",
+                             grbm_branch=False, mmd_chunk=1024)
     worst, stock = {}, {}
     for name, g in got_grads.items():
         if ho.zero_true_gradient(name):
@@ -101,8 +102,11 @@ def _check_step_against_float64(tmp_path, cfg, grad_bar):
     assert not bad, bad
     print("gradient rel-L2 vs float64, HIP / stock float32 (worst 6):",
           [(k, f"{v:.2e}", f"{stock[k]:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]])
-    # GRBM sufficient statistics: sums of +-1 products, exact in either arithmetic up to the final mean
-    assert _rel_l2(g_lin, w["grad_linear"]) < 1e-5 and _rel_l2(g_quad, w["grad_quadratic"]) < 1e-5
+    # GRBM sufficient statistics: means of +-1 products, exact in either arithmetic -- on the same spins.  A handful of the
+    # B R n Gumbel arg-max decisions sit within float32 rounding of a tie and come out differently in float64 (measured at
+    # c3: 14 of 16.8 M spins); each moves one entry of the data mean by 2 / (B R), i.e. ~2.5e-5 of the vector's norm at c3.
+    assert _rel_l2(g_lin, w["grad_linear"]) < 2e-4 and _rel_l2(g_quad, w["grad_quadratic"]) < 2e-4
+    assert float((g_lin.double() - w["grad_linear"]).abs().max()) <= 4.0 / (cfg["B"] * cfg["R"]) + 1e-6
     return worst
 
 
