@@ -108,6 +108,8 @@ SIGNATURES = {
         [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "dvg_gumbel_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "dvg_gumbel_bwd2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "dvg_scalar_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvg_heaviside_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "dvg_resize_binarise": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "dvg_gather_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

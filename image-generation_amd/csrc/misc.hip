@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ dspin,
+// gs2 (optional): a second gradient wrt the spins, added to the first on the way in (the training step has two: the
+// decoder's and the MMD's; summing them here saves the separate add pass over (B, R, n))
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ gs2,
+                                                         const float* __restrict__ dspin,
                                                          int64_t B, int n, int R, float* __restrict__ gl) {
   const int64_t total = B * (int64_t)n;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -51,10 +54,15 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict
     float acc = 0.f;
     for (int r = 0; r < R; ++r) {
       const int64_t k = (b * R + r) * n + i;
-      acc += gs[k] * dspin[k];
+      const float g = gs2 ? __fadd_rn(gs[k], gs2[k]) : gs[k];
+      acc += g * dspin[k];
     }
     gl[e] = acc;
   }
+}
+
+__global__ void scalar_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+  if (threadIdx.x == 0) out[0] = __fadd_rn(a[0], b[0]);
 }
 
 __global__ __launch_bounds__(256) void heaviside_kernel(const float* __restrict__ l, int64_t numel, float* __restrict__ s) {
@@ -140,12 +148,23 @@ extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, floa
   return DVG_OK;
 }
 
-extern "C" int dvg_gumbel_bwd(const float* grad_spins, const float* dspin, int64_t B, int n, int R,
-                              float* grad_logits, dvg_stream_t stream) {
+extern "C" int dvg_gumbel_bwd2(const float* grad_spins, const float* grad_spins2, const float* dspin, int64_t B, int n,
+                               int R, float* grad_logits, dvg_stream_t stream) {
   DVG_REQUIRE(grad_spins && dspin && grad_logits, "gumbel_bwd: null argument");
   DVG_REQUIRE(B > 0 && n > 0 && R > 0, "gumbel_bwd: bad shape");
   DVG_LAUNCH(K_GUMBEL_BWD, gumbel_bwd_kernel, dim3(grid_for(B * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
-             grad_spins, dspin, B, n, R, grad_logits);
+             grad_spins, grad_spins2, dspin, B, n, R, grad_logits);
+  return DVG_OK;
+}
+
+extern "C" int dvg_gumbel_bwd(const float* grad_spins, const float* dspin, int64_t B, int n, int R,
+                              float* grad_logits, dvg_stream_t stream) {
+  return dvg_gumbel_bwd2(grad_spins, nullptr, dspin, B, n, R, grad_logits, stream);
+}
+
+extern "C" int dvg_scalar_add(const float* a, const float* b, float* out, dvg_stream_t stream) {
+  DVG_REQUIRE(a && b && out, "scalar_add: null argument");
+  DVG_LAUNCH(K_MISC, scalar_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);
   return DVG_OK;
 }
 

@@ -123,6 +123,51 @@ def gumbel_latent_to_discrete(logits, n_samples, gumbels=None, tau=GUMBEL_TAU, s
     return _Gumbel.apply(logits, n_samples, tau, gumbels, seed, offset)
 
 
+def gumbel_forward_raw(logits, n_samples, gumbels=None, tau=GUMBEL_TAU, seed=0, offset=0):
+    """``(spins (B,R,n), dspin (B,R,n))`` outside autograd, for callers that run the backward themselves
+    (:func:`gumbel_backward`): the training step feeds it the SUM of two spin gradients in one kernel."""
+    L = lib()
+    lg = require_cuda(logits.detach().float().contiguous(), "logits")
+    B, n = lg.shape
+    R = int(n_samples)
+    spins = torch.empty((B, R, n), dtype=torch.float32, device=lg.device)
+    dspin = torch.empty_like(spins)
+    gb = None
+    if gumbels is not None:
+        gb = require_cuda(gumbels.detach().float().contiguous(), "gumbels")
+        if tuple(gb.shape) != (B, R, n, 2):
+            raise ValueError(f"gumbels must have shape {(B, R, n, 2)}, got {tuple(gb.shape)}")
+    with torch.cuda.device(lg.device):
+        check(L.dvg_gumbel_fwd(lg.data_ptr(), B, n, R, float(tau), _lib.ptr(gb), int(seed) & (2**64 - 1),
+                               int(offset) & (2**64 - 1), spins.data_ptr(), dspin.data_ptr(), _lib.DYN,
+                               stream_ptr(lg.device)), "dvg_gumbel_fwd")
+    return spins, dspin
+
+
+def gumbel_backward(dspin, grad_spins, grad_spins2=None):
+    """``d loss / d logits (B,n) = sum_r (grad_spins + grad_spins2) * dspin``: one kernel, no separate add pass."""
+    B, R, n = dspin.shape
+    g1 = require_cuda(grad_spins.detach().float().contiguous(), "grad_spins")
+    g2 = None if grad_spins2 is None else require_cuda(grad_spins2.detach().float().contiguous(), "grad_spins2")
+    if g1.numel() != dspin.numel() or (g2 is not None and g2.numel() != dspin.numel()):
+        raise ValueError("gumbel_backward: gradients must have the spins' shape")
+    gl = torch.empty((B, n), dtype=torch.float32, device=dspin.device)
+    with torch.cuda.device(dspin.device):
+        check(lib().dvg_gumbel_bwd2(g1.data_ptr(), _lib.ptr(g2), dspin.data_ptr(), B, n, R, gl.data_ptr(),
+                                    stream_ptr(dspin.device)), "dvg_gumbel_bwd2")
+    return gl
+
+
+def scalar_add(a, b):
+    """``a + b`` of two device scalars by the library (the step's ``mse + mmd``)."""
+    a = require_cuda(a.detach().float().reshape(()), "a")
+    b = require_cuda(b.detach().float().reshape(()), "b")
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().dvg_scalar_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), stream_ptr(a.device)), "dvg_scalar_add")
+    return out
+
+
 class _Heaviside(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits):

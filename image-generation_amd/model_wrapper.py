@@ -450,7 +450,12 @@ class ModelWrapper:
             # the decoder forward and the MSE; the streams join before the two losses are added.
             main, side = torch.cuda.current_stream(self._device), self._side_stream
             latents = self._dvae.encoder(images)
-            spins = self._dvae.latent_to_discrete(latents, self.N_REPLICAS)
+            # The default (Gumbel) latent_to_discrete runs outside autograd: its backward is fed the SUM of the two spin
+            # gradients (through the decoder and from the MMD) by ONE kernel -- dvg_gumbel_bwd2 -- instead of an add pass
+            # over (B, R, n) followed by the single-gradient kernel.  A custom latent_to_discrete (heaviside) stays an
+            # autograd node and gets the two terms added by the engine.
+            raw = self._dvae.default_l2d_raw(latents, self.N_REPLICAS)
+            spins, dspin = raw if raw is not None else (self._dvae.latent_to_discrete(latents, self.N_REPLICAS), None)
             spins_ready = torch.cuda.Event()
             spins_ready.record(main)
             # Order of enqueueing matters under hipGraph capture: the first kernel node captured after a fork keeps
@@ -467,27 +472,27 @@ class ModelWrapper:
             flat = spins.reshape(-1, spins.shape[-1])
             with torch.cuda.stream(side):
                 _mmd_loss, g_spins = maximum_mean_discrepancy_loss_and_grad(x=flat, y=samples, kernel=self._tpar["kernel"])
-            if self._defer_mmd_join(flat, samples):
-                # Large pair counts (c3: the pair kernel runs 1.4 ms past the decoder forward, which the main stream
-                # used to sit out): the autograd graph is cut at the spins -- the decoder's backward needs only the
-                # MSE gradient -- so the join with the MMD stream moves behind the decoder's backward; the two spin
-                # gradients are added (the same two terms the autograd engine adds) and seed the encoder's backward.
-                # (Measured: c3 23.65 -> 22.93 ms; at c2 / c1, where the MMD ends well inside the decoder forward,
-                # the mid-backward join costs 45 us, so small problems keep the single backward call.)
-                spins_cut = spins.detach().requires_grad_(True)
-                reconstructed_images = self._dvae.decoder(spins_cut)
-                mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
-                torch.autograd.backward([reconstructed_images], [g_recon])
+            # The autograd graph is cut at the spins: the decoder's backward needs only the MSE gradient, so the join with
+            # the MMD stream can sit IN FRONT of the decoder's backward (small problems: the MMD ends well inside the
+            # decoder forward, and a mid-backward join costs 45 us there) or BEHIND it (large pair counts -- c3: the pair
+            # kernel runs 1.4 ms past the decoder forward, which the main stream used to sit out; 23.65 -> 22.93 ms).
+            defer = self._defer_mmd_join(flat, samples)
+            spins_cut = spins.detach().requires_grad_(True)
+            reconstructed_images = self._dvae.decoder(spins_cut)
+            mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
+            if not defer:
                 main.wait_stream(side)
-                g_spins.record_stream(main)
-                torch.autograd.backward([spins], [spins_cut.grad.add_(g_spins.view_as(spins_cut))])
+            torch.autograd.backward([reconstructed_images], [g_recon])
+            if defer:
+                main.wait_stream(side)
+            g_spins.record_stream(main)
+            if dspin is not None:
+                gl = F.gumbel_backward(dspin, spins_cut.grad, g_spins)  # (the same two terms the autograd engine would add)
+                torch.autograd.backward([latents], [gl])
             else:
-                reconstructed_images = self._dvae.decoder(spins)
-                mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
-                main.wait_stream(side)
-                g_spins.record_stream(main)
-                torch.autograd.backward([reconstructed_images, flat], [g_recon, g_spins])
-            dvae_loss = mse_loss + _mmd_loss
+                torch.autograd.backward([spins], [spins_cut.grad.add_(g_spins.view_as(spins_cut))])
+            _mmd_loss.record_stream(main)
+            dvae_loss = F.scalar_add(mse_loss, _mmd_loss)
             self._reduce_and_step(self._dvae_optimizer)
             return mse_loss, dvae_loss, _mmd_loss, flat.detach()
         _, spins, reconstructed_images = self._dvae(images, self.N_REPLICAS)

@@ -51,6 +51,16 @@ class DiscreteVariationalAutoencoder(torch.nn.Module):
         self._gumbel_calls += 1
         return F.gumbel_latent_to_discrete(logits, n_samples, gumbels=g, seed=self.gumbel_seed, offset=offset)
 
+    def default_l2d_raw(self, logits: torch.Tensor, n_samples: int):
+        """The default latent_to_discrete outside autograd: ``(spins, dspin)`` (same noise stream / injected noise as
+        :meth:`_default_l2d`); ``None`` when a custom latent_to_discrete is installed."""
+        if self._custom_l2d is not None:
+            return None
+        g, self._injected_gumbels = self._injected_gumbels, None
+        offset = self._gumbel_calls
+        self._gumbel_calls += 1
+        return F.gumbel_forward_raw(logits, n_samples, gumbels=g, seed=self.gumbel_seed, offset=offset)
+
     @property
     def latent_to_discrete(self):
         return self._custom_l2d if self._custom_l2d is not None else self._default_l2d

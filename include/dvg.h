@@ -145,6 +145,14 @@ int dvg_gumbel_fwd(const float *logits, int64_t B, int n, int R, float tau, cons
 /* grad_logits (B, n) = sum_r grad_spins[b,r,:] * dspin[b,r,:] */
 int dvg_gumbel_bwd(const float *grad_spins, const float *dspin, int64_t B, int n, int R,
                    float *grad_logits, dvg_stream_t stream);
+/* the same with TWO gradients wrt the spins (grad_spins2 may be NULL): grad_logits = sum_r (g1 + g2) * dspin.  The step
+ * has two -- through the decoder (MSE) and from the MMD, /root/reference/src/model_wrapper.py:322-326 backpropagates
+ * their sum -- and adding them here saves a pass over (B, R, n). */
+int dvg_gumbel_bwd2(const float *grad_spins, const float *grad_spins2, const float *dspin, int64_t B, int n, int R,
+                    float *grad_logits, dvg_stream_t stream);
+/* out[0] = a[0] + b[0] on the device (dvae_loss = mse + mmd, /root/reference/src/model_wrapper.py:322, without a host
+ * synchronisation and without a framework kernel in the captured step) */
+int dvg_scalar_add(const float *a, const float *b, float *out, dvg_stream_t stream);
 /* "heaviside" mode (/root/reference/src/utils/common.py:160-173): spins (B,1,n) = 2*H(l)-1 with
  * H(0)=0; the backward is the identity and needs no kernel. */
 int dvg_heaviside_fwd(const float *logits, int64_t numel, float *spins, dvg_stream_t stream);
