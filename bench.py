@@ -354,7 +354,7 @@ def main():
     L = _lib.lib()
     _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
-    is_gemm = lambda nm: nm.startswith("conv_igemm_kernel") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
+    is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm) or nm == "gibbs_sweeps") if not args.breakdown else (1 << len(names)) - 1
     # The autoencoder half of every step is replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); on every 10th step the GRBM quasi-NLL update runs eagerly behind it.  --eager disables the graph.
@@ -430,10 +430,10 @@ def main():
         # parts out.  General rows run on the f32 MFMA ("mmd_main").  A candidate whose rate exceeds its peak is a
         # mislabelled launch and is dropped.
         lib_hash = L.dvg_source_hash().decode()
-        # --precision f32x3: the launches of the two large tile configurations run their float32 operands as three bf16 pieces,
+        # --precision f32x3: the forward / data-gradient launches run their float32 operands as three bf16 pieces,
         # i.e. they EXECUTE six bf16 products per algorithmic multiply-add: priced as 6 x the algorithmic FLOPs against the
         # bf16 peak (the library's work counter holds the algorithmic count; `algorithmic_f32_tflops` keeps it visible)
-        split_gemm = lambda nm: args.precision == "f32x3" and nm in ("conv_igemm_kernel<128,128,2,2,1>", "conv_igemm_kernel<128,64,2,2,1>")  # noqa: E731
+        split_gemm = lambda nm: args.precision == "f32x3" and nm.startswith("conv_igemm_kernel")  # noqa: E731  (every forward / data-gradient launch; the weight-space products have their own id)
         for k, v in per_kernel.items():
             if split_gemm(k):
                 v["algorithmic_work"] = v["work"]

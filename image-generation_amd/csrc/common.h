@@ -76,6 +76,7 @@ enum KernelId : int {
   K_MSE,
   K_ADAM,
   K_MISC,
+  K_IGEMM_WSPACE,   // conv_igemm_kernel launches on weights only (the composed decoder layers' weight-space products)
   K_COUNT
 };
 

@@ -113,11 +113,14 @@ struct ConvArgs {
   int fold = 0;
   float* splitk_ws;   // scratch of conv_splitk_floats() floats, or null: never split K
   int ksplit;         // set by launch_conv_igemm
-  // bf16 = 1: "bf16 GEMM inputs, f32 accumulate" (conv_precision_mode() == 1): `wp` then points at the bf16 K-major pack
-  // Wp16[tap][b][a] (PackJob.bf16t) and the activations are rounded to bf16 (RNE) on their way into LDS.
-  // bf16 = 2: float32 operands as three bf16 pieces (conv_precision_mode() == 2): `wp` points at three such K-major planes
-  // (hi, mid, lo; PackJob.bf16t = 2) and the activations are split into their three pieces on the way into LDS.
+  // operand form of the launch (set by launch_conv_igemm from conv_launch_mode; the PM argument of conv_igemm_kernel):
+  // 0 float32 staged through registers (`wp` = [tap][Cin][Cout]); 3 float32 by LDS-DMA; 4 float32 operands as three bf16
+  // pieces, split at operand-read time ("f32x3"); 5 operands rounded to bf16 at operand-read time ("bf16 inputs").
+  // 3 / 4 / 5 read the same float32 K-major pack `wp` = [tap][Cout][Cin].
   int bf16 = 0;
+  // force_f32 = 1: this launch runs in float32 (form 3 or 0) whatever the process-wide mode: the weight-space products of
+  // the composed decoder layers (their operands are weights, not activations of the network)
+  int force_f32 = 0;
   // bias_perm = n > 0: column j = p*n + c takes bias[c*4 + p] (the decoder's Linear(n, 4n) bias in checkpoint order)
   int bias_perm = 0;
   // bias_mod = C > 0: column j = p*C + c takes bias[c] (the dense 2x2 form: one bias per channel, four pixels per row)
@@ -131,8 +134,8 @@ struct ConvArgs {
 // process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
 bool conv_precision_bf16();
 int conv_precision_mode();  // 0 f32, 1 bf16 inputs, 2 f32 as three bf16 pieces
-// packed-weight buffers are sized for the largest format: three bf16 planes = 6 bytes per entry
-static inline size_t conv_pack_floats(size_t entries) { return (entries * 3 + 1) / 2; }
+// packed-weight buffers: one float32 per entry (every operand form reads a float32 pack)
+static inline size_t conv_pack_floats(size_t entries) { return entries; }
 void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
 bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
@@ -179,14 +182,13 @@ int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, fl
 // Wp[tap][a][b] <- checkpoint-layout weight
 int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStream_t s, int bf16t = -1);  // -1: the process-wide mode
 // several packs in ONE launch (forward and data-gradient packs of a whole network)
-// bf16t = 1: the pack is written as bf16 (RNE), K-major: Wp16[tap][b][a] (2 bytes per entry in the same buffer);
-// bf16t = 2: three such planes back to back (hi, mid, lo pieces of every weight: hi + mid + lo == w)
+// bf16t: the operand form of the launch the pack feeds (conv_launch_mode): 0 -> [tap][a][b], 3 / 4 / 5 -> K-major [tap][b][a]
 // rows: GEMM rows of the launch this pack feeds (launch_conv_igemm's M over all classes): together with map.Cb it
 // decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
 struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; };
-// operand format of one forward / data-gradient launch: the process-wide mode, except that the split mode (2) only
-// serves launches large enough for the 128 x 128 / 128 x 64 tiles (smaller ones are latency-bound: the float32 kernel is faster)
+// operand form of one forward / data-gradient launch (ConvArgs.bf16): the process-wide mode mapped onto the kernels
 int conv_launch_mode(int64_t gemm_rows, int Cout);
+bool conv_pack_is_f32_kmajor(int launch_mode);  // the pack such a launch reads is the float32 K-major one
 constexpr int MAX_PACK_JOBS = 8;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);
 

@@ -22,54 +22,66 @@ namespace dvg {
 // run MFMAs together -- and WK = 2 measured 0 % on that layer and -3.5 % on the c2 step.  (The other route, pairs of
 // half-K blocks combined in-kernel through an arrival counter, is correct and deterministic but 2x slower: its
 // agent-scope release fence writes back the XCD's L2.)
-// BF = true: bf16 operands in LDS (activations rounded on the way in, weights pre-packed K-major as bf16),
-// v_mfma_f32_32x32x16_bf16, f32 accumulators: same tiles, loaders of A, neighbour table and epilogues.
-// (K depth per iteration measured for the bf16 form: 64 as in the f32 form; 32 and 128 both cost c3 +19 %, c2 +2 %.)
-// PM = 2: float32 operands as three bf16 pieces each (f32_split3), six piece products per k-step (everything down to
-// 2^-16 of a product; the three dropped ones are below 2^-23): float32-class results on the bf16 MFMA at 6/16 of the f32
-// MFMA's matrix time.  One 32-channel chunk per iteration (three bf16 images of a 32-deep slab fill the LDS a 64-deep
-// float32 slab does: two blocks per CU stay resident), six times the MFMA work of the bf16 form per staged byte.
+// PM = 0: float32 operands staged through registers (the first form of this kernel; kept as the A/B reference the LDS-DMA
+// form is tested bit-identical against: DVG_IGEMM_DMA=0).
 // PM = 3: the float32 form with LDS-DMA staging (global_load_lds_dwordx4: no staging registers, no ds_write pass, no
 // mask multiply).  One 32-channel chunk per iteration, two LDS stages, ONE barrier per iteration; both operands sit in
 // LDS as [row][32 floats] (weights packed K-major, PackJob.bf16t = 3), 16-byte slots XOR-swizzled on the per-lane SOURCE
 // address, and the MFMA's two k-lanes take k = s and k = 16 + s at step s, so a lane's 16 operands of a chunk are
 // four ds_read_b128 instead of sixteen ds_read_b32.  The transfers are raw buffer loads: padding rows carry an
 // out-of-range offset, for which the hardware writes zeros.
+// PM = 4, 5: the SAME staging, LDS image, tiles, position-major / folded / composed forms and epilogues as PM = 3 -- the
+// operands arrive in LDS as float32 -- with the arithmetic on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulators),
+// the conversion happening at OPERAND-READ time, in registers, between the ds_read_b128 and the MFMA:
+//   PM = 4 ("f32x3"): every float32 operand is split into three bf16 pieces by truncation (hi + mid + lo == x bit for
+//     bit: 3 x 8 significand bits) and each 16-deep k-step issues the six piece products down to 2^-16 of a product,
+//     smallest first, into ONE accumulator (the three dropped ones are below 2^-23): float32-class results at 6/16 of
+//     the f32 MFMA's matrix time.  ~5 VALU instructions per operand element, issued under the MFMAs.
+//   PM = 5 ("bf16 inputs"): every operand is rounded to bf16 (round to nearest even, v_cvt_pk_bf16_f32): the product of
+//     the bf16-rounded operands, accumulated in float32.
+// A lane's 16 floats of a chunk (k = 16 hh .. 16 hh + 15) feed two k-steps of 8; A and B are converted by the same code
+// in the same element order, so the pairing of k indices is the f32 form's.  (Rounds 1-2 staged these two modes through
+// registers, converting on the way INTO LDS; they could not use the LDS-DMA path, the position-major tiles or the composed
+// first decoder layers, and by the end of round 2 the f32x3 mode was slower than strict float32.)
 
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a) {
-  constexpr bool BF = PM == 1 || PM == 2;  // operands live in LDS as bf16
-  constexpr bool DMA = PM == 3;
+  static_assert(PM == 0 || PM == 3 || PM == 4 || PM == 5, "operand forms: 0 register-staged f32, 3 / 4 / 5 LDS-DMA");
+  constexpr bool DMA = PM >= 3;
   static_assert(!DMA || WK == 1, "LDS-DMA form: no K wave groups");
-  constexpr int NP = PM == 2 ? 3 : 1;    // bf16 pieces per operand
-  static_assert(!BF || WK == 1, "bf16 forms: no K wave groups");
-  constexpr int NT = WM * WN * WK * 64, NTG = WM * WN * 64;
+  // (A dedicated loader wave per block -- every buffer_load ... lds of the block issued by a fifth wave -- was built and
+  // measured in round 3: 1.3x SLOWER for float32 and 2.3x for the bf16 forms.  One wave's LDS-DMA issue rate, ~25 GB/s,
+  // is a fraction of what four waves issuing their own pieces reach, and with two stages its issue and its wait for
+  // landing serialise.  The pieces stay with the compute waves; what pays is WHERE in the instruction stream they sit.)
+  constexpr int NTC = WM * WN * WK * 64, NT = NTC, NTG = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int BK = (PM == 2 || PM == 3) ? 32 : 64;  // K per wave group and iteration: 32-channel chunks (possibly of different taps)
+  constexpr int BK = DMA ? 32 : 64;  // K per wave group and iteration: 32-channel chunks (possibly of different taps)
   constexpr int KH = (BK / 32) * WK, BKT = BK * WK;  // chunks / K extent staged per iteration by the whole block
   // A rows are 16-byte aligned so the staging stores are ds_write_b128; the MFMA A-operand reads (one float per lane,
   // row stride AP) then see a 2-way bank conflict, which costs less than the 4x ds_write_b32 a 65-float pitch needs
   constexpr int AP = BKT + 4, BP = BN + 4;
-  constexpr int RA = BM * 8 / NT;        // float4 loads of A per thread per 32-chunk
-  constexpr int NB16 = BF ? 4 * BN : 8 * BN;  // 16-byte loads of B per 32-chunk (bf16: 64 bytes per column)
-  constexpr int RB = (NB16 + NT - 1) / NT;    // ... per thread
-  constexpr bool BPART = RB * NT != NB16;     // fewer B loads than threads (32-column tile, 512 threads)
-  constexpr int AP16 = BKT + 8;               // bf16 form: row pitch of both tiles in bf16 elements (144 bytes)
-  static_assert(RA * NT == 8 * BM && (!BPART || RB == 1), "tile loaders must divide evenly");
+  constexpr int RA = BM * 8 / NTC;       // float4 loads of A per thread per 32-chunk (register-staged form)
+  constexpr int NB16 = 8 * BN;                // 16-byte loads of B per 32-chunk
+  constexpr int RB = (NB16 + NTC - 1) / NTC;  // ... per thread
+  constexpr bool BPART = RB * NTC != NB16;    // fewer B loads than threads (32-column tile, 512 threads)
+  static_assert(RA * NTC == 8 * BM && (!BPART || RB == 1), "tile loaders must divide evenly");
   // taps per row in the neighbour table: 16 for the folded data gradient, else 9 (a 128-row table is 4.5 KB instead of
   // 8: with it three blocks of the 128x64 LDS-DMA form fit a CU's 160 KB)
   const int NBS = a.ntaps > 9 ? 16 : 9;
   extern __shared__ __align__(16) unsigned char igemm_smem[];  // conv_igemm_lds_bytes<...>() bytes
   float* As = reinterpret_cast<float*>(igemm_smem);            // [BM][AP]
   float* Bs = As + BM * AP;                                    // [BKT][BP]
-  uint16_t* As16 = reinterpret_cast<uint16_t*>(igemm_smem);    // bf16 forms: [NP][BM][AP16], then Bs16 [NP][BN][AP16] (K-major)
-  uint16_t* Bs16 = As16 + NP * BM * AP16;
   constexpr int STAGE = (BM + BN) * 128;  // LDS-DMA form: one stage = A [BM][32 f32] then B [BN][32 f32]
+  // Stages of the LDS ring.  Three (two chunks in flight per block) were measured for the bf16-MFMA forms, whose chunk of
+  // matrix work is shorter than the LDS-DMA round trip: SLOWER (128 -> 128 layer: f32x3 938 -> 1173 us, bf16 inputs
+  // 405 -> 616 us) because the third stage costs the second resident block per CU; co-resident blocks hide that round
+  // trip better than a deeper ring does.
+  constexpr int NS = 2;
   // [WM][BN][2] BatchNorm partials of the epilogue (LDS-DMA form: on top of the then-dead stage 0, behind a barrier)
   float* red = DMA ? reinterpret_cast<float*>(igemm_smem)
-               : BF ? reinterpret_cast<float*>(Bs16 + NP * BN * AP16) : Bs + BKT * BP;
+               : Bs + BKT * BP;
   // [BM][NBS] source row of every (tile row, tap), -1 = padding
-  int* nbr = DMA ? reinterpret_cast<int*>(igemm_smem + 2 * STAGE) : reinterpret_cast<int*>(red + WM * BN * 2);
+  int* nbr = DMA ? reinterpret_cast<int*>(igemm_smem + NS * STAGE) : reinterpret_cast<int*>(red + WM * BN * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kg = wave / (WM * WN), wv = wave - kg * (WM * WN);  // K group, wave within the (WM x WN) tile grid
@@ -143,8 +155,6 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   const char* in_bytes = reinterpret_cast<const char*>(a.in);
   const char* wp_bytes = reinterpret_cast<const char*>(a.wp);
   const uint32_t row_bytes = (uint32_t)a.Cin * 4u, wrow_bytes = (uint32_t)a.Cout * 4u;
-  // split mode: byte distance between the piece planes of the packed weights ([taps][Cout][Cin] bf16 each)
-  const uint32_t plane_bytes = (uint32_t)((a.fold == 1 ? 16 : a.ntaps) * a.Cin * a.Cout) * 2u;
   const int nci = a.Cin >> 5, nchunk = ntv * nci, niter = (nchunk + KH - 1) / KH;
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       /* 32-bit byte offsets from the (wave-uniform) tensor bases: every tensor here is < 4 GiB */                    \
       const uint32_t a_col = (uint32_t)(cc * 128 + ac4 * 16);                                                         \
       _Pragma("unroll") for (int q = 0; q < RA; ++q) {                                                                \
-        const int src = nbr[((tid >> 3) + (NT >> 3) * q) * NBS + tap];                                                \
+        const int src = nbr[((tid >> 3) + (NTC >> 3) * q) * NBS + tap];                                                \
         const bool ok = live && src >= 0;                                                                             \
         /* branch-free zero padding: always load (from a valid address); the 0/1 mask is applied when the */         \
         /* registers are parked in LDS (a select or multiply here would make the in-order issue wait)      */         \
@@ -184,14 +194,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       const uint32_t b_row0 =                                                                                         \
           (uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cin + cc * 32) * wrow_bytes + (uint32_t)n0 * 4u;             \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
-        const int idx = BPART ? (tid < NB16 ? tid : NB16 - 1) : tid + NT * q;  /* clamped: spare threads re-read */   \
-        if constexpr (BF) {  /* Wp16[piece][tap][col][ci]: 4 x 16 bytes per column, chunk and piece */                \
-          const int col = idx >> 2, q4 = idx & 3;                                                                     \
-          const uint32_t off = ((uint32_t)((cls * 4 * (a.fold == 1) + tap) * a.Cout + n0 + col) * (uint32_t)a.Cin +  \
-                                (uint32_t)(cc * 32 + q4 * 8)) * 2u;                                                   \
-          _Pragma("unroll") for (int pc = 0; pc < NP; ++pc)                                                           \
-            BREG[h][q * NP + pc] = *reinterpret_cast<const f32x4*>(wp_bytes + (off + (uint32_t)pc * plane_bytes));    \
-        } else {                                                                                                      \
+        const int idx = BPART ? (tid < NB16 ? tid : NB16 - 1) : tid + NTC * q;  /* clamped: spare threads re-read */   \
+        {                                                                                                             \
           const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
           BREG[h][q] = *reinterpret_cast<const f32x4*>(wp_bytes + (b_row0 + (uint32_t)krow * wrow_bytes + (uint32_t)c4 * 16u)); \
         }                                                                                                             \
@@ -204,35 +208,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   do {                                                                                                                \
     _Pragma("unroll") for (int h = 0; h < KH; ++h) {                                                                  \
       _Pragma("unroll") for (int q = 0; q < RA; ++q) {                                                                \
-        const int row = (tid + NT * q) >> 3;                                                                          \
+        const int row = (tid + NTC * q) >> 3;                                                                          \
         const float mk = AMASK[h][q];                                                                                 \
         const f32x4 v = AREG[h][q] * mk;                                                                              \
-        if constexpr (PM == 2) {                                                                                      \
-          /* truncation split: 5 VALU per element, exact (hi + mid + lo == v bit for bit) */                        \
-          uint32_t ph[4], pm[4], pl[4];                                                                               \
-          _Pragma("unroll") for (int u = 0; u < 4; ++u) f32_split3_trunc(v[u], ph[u], pm[u], pl[u]);                  \
-          uint16_t* dst = As16 + row * AP16 + h * 32 + ac4 * 4;                                                       \
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]));             \
-          *reinterpret_cast<uint2*>(dst + BM * AP16) = make_uint2(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3])); \
-          *reinterpret_cast<uint2*>(dst + 2 * BM * AP16) = make_uint2(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3])); \
-        } else if constexpr (BF) {                                                                                    \
-          uint2 pk;                                                                                                   \
-          pk.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);                           \
-          pk.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);                           \
-          *reinterpret_cast<uint2*>(As16 + row * AP16 + h * 32 + ac4 * 4) = pk;                                       \
-        } else {                                                                                                      \
-          *reinterpret_cast<f32x4*>(As + row * AP + h * 32 + ac4 * 4) = v;                                            \
-        }                                                                                                             \
+        *reinterpret_cast<f32x4*>(As + row * AP + h * 32 + ac4 * 4) = v;                                              \
       }                                                                                                               \
       _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                                \
-        const int idx = tid + NT * q;                                                                                 \
-        if constexpr (BF) {                                                                                           \
-          if (!BPART || idx < NB16) {                                                                                 \
-            _Pragma("unroll") for (int pc = 0; pc < NP; ++pc)                                                         \
-              *reinterpret_cast<f32x4*>(Bs16 + pc * BN * AP16 + (idx >> 2) * AP16 + h * 32 + (idx & 3) * 8) =         \
-                  BREG[h][q * NP + pc];                                                                               \
-          }                                                                                                           \
-        } else {                                                                                                      \
+        const int idx = tid + NTC * q;                                                                                \
+        {                                                                                                             \
           const int krow = idx / (BN / 4), c4 = idx % (BN / 4);                                                       \
           if (!BPART || idx < NB16) *reinterpret_cast<f32x4*>(Bs + (h * 32 + krow) * BP + c4 * 4) = BREG[h][q];      \
         }                                                                                                             \
@@ -322,15 +305,125 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       fetch_nbr();
       issue(0);
       if (it_beg + 1 < it_end) fetch_nbr();
+      if constexpr (NS == 3) {
+        if (it_beg + 1 < it_end) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issue(1);
+          if (it_beg + 2 < it_end) fetch_nbr();
+        }
+      }
+    }
+    constexpr int NPC = PM == 4 ? 3 : 1;  // bf16 pieces per operand (forms 4 / 5)
+    bf16x8v pa[NPC][TM], pb[NPC][TN];     // converted operands of the pending k-step (forms 4 / 5)
+    if constexpr (PM == 4 || PM == 5) {
+      const bf16x8v zero8 = __builtin_bit_cast(bf16x8v, (u32x4v){0u, 0u, 0u, 0u});
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) pa[pc][i] = zero8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) pb[pc][j] = zero8;
+      }
     }
     for (int it = it_beg; it < it_end; ++it) {
-      const int buf = (it - it_beg) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it` have landed ...
-      __syncthreads();                                    // ... everyone's have, and stage buf^1 is free again
-      if (it + 1 < it_end) issue(buf ^ 1);
-      if (it + 2 < it_end) fetch_nbr();
+      const int buf = (it - it_beg) % NS;
+      // this wave's pieces of chunk `it` have landed (ring of three: those of chunk it+1 may still be in flight) ...
+      if (NS == 3 && it + 1 < it_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAW + PBW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                    // ... everyone's have, and the stage read last iteration is free
+      if constexpr (NS == 2) {
+        if (it + 1 < it_end) issue(buf ^ 1);
+        if (it + 2 < it_end) fetch_nbr();
+      } else {
+        if (it + 2 < it_end) issue((it - it_beg + 2) % NS);
+        if (it + 3 < it_end) fetch_nbr();
+      }
       const unsigned char* Ab = stg + buf * STAGE + wm * TM * 32 * 128;
       const unsigned char* Bb = stg + buf * STAGE + BM * 128 + wn * TN * 32 * 128;
+      if constexpr (PM == 4 || PM == 5) {
+        // bf16 MFMA on the float32 LDS image: two k-steps of 16 per chunk; step st takes this lane's floats
+        // 16 hh + 8 st .. + 7 (logical slots 4 hh + 2 st, + 1) of every row / column and converts them in registers.
+        // Software pipeline INSIDE the wave, one k-step deep and across the chunk barrier: the MFMAs of k-step t run
+        // while the VALU converts the operands of k-step t+1 (the waves of a block share its barriers and stay in phase,
+        // so VALU work of one wave does not land under the MFMAs of another by itself: measured 37 % matrix-pipe use
+        // with convert -> MFMA in sequence).  `pa / pb` carry the converted operands of the pending k-step into the
+        // next iteration; they start as zeros (one k-step of MFMAs on zeros per block instead of a peeled first pass).
+        constexpr int NMF = TM * TN * (PM == 4 ? 6 : 1);  // MFMAs per k-step
+        // VALU instructions of one k-step's conversions (measured on the ISA: 11 per pair of elements of the split, the
+        // round-to-nearest form one v_cvt_pk per pair) spread over the gaps between that phase's MFMAs
+        constexpr int NVT = (PM == 4 ? 44 : 4) * (TM + TN);
+        constexpr int NVA = (NVT + NMF - 1) / NMF;
+        constexpr int LEAD = NMF >= 8 ? 3 : 1;  // MFMAs issued ahead of the first conversion (they cover the LDS read latency)
+        auto mfma_step = [&](const bf16x8v (&xa)[NPC][TM], const bf16x8v (&xb)[NPC][TN]) {
+          if constexpr (PM == 4) {
+            // six piece products, smallest first (lo hi, hi lo, mid mid, mid hi, hi mid, hi hi), into ONE accumulator
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int NT6 = 6;
+#pragma unroll
+            for (int t = 0; t < NT6; ++t)
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[t]][i], xb[PB[t]][j], acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[0][i], xb[0][j], acc[i][j], 0, 0, 0);
+          }
+        };
+        auto convert_step = [&](const f32x4 (&xa)[TM][2], const f32x4 (&xb)[TN][2], bf16x8v (&oa)[NPC][TM], bf16x8v (&ob)[NPC][TN]) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            if constexpr (PM == 4) f32x8_split3(xa[i][0], xa[i][1], oa[0][i], oa[1][i], oa[2][i]);
+            else oa[0][i] = f32x8_to_bf16(xa[i][0], xa[i][1]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (PM == 4) f32x8_split3(xb[j][0], xb[j][1], ob[0][j], ob[1][j], ob[2][j]);
+            else ob[0][j] = f32x8_to_bf16(xb[j][0], xb[j][1]);
+          }
+        };
+        // both k-steps' raw operands of this chunk: 4 (TM + TN) ds_read_b128, issued at once
+        f32x4 ra[2][TM][2], rb[2][TN][2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            ra[st][i][0] = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offl[2 * st]);
+            ra[st][i][1] = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offl[2 * st + 1]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            rb[st][j][0] = *reinterpret_cast<const f32x4*>(Bb + j * 4096 + offl[2 * st]);
+            rb[st][j][1] = *reinterpret_cast<const f32x4*>(Bb + j * 4096 + offl[2 * st + 1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the reads and their address arithmetic: a scheduling region of their own)
+        bf16x8v na[NPC][TM], nb[NPC][TN];
+        // phase A: MFMAs of the pending k-step (the previous chunk's second) over the conversion of this chunk's first
+        mfma_step(pa, pb);
+        convert_step(ra[0], rb[0], na, nb);
+        __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+#pragma unroll
+        for (int g = LEAD; g < NMF; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x002, NVA + 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase B: MFMAs of this chunk's first k-step over the conversion of its second (pending into the next iteration)
+        mfma_step(na, nb);
+        convert_step(ra[1], rb[1], pa, pb);
+#pragma unroll
+        for (int g = 0; g < NMF; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NVA, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       f32x4 av[2][TM], bv[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offl[0]);
@@ -358,58 +451,31 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
       }
     }
+    if constexpr (PM == 4 || PM == 5) {  // the last k-step's MFMAs
+      if constexpr (PM == 4) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[PA[t]][i], pb[PB[t]][j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0][i], pb[0][j], acc[i][j], 0, 0, 0);
+      }
+    }
   } else {
-    f32x4 aA[KH][RA], bA[KH][RB * NP];
+    f32x4 aA[KH][RA], bA[KH][RB];
     float mA[KH][RA];
     for (int it = it_beg; it <= it_end; ++it) {
       if (it < it_end) IGEMM_LOAD(aA, bA, mA, it);
       if (it > it_beg) {
-        if constexpr (PM == 2) {
-          // two 16-deep k-steps per 32-deep slab; per step the three pieces of every A row / B column fragment, then
-          // the six piece products, smallest first (lo hi, hi lo, mid mid, mid hi, hi mid, hi hi) into ONE accumulator
-          const uint16_t* ap = As16 + (wm * TM * 32 + c) * AP16 + 8 * hh;
-          const uint16_t* bp = Bs16 + (wn * TN * 32 + c) * AP16 + 8 * hh;
-#pragma unroll
-          for (int s = 0; s < BK / 16; ++s) {
-            bf16x8v av[3][TM], bv[3][TN];
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-#pragma unroll
-              for (int i = 0; i < TM; ++i)
-                av[pc][i] = *reinterpret_cast<const bf16x8v*>(ap + pc * BM * AP16 + i * 32 * AP16 + 16 * s);
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                bv[pc][j] = *reinterpret_cast<const bf16x8v*>(bp + pc * BN * AP16 + j * 32 * AP16 + 16 * s);
-            }
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[PA[t]][i], bv[PB[t]][j], acc[i][j], 0, 0, 0);
-          }
-        } else if constexpr (BF) {
-          // four 16-deep k-steps per 64-deep slab; operands are 16-byte LDS reads (8 bf16 of this lane's row / column)
-          const uint16_t* ap = As16 + (wm * TM * 32 + c) * AP16 + 8 * hh;
-          const uint16_t* bp = Bs16 + (wn * TN * 32 + c) * AP16 + 8 * hh;
-#pragma unroll
-          for (int s = 0; s < BK / 16; ++s) {
-            bf16x8v av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8v*>(ap + i * 32 * AP16 + 16 * s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const bf16x8v*>(bp + j * 32 * AP16 + 16 * s);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-          }
-        } else {
-          IGEMM_MFMA();
-        }
+        IGEMM_MFMA();
       }
       __syncthreads();
       if (it < it_end) IGEMM_STORE(aA, bA, mA);
@@ -582,19 +648,17 @@ static int igemm_cfg(int64_t M, int Cout) {
 }
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static constexpr size_t conv_igemm_lds_bytes() {
-  if (PM == 3) return (size_t)(2 * (BM + BN) * 128);  // + the neighbour table (launch_igemm_cfg); the BN partials overlay a stage
-  if (PM == 2) return sizeof(uint16_t) * (size_t)(3 * (BM + BN) * (32 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
-  if (PM == 1) return sizeof(uint16_t) * (size_t)((BM + BN) * (64 + 8)) + sizeof(float) * (size_t)(WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
+  if (PM >= 3) return (size_t)(2 * (BM + BN) * 128);  // + the neighbour table (launch_igemm_cfg); the BN partials overlay a stage
   return sizeof(float) * (size_t)(BM * (64 * WK + 4) + 64 * WK * (BN + 4) + WM * BN * 2) + sizeof(int) * (size_t)(BM * 16);
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>
 static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, hipStream_t s) {
   // (LDS-DMA form: the neighbour table is sized by the launch's tap count; the other forms always carry 16 per row)
-  const size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM == 3 ? sizeof(int) * (size_t)BM * (a.ntaps > 9 ? 16 : 9) : 0);
+  const size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM >= 3 ? sizeof(int) * (size_t)BM * (a.ntaps > 9 ? 16 : 9) : 0);
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, PM>;
   static bool attr_set = false;  // one instantiation = one static
-  constexpr size_t lds_max = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM == 3 ? sizeof(int) * (size_t)BM * 16 : 0);
+  constexpr size_t lds_max = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM >= 3 ? sizeof(int) * (size_t)BM * 16 : 0);
   if (lds_max > 64 * 1024 && !attr_set) {
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
@@ -603,24 +667,20 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
   return DVG_OK;
 }
 
-// DVG_SPLIT3_ALL=1: the split form for every tile configuration (tests, A/B runs)
 // DVG_IGEMM_DMA = 0: the register-staged form of the float32 kernel instead of the LDS-DMA form (tests, A/B runs)
 static int igemm_dma_env() {
   const char* e = getenv("DVG_IGEMM_DMA");  // (read per call: the tests flip it inside one process)
   return !e ? -1 : (e[0] == '1' ? 1 : 0);
 }
+// Operand form of one forward / data-gradient launch (the PM argument of conv_igemm_kernel): the process-wide mode
+// (dvg_set_conv_precision) mapped onto the LDS-DMA kernels.  All three modes read the SAME float32 K-major weight pack.
 int conv_launch_mode(int64_t gemm_rows, int Cout) {
+  (void)gemm_rows; (void)Cout;
   const int mode = conv_precision_mode();
-  if (mode == 0) {
-    return igemm_dma_env() != 0 ? 3 : 0;  // (measured faster for every tile configuration and launch size: tools/igemm_ab.py)
-  }
-  if (mode != 2) return mode;
-  const char* e = getenv("DVG_SPLIT3_ALL");  // (read per call: the tests flip it inside one process)
-  // measured at c3 (in-situ, per launch): 128x128 tile 1046 -> 778 us, 128x64 728 -> 609, 128x32 852 -> 972 (wave tile
-  // 32x32: six MFMAs per six operand reads -- not enough matrix work per staged byte), small launches (c2) slower
-  const int cfg = igemm_cfg(gemm_rows, Cout);
-  return ((e && e[0] == '1') || cfg == 4 || cfg == 0) ? 2 : 0;
+  if (mode == 0) return igemm_dma_env() != 0 ? 3 : 0;  // (measured faster for every tile configuration and launch size: tools/igemm_ab.py)
+  return mode == 2 ? 4 : 5;
 }
+bool conv_pack_is_f32_kmajor(int launch_mode) { return launch_mode >= 3; }
 
 static int igemm_bm(int cfg) { return cfg == 1 ? 64 : cfg == 3 ? 32 : 128; }
 static int igemm_bn(int cfg) { return cfg == 2 ? 32 : cfg == 4 ? 128 : 64; }
@@ -652,6 +712,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   ConvArgs a = a_in;
   // (the packs were written in the matching format: launch_weight_pack_multi makes the same decision per job)
   a.bf16 = conv_launch_mode(a.fold == 1 ? a.M * 4 : a.M, a.Cout);
+  if (a.force_f32 && a.bf16 > 3) a.bf16 = 3;
   const bool taps_ok = a.fold == 1 ? a.ntaps == 4 : a.fold == 2 ? a.ntaps == 16 : (a.ntaps == 9 || a.ntaps == 1);
   if (a.fold && (a.ups || a.poolsum || !conv_fold_ok(a.M))) {
     set_error("conv_igemm: fold=%d needs ups=poolsum=0 and whole 128-row blocks (M=%lld)", a.fold, (long long)a.M);
@@ -679,7 +740,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     const int bm_ = igemm_bm(igemm_cfg(Mg, a.Cout));
     const int64_t nimg = a.L >= 1 ? a.M >> (2 * a.L) : 0;
     const bool taps9 = !a.fold && a.ntaps == 9;
-    a.posmajor = !(e && e[0] == '1') && a.bf16 == 3 && (taps9 || a.fold) && !a.ups && !a.poolsum && a.ksplit == 1 &&
+    a.posmajor = !(e && e[0] == '1') && a.bf16 >= 3 && (taps9 || a.fold) && !a.ups && !a.poolsum && a.ksplit == 1 &&
                  a.L >= 1 && a.L <= 5 && nimg > 0 && (nimg << (2 * a.L)) == a.M && nimg % bm_ == 0;
     if (a.posmajor) {
       // executed FLOPs: the (pixel, [class,] tap) combinations whose displacement stays inside the image
@@ -704,38 +765,21 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   const int bm = igemm_bm(cfg), bn = igemm_bn(cfg);
   const dim3 grid(cm * (unsigned)ceil_div(a.M, bm), (unsigned)(a.Cout / bn), kz);
   int rc;
-  if (a.bf16 == 3) {
-    switch (cfg) {
-      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 3>(K_IGEMM_128x64, flops_exec, grid, a, s); break;
-      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 3>(K_IGEMM_64x64, flops_exec, grid, a, s); break;
-      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 3>(K_IGEMM_32x64, flops_exec, grid, a, s); break;
-      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 3>(K_IGEMM_128x128, flops_exec, grid, a, s); break;
-      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 3>(K_IGEMM_128x32, flops_exec, grid, a, s); break;
-    }
-  } else if (a.bf16 == 2) {
-    switch (cfg) {
-      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 2>(K_IGEMM_128x64, flops, grid, a, s); break;
-      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 2>(K_IGEMM_64x64, flops, grid, a, s); break;
-      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 2>(K_IGEMM_32x64, flops, grid, a, s); break;
-      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 2>(K_IGEMM_128x128, flops, grid, a, s); break;
-      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 2>(K_IGEMM_128x32, flops, grid, a, s); break;
-    }
-  } else if (a.bf16) {
-    switch (cfg) {
-      case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
-      case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, 1>(K_IGEMM_64x64, flops, grid, a, s); break;
-      case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, 1>(K_IGEMM_32x64, flops, grid, a, s); break;
-      case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, 1>(K_IGEMM_128x128, flops, grid, a, s); break;
-      default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, 1>(K_IGEMM_128x32, flops, grid, a, s); break;
-    }
-  } else
-  switch (cfg) {
-    case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1>(K_IGEMM_128x64, flops, grid, a, s); break;
-    case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1>(K_IGEMM_64x64, flops, grid, a, s); break;
-    case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1>(K_IGEMM_32x64, flops, grid, a, s); break;
-    case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1>(K_IGEMM_128x128, flops, grid, a, s); break;
-    default: rc = launch_igemm_cfg<128, 32, 4, 1, 1>(K_IGEMM_128x32, flops, grid, a, s); break;
+  // (weight-space products of the composed decoder layers: their own profiler id, always float32)
+  const bool wspace = a.force_f32 != 0;
+#define IGEMM_LAUNCH_PM(PMV, FL)                                                                                        \
+  switch (cfg) {                                                                                                        \
+    case 0: rc = launch_igemm_cfg<128, 64, 2, 2, 1, PMV>(wspace ? K_IGEMM_WSPACE : K_IGEMM_128x64, FL, grid, a, s); break;   \
+    case 1: rc = launch_igemm_cfg<64, 64, 2, 2, 1, PMV>(wspace ? K_IGEMM_WSPACE : K_IGEMM_64x64, FL, grid, a, s); break;     \
+    case 3: rc = launch_igemm_cfg<32, 64, 1, 2, 1, PMV>(wspace ? K_IGEMM_WSPACE : K_IGEMM_32x64, FL, grid, a, s); break;     \
+    case 4: rc = launch_igemm_cfg<128, 128, 2, 2, 1, PMV>(wspace ? K_IGEMM_WSPACE : K_IGEMM_128x128, FL, grid, a, s); break; \
+    default: rc = launch_igemm_cfg<128, 32, 4, 1, 1, PMV>(wspace ? K_IGEMM_WSPACE : K_IGEMM_128x32, FL, grid, a, s); break;  \
   }
+  if (a.bf16 == 3) { IGEMM_LAUNCH_PM(3, flops_exec) }
+  else if (a.bf16 == 4) { IGEMM_LAUNCH_PM(4, flops_exec) }
+  else if (a.bf16 == 5) { IGEMM_LAUNCH_PM(5, flops_exec) }
+  else { IGEMM_LAUNCH_PM(0, flops) }
+#undef IGEMM_LAUNCH_PM
   DVG_TRY(rc);
   if (a.ksplit > 1) {
     // row blocks in units of OUTPUT rows; for the BN partials they coincide with the unsplit kernel's blocks

@@ -45,6 +45,33 @@ __device__ __forceinline__ void f32_split3_trunc(float x, uint32_t& hi, uint32_t
 }
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
+// Eight float32 operands (two ds_read_b128 of a row of the LDS image) -> the operand registers of ONE bf16 MFMA k-step.
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+// ... as three bf16 pieces each, by truncation (f32_split3_trunc): hi + mid + lo == x bit for bit
+__device__ __forceinline__ void f32x8_split3(const f32x4& q0, const f32x4& q1, bf16x8v& hi, bf16x8v& mid, bf16x8v& lo) {
+  u32x4v h, m, l;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float x0 = u < 2 ? q0[2 * u] : q1[2 * u - 4], x1 = u < 2 ? q0[2 * u + 1] : q1[2 * u - 3];
+    const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const float t0 = r0 - __uint_as_float(m0), t1 = r1 - __uint_as_float(m1);  // (<= 8 significant bits left: exact in bf16)
+    h[u] = pack_hi16(h0, h1);
+    m[u] = pack_hi16(m0, m1);
+    l[u] = pack_hi16(__float_as_uint(t0), __float_as_uint(t1));
+  }
+  hi = __builtin_bit_cast(bf16x8v, h);
+  mid = __builtin_bit_cast(bf16x8v, m);
+  lo = __builtin_bit_cast(bf16x8v, l);
+}
+// ... rounded to bf16, round to nearest even (v_cvt_pk_bf16_f32): the "bf16 GEMM inputs" mode
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8v f32x8_to_bf16(const f32x4& q0, const f32x4& q1) {
+  const f32x8v x = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+  return __builtin_convertvector(x, bf16x8v);
+}
+
 // Diagnostic build only (-DDVG_STAMP): per-phase cycle sums of the main loop, written to ConvArgs.stats
 // (which the diagnostic harness points at a debug buffer: 8 uint64 per block).  Never in the product build.
 #ifdef DVG_STAMP

@@ -833,20 +833,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// one packed entry in the format `fmt`: 0 = f32 [tap][a][b] (index e); 1 = bf16 K-major [tap][b][a] (index kmaj);
-// 2 = three bf16 K-major planes, the exact pieces hi + mid + lo of the weight; 3 = f32 K-major
+// one packed entry in the format `fmt` (the operand form of the launch the pack feeds): 0 = f32 [tap][a][b] (index e);
+// 3 / 4 / 5 = f32 K-major [tap][b][a] (index kmaj): the LDS-DMA forms of the GEMM kernel
 __device__ __forceinline__ void pack_store(float* wp, int64_t total, int64_t kmaj, int64_t e, float v, int fmt) {
-  if (fmt == 0) { wp[e] = v; return; }
-  if (fmt == 3) { wp[kmaj] = v; return; }  // f32 K-major [tap][b][a]: the LDS-DMA form of the float32 GEMM kernel
-  uint16_t* w16 = reinterpret_cast<uint16_t*>(wp);
-  const uint16_t hi = f32_to_bf16_rne(v);
-  w16[kmaj] = hi;
-  if (fmt == 2) {
-    const float r1 = v - bf16_to_f32(hi);
-    const uint16_t mid = f32_to_bf16_rne(r1);
-    w16[total + kmaj] = mid;
-    w16[2 * total + kmaj] = f32_to_bf16_rne(r1 - bf16_to_f32(mid));
-  }
+  (void)total;
+  wp[fmt == 0 ? e : kmaj] = v;
 }
 
 __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ wp,

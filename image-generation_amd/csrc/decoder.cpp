@@ -113,11 +113,10 @@ DecPlan dec_plan(int64_t N, int n) {
     if (act > max_dx) max_dx = act;  // dXs[l] has the shape of Xs[l]
   }
   {
-    // composed form: float32 LDS-DMA GEMMs only (their K-major float32 packs double as plain row-major matrices)
     const int C = ch[1], env = lc0_env();
-    p.lc0 = p.d22 && env != 0 && (N >= 4096 || env == 1) && conv_launch_mode(N, 4 * C) == 3 && conv_launch_mode(N, n) == 3 &&
-            conv_launch_mode(N, 4 * n) == 3 && conv_launch_mode(4 * C, n) == 3 && conv_launch_mode(n, 4 * C) == 3 &&
-            conv_launch_mode(4 * n, n) == 3 && conv_launch_mode(4 * n, 4 * C) == 3;
+    // composed form: the LDS-DMA GEMMs only (their K-major float32 packs double as plain row-major matrices); every
+    // operand mode has them (conv_launch_mode: 3 float32, 4 f32x3, 5 bf16 inputs), the register-staged A/B form does not
+    p.lc0 = p.d22 && env != 0 && (N >= 4096 || env == 1) && conv_pack_is_f32_kmajor(conv_launch_mode(N, 4 * C));
     if (p.lc0) {
       p.WcT = bump(o, (size_t)4 * C * n);
       p.Wc = bump(o, (size_t)n * 4 * C);
@@ -216,6 +215,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     const int C = pl.ch[1];
     ConvArgs a;
     a.bias = nullptr; a.stats = nullptr; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0; a.splitk_ws = nullptr;
+    a.force_f32 = 1;  // products of WEIGHTS: float32 in every operand mode (the modes are about the network's activations)
     a.in = W + pl.wp[0]; a.wp = W + pl.wpd_lin; a.out = W + pl.WcT; a.M = 4 * C; a.Cin = 4 * n; a.Cout = n;
     DVG_TRY(launch_conv_igemm(a, s));
     a.in = W + pl.wpd_lin; a.wp = W + pl.wp[0]; a.out = W + pl.Wc; a.M = n; a.Cin = 4 * n; a.Cout = 4 * C;
@@ -357,6 +357,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       DVG_TRY(launch_slab_sum(W + pl.slabs, pl.ksplit_c, n, C4, W + pl.dWc, W + pl.dWcT, s2));
       ConvArgs b;
       b.bias = nullptr; b.stats = nullptr; b.L = 0; b.ntaps = 1; b.ups = 0; b.poolsum = 0; b.splitk_ws = nullptr;
+      b.force_f32 = 1;  // weight-space products (see the forward call)
       // T1[j][i] = sum_o Weff[j][o] dWc[i][o]: rows of the dense-2x2 data-gradient pack [j][o] x dWc as the K-major operand
       b.in = W + pl.wpd[0]; b.wp = W + pl.dWc; b.out = W + pl.T1; b.M = n4; b.Cin = C4; b.Cout = n;
       DVG_TRY(launch_conv_igemm(b, s2));
