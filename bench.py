@@ -264,12 +264,12 @@ def layerwise_run(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup",
            str(args.warmup), "--no-cpu-baseline", "--child"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, DVG_NO_LC0="1", DVG_NO_D22="1"))
+        r = subprocess.run(cmd + ["--option", "dec_lc0=0", "--option", "dec_d22=0"], capture_output=True, text=True, timeout=900)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
         d = json.loads(lines[-1])
         return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                 "net_gflop_per_step": d["config"].get("net_gflop_per_step"),
-                "note": "DVG_NO_LC0=1 DVG_NO_D22=1: Linear and the first ConvTranspose layer as two layer-by-layer GEMMs (9 taps)"}
+                "note": "options dec_lc0 = 0, dec_d22 = 0: Linear and the first ConvTranspose layer as two layer-by-layer GEMMs (9 taps)"}
     except Exception as exc:  # the headline line must not depend on the extra runs
         return {"error": repr(exc)}
 
@@ -314,6 +314,8 @@ def main():
     ap.add_argument("--parity", action="store_true", help="(internal) run the 12-step loss-parity check in this arithmetic mode")
     ap.add_argument("--eager", action="store_true", help="no hipGraph replay: every step launches its kernels one by one")
     ap.add_argument("--breakdown", default="", help="write the per-kernel HIP-event breakdown (JSON) to this path")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a kernel-form option of the library (dvg_set_option), e.g. dec_lc0=0; may be repeated")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="operands of the forward / data-gradient convolution GEMMs: f32 (the 1e-5 loss parity; the bench "
                          "line) or bf16 inputs with f32 accumulate (BASELINE.json configs[1] names bf16; reported beside it)")
@@ -352,6 +354,9 @@ def main():
     model.keep_step_losses = False  # ... and no per-step copies of the loss scalars into the history lists
 
     L = _lib.lib()
+    for item in args.option:
+        name, value = item.split("=")
+        _lib.set_option(name, int(value))
     _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
     is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
@@ -516,10 +521,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
             out["loss_parity"] = loss_parity()
         if args.parity and args.gpus == 1:
-            # (the fixture's launches are small: force the split kernels onto every tile configuration for the check)
-            os.environ["DVG_SPLIT3_ALL"] = "1"
-            out["loss_parity"] = dict(loss_parity(), note="12 fixture steps with the split kernels forced onto every launch")
-            os.environ.pop("DVG_SPLIT3_ALL", None)
+            out["loss_parity"] = dict(loss_parity(), note="12 fixture steps in this arithmetic mode (every forward / data-gradient launch)")
         if args.gpus == 1 and not args.child and not args.no_cpu_baseline and args.precision == "f32":
             out["f32x3"] = split3_run(args)
             out["bf16_inputs"] = bf16_inputs_run(args)

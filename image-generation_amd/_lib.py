@@ -155,6 +155,12 @@ SIGNATURES = {
     "dvg_stream_anchor": (c_int, [c_void_p]),
     "dvg_set_conv_precision": (c_int, [c_int]),
     "dvg_get_conv_precision": (c_int, []),
+    "dvg_option_count": (c_int, []),
+    "dvg_option_name": (c_char_p, [c_int]),
+    "dvg_option_doc": (c_char_p, [c_int]),
+    "dvg_set_option": (c_int, [c_char_p, c_int64]),
+    "dvg_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
+    "dvg_reset_options": (c_int, []),
     "dvg_prof_enable": (c_int, [c_uint64]),
     "dvg_prof_reset": (c_int, []),
     "dvg_prof_num_kernels": (c_int, []),
@@ -248,6 +254,45 @@ def set_conv_precision(mode: str) -> None:
     if mode not in modes:
         raise ValueError(f"conv precision must be one of {sorted(modes)}, got {mode!r}")
     check(lib().dvg_set_conv_precision(modes[mode]), "dvg_set_conv_precision")
+
+
+def set_option(name: str, value: int) -> None:
+    """A kernel-form option of the library (include/dvg.h, dvg_set_option; ``options()`` lists them)."""
+    check(lib().dvg_set_option(name.encode(), int(value)), f"dvg_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = c_int64()
+    check(lib().dvg_get_option(name.encode(), ctypes.byref(v)), f"dvg_get_option({name})")
+    return int(v.value)
+
+
+def options() -> dict:
+    """name -> (value, doc) of every kernel-form option."""
+    L = lib()
+    out = {}
+    for i in range(L.dvg_option_count()):
+        name = L.dvg_option_name(i).decode()
+        out[name] = (get_option(name), L.dvg_option_doc(i).decode())
+    return out
+
+
+class option_scope:
+    """``with option_scope(dec_lc0=0, dec_d22=0): ...`` sets options for the block and restores the previous values."""
+
+    def __init__(self, **values):
+        self.values, self.saved = values, {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.saved[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            set_option(k, v)
+        return False
 
 
 def get_conv_precision() -> str:

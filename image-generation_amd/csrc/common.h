@@ -80,6 +80,14 @@ enum KernelId : int {
   K_COUNT
 };
 
+// Kernel-form options (options.cpp): set through dvg_set_option, read per call.
+enum Opt : int {
+  OPT_IGEMM_DMA = 0, OPT_IGEMM_POSMAJOR, OPT_IGEMM_THR128, OPT_IGEMM_THR64, OPT_IGEMM_THR32, OPT_IGEMM_NO32, OPT_WGRAD_DMA,
+  OPT_DEC_FOLD, OPT_DEC_D22, OPT_DEC_LC0, OPT_MMD_W128, OPT_MMD_D256, OPT_MMD_BLOCKS, OPT_GIBBS_GENERIC, OPT_GIBBS_WAVES,
+  OPT_GIBBS_BIGFAST, OPT_SIDE_STREAM, OPT_COUNT
+};
+int64_t opt(Opt id);
+
 // Fork/join helpers (streams.cpp).  side_stream(s) is the library's side stream of the current device (or `s` itself
 // when DVG_NO_SIDE_STREAM is set); stream_order_after(w, p) makes everything enqueued on `w` from now on wait for what
 // has been enqueued on `p` so far (no-op when w == p).  Capture-safe.

@@ -136,6 +136,8 @@ bool conv_precision_bf16();
 int conv_precision_mode();  // 0 f32, 1 bf16 inputs, 2 f32 as three bf16 pieces
 // packed-weight buffers: one float32 per entry (every operand form reads a float32 pack)
 static inline size_t conv_pack_floats(size_t entries) { return entries; }
+void plan_note_forward(const void* ws, uint32_t signature);      // forward calls: what shaped the workspace's contents
+bool plan_matches_forward(const void* ws, uint32_t signature);   // backward calls: the same plan as the forward's?
 void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
 bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);

@@ -23,7 +23,7 @@ namespace dvg {
 // half-K blocks combined in-kernel through an arrival counter, is correct and deterministic but 2x slower: its
 // agent-scope release fence writes back the XCD's L2.)
 // PM = 0: float32 operands staged through registers (the first form of this kernel; kept as the A/B reference the LDS-DMA
-// form is tested bit-identical against: DVG_IGEMM_DMA=0).
+// form is tested bit-identical against: option igemm_dma = 0).
 // PM = 3: the float32 form with LDS-DMA staging (global_load_lds_dwordx4: no staging registers, no ds_write pass, no
 // mask multiply).  One 32-channel chunk per iteration, two LDS stages, ONE barrier per iteration; both operands sit in
 // LDS as [row][32 floats] (weights packed K-major, PackJob.bf16t = 3), 16-byte slots XOR-swizzled on the per-lane SOURCE
@@ -630,19 +630,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Tile configuration: 0 = 128x64, 4 = 128x128 (large launches), 1 = 64x64, 2 = 128x32 (Cout = 32), 3 = 32x64 (two waves) for launches whose 64-row
 // tiling would leave most CUs without a block (small-M layers: a finer tiling fills the chip without the split-K slabs
-// and their reduce pass).  DVG_IGEMM_NO32=1 disables 3 (A/B runs).
+// and their reduce pass).  option igemm_no32 = 1 disables 3 (A/B runs).
 static int igemm_cfg(int64_t M, int Cout) {
-  static const bool no32 = [] { const char* e = getenv("DVG_IGEMM_NO32"); return e && e[0] == '1'; }();
+  const bool no32 = opt(OPT_IGEMM_NO32) != 0;
   if (Cout % 64) return 2;
   // 4 = 128x128 (wave tile 64x64: half the LDS operand reads and half the L2 -> LDS bytes per FLOP of 128x64) once
   // the launch still has >= 512 blocks of that size (two per CU are resident: 79 KB of LDS, 231 VGPRs).  c3: the
   // launches that qualify run at 82 instead of 59 TFLOP/s in-situ, step 22.9 -> 22.55 ms; 256 / 128 measured no
-  // better, c2 has no such launch.  (DVG_IGEMM_THR128 overrides: tuning runs.)
-  static const int64_t thr128 = [] { const char* e = getenv("DVG_IGEMM_THR128"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+  // better, c2 has no such launch.  (option igemm_thr128 overrides: tuning runs.)
+  const int64_t thr128 = opt(OPT_IGEMM_THR128);
   if (Cout % 128 == 0 && ceil_div(M, 128) * (Cout / 128) >= thr128) return 4;
-  static const int64_t thr64 = [] { const char* e = getenv("DVG_IGEMM_THR64"); return e ? (int64_t)atoll(e) : (int64_t)512; }();
+  const int64_t thr64 = opt(OPT_IGEMM_THR64);
   if (ceil_div(M, 128) * (Cout / 64) >= thr64) return 0;
-  static const int64_t thr32 = [] { const char* e = getenv("DVG_IGEMM_THR32"); return e ? (int64_t)atoll(e) : (int64_t)96; }();
+  const int64_t thr32 = opt(OPT_IGEMM_THR32);
   if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;
 }
@@ -667,11 +667,8 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
   return DVG_OK;
 }
 
-// DVG_IGEMM_DMA = 0: the register-staged form of the float32 kernel instead of the LDS-DMA form (tests, A/B runs)
-static int igemm_dma_env() {
-  const char* e = getenv("DVG_IGEMM_DMA");  // (read per call: the tests flip it inside one process)
-  return !e ? -1 : (e[0] == '1' ? 1 : 0);
-}
+// option igemm_dma = 0: the register-staged form of the float32 kernel instead of the LDS-DMA form (tests, A/B runs)
+static int igemm_dma_env() { return opt(OPT_IGEMM_DMA) != 0 ? 1 : 0; }
 // Operand form of one forward / data-gradient launch (the PM argument of conv_igemm_kernel): the process-wide mode
 // (dvg_set_conv_precision) mapped onto the LDS-DMA kernels.  All three modes read the SAME float32 K-major weight pack.
 int conv_launch_mode(int64_t gemm_rows, int Cout) {
@@ -735,12 +732,11 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
   double flops_exec = flops;
   {
     // position-major tiles: plain 3x3 launches of the LDS-DMA form whose images fill whole row blocks (then the grid and
-    // the BatchNorm partial rows are what they were).  DVG_NO_POSMAJOR=1: pixel-major tiles everywhere (A/B runs, tests)
-    const char* e = getenv("DVG_NO_POSMAJOR");  // (read per call: the tests flip it inside one process)
+    // the BatchNorm partial rows are what they were).  option igemm_posmajor = 0: pixel-major tiles everywhere (A/B runs, tests)
     const int bm_ = igemm_bm(igemm_cfg(Mg, a.Cout));
     const int64_t nimg = a.L >= 1 ? a.M >> (2 * a.L) : 0;
     const bool taps9 = !a.fold && a.ntaps == 9;
-    a.posmajor = !(e && e[0] == '1') && a.bf16 >= 3 && (taps9 || a.fold) && !a.ups && !a.poolsum && a.ksplit == 1 &&
+    a.posmajor = opt(OPT_IGEMM_POSMAJOR) != 0 && a.bf16 >= 3 && (taps9 || a.fold) && !a.ups && !a.poolsum && a.ksplit == 1 &&
                  a.L >= 1 && a.L <= 5 && nimg > 0 && (nimg << (2 * a.L)) == a.M && nimg % bm_ == 0;
     if (a.posmajor) {
       // executed FLOPs: the (pixel, [class,] tap) combinations whose displacement stays inside the image

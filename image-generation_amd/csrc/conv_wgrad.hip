@@ -672,10 +672,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_reduce_kernel(const float* __r
   }
 }
 
-static bool wgrad_dma_on() {
-  const char* e = getenv("DVG_WGRAD_DMA");  // (read per call: the tests flip it inside one process)
-  return !(e && e[0] == '0');
-}
+static bool wgrad_dma_on() { return opt(OPT_WGRAD_DMA) != 0; }  // (read per call: the tests flip it inside one process)
 // the 1-tap form: 128 x 128 channel tiles (DMA kernel) when both channel counts allow and the tensors fit 32-bit offsets
 static bool wgrad1_dma_ok(int64_t M, int Cin, int Cout) {
   // (and enough rows that the 128 x 128 tiles still fill the chip: c2's Linear layer has 2048 rows -- 32 such blocks)
@@ -772,9 +769,9 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     const dim3 g9((unsigned)((a.Cin / ba) * (a.Cout / bb)), (unsigned)a.ksplit);
     // 64x64 channel tile: two tap groups (8 waves, 5 / 4 accumulator tiles per wave, two waves per SIMD) instead of one
     // (4 waves x 9 tiles, one per SIMD): +10 % on the kernel in-situ (c3 53 -> 59, c2 41 -> 45 TFLOP/s), steps neutral
-    // to -1 %.  DVG_WGRAD9_WT2=0 restores the 4-wave form (A/B runs).
-    static const bool wt2 = [] { const char* e = getenv("DVG_WGRAD9_WT2"); return !e || e[0] != '0'; }();
-    // LDS-DMA form (32-bit offsets: both tensors below 0xFFFF0000 bytes); DVG_WGRAD_DMA=0: the register-staged form
+    // to -1 %.  (The 4-wave form is still instantiated for the shapes that need it.)
+    constexpr bool wt2 = true;
+    // LDS-DMA form (32-bit offsets: both tensors below 0xFFFF0000 bytes); option wgrad_dma = 0: the register-staged form
     const double xbytes = (double)(a.ups ? a.M / 4 : a.M) * a.Cin * 4.0, ybytes = (double)a.M * a.Cout * 4.0;
     if (wgrad_dma_on() && xbytes < 4294901760.0 && ybytes < 4294901760.0) {
       if (a64 && b64) return launch_wgrad9_dma<2, 2, 2>(K_WGRAD_2x2, flops, g9, a, s);

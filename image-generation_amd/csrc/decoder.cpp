@@ -4,8 +4,6 @@
 //   previous stage fused into the gather (never materialised); layer 3 (32->1 @16x16) and the final 1->1 @32x32
 //   ConvTranspose: VALU kernels.  Each of layers 0-3 is followed by BN(batch stats) -> Dropout2d -> LeakyReLU.
 //   Backward data-gradients of the upsample-fused layers sum each 2x2 quad in the MFMA epilogue.
-#include <cstdlib>
-
 #include "conv.h"
 #include "kernels.h"
 
@@ -37,24 +35,17 @@ struct DecPlan {
   size_t total_floats;
 };
 
-// DVG_NO_FOLD=1 keeps the upsample-fused 9-tap form everywhere (A/B runs)
-bool fold_enabled() {
-  static const bool off = [] { const char* e = getenv("DVG_NO_FOLD"); return e && e[0] == '1'; }();
-  return !off;
-}
+// option dec_fold = 0 keeps the upsample-fused 9-tap form everywhere (A/B runs)
+bool fold_enabled() { return opt(OPT_DEC_FOLD) != 0; }
 
-// DVG_NO_D22=1 keeps the 9-tap form for the first ConvTranspose layer (A/B runs, tests)
-bool d22_enabled() {
-  const char* e = getenv("DVG_NO_D22");  // (read per call: the tests flip it inside one process)
-  return !(e && e[0] == '1');
-}
+// option dec_d22 = 0 keeps the 9-tap form for the first ConvTranspose layer (A/B runs, tests)
+bool d22_enabled() { return opt(OPT_DEC_D22) != 0; }
 
-// DVG_NO_LC0=1: never compose the Linear layer with layer 0 (A/B runs, tests); DVG_LC0=1: also for small batches (tests)
+// option dec_lc0 = 0: never compose the Linear layer with layer 0 (A/B runs, tests); 1: also for small batches (tests);
+// -1 (default): from 4096 rows up
 int lc0_env() {
-  const char* off = getenv("DVG_NO_LC0");  // (read per call: the tests flip it inside one process)
-  if (off && off[0] == '1') return 0;
-  const char* on = getenv("DVG_LC0");
-  return on && on[0] == '1' ? 1 : -1;
+  const int64_t v = opt(OPT_DEC_LC0);
+  return v < 0 ? -1 : (v ? 1 : 0);
 }
 
 size_t bump(size_t& o, size_t count) {
@@ -153,6 +144,12 @@ DecPlan dec_plan(int64_t N, int n) {
   return p;
 }
 
+// what of the plan the backward relies on the forward having done (which buffers hold what, in which pack format)
+uint32_t plan_signature(const DecPlan& pl) {
+  return (uint32_t)pl.d22 | (uint32_t)pl.lc0 << 1 | (uint32_t)pl.fold[1] << 2 | (uint32_t)pl.fold[2] << 3 |
+         (uint32_t)conv_launch_mode(pl.N, 128) << 4;
+}
+
 int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws, size_t ws_bytes, const DecPlan& pl) {
   DVG_REQUIRE(p && ws, "decoder: null params/workspace");
   DVG_REQUIRE(n >= 32 && n % 32 == 0 && n <= 4096, "decoder: n_latents=%d must be a multiple of 32", n);
@@ -182,6 +179,7 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
+  plan_note_forward(ws, plan_signature(pl));
   DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
@@ -291,6 +289,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "decoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_matches_forward(ws, plan_signature(pl)), "decoder_bwd: a kernel-form option (dvg_set_option: dec_fold / dec_d22 / dec_lc0 / igemm_dma) changed since the forward call on this workspace");
   DVG_REQUIRE(spins && grad_out && g, "decoder_bwd: null argument");
   DVG_REQUIRE(g->lin_w && g->lin_b, "decoder_bwd: null linear gradient buffer");
   for (int l = 0; l < 5; ++l) DVG_REQUIRE(g->conv_w[l] && g->conv_b[l], "decoder_bwd: null conv gradient buffer %d", l);
@@ -371,18 +370,10 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     }
     if (l == 3) {
       // data gradient and weight-gradient partials in ONE pass over the images on the caller's stream (special.hip); only
-      // the column sums go to the side stream.  DVG_CONV3_SPLIT=1: the two separate kernels (A/B runs, tests)
-      const char* e3 = getenv("DVG_CONV3_SPLIT");
-      int w3_blocks = stream_blocks(N);  // partial rows of the weight gradient
-      if (e3 && e3[0] == '1') {
-        DVG_TRY(launch_dec_conv3_dgrad(dY, N, p->conv_w[3], dX, s));
-        if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-        DVG_TRY(launch_dec_conv3_wgrad(xin, N, dY, partW, s2));
-        w3_blocks = EW_BLOCKS;
-      } else {
-        // (no fork here: the column sums of this layer are in the batch at the end of the side chain)
-        DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
-      }
+      // the column sums go to the side stream (no fork here: they are in the batch at the end of the side chain).  (The two
+      // separate kernels this replaced were retired in round 3.)
+      const int w3_blocks = stream_blocks(N);  // partial rows of the weight gradient
+      DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
       DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
                   sums.add(partW, w3_blocks, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
                   "decoder_bwd: column-sum batch full");

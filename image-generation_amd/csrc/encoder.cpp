@@ -116,6 +116,7 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
+  plan_note_forward(ws, (uint32_t)conv_launch_mode(B, 64));  // (the pack format the backward will read)
   DVG_REQUIRE(images && logits, "encoder_fwd: null images/logits");
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
@@ -156,6 +157,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "encoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_matches_forward(ws, (uint32_t)conv_launch_mode(B, 64)), "encoder_bwd: option igemm_dma changed since the forward call on this workspace");
   DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
   for (int l = 0; l < 4; ++l)
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);

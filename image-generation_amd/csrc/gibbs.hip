@@ -366,13 +366,13 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
   const int mc = g->max_class;
   const bool big = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 4) > 72 * 1024;
-  // (DVG_GIBBS_GENERIC=1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
-  static const bool force_generic = [] { const char* e = getenv("DVG_GIBBS_GENERIC"); return e && e[0] == '1'; }();
+  // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
+  const bool force_generic = opt(OPT_GIBBS_GENERIC) != 0;
   const bool fast = !force_generic;
-  // Waves per workgroup (DVG_GIBBS_WAVES = 1, 2, 4 or 8 overrides for tuning runs).  Measured on the c2 step with the
+  // Waves per workgroup (option gibbs_waves = 1, 2, 4 or 8 overrides for tuning runs).  Measured on the c2 step with the
   // draw overlapped with the encoder forward: 4 -> 1.237 ms, 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for
   // issue slots, fatter workgroups do not pay for the CUs they free.
-  static const int waves_env = [] { const char* e = getenv("DVG_GIBBS_WAVES"); return e ? atoi(e) : 0; }();
+  const int waves_env = (int)opt(OPT_GIBBS_WAVES);
   // Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one wave per
   // workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger
   // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
@@ -388,10 +388,10 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
     if (wv <= 4) return launch_gibbs<64, 4>(a, s, fast, mc);
     if (wv <= 8) return launch_gibbs<64, 8>(a, s, fast, mc);
     // The register-resident schedule with 24 slots needs the 256-register budget of an 8-wave workgroup.  Opt-in
-    // (DVG_GIBBS_BIGFAST=1): alone it is the faster draw (2048 chains x 1024 spins x 50 sweeps: 1.49 ms against 2.20),
+    // (option gibbs_bigfast = 1): alone it is the faster draw (2048 chains x 1024 spins x 50 sweeps: 1.49 ms against 2.20),
     // but 8-wave workgroups put a ~110 KB LDS footprint on EVERY CU and starve the encoder's convolutions that run
     // beside the draw in a training step (c5 step 5.0 ms against 4.0 with the 16-wave rolled form on half the CUs).
-    static const bool big_fast = [] { const char* e = getenv("DVG_GIBBS_BIGFAST"); return e && e[0] == '1'; }();
+    const bool big_fast = opt(OPT_GIBBS_BIGFAST) != 0;
     if (fast && big_fast && !waves_env && g->n_colours * ((mc + 63) / 64) <= GIBBS_MAXS_BIG)
       return launch_gibbs<64, 8, GIBBS_MAXS_BIG>(a, s, true, mc);
     return launch_gibbs<64, 16>(a, s, fast, mc);

@@ -93,11 +93,9 @@ int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const 
 int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s);
 int dec_conv3_blocks(int64_t N);
-int launch_dec_conv3_dgrad(const float* dY, int64_t N, const float* w, float* dX, hipStream_t s);
 // part [EW_BLOCKS][288] indexed tap*32 + ci (tap = kh*3+kw of the checkpoint weight)
-// data gradient + weight-gradient partials in one pass (part as launch_dec_conv3_wgrad)
+// data gradient + weight-gradient partials in one pass over the images
 int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float* w, float* dX, float* part, hipStream_t s);
-int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* part, hipStream_t s);
 // decoder final ConvTranspose2d(1,1) at 32x32 from the upsampled 16x16 map; row-major output
 int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s);
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s);

@@ -1684,15 +1684,15 @@ struct MmdPlan {
   int64_t rb128x, rb128y;
 };
 
-// DVG_MMD_W128 = 1 / 0 forces the 128-row-block pair kernel on (wherever the shape allows it) / off: tests, A/B runs
+// option mmd_w128 = 1 / 0 forces the 128-row-block pair kernel on (wherever the shape allows it) / off: tests, A/B runs
 static int mmd_w128_env() {  // (read per call: the tests flip it inside one process)
-  const char* e = getenv("DVG_MMD_W128");
-  return e ? (e[0] == '1' ? 1 : 0) : -1;
+  const int64_t v = opt(OPT_MMD_W128);
+  return v < 0 ? -1 : (v ? 1 : 0);
 }
 
-// column splits of the pair kernel aim for this many blocks (env DVG_MMD_BLOCKS overrides: tuning runs)
+// column splits of the pair kernel aim for this many blocks (option mmd_blocks: tuning runs)
 static int64_t mmd_target_blocks() {
-  static const int64_t v = [] { const char* e = getenv("DVG_MMD_BLOCKS"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+  const int64_t v = opt(OPT_MMD_BLOCKS);
   return v < 1 ? 1 : v;
 }
 
@@ -1731,8 +1731,8 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   // (T+1)/S1 tiles each, two blocks per CU wanted; other shapes one block per 32-row block
   int64_t S1;
   {
-    const char* e = getenv("DVG_MMD_D256");  // 0: never, 1: whenever the shape allows (tests); read per call
-    const int env = !e ? -1 : (e[0] == '1' ? 1 : 0);
+    const int64_t ov = opt(OPT_MMD_D256);  // 0: never, 1: whenever the shape allows (tests); read per call
+    const int env = ov < 0 ? -1 : (ov ? 1 : 0);
     const int64_t t256 = ceil_div(nx + ny, 256);
     p.d256 = p.pm1_ok && env != 0 && d % 128 == 0 && d <= 512 && (t256 >= 32 || env == 1) && (nx + ny) * (int64_t)d < 2147483647LL;
   }
@@ -1859,11 +1859,9 @@ static int launch_pair(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
-// DVG_MMD_SLICES=2: the two-feature-slice form of the 128-row-block pair kernel at d > 256 (A/B runs; read per call)
-static bool mmd_two_slices() {
-  const char* esl = getenv("DVG_MMD_SLICES");
-  return esl && esl[0] == '2';
-}
+// (the two-feature-slice form of the 128-row-block pair kernel at d > 256 -- the Gram and the lookups computed once per
+// slice -- was retired in round 3: the single-slice form replaced it at 2.70 -> 2.10 ms)
+static constexpr bool mmd_two_slices() { return false; }
 
 }  // namespace dvg
 
@@ -1977,16 +1975,14 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     // Large spin problems: 128-row blocks.  General (not +-1) rows cannot be known on the host without a sync, so the
     // f32 kernel is launched behind it with the same split count and stands down on the device flag (its blocks exit at
     // once; it writes the same loss_part / grad_part slots when it does run).
-    const bool two_slices = mmd_two_slices();
     switch (dim / 128) {
       case 1: rc = launch_pair_w128<4, 4>(a, p, s); break;
       case 2: rc = launch_pair_w128<8, 8>(a, p, s); break;
       // One feature slice per block wherever the accumulators fit the 512-register file (d = 512: 256 of them hold G^T,
       // the compiler places the Gram tile and the operands in the other half without spills): the Gram and the lookups
-      // are then computed once, 80 instead of 96 MFMAs per chunk: 2.70 -> 2.10 ms at c3.  DVG_MMD_SLICES=2 restores the
-      // two-slice form (A/B runs).
-      case 3: rc = two_slices ? launch_pair_w128<12, 6>(a, p, s) : launch_pair_w128<12, 12>(a, p, s); break;
-      default: rc = two_slices ? launch_pair_w128<16, 8>(a, p, s) : launch_pair_w128<16, 16>(a, p, s); break;
+      // are then computed once, 80 instead of 96 MFMAs per chunk: 2.70 -> 2.10 ms at c3 (the two-slice form is retired).
+      case 3: rc = launch_pair_w128<12, 12>(a, p, s); break;
+      default: rc = launch_pair_w128<16, 16>(a, p, s); break;
     }
     DVG_TRY(rc);
     MmdArgs g = a;
@@ -2002,9 +1998,8 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     // feature blocks per launch slice: the largest of 8/4/2/1 that divides d/32 (no feature guards in the spin body;
     // 16 blocks = 256 accumulator registers makes the compiler shuffle accumulators through scratch)
     const int fbt = dim / 32;
-    // d = 128, 256, 384, 512: feature-quarter form (DVG_MMD_NO_FQ=1: the sliced form, A/B runs)
-    static const bool no_fq = [] { const char* e = getenv("DVG_MMD_NO_FQ"); return e && e[0] == '1'; }();
-    if (!no_fq && dim % 128 == 0 && dim <= 512) {
+    // d = 128, 256, 384, 512: feature-quarter form; other widths: the sliced form
+    if (dim % 128 == 0 && dim <= 512) {
       switch (dim / 128) {
         case 1: rc = launch_pair_fq<1>(a, p, s); break;
         case 2: rc = launch_pair_fq<2>(a, p, s); break;

@@ -1,0 +1,81 @@
+// Kernel-form options of libdvg.so: ONE registry, set through the C ABI (dvg_set_option / dvg_get_option, include/dvg.h).
+// Rounds 1-2 selected kernel forms through ~26 environment variables read at scattered getenv() sites, some once per
+// process, some per call; the boundary, not the environment, selects them now.  Every option has a default that is the
+// product's path; the others exist for A/B measurements and for the tests that compare two forms of the same function.
+// Values are read per call (relaxed atomics): an option may be flipped between calls, and the forward / backward pair of
+// a network call records the plan-shaping ones in its workspace (decoder.cpp) so that a flip in between is an error,
+// not silent garbage.
+#include <atomic>
+#include <cstring>
+
+#include "common.h"
+
+namespace dvg {
+namespace {
+struct OptDef { const char* name; int64_t def; const char* doc; };
+// (order = enum Opt in common.h)
+const OptDef kDefs[OPT_COUNT] = {
+    {"igemm_dma", 1, "float32 forward / data-gradient GEMM: 1 LDS-DMA staging (default), 0 register staging (A/B reference)"},
+    {"igemm_posmajor", 1, "position-major tiles (padding taps of small images never multiplied): 1 on, 0 pixel-major tiles"},
+    {"igemm_thr128", 512, "blocks a launch must have for the 128x128 tile"},
+    {"igemm_thr64", 512, "blocks a launch must have for the 128x64 tile"},
+    {"igemm_thr32", 96, "blocks below which the 32x64 tile replaces the 64x64 tile"},
+    {"igemm_no32", 0, "1: never the 32x64 tile"},
+    {"wgrad_dma", 1, "weight-gradient GEMMs: 1 LDS-DMA staging (default), 0 register staging"},
+    {"dec_fold", 1, "decoder: Upsample(x2) + ConvTranspose as 4 class GEMMs with pre-summed taps (4/9 of the FLOPs)"},
+    {"dec_d22", 1, "decoder: first ConvTranspose layer on 2x2 images as one dense map per image (16/36 of the FLOPs)"},
+    {"dec_lc0", -1, "decoder: Linear composed with that map: -1 from 4096 rows up (default), 0 never, 1 always"},
+    {"mmd_w128", -1, "MMD: 128-row-block pair kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows"},
+    {"mmd_d256", -1, "MMD: 256-row distance-sum kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows"},
+    {"mmd_blocks", 256, "MMD: target workgroup count of the pair kernels' column split"},
+    {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule (bit-identical; A/B reference)"},
+    {"gibbs_waves", 0, "sampler: waves per workgroup (0 = chosen by graph size)"},
+    {"gibbs_bigfast", 0, "sampler: 1 = 8-wave unrolled form for graphs above 72 KB of tables (faster alone, slower in a step)"},
+    {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
+};
+std::atomic<int64_t> g_val[OPT_COUNT];
+std::atomic<bool> g_init{false};
+void init_once() {
+  if (g_init.load(std::memory_order_acquire)) return;
+  for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
+  g_init.store(true, std::memory_order_release);
+}
+}  // namespace
+
+int64_t opt(Opt id) {
+  init_once();
+  return g_val[id].load(std::memory_order_relaxed);
+}
+}  // namespace dvg
+
+using namespace dvg;
+
+extern "C" int dvg_option_count(void) { return OPT_COUNT; }
+
+extern "C" const char* dvg_option_name(int index) { return index >= 0 && index < OPT_COUNT ? kDefs[index].name : nullptr; }
+
+extern "C" const char* dvg_option_doc(int index) { return index >= 0 && index < OPT_COUNT ? kDefs[index].doc : nullptr; }
+
+extern "C" int dvg_set_option(const char* name, int64_t value) {
+  DVG_REQUIRE(name, "dvg_set_option: null name");
+  init_once();
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(name, kDefs[i].name)) { g_val[i].store(value, std::memory_order_relaxed); return DVG_OK; }
+  set_error("dvg_set_option: unknown option '%s'", name);
+  return DVG_E_INVALID;
+}
+
+extern "C" int dvg_get_option(const char* name, int64_t* value) {
+  DVG_REQUIRE(name && value, "dvg_get_option: null argument");
+  init_once();
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (!strcmp(name, kDefs[i].name)) { *value = g_val[i].load(std::memory_order_relaxed); return DVG_OK; }
+  set_error("dvg_get_option: unknown option '%s'", name);
+  return DVG_E_INVALID;
+}
+
+extern "C" int dvg_reset_options(void) {
+  init_once();
+  for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
+  return DVG_OK;
+}

@@ -22,6 +22,21 @@ namespace {
 std::atomic<int> g_mode{-1};
 std::mutex g_ws_mutex;
 std::unordered_map<const void*, int> g_ws_mode;  // mode of the last forward call per workspace
+std::unordered_map<const void*, uint32_t> g_ws_plan;  // plan signature of the last forward call per workspace
+}
+
+// The same bookkeeping for everything else that shapes what a forward call leaves in its workspace (pack formats, which
+// of the decoder's algebraic forms ran): options may be flipped between calls (dvg_set_option), and a backward call that
+// would read buffers its forward never wrote must fail loudly instead.
+void plan_note_forward(const void* ws, uint32_t signature) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (g_ws_plan.size() > 4096) g_ws_plan.clear();
+  g_ws_plan[ws] = signature;
+}
+bool plan_matches_forward(const void* ws, uint32_t signature) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  auto it = g_ws_plan.find(ws);
+  return it == g_ws_plan.end() || it->second == signature;
 }
 
 // A backward call reuses the weight packs its forward call left in the workspace, so it must run in the mode that wrote
@@ -39,11 +54,8 @@ bool conv_precision_matches_forward(const void* ws) {
 
 int conv_precision_mode() {
   int m = g_mode.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char* e = getenv("DVG_CONV_BF16");
-    const char* e2 = getenv("DVG_CONV_MODE");  // 0 / 1 / 2
-    m = (e && e[0] == '1') ? 1 : 0;
-    if (e2 && e2[0] >= '0' && e2[0] <= '2') m = e2[0] - '0';
+  if (m < 0) {  // never set: float32 (the mode is chosen through dvg_set_conv_precision, not the environment)
+    m = 0;
     g_mode.store(m, std::memory_order_relaxed);
   }
   return m;

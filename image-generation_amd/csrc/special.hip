@@ -85,10 +85,7 @@ __global__ __launch_bounds__(256) void enc_conv0_fwd_kernel(const float* __restr
 
 // Grid cap of the kernels that emit BatchNorm partials per block: below the 1024 rows at which launch_bn_finalize
 // inserts its fold pass (768 instead of 1024: c2 1.088 -> 1.080 ms, two launches fewer on the chain; c3 unchanged).
-static int special_block_cap() {
-  static const int cap = [] { const char* e = getenv("DVG_SPECIAL_BLOCKS"); return e ? atoi(e) : 768; }();
-  return cap < 64 ? 64 : cap;
-}
+static int special_block_cap() { return 768; }
 int enc_conv0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > special_block_cap() ? special_block_cap() : b); }
 
 int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const float* b, float* Y, float* stats_part,
@@ -312,89 +309,8 @@ int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float*
   return DVG_OK;
 }
 
-// dX_small[q][ci] = sum over the 4 up-pixels (y,x) of quad q and taps: dY(y+kh-1, x+kw-1) Wt[ci][kh][kw]
-// thread = (small pixel, group of 8 channels)
-__global__ __launch_bounds__(256) void dec_conv3_dgrad_kernel(const float* __restrict__ dY, int64_t N,
-                                                              const float* __restrict__ w, float* __restrict__ dX) {
-  __shared__ float ws[9 * 32];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += 256) ws[(i % 9) * 32 + i / 9] = w[i];
-  __syncthreads();
-  const int64_t total = N * 64 * 4;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < total; e += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(e & 3);
-    const int64_t q = e >> 2;  // global small pixel
-    const int64_t img = q >> 6;
-    const uint32_t ps = (uint32_t)(q & 63);
-    const int ys = (int)morton_y(ps), xs = (int)morton_x(ps);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        const int y = 2 * ys + sy, x = 2 * xs + sx;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int yy = y + kh - 1, xx = x + kw - 1;
-            if (yy >= 0 && yy < 16 && xx >= 0 && xx < 16) {
-              const float g = dY[img * 256 + morton((uint32_t)yy, (uint32_t)xx)];
-              const float* wr = ws + (kh * 3 + kw) * 32 + cg * 8;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) acc[k] = fmaf(g, wr[k], acc[k]);
-            }
-          }
-      }
-    float4* dst = reinterpret_cast<float4*>(dX + q * 32 + cg * 8);
-    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-  }
-}
-
-int launch_dec_conv3_dgrad(const float* dY, int64_t N, const float* w, float* dX, hipStream_t s) {
-  const int64_t g = ceil_div(N * 256, 256);
-  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_dgrad_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, dY, N, w, dX);
-  return DVG_OK;
-}
-
-// dWt[ci][kh][kw] = sum_{img,y,x} dY(y,x) * Xup(y+1-kh, x+1-kw)[ci]; part[blk][tap*32 + ci]
-// block = 288 threads (tap, ci); one image (256 output pixels) per iteration
-// Per image: first fold the output gradient onto the 8x8 input grid,
-//   G[q][tap] = sum of dY over the (<= 4) output pixels whose tap reads input pixel q,
-// then dW[tap][ci] += sum_q G[q][tap] * X[q][ci]  (64 coalesced row reads instead of 256 gathers).
-__global__ __launch_bounds__(288) void dec_conv3_wgrad_kernel(const float* __restrict__ X, int64_t N,
-                                                              const float* __restrict__ dY, float* __restrict__ part) {
-  __shared__ float dys[256];
-  __shared__ float G[64 * 9];
-  const int tid = threadIdx.x;
-  const int tap = tid >> 5, ci = tid & 31;
-  float acc = 0.f;
-  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
-    __syncthreads();
-    if (tid < 256) dys[tid] = dY[img * 256 + tid];
-    __syncthreads();
-    for (int e = tid; e < 576; e += 288) {
-      const int q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
-      const int ys = (int)morton_y((uint32_t)q), xs = (int)morton_x((uint32_t)q);
-      float g = 0.f;
-#pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-          // output pixel (y,x) reads input (y+1-kh, x+1-kw); that lands in quad q for these (y,x):
-          const int y = 2 * ys + sy - 1 + kh, x = 2 * xs + sx - 1 + kw;
-          if (y >= 0 && y < 16 && x >= 0 && x < 16) g += dys[morton((uint32_t)y, (uint32_t)x)];
-        }
-      G[e] = g;
-    }
-    __syncthreads();
-    const float* xb = X + img * 64 * 32 + ci;
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) acc = fmaf(G[q * 9 + tap], xb[q * 32], acc);
-  }
-  part[(size_t)blockIdx.x * 288 + tid] = acc;
-}
+// (the separate data-gradient and weight-gradient kernels of this layer were retired in round 3: dec_conv3_bwd_kernel below
+// produces both from one pass over the images)
 
 // Data gradient AND weight gradient in one pass over the images.  Both are products with the same small matrix
 //   G[q][tap] = sum of dY over the (<= 4) output pixels whose tap reads source pixel q        (64 x 9 per image):
@@ -468,10 +384,6 @@ int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float
   return DVG_OK;
 }
 
-int launch_dec_conv3_wgrad(const float* X, int64_t N, const float* dY, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_wgrad_kernel, dim3(EW_BLOCKS), dim3(288), 0, s, X, N, dY, part);
-  return DVG_OK;
-}
 
 // ------------------------------------------------------------------------------ decoder final conv (1 -> 1)
 // X [N*256 (16x16 Morton)] upsampled to 32x32; out (N,32,32) row-major

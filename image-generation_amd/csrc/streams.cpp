@@ -5,7 +5,7 @@
 // on a side stream behind an event of the caller's stream and joined back before the call returns, so to the caller
 // the call is still "a sequence of work on `stream`".  The pattern is capture-safe: under hipStreamBeginCapture the
 // event wait pulls the side stream into the capture and the join closes the fork, so the captured graph simply gets
-// two parallel branches.  DVG_NO_SIDE_STREAM=1 keeps everything on the caller's stream (A/B measurements, debugging).
+// two parallel branches.  Option side_stream = 0 keeps everything on the caller's stream (A/B measurements, debugging).
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -50,13 +50,7 @@ bool side_enabled();
 // dvg_graph_create call this, and they always precede the first captured step).
 void side_stream_warm() { if (side_enabled()) (void)ctx(); }
 
-bool side_enabled() {
-  static const bool off = [] {
-    const char* e = std::getenv("DVG_NO_SIDE_STREAM");
-    return e && e[0] && e[0] != '0';
-  }();
-  return !off;
-}
+bool side_enabled() { return opt(OPT_SIDE_STREAM) != 0; }
 
 hipStream_t side_stream(hipStream_t fallback) {
   if (!side_enabled()) return fallback;

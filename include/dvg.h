@@ -297,6 +297,19 @@ int dvg_stream_anchor(dvg_stream_t stream);
 int dvg_set_conv_precision(int mode);
 int dvg_get_conv_precision(void);
 
+/* ------------------------------------------------------------------ kernel-form options
+ * The library has ONE path per operation by default; a handful of named integer options select alternative kernel forms
+ * of the same function (A/B measurements; tests that compare two forms).  They are part of this boundary -- nothing in
+ * the library reads the environment.  Names and meanings: dvg_option_name(i) / dvg_option_doc(i), i < dvg_option_count();
+ * INTEGRATION.md lists them.  Options may be changed between calls; a backward call whose forward ran under another plan
+ * fails with DVG_E_INVALID.  dvg_reset_options restores every default. */
+int dvg_option_count(void);
+const char *dvg_option_name(int index);
+const char *dvg_option_doc(int index);
+int dvg_set_option(const char *name, int64_t value);
+int dvg_get_option(const char *name, int64_t *value);
+int dvg_reset_options(void);
+
 /* ------------------------------------------------------------------ profiler
  * Optional per-kernel HIP-event timing inside the library (used by bench.py for
  * the `roofline` object).  Off by default.  `kernel_mask` bit i enables kernel id i

@@ -49,3 +49,24 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DvgError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_kernel_form_options_live_in_the_abi_not_in_the_environment():
+    """dvg_set_option / dvg_get_option / dvg_reset_options (include/dvg.h): every option has a name, a documented meaning
+    and a default; unknown names are errors; and no source file of the library reads the environment any more."""
+    opts = _lib.options()
+    assert {"igemm_dma", "igemm_posmajor", "dec_d22", "dec_lc0", "mmd_w128", "wgrad_dma", "side_stream"} <= set(opts)
+    assert all(doc for _v, doc in opts.values())
+    assert opts["dec_lc0"][0] == -1 and opts["igemm_dma"][0] == 1
+    with _lib.option_scope(dec_lc0=0, igemm_posmajor=0):
+        assert _lib.get_option("dec_lc0") == 0 and _lib.get_option("igemm_posmajor") == 0
+    assert _lib.get_option("dec_lc0") == -1 and _lib.get_option("igemm_posmajor") == 1
+    with pytest.raises(_lib.DvgError, match="unknown option"):
+        _lib.set_option("no_such_option", 1)
+    _lib.set_option("mmd_blocks", 128)
+    _lib.check(_lib.lib().dvg_reset_options())
+    assert _lib.get_option("mmd_blocks") == 256
+    src = os.path.join(ROOT, "image-generation_amd", "csrc")
+    offenders = [f for f in os.listdir(src) if os.path.isfile(os.path.join(src, f))
+                 and "getenv(" in open(os.path.join(src, f)).read().replace("getenv() sites", "")]
+    assert offenders == [], offenders

@@ -48,12 +48,13 @@ def test_gibbs_bit_exact(fam, n, C, sweeps):
 
 
 def test_gibbs_many_slot_fast_form_bit_exact():
-    """DVG_GIBBS_BIGFAST=1 selects the register-resident schedule for the 1024-spin graphs (24 slots, 8-wave
-    workgroups); the switch is read once per process, so the case runs in a child."""
+    """Option gibbs_bigfast = 1 selects the register-resident schedule for the 1024-spin graphs (24 slots, 8-wave
+    workgroups); the bit-exactness cases re-run under it in a child (tests/conftest.py applies DVG_TEST_OPTIONS through
+    dvg_set_option)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, DVG_GIBBS_BIGFAST="1")
+    env = dict(os.environ, DVG_TEST_OPTIONS="gibbs_bigfast=1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_gibbs.py"), "-q", "-m", "gpu",
                         "-k", "test_gibbs_bit_exact and 1024"], env=env, cwd=root, capture_output=True, text=True,

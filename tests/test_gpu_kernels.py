@@ -15,12 +15,12 @@ def _rel(a, b):
 
 @pytest.fixture(params=["reg", "dma"])
 def staging(request):
-    """Both staging forms of the float32 GEMM kernels (DVG_IGEMM_DMA, DVG_WGRAD_DMA; the product runs the LDS-DMA forms):
+    """Both staging forms of the float32 GEMM kernels (options igemm_dma, wgrad_dma; the product runs the LDS-DMA forms):
     register-staged with ds_write, and LDS-DMA (forward / data-gradient with K-major packed weights; 3x3 weight gradient)."""
-    import os
-    os.environ["DVG_IGEMM_DMA"] = os.environ["DVG_WGRAD_DMA"] = "1" if request.param == "dma" else "0"
-    yield request.param
-    os.environ.pop("DVG_IGEMM_DMA", None); os.environ.pop("DVG_WGRAD_DMA", None)
+    from image_generation_amd import _lib
+    v = 1 if request.param == "dma" else 0
+    with _lib.option_scope(igemm_dma=v, wgrad_dma=v):
+        yield request.param
 
 
 @pytest.mark.parametrize("N,Cin,Cout,side", [(3, 32, 64, 16), (5, 64, 128, 8), (7, 128, 96, 4), (2, 64, 32, 8), (33, 32, 32, 4),
@@ -51,18 +51,16 @@ def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side, staging):
 @pytest.mark.parametrize("N,Cin,Cout,side", [(1024, 32, 64, 4), (8192, 32, 64, 2), (1024, 128, 128, 8)])
 def test_position_major_tiles_are_bit_identical_to_pixel_major_tiles(N, Cin, Cout, side):
     """Position-major tiles (conv.h: ConvArgs.posmajor) skip the taps that fall outside the image -- multiplications by
-    zero padding -- and keep the order of the rest: the same bits as pixel-major tiles (DVG_NO_POSMAJOR=1)."""
+    zero padding -- and keep the order of the rest: the same bits as pixel-major tiles (option igemm_posmajor = 0)."""
     import os
     torch.manual_seed(N + side)
     L, M = side.bit_length() - 1, N * side * side
     x = torch.randn(M, Cin, device="cuda"); w = (torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5)).cuda(); b = torch.randn(Cout).cuda()
     outs = {}
-    for flag in ("1", "0"):
-        os.environ["DVG_NO_POSMAJOR"] = flag
-        try:
+    from image_generation_amd import _lib
+    for flag in ("1", "0"):  # "1": pixel-major tiles
+        with _lib.option_scope(igemm_posmajor=0 if flag == "1" else 1):
             outs[flag] = dev.conv_igemm(x, w, 0, M, Cin, Cout, L, bias=b, stats=True)
-        finally:
-            os.environ.pop("DVG_NO_POSMAJOR", None)
     assert torch.equal(outs["0"][0], outs["1"][0])
     # (the BatchNorm partial rows group other pixels: their totals agree to float32 rounding)
     assert _rel(outs["0"][1].sum(0), outs["1"][1].sum(0)) < 1e-5
@@ -183,18 +181,13 @@ def test_bf16_inputs_linear_as_one_tap_gemm():
 # accumulation.  The bar is the float32 kernel's own: against float64 it must be as close as the f32-MFMA form is.
 
 class _split3:
-    """(DVG_SPLIT3_ALL: the split form for every tile configuration -- the product only uses it for launches large
-    enough for the 128 x 128 tile)"""
+    """(the split form serves every tile configuration of the LDS-DMA kernel)"""
     def __enter__(self):
-        import os
         from image_generation_amd import _lib
         self.lib = _lib.lib()
-        os.environ["DVG_SPLIT3_ALL"] = "1"
         assert self.lib.dvg_set_conv_precision(2) == 0 and self.lib.dvg_get_conv_precision() == 2
 
     def __exit__(self, *exc):
-        import os
-        os.environ.pop("DVG_SPLIT3_ALL", None)
         assert self.lib.dvg_set_conv_precision(0) == 0
 
 

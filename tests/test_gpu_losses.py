@@ -54,13 +54,13 @@ def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
     want, gwant = _ref_mmd(x, y, **kw)
     w32, _ = _ref_mmd(x, y, dtype=torch.float32, **kw)
     out = {}
+    from image_generation_amd import _lib
     for flag in ("1", "0"):
-        monkeypatch.setenv("DVG_MMD_W128", flag)
-        monkeypatch.setenv("DVG_MMD_D256", flag)  # (and the 256-row-block distance-sum kernel with it)
-        xg = x.cuda().requires_grad_(True)
-        loss = F.mmd_loss(xg, y.cuda(), **kw)
-        loss.backward()
-        out[flag] = (float(loss.detach()), xg.grad.cpu().double())
+        with _lib.option_scope(mmd_w128=int(flag), mmd_d256=int(flag)):  # (and the 256-row-block distance-sum kernel with it)
+            xg = x.cuda().requires_grad_(True)
+            loss = F.mmd_loss(xg, y.cuda(), **kw)
+            loss.backward()
+            out[flag] = (float(loss.detach()), xg.grad.cpu().double())
     for flag, (lv, g) in out.items():
         err = abs(lv - float(want))
         assert err <= max(1e-5 * abs(float(want)), 2e-7, 2 * abs(float(w32) - float(want))), (flag, lv, float(want))
@@ -72,7 +72,9 @@ def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
 def test_mmd_128_row_block_kernel_loss_only_and_float_rows(monkeypatch):
     """No gradient asked for (loss-only walk), and general float rows under the forced flag (the spin kernel stands down
     on the device flag and the f32 kernel behind it serves the call)."""
-    monkeypatch.setenv("DVG_MMD_W128", "1")
+    from image_generation_amd import _lib
+    _lib.set_option("mmd_w128", 1)
+    # (options are reset after every test by the autouse fixture in conftest.py)
     rng = np.random.default_rng(5)
     x, y = _spins(rng, 700, 256, 0.4), _spins(rng, 90, 256, 0.5)
     want, gwant = _ref_mmd(x, y)

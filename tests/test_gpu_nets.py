@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import gen
+from image_generation_amd import _lib
 from image_generation_amd.modules import Decoder, Encoder
 from oracle import nets
 
@@ -199,15 +200,12 @@ def test_decoder_gradients_do_not_depend_on_the_staging_form(n, B, R):
     go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
     grads = {}
     for form in ("0", "1"):
-        os.environ["DVG_WGRAD_DMA"] = form
-        try:
+        with _lib.option_scope(wgrad_dma=int(form)):
             dec = _load(Decoder(n), params).train()
             dec.inject_dropout_masks(masks)
             sg = spins.clone().requires_grad_(True)
             (dec(sg) * go).sum().backward()
             grads[form] = {k: v.grad.clone() for k, v in dec.named_parameters()}
-        finally:
-            os.environ.pop("DVG_WGRAD_DMA", None)
     for k in grads["0"]:
         if k == "increase_latent_dim.weight" and n % 128 == 0:
             _close(grads["1"][k].cpu(), grads["0"][k].cpu(), 2e-6, k)
@@ -218,10 +216,10 @@ def test_decoder_gradients_do_not_depend_on_the_staging_form(n, B, R):
 @pytest.mark.parametrize("n,B,R,gtol", [(32, 7, 2, 2e-5), (64, 5, 3, 2e-5), (128, 16, 8, 2e-5), (256, 33, 4, 2e-5), (128, 64, 8, 2e-3)])
 def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B, R, gtol):
     """ConvTranspose2d 3x3 on the 2x2 images behind the Linear layer runs as one dense map per image (only the 4 of 9
-    taps that land inside the image: 16/36 of the FLOPs; DVG_NO_D22=1 keeps the 9-tap implicit GEMM), and for large
+    taps that land inside the image: 16/36 of the FLOPs; option dec_d22 = 0 keeps the 9-tap implicit GEMM), and for large
     batches the Linear layer and that map are composed into ONE linear map per image whose weight is formed per step,
-    the gradients of both original weights following by the chain rule in weight space (DVG_LC0=1 forces it on small
-    batches, DVG_NO_LC0=1 keeps the two GEMMs).  Same output, same gradients of every parameter (summation order apart),
+    the gradients of both original weights following by the chain rule in weight space (option dec_lc0 = 1 forces it on small
+    batches, dec_lc0 = 0 keeps the two GEMMs).  Same output, same gradients of every parameter (summation order apart),
     same BatchNorm statistics.  (Gradient bar 2e-5 on the small cases; the 512-image case has enough activations --
     ~10^6 -- that one of them sits within the forms' 1e-6 forward difference of LeakyReLU's kink and takes the other
     slope in the backward pass: measured 3e-4 there, between ANY two forms, so its bar is 2e-3.)"""
@@ -229,11 +227,10 @@ def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B
     spins = torch.from_numpy(gen.make_spins(B, R, n, 13)).cuda()
     masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 10)]
     go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(6)).cuda()
-    forms = {"9tap": {"DVG_NO_D22": "1", "DVG_NO_LC0": "1"}, "dense": {"DVG_NO_LC0": "1"}, "composed": {"DVG_LC0": "1"}}
+    forms = {"9tap": dict(dec_d22=0, dec_lc0=0), "dense": dict(dec_lc0=0), "composed": dict(dec_lc0=1)}
     res = {}
-    for name, env in forms.items():
-        os.environ.update(env)
-        try:
+    for name, opts in forms.items():
+        with _lib.option_scope(**opts):
             dec = _load(Decoder(n), params).train()
             dec.inject_dropout_masks(masks)
             sg = spins.clone().requires_grad_(True)
@@ -244,9 +241,6 @@ def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B
             dec.eval()
             with torch.no_grad():
                 res[name] += (dec(spins).cpu(),)
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
     for name in ("dense", "composed"):
         _close(res[name][0], res["9tap"][0], 1e-5, name + " output")
         _close(res[name][4], res["9tap"][4], 1e-5, name + " eval output")
@@ -262,7 +256,7 @@ def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B
 def test_position_major_tiles_equal_pixel_major_tiles():
     """Launches whose images fill whole row blocks run position-major tiles (a tile = one pixel position of 64..128
     images; the K loop skips the taps that fall outside the image: conv_igemm.hip) -- plain 3x3 and both folded forms.
-    DVG_NO_POSMAJOR=1 keeps pixel-major tiles.  Same networks, 1024 images: outputs to 1e-5 (the BatchNorm partial sums
+    option igemm_posmajor = 0 keeps pixel-major tiles.  Same networks, 1024 images: outputs to 1e-5 (the BatchNorm partial sums
     group other rows), gradients to 2e-3 (LeakyReLU kink, see the composed-form test)."""
     n, B, R = 64, 128, 8
     dparams, eparams = gen.make_params(n, "decoder", 9), gen.make_params(n, "encoder", 10)
@@ -272,9 +266,8 @@ def test_position_major_tiles_equal_pixel_major_tiles():
     imgs = torch.from_numpy(gen.make_images(1024, 5)).cuda()
     gl = torch.randn(1024, n, generator=torch.Generator().manual_seed(9)).cuda()
     res = {}
-    for flag in ("1", "0"):
-        os.environ["DVG_NO_POSMAJOR"] = flag
-        try:
+    for flag in ("1", "0"):  # "1": pixel-major tiles (igemm_posmajor = 0), "0": the default
+        with _lib.option_scope(igemm_posmajor=0 if flag == "1" else 1):
             dec = _load(Decoder(n), dparams).train()
             dec.inject_dropout_masks(masks)
             sg = spins.clone().requires_grad_(True)
@@ -286,8 +279,6 @@ def test_position_major_tiles_equal_pixel_major_tiles():
             res[flag] = (out.detach().cpu(), logits.detach().cpu(), sg.grad.cpu(),
                          {"dec." + k: v.grad.cpu() for k, v in dec.named_parameters()} |
                          {"enc." + k: v.grad.cpu() for k, v in enc.named_parameters()})
-        finally:
-            os.environ.pop("DVG_NO_POSMAJOR", None)
     _close(res["0"][0], res["1"][0], 1e-5, "decoder output")
     _close(res["0"][1], res["1"][1], 1e-5, "encoder logits")
     _close(res["0"][2], res["1"][2], 2e-3, "grad spins")
@@ -534,15 +525,15 @@ def test_operand_mode_must_not_change_between_forward_and_backward():
 
 
 def test_wide_tile_configuration_in_a_child_process():
-    """The 128x128 convolution tile serves launches of >= 512 such blocks (c3-scale batches); DVG_IGEMM_THR128=1 sends
-    every 128-multiple layer of the small fixtures through it.  The switch is read once per process: child run."""
+    """The 128x128 convolution tile serves launches of >= 512 such blocks (c3-scale batches); option igemm_thr128 = 1 sends
+    every 128-multiple layer of the small fixtures through it.  The whole selection of tests re-runs under it in a child."""
     import os
     import subprocess
     import sys
-    if os.environ.get("DVG_IGEMM_THR128"):
+    if os.environ.get("DVG_TEST_OPTIONS"):
         pytest.skip("already inside the child")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DVG_IGEMM_THR128="1")
+    env = dict(os.environ, DVG_TEST_OPTIONS="igemm_thr128=1")  # (tests/conftest.py applies it through dvg_set_option)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_nets.py"),
                         os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-m", "gpu", "-k",
                         "decoder_matches_oracle_full_gradients or matches_reference_fixture or bf16 or conv2d_fwd_dgrad_wgrad"],

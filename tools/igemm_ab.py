@@ -1,11 +1,11 @@
-"""A/B of the float32 implicit-GEMM kernel's two staging forms (register-staged vs LDS-DMA, DVG_IGEMM_DMA) on c3- and
+"""A/B of the float32 implicit-GEMM kernel's two staging forms (register-staged vs LDS-DMA, option igemm_dma) on c3- and
 c2-sized layer shapes: `PYTHONPATH=. python tools/igemm_ab.py` on an MI355X.  Also checks that both give the same answer."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from image_generation_amd import dev
+from image_generation_amd import _lib, dev
 
 def run(M, Cin, Cout, L, dma, x, w, reps=20):
-    os.environ["DVG_IGEMM_DMA"] = dma
+    _lib.set_option("igemm_dma", int(dma))
     wp = torch.empty(9 * Cin * Cout * 2, device="cuda")
     out = dev.conv_igemm(x, w, 2, M, Cin, Cout, L, 9, 0, 0, wp=wp)
     torch.cuda.synchronize()

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import image_generation_amd  # noqa: E402,F401
-from image_generation_amd import functional as F  # noqa: E402
+from image_generation_amd import _lib, functional as F  # noqa: E402
 from oracle import plugin  # noqa: E402
 
 nx, ny, d = 32768, 256, 512
@@ -51,9 +51,9 @@ def run(label, yy):
           f" {float(err.abs().max()) / parts:.2e} of the parts; mean signed err / parts {float(err.mean()) / parts:+.2e}")
 
 
-os.environ["DVG_MMD_W128"] = "1"
+_lib.set_option("mmd_w128", 1)
 run("(a) 128-row-block spin kernel, 2 bf16 terms", y)
-os.environ["DVG_MMD_W128"] = "0"
+_lib.set_option("mmd_w128", 0)
 run("(b) 32-row-block spin kernel, 3 bf16 terms", y)
 y2 = y.clone()
 y2[-1, -1] = torch.nextafter(y2[-1, -1], torch.tensor(0.0, device="cuda"))

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 if "--w128" in sys.argv:
-    os.environ["DVG_MMD_W128"] = sys.argv[sys.argv.index("--w128") + 1]
+    _lib.set_option("mmd_w128", int(sys.argv[sys.argv.index("--w128") + 1]))
 import torch  # noqa: E402
 
 import image_generation_amd  # noqa: E402,F401
@@ -44,4 +44,4 @@ for i, nm in enumerate(names):
         tot += ms.value / reps
         extra = f"  {work.value / (ms.value * 1e-3) / 1e12:8.1f} TFLOP/s-equivalent" if work.value and nm == "mmd_pm1" else ""
         print(f"{nm:16s} {ms.value / reps * 1e3:10.1f} us/call  ({cnt.value // reps} launches){extra}")
-print(f"sum of kernels   {tot * 1e3:10.1f} us/call   shape ({nx}, {ny}, {d})  DVG_MMD_W128={os.environ.get('DVG_MMD_W128')}")
+print(f"sum of kernels   {tot * 1e3:10.1f} us/call   shape ({nx}, {ny}, {d})  mmd_w128={_lib.get_option('mmd_w128')}")

@@ -1,11 +1,11 @@
-"""A/B of the 3x3 weight-gradient kernel's two staging forms (register-staged vs LDS-DMA, DVG_WGRAD_DMA) on c3- and
+"""A/B of the 3x3 weight-gradient kernel's two staging forms (register-staged vs LDS-DMA, option wgrad_dma) on c3- and
 c2-sized layer shapes: `PYTHONPATH=. python tools/wgrad_ab.py` on an MI355X (times include the slab reduce pass)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from image_generation_amd import dev
+from image_generation_amd import _lib, dev
 
 def run(x, dy, M, Cin, Cout, L, ups, dma, reps=10):
-    os.environ["DVG_WGRAD_DMA"] = dma
+    _lib.set_option("wgrad_dma", int(dma))
     shape = (Cin, Cout, 3, 3)
     g = dev.conv_wgrad(x, dy, 2, shape, M, Cin, Cout, L, ups=ups)
     torch.cuda.synchronize()
