@@ -77,6 +77,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
   // 405 -> 616 us) because the third stage costs the second resident block per CU; co-resident blocks hide that round
   // trip better than a deeper ring does.
   constexpr int NS = 2;
+#ifndef IGEMM_LATE_ISSUE
+#define IGEMM_LATE_ISSUE 1
+#endif
   // [WM][BN][2] BatchNorm partials of the epilogue (LDS-DMA form: on top of the then-dead stage 0, behind a barrier)
   float* red = DMA ? reinterpret_cast<float*>(igemm_smem)
                : Bs + BKT * BP;
@@ -305,13 +308,6 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       fetch_nbr();
       issue(0);
       if (it_beg + 1 < it_end) fetch_nbr();
-      if constexpr (NS == 3) {
-        if (it_beg + 1 < it_end) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          issue(1);
-          if (it_beg + 2 < it_end) fetch_nbr();
-        }
-      }
     }
     constexpr int NPC = PM == 4 ? 3 : 1;  // bf16 pieces per operand (forms 4 / 5)
     bf16x8v pa[NPC][TM], pb[NPC][TN];     // converted operands of the pending k-step (forms 4 / 5)
@@ -326,17 +322,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       }
     }
     for (int it = it_beg; it < it_end; ++it) {
-      const int buf = (it - it_beg) % NS;
-      // this wave's pieces of chunk `it` have landed (ring of three: those of chunk it+1 may still be in flight) ...
-      if (NS == 3 && it + 1 < it_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAW + PBW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                    // ... everyone's have, and the stage read last iteration is free
-      if constexpr (NS == 2) {
+      const int buf = (it - it_beg) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it` have landed ...
+      __syncthreads();                                    // ... everyone's have, and stage buf^1 is free again
+      if constexpr (PM != 3 || !IGEMM_LATE_ISSUE) {
         if (it + 1 < it_end) issue(buf ^ 1);
         if (it + 2 < it_end) fetch_nbr();
-      } else {
-        if (it + 2 < it_end) issue((it - it_beg + 2) % NS);
-        if (it + 3 < it_end) fetch_nbr();
       }
       const unsigned char* Ab = stg + buf * STAGE + wm * TM * 32 * 128;
       const unsigned char* Bb = stg + buf * STAGE + BM * 128 + wn * TN * 32 * 128;
@@ -449,6 +440,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i][e], bv[cur][j][e], acc[i][j], 0, 0, 0);
         if (j4 < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+        if constexpr (IGEMM_LATE_ISSUE) {
+          if (j4 == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < it_end) issue(buf ^ 1);
+            if (it + 2 < it_end) fetch_nbr();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
     if constexpr (PM == 4 || PM == 5) {  // the last k-step's MFMAs
