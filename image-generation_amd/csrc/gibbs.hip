@@ -131,8 +131,14 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 //     the adds stay sequential -- the rolled loop paid two dependent LDS latencies per neighbour.
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
 constexpr int GIBBS_MAXS_BIG = 24;   // 8-wave instantiation for the 1024-spin graphs (20 slots at 64 lanes per chain)
-template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
+//   * (round 3) WPC = 2: TWO waves per chain (LPC = 64): a colour class of up to 128 spins is one pass of 128 lanes
+//     instead of two passes of 64, which halves the dependent slot-steps of a sweep.  With few chains (c3: 256) the draw is
+//     one instruction stream per chain on a quarter of the chip's SIMDs, issue-bound at one wave per SIMD (~4000
+//     instructions per sweep); it runs beside the encoder forward and the MMD cannot start before it ends.  The two waves
+//     of a chain meet at a workgroup barrier per colour class (every wave of the workgroup runs the same classes).
+template <int LPC, int WAVES, int MAXS = GIBBS_MAXS, int WPC = 1>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
+  static_assert(WPC == 1 || (LPC == 64 && WAVES % WPC == 0 && MAXS <= GIBBS_MAXS), "two waves per chain: 64-lane chains only");
   extern __shared__ __align__(16) unsigned char smem[];
   const int n = a.n, n_adj = a.n_adj;
   float* s_hs = reinterpret_cast<float*>(smem);
@@ -159,11 +165,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   __syncthreads();
 
   constexpr int CPW = 64 / LPC;
+  constexpr int LPCE = LPC * WPC;  // lanes that work on one chain
   const int wave = tid >> 6, lane = tid & 63;
-  const int sub = lane / LPC, l = lane % LPC;
-  const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
+  const int sub = lane / LPC, l = WPC == 1 ? lane % LPC : lane + 64 * (wave % WPC);
+  const int chain = WPC == 1 ? (blockIdx.x * WAVES + wave) * CPW + sub : blockIdx.x * (WAVES / WPC) + wave / WPC;
   const bool valid = chain < a.n_chains;
-  int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
+  int8_t* st = s_state + (size_t)(WPC == 1 ? wave * CPW + sub : wave / WPC) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
   // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
@@ -171,18 +178,22 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if (valid) {
     if (a.init) {
-      for (int i = l; i < n; i += LPC) {
+      for (int i = l; i < n; i += LPCE) {
         u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
         st[i] = (r.x >> 31) ? 1 : -1;
       }
     } else {
       const int8_t* src = a.state + (size_t)chain * n;
-      for (int i = l; i < n; i += LPC) st[i] = src[i];
+      for (int i = l; i < n; i += LPCE) st[i] = src[i];
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  if (!valid) return;
+  if constexpr (WPC > 1) {
+    __syncthreads();  // (both waves of a chain wrote its start state; invalid chains keep the barriers company below)
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (!valid) return;
+  }
 
   const int passes = a.passes, n_slots = a.n_colours * passes;
   if constexpr (MAXS > GIBBS_MAXS) {
@@ -252,8 +263,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
     sp[k] = -1; q0[k] = 0; q1[k] = 0; hs[k] = 0.f;
     if (k < n_slots) {
       const int col = k / passes, pass = k - col * passes;
-      const int p = s_cls[col] + pass * LPC + l;
-      if (p < s_cls[col + 1]) {
+      const int p = s_cls[col] + pass * LPCE + l;
+      if (valid && p < s_cls[col + 1]) {
         const int i = s_order[p];
         sp[k] = i; q0[k] = s_adjptr[i]; q1[k] = s_adjptr[i + 1]; hs[k] = s_hs[i];
       }
@@ -295,16 +306,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
           const float b = __fmul_rn(u01, __fadd_rn(1.0f, tt));
           st[sp[k]] = (b < 1.0f) ? 1 : -1;
         }
-        // the next class reads what this one wrote (same wave): order LDS traffic.  (Passes of one class are
-        // independent of each other, so a fence between them is harmless.)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        // the next class reads what this one wrote (same wave, or the chain's two waves): order LDS traffic.  (Passes of
+        // one class are independent of each other, so a fence between them is harmless.)
+        if constexpr (WPC > 1) {
+          __syncthreads();
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
   }
   }
+  if (!valid) return;
   int8_t* dst = a.state + (size_t)chain * n;
-  for (int i = l; i < n; i += LPC) {
+  for (int i = l; i < n; i += LPCE) {
     const int8_t v = st[i];
     dst[i] = v;
     if (a.samples_out) a.samples_out[(size_t)chain * n + i] = (float)v;
@@ -318,6 +334,19 @@ static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_bl
   b += sizeof(uint16_t) * (size_t)(((n + 2) & ~1) + ((n + 1) & ~1) + ((n_adj + 1) & ~1));
   b += (size_t)chains_per_block * ((n + 15) & ~15);
   return b;
+}
+
+// two waves per chain (fast kernel only): 4-wave workgroups of two chains
+static int launch_gibbs_wpc2(GibbsArgs a, hipStream_t s, int max_class) {
+  constexpr int WAVES = 4, CPB = 2;
+  a.passes = (max_class + 127) / 128;
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_adj, a.n_colours, CPB);
+  auto kern = gibbs_fast_kernel<64, WAVES, GIBBS_MAXS, 2>;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)ceil_div(a.n_chains, CPB);
+  DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  return DVG_OK;
 }
 
 template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
@@ -403,6 +432,10 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
     case 8: return launch_gibbs<LPC, 8>(a, s, fast, mc);                     \
     default: return launch_gibbs<LPC, 4>(a, s, fast, mc);                    \
   }
+  // classes of 65..128 spins with few chains (c3: 512 spins, 256 chains): two waves per chain, one pass per class
+  if (fast && !waves_env && mc > 64 && mc <= 128 && g->n_colours <= GIBBS_MAXS && n_chains <= 1024 &&
+      gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) != 1)
+    return launch_gibbs_wpc2(a, s, mc);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
   if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }
   DVG_GIBBS_DISPATCH(64)
