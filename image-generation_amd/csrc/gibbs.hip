@@ -432,9 +432,12 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
     case 8: return launch_gibbs<LPC, 8>(a, s, fast, mc);                     \
     default: return launch_gibbs<LPC, 4>(a, s, fast, mc);                    \
   }
-  // classes of 65..128 spins with few chains (c3: 512 spins, 256 chains): two waves per chain, one pass per class
+  // classes of 65..128 spins with few chains (c3: 512 spins, 256 chains): two waves per chain, one pass per class --
+  // option gibbs_waves_per_chain = 2.  Alone it is the faster draw (1.79 -> 1.38 ms); inside a training step it runs
+  // beside the encoder forward on twice the workgroups and the STEP does not move (c3 11.74 vs 11.76 ms, the encoder's
+  // GEMMs 433 -> 450-500 us each in-situ), so the default stays one wave per chain.
   if (fast && !waves_env && mc > 64 && mc <= 128 && g->n_colours <= GIBBS_MAXS && n_chains <= 1024 &&
-      gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) != 1)
+      gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) == 2)
     return launch_gibbs_wpc2(a, s, mc);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
   if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }

@@ -31,7 +31,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule (bit-identical; A/B reference)"},
     {"gibbs_waves", 0, "sampler: waves per workgroup (0 = chosen by graph size)"},
     {"gibbs_bigfast", 0, "sampler: 1 = 8-wave unrolled form for graphs above 72 KB of tables (faster alone, slower in a step)"},
-    {"gibbs_waves_per_chain", 0, "sampler: 0 two waves per chain where colour classes hold 65..128 spins and chains are few (default), 1 always one"},
+    {"gibbs_waves_per_chain", 1, "sampler: 2 = two waves per chain where colour classes hold 65..128 spins and chains are few (the faster draw ALONE: generation; neutral inside a training step), 1 = one (default)"},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];

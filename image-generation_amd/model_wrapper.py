@@ -482,15 +482,24 @@ class ModelWrapper:
             mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
             if not defer:
                 main.wait_stream(side)
-            torch.autograd.backward([reconstructed_images], [g_recon])
+            # torch.autograd.grad hands the decoder's spin gradient back as the tensor the backward kernel wrote; .backward()
+            # would route it through AccumulateGrad of the leaf, which CLONES it (67 MB at c3: an 86 us copy on the critical
+            # chain).  The decoder's parameter gradients do not travel through autograd at all here: its backward writes
+            # them into the optimizer's flat buffer and sets .grad itself (modules._grad_targets).
+            dec = self._dvae.decoder
+            if getattr(dec, "_grad_sink", None) is not None and all(p.grad is None for p in dec._trainable()):
+                (g_dec,) = torch.autograd.grad([reconstructed_images], [spins_cut], [g_recon])
+            else:
+                torch.autograd.backward([reconstructed_images], [g_recon])
+                g_dec = spins_cut.grad
             if defer:
                 main.wait_stream(side)
             g_spins.record_stream(main)
             if dspin is not None:
-                gl = F.gumbel_backward(dspin, spins_cut.grad, g_spins)  # (the same two terms the autograd engine would add)
+                gl = F.gumbel_backward(dspin, g_dec, g_spins)  # (the same two terms the autograd engine would add)
                 torch.autograd.backward([latents], [gl])
             else:
-                torch.autograd.backward([spins], [spins_cut.grad.add_(g_spins.view_as(spins_cut))])
+                torch.autograd.backward([spins], [g_dec.add_(g_spins.view_as(g_dec))])
             _mmd_loss.record_stream(main)
             dvae_loss = F.scalar_add(mse_loss, _mmd_loss)
             self._reduce_and_step(self._dvae_optimizer)

@@ -16,7 +16,7 @@ lin = torch.from_numpy((0.05 * rng.uniform(-1, 1, n)).astype(np.float32)).cuda()
 quad = torch.from_numpy((5.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)).cuda()
 print(f"n={n} chains={C} sweeps={sweeps} colours={plan.n_colours} max class={max(np.diff(plan.class_ptr))} "
       f"max degree={int(np.diff(plan.adj_ptr).max())}")
-for name, opts in (("default", dict()), ("one wave per chain", dict(gibbs_waves_per_chain=1)), ("rolled reference", dict(gibbs_generic=1))):
+for name, opts in (("default (1 wave / chain)", dict()), ("two waves per chain", dict(gibbs_waves_per_chain=2)), ("rolled reference", dict(gibbs_generic=1))):
     with _lib.option_scope(**opts):
         s = smp.GibbsSampler(plan, nodes, beta=20.0, sweeps=sweeps, seed=seed, persistent=True)
         s.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=C)
@@ -27,4 +27,4 @@ for name, opts in (("default", dict()), ("one wave per chain", dict(gibbs_waves_
             out = s.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=C)
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 5
-        print(f"  {name:18s} {t*1e3:9.1f} us per draw  {C*n*sweeps/t/1e6:8.2f} G spin updates/s  checksum {float(out.sum()):.0f}")
+        print(f"  {name:26s} {t*1e3:9.1f} us per draw  {C*n*sweeps/t/1e6:8.2f} G spin updates/s  checksum {float(out.sum()):.0f}")

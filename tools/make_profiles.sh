@@ -1,16 +1,16 @@
 #!/bin/bash
 # Regenerates everything under profiles/ on a GPU box (run from the repo root through gpurun; outputs land in
 # gpurun_out/profiles_new/, to be copied into profiles/ and committed):
-#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/make_profiles.sh r02'
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/make_profiles.sh r03'
 # Every JSON written by the aggregators carries kernels_hash = dvg_source_hash() of the library measured; bench.py drops
 # profiles whose hash differs from the library it runs.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
 last() { grep '^{"metric"' "$1" | tail -1 > "$2"; }
-# `bash tools/make_profiles.sh r02 bench`: only the bench lines of step 3 (the PMC files already in profiles/ must be of
+# `bash tools/make_profiles.sh r03 bench`: only the bench lines of step 3 (the PMC files already in profiles/ must be of
 # this build of the kernels: bench.py checks their hash)
 if [ "${2:-all}" != "bench" ]; then
 # 1. rocprofv3 kernel stats of the headline command (c3) and of c2
@@ -36,7 +36,7 @@ cp $OUT/${R}_pmc_*.json $ROOT/profiles/
 fi
 # 3. bench lines LAST (they read the PMC files of this build from profiles/)
 cd $ROOT
-python bench.py --breakdown $OUT/${R}_hip_event_breakdown_c3.json > $OUT/c3.log 2>&1; last $OUT/c3.log $OUT/${R}_bench_c3.json
+T0=$SECONDS; python bench.py --breakdown $OUT/${R}_hip_event_breakdown_c3.json > $OUT/c3.log 2>&1; echo "default bench.py (all child runs, CPU baseline, parity): $((SECONDS - T0)) s wall" > $OUT/${R}_bench_default_wall_seconds.txt; last $OUT/c3.log $OUT/${R}_bench_c3.json; tail -5 $OUT/c3.log > $OUT/c3_tail.txt
 python bench.py --config c2 --no-cpu-baseline --steps 30 --breakdown $OUT/${R}_hip_event_breakdown_c2.json > $OUT/c2.log 2>&1; last $OUT/c2.log $OUT/${R}_bench_c2.json
 python bench.py --config c5 --no-cpu-baseline --steps 20 > $OUT/c5.log 2>&1; last $OUT/c5.log $OUT/${R}_bench_c5.json
 python bench.py --config c3 --precision bf16 --no-cpu-baseline --steps 10 > $OUT/c3b.log 2>&1; last $OUT/c3b.log $OUT/${R}_bench_c3_bf16_inputs.json
@@ -44,6 +44,15 @@ python bench.py --config c3 --precision f32x3 --no-cpu-baseline --parity --steps
 python tools/mmd_accuracy.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_accuracy_c3.txt
 python tools/mmd_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_kernels_c3.txt
 python tools/igemm_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_igemm_staging_ab.txt
+python tools/igemm_modes.py 2>&1 | grep -v amdgpu > $OUT/${R}_igemm_operand_modes.txt
+python tools/gibbs_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_gibbs_draw_alone_c3.txt
+python tools/gibbs_bench.py 1024 2048 50 2>&1 | grep -v amdgpu > $OUT/${R}_gibbs_draw_alone_c5.txt
+# the driver's multi-GPU command shape, with the one rank this box has (a forced single-rank RCCL group): the line's `dist`
+# object shows what the process group looked like from inside
+HSA_ENABLE_IPC_MODE_LEGACY=0 DVG_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --child > $OUT/tr1.log 2>&1; last $OUT/tr1.log $OUT/${R}_bench_c3_torchrun_nproc1_forced_dist.json
+# kernel timeline of one c3 step
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $ROOT/bench.py --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
+python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c3_step.txt; rm -rf $OUT/tr
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
-rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/*.log
+rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_*
 ls -la $OUT
