@@ -498,3 +498,50 @@ def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
     assert r["gibbs_spin_mismatches"] == 0
     for name, dev_ in r["max_rel_dev"].items():
         assert dev_ <= 1e-5, (name, dev_)
+
+
+def test_deferred_decoder_join_pins_its_buffers_and_failures_close_the_fork(golden_dir, monkeypatch):
+    """with the decoder's weight-gradient join deferred, the library's side stream still reads the
+    decoder workspace / upstream gradient / spins after ``dvg_decoder_bwd_ex`` returns, and torch's allocator knows nothing
+    of that stream -- so the backward pins those tensors on the module until ``ModelWrapper._join_deferred`` has joined the
+    streams.  And (ADVICE low): an exception between the deferral and the join leaves neither the flag set nor the fork open."""
+    import image_generation_amd.functional as Fn
+
+    torch.manual_seed(0)
+    m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+    B = m.BATCH_SIZE
+    imgs = torch.from_numpy(gen.make_images(B * 3, seed=12)).reshape(3, B, 1, 32, 32).cuda()
+    m.set_dataloader([(imgs[k], None) for k in range(3)])
+    m.train_init(1)
+    dec = m._dvae.decoder
+    # a standalone deferred backward: the pins are there until the join
+    m._dvae.train()
+    m._dvae_optimizer.zero_grad()
+    dec._defer_join = True
+    spins = torch.from_numpy(gen.make_spins(B, int(m.N_REPLICAS), 64, 3)).cuda().requires_grad_(True)
+    out = dec(spins)
+    out.sum().backward()
+    keep = dec._deferred_keep
+    assert keep is not None and keep[0].numel() >= 16 and keep[2].shape == spins.shape  # (workspace, grad_out, spins, ...)
+    ws_ptr = keep[0].data_ptr()
+    scratch = torch.empty(keep[0].numel(), dtype=torch.uint8, device="cuda")  # an allocation made BEFORE the join ...
+    assert scratch.data_ptr() != ws_ptr                                        # ... cannot be carved out of the pinned workspace
+    m._join_deferred()
+    assert dec._deferred_keep is None and dec._defer_join is False
+    torch.cuda.synchronize()
+    # a failure in the middle of the half step: flag cleared, pins dropped, the next step runs
+    real = Fn.replicated_mse_loss_and_grad
+    calls = {"n": 0}
+
+    def boom(*a, **k):
+        calls["n"] += 1
+        raise RuntimeError("injected failure after the decoder forward")
+
+    monkeypatch.setattr(Fn, "replicated_mse_loss_and_grad", boom)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        m.step((imgs[0], None), epoch=0)
+    assert calls["n"] == 1 and dec._defer_join is False and dec._deferred_keep is None
+    monkeypatch.setattr(Fn, "replicated_mse_loss_and_grad", real)
+    m.step((imgs[1], None), epoch=0)
+    torch.cuda.synchronize()
+    assert np.isfinite(m.losses["mse_losses"][-1])
