@@ -286,18 +286,26 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void conv_igemm_kernel(ConvArgs a)
       for (int q = 0; q < PAW; ++q) srcn[q] = (uint32_t)nbr[arow[q] + tf];  // (used a whole chunk later: no wait here)
       if (++fcc == nci) { fcc = 0; ++ftap; }
     };
+    // LDS byte address of the stage ring as a SCALAR: the destination of a buffer_load ... lds travels in M0, and a
+    // destination the compiler cannot prove wave-uniform costs a readfirstlane waterfall loop (~10 instructions and a
+    // branch) per 1 KiB piece -- eight of them per chunk and wave in rounds 2-3a (visible in the ISA; the "100-185 cycles
+    // per piece" of the issue-cost table).
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t stg_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_byte*)stg);
     auto issue = [&](int buf) {
-      unsigned char* dstA = stg + buf * STAGE + wave_u * PAW * 1024;
-      const int ccb = icc * 128;  // wave-uniform: the instruction's scalar offset
+      const uint32_t dstA = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stg_lds + (uint32_t)(buf * STAGE + wave_u * PAW * 1024)));
+      // (the instruction's scalar offset: forced into an SGPR -- the chunk counters are wave-uniform, but the compiler
+      // keeps them in vector registers and then wraps every buffer_load in a readfirstlane waterfall loop)
+      const int ccb = __builtin_amdgcn_readfirstlane(icc * 128);
 #pragma unroll
       for (int q = 0; q < PAW; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dstA + q * 1024), 16, (int)(srcn[q] + acol[q]), ccb, 0, 0);
-      unsigned char* dstB = stg + buf * STAGE + BM * 128 + wave_u * PBW * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(uintptr_t)(dstA + q * 1024), 16, (int)(srcn[q] + acol[q]), ccb, 0, 0);
+      const uint32_t dstB = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stg_lds + (uint32_t)(buf * STAGE + BM * 128 + wave_u * PBW * 1024)));
       const int ti = PMJ ? (int)((tap_list >> (4 * itap)) & 15) : itap;
-      const int boff = (int)(cls_off + (uint32_t)ti * tap_bytes) + ccb;
+      const int boff = __builtin_amdgcn_readfirstlane((int)(cls_off + (uint32_t)ti * tap_bytes) + ccb);
 #pragma unroll
       for (int q = 0; q < PBW; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(dstB + q * 1024), 16, (int)bcol[q], boff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(uintptr_t)(dstB + q * 1024), 16, (int)bcol[q], boff, 0, 0);
       if (++icc == nci) { icc = 0; ++itap; }
     };
     // operand reads: lane (c, hh) owns floats 16 hh .. 16 hh + 15 of row / column c: logical slots 4 hh + j

@@ -49,17 +49,20 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return _
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 // ... as three bf16 pieces each, by truncation (f32_split3_trunc): hi + mid + lo == x bit for bit
 __device__ __forceinline__ void f32x8_split3(const f32x4& q0, const f32x4& q1, bf16x8v& hi, bf16x8v& mid, bf16x8v& lo) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
   u32x4v h, m, l;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const float x0 = u < 2 ? q0[2 * u] : q1[2 * u - 4], x1 = u < 2 ? q0[2 * u + 1] : q1[2 * u - 3];
-    const uint32_t h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
-    const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
-    const uint32_t m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
-    const float t0 = r0 - __uint_as_float(m0), t1 = r1 - __uint_as_float(m1);  // (<= 8 significant bits left: exact in bf16)
-    h[u] = pack_hi16(h0, h1);
-    m[u] = pack_hi16(m0, m1);
-    l[u] = pack_hi16(__float_as_uint(t0), __float_as_uint(t1));
+    const float h0 = __uint_as_float(__float_as_uint(x0) & 0xffff0000u), h1 = __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+    const float r0 = x0 - h0, r1 = x1 - h1;
+    const float m0 = __uint_as_float(__float_as_uint(r0) & 0xffff0000u), m1 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float t0 = r0 - m0, t1 = r1 - m1;  // (<= 8 significant bits left: exact in bf16)
+    // the pieces have zero low halves, so the round-to-nearest pack (v_cvt_pk_bf16_f32: one instruction per pair) is exact
+    h[u] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){h0, h1}, bf16x2v));
+    m[u] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){m0, m1}, bf16x2v));
+    l[u] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){t0, t1}, bf16x2v));
   }
   hi = __builtin_bit_cast(bf16x8v, h);
   mid = __builtin_bit_cast(bf16x8v, m);
