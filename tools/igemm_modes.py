@@ -18,6 +18,10 @@ def run(M, Cin, Cout, L, x, w, reps=20):
     return out, e0.elapsed_time(e1) / reps * 1e3
 
 
+for arg in [a for a in sys.argv[1:] if "=" in a]:
+    name, value = arg.split("=")
+    _lib.set_option(name, int(value))
+    sys.argv.remove(arg)
 shapes = [(128, 128, 2, 32768), (128, 128, 3, 8192), (64, 128, 3, 32768), (128, 64, 3, 32768), (64, 32, 4, 32768), (512, 128, 1, 32768)]
 if len(sys.argv) > 1:
     shapes = shapes[: int(sys.argv[1])]
