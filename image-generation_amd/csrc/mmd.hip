@@ -392,8 +392,8 @@ __device__ __forceinline__ void mmd_distsum_generic(const MmdArgs& a, unsigned c
 
 // Spin rows, d = 128 .. 512 in steps of 128, many rows (c3): 256 rows per block, 64 per wave, resident in registers as
 // int8 MFMA B fragments; the rows of x and y are ONE contiguous int8 array (x then y), walked as a triangle of
-// 256-row blocks x 32-row column chunks (block b takes row blocks b and T-1-b; the chunks of a row block are dealt to
-// gridDim.y blocks).  The kernel is bound by the L2 -> LDS traffic of the column rows, which this shape halves against
+// 256-row blocks x 32-row column chunks (the chunks of a row block are dealt to gridDim.y streams; the blocks of a
+// stream share its row blocks' chunks evenly, see the walk below).  The kernel is bound by the L2 -> LDS traffic of the column rows, which this shape halves against
 // the 128-row form; the chunks [32][d] arrive by LDS-DMA (buffer_load ... lds, double-buffered, 16-byte slots swizzled
 // on the source address, rows past the end read zeros and are masked), one barrier per chunk.  A pair's distance is
 // symmetric and zero on the diagonal: chunks inside the row block's own range count once (the square holds both
@@ -411,11 +411,24 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
   }
   const int N = (int)(a.nx + a.ny);
   const int T = (N + 255) >> 8, TC = (N + 31) >> 5;  // 256-row blocks, 32-row chunks
+  // XCD-aware block -> (row-block pair bx, chunk stream by) map.  The array (c3: 17 MB) does not fit one XCD's 4 MB L2,
+  // and with the plain grid map the blocks that walk the same chunk stream sit on different XCDs (workgroups go
+  // round-robin to the 8 XCDs in linear order): 82 % of the chunk bytes missed L2 (PMC, round 3: 0.89 GB fetched per
+  // launch for 1.09 GB of chunks) and the fabric, not the MFMA, set the pace.  Here every stream lives on ONE XCD
+  // (stream by on XCD by % 8) with its row blocks side by side: block bx reads at step k the chunk its neighbour
+  // bx + 1 read at step k - 1, so a chunk is fetched once per XCD and hit by the other blocks.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = (int)(blockIdx.x + blockIdx.y * gridDim.x), per = (int)gridDim.y >> 3;
+    const int idx = lin >> 3;
+    by = (lin & 7) + 8 * (idx % per);
+    bx = idx / per;
+  }
   const int lane = threadIdx.x & 63, hh = lane >> 5, c = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.zi8), 0, N * D, 0x00020000);
   // DMA pieces: piece q of this wave covers bytes 1024 (NPW wave + q) + 16 lane of the chunk image: row r, physical slot
-  // sl; it fetches logical slot sl ^ f(r)
+  // sl; it fetches logical slot sl ^ f(r)  (a pre-swizzled copy that makes the pieces contiguous measured no faster)
   int poff[NPW];
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
@@ -431,12 +444,37 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(dst + q * 1024), 16, poff[q], t * CH, 0, 0);
   };
   const int fc = (D % 256 == 0) ? (c & 15) : ((c >> 1) & 7);
-  const int tb2 = 2048 + 2 * D;  // LDS byte address of Dtab[h] for Gram value S: tb2 - 2 S  (h = (D - S) / 2)
+  // LDS byte address of Dtab[h] for Gram value S: tb2 - 2 S  (h = (D - S) / 2).  The lookups address LDS absolutely
+  // (accumulator value + immediate offset, no VALU in between): the kernel's dynamic LDS block must start at address 0.
+  constexpr int tb2 = 2048 + 2 * D;
+  typedef __attribute__((address_space(3))) const float lds_cfloat;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  typedef __attribute__((address_space(3))) const i32x4 lds_ci32x4;
+  if ((uint32_t)(uintptr_t)(lds_byte*)dsm != 0u) __builtin_trap();
+  uint32_t zaddr[8];  // absolute LDS addresses of this lane's operand slots in stage 0 (see zread below)
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    zaddr[j] = (uint32_t)(2048 + ((D + 1) * 4 + 1023) / 1024 * 1024) + (uint32_t)(c * D + ((((hh ^ fc) ^ (2 * j)) & 15) << 4));
   double total = 0.0;
   __syncthreads();
-  for (int seg = 0; seg < 2; ++seg) {
-    const int g = seg == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x;
-    if (g >= T || (seg == 1 && g <= (int)blockIdx.x)) break;  // (block-uniform)
+  // The walk of stream `by`: row blocks in the order 0, T-1, 1, T-2, ... (long and short alternate), row block g holding
+  // the chunks t = 8 g + by + S k, k < seglen(g).  The gridDim.x blocks of the stream cut that walk into EQUAL runs of
+  // chunks -- a run covers parts of two to four row blocks -- so that exactly 2 x 256 blocks of equal work fill the chip
+  // (round 2 dealt whole row-block pairs: c3's 65 pairs x 8 streams = 520 blocks for 512 slots, i.e. a second round of 8
+  // blocks that doubled the kernel's time at 41 % MFMA busy).  Everything here is block-uniform scalar work.
+  const int S = (int)gridDim.y, NB = (int)gridDim.x;
+  auto seglen = [&](int g) { const int r = TC - g * 8 - by; return r > 0 ? (r + S - 1) / S : 0; };
+  auto walk_g = [&](int q) { return (q & 1) ? T - 1 - (q >> 1) : (q >> 1); };
+  int walk_total = 0;
+  for (int q = 0; q < T; ++q) walk_total += seglen(walk_g(q));
+  const int per = (walk_total + NB - 1) / NB;
+  const int lo = bx * per, hi = lo + per < walk_total ? lo + per : walk_total;
+  int base = 0;
+  for (int q = 0; q < T && base < hi; ++q) {
+    const int g = walk_g(q), len = seglen(g);
+    const int k0 = lo > base ? lo - base : 0, k1 = hi - base < len ? hi - base : len;
+    base += len;
+    if (k1 <= k0) continue;  // (block-uniform)
     i32x4 xb[2][NST];
     bool vi[2];
 #pragma unroll
@@ -445,9 +483,15 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
       vi[rs] = gi < N;
       const int8_t* xrow = a.zi8 + (int64_t)(vi[rs] ? gi : N - 1) * D + hh * 16;
 #pragma unroll
-      for (int s = 0; s < NST; ++s) xb[rs][s] = *reinterpret_cast<const i32x4*>(xrow + s * 32);
+      for (int s = 0; s < NST; ++s) {
+        // B operand = -2 x (bytes +1 / -1 -> 0xFE / 0x02): the Gram accumulator then holds -2 S, which IS the byte offset
+        // of the pair's distance in the table (tb2 - 2 S) -- no address arithmetic between the MFMA and the lookup
+        const i32x4 w = *reinterpret_cast<const i32x4*>(xrow + s * 32);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xb[rs][s][u] = (int)((((uint32_t)w[u] << 1) & 0xFEFEFEFEu) ^ 0xFCFCFCFCu);
+      }
     }
-    const int t0 = g * 8 + (int)blockIdx.y, t_own_end = g * 8 + 8;
+    const int t0 = g * 8 + by + S * k0, t_end = g * 8 + by + S * k1, t_own_end = g * 8 + 8;
     float part[2] = {0.f, 0.f};  // this segment's sums of the two row sets, flushed to double below
     double segsum[2] = {0.0, 0.0};
     // distances of one chunk's two Gram tiles (`masked`: the last chunk of the array may hold rows past the end)
@@ -455,8 +499,8 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
       float p0 = 0.f, p1 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float d0 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * g0[r]));
-        const float d1 = *reinterpret_cast<const float*>(dsm + (tb2 - 2 * g1[r]));
+        const float d0 = *reinterpret_cast<lds_cfloat*>((uintptr_t)(uint32_t)(g0[r] + tb2));
+        const float d1 = *reinterpret_cast<lds_cfloat*>((uintptr_t)(uint32_t)(g1[r] + tb2));
         const bool vj = !masked || t * 32 + crow(r, hh) < N;
         p0 += vj ? d0 : 0.f;
         p1 += vj ? d1 : 0.f;
@@ -465,40 +509,79 @@ __device__ __forceinline__ void mmd_distsum_spin256(const MmdArgs& a, unsigned c
       part[0] = fmaf(p0, wgt, part[0]);
       part[1] = fmaf(p1, wgt, part[1]);
     };
-    if (t0 < TC) issue(t0, 0);
-    int buf = 0, tp = -1, since_flush = 0;
-    i32x16 accp[2];  // the previous chunk's Gram tiles: their lookups run under this chunk's MFMAs
-    accp[0] = (i32x16){0}; accp[1] = (i32x16){0};
-    for (int t = t0; t < TC; t += (int)gridDim.y, buf ^= 1) {
+    issue(t0, 0);
+    int tp = -1, since_flush = 0;
+    // One straight-line stream per chunk, pinned step by step (left alone the compiler waits on every operand read with
+    // one read in flight and puts the 32 table lookups BEHIND the 2 NST MFMAs: round-3 PMC, 0.41 MFMA busy with nothing
+    // else busy either).  Step s: the lookups of rows [rb(s), rb(s+1)) of the PREVIOUS chunk's two Gram tiles go out,
+    // then the operand read of step s + PF; the step's two MFMAs; the adds of the lookups issued PF steps ago (LDS
+    // returns in order: they have landed once this step's operand has).  A chunk that is looked up here is never the
+    // array's last one (that one ends its row block's run of chunks), so there are no masks; the first chunk of a run
+    // looks up a zero tile with weight 0.  The two tile pairs swap roles from chunk to chunk (no register copies).
+    constexpr int PF = NST >= 16 ? 4 : (NST >= 8 ? 2 : 1);
+    auto chunk = [&](int t, auto bufc, const i32x16 (&prev)[2], i32x16 (&cur)[2]) {
+      constexpr int buf = decltype(bufc)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t + (int)gridDim.y < TC) issue(t + (int)gridDim.y, buf ^ 1);
-      const unsigned char* zrow = zbuf + buf * CH + c * D;
-      i32x16 acc[2];
-      acc[0] = (i32x16){0}; acc[1] = (i32x16){0};
+      if (t + S < t_end) issue(t + S, buf ^ 1);
+      // operand read of step s: slot (2 s + hh) ^ fc = ((hh ^ fc) ^ (2 s & 15)) | (2 s & 16): one of 8 per-lane addresses
+      // plus compile-time offsets (stage, upper half of the row) -- 8 address registers instead of 2 NST
+      auto zread = [&](int st) -> i32x4 {
+        return *reinterpret_cast<lds_ci32x4*>((uintptr_t)(zaddr[st & 7] + (uint32_t)(buf * CH + (st >> 3) * 256)));
+      };
+      auto rb = [](int st) { return (16 * st) / NST; };
+      i32x4 zr[NST];
+      float lk0[16], lk1[16], p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < PF; ++s) zr[s] = zread(s);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < NST; ++s) {
-        const i32x4 za = *reinterpret_cast<const i32x4*>(zrow + (((2 * s + hh) ^ fc) << 4));
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[0][s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[1][s], acc[1], 0, 0, 0);
+#pragma unroll
+        for (int r = rb(s); r < rb(s + 1); ++r) {
+          lk0[r] = *reinterpret_cast<lds_cfloat*>((uintptr_t)(uint32_t)(prev[0][r] + tb2));
+          lk1[r] = *reinterpret_cast<lds_cfloat*>((uintptr_t)(uint32_t)(prev[1][r] + tb2));
+        }
+        if (s + PF < NST) zr[s + PF] = zread(s + PF);
+        __builtin_amdgcn_sched_barrier(0);
+        cur[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(zr[s], xb[0][s], s == 0 ? (i32x16){0} : cur[0], 0, 0, 0);
+        cur[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(zr[s], xb[1][s], s == 0 ? (i32x16){0} : cur[1], 0, 0, 0);
+        if (s >= PF) {
+#pragma unroll
+          for (int r = rb(s - PF); r < rb(s - PF + 1); ++r) { p0 += lk0[r]; p1 += lk1[r]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // (a chunk that is looked up here is never the array's last one: that one is always some block's final chunk)
-      if (tp >= 0) lookups(accp[0], accp[1], tp, false);
-      accp[0] = acc[0]; accp[1] = acc[1];
+#pragma unroll
+      for (int r = rb(NST - PF); r < 16; ++r) { p0 += lk0[r]; p1 += lk1[r]; }
+      const float wgt = tp < 0 ? 0.0f : (tp < t_own_end ? 1.0f : 2.0f);
+      part[0] = fmaf(p0, wgt, part[0]);
+      part[1] = fmaf(p1, wgt, part[1]);
       tp = t;
       if (++since_flush == 16) {  // keep the float32 running sums short
         segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
         part[0] = 0.f; part[1] = 0.f;
         since_flush = 0;
       }
+    };
+    i32x16 accp[2], accq[2];  // Gram tiles of the previous / the current chunk: their lookups run under the next MFMAs
+    accp[0] = (i32x16){0}; accp[1] = (i32x16){0};
+    bool last_in_q = false;
+    for (int t = t0; t < t_end; t += 2 * S) {
+      chunk(t, std::integral_constant<int, 0>{}, accp, accq);
+      last_in_q = true;
+      if (t + S >= t_end) break;
+      chunk(t + S, std::integral_constant<int, 1>{}, accq, accp);
+      last_in_q = false;
     }
+    if (last_in_q) { accp[0] = accq[0]; accp[1] = accq[1]; }  // (block-uniform)
     if (tp >= 0) lookups(accp[0], accp[1], tp, tp * 32 + 32 > N);
     segsum[0] += (double)part[0]; segsum[1] += (double)part[1];
     total += (vi[0] ? segsum[0] : 0.0) + (vi[1] ? segsum[1] : 0.0);
     __syncthreads();  // (the next segment's first DMA must not overtake a straggler's reads of stage 0)
   }
   const double sum = block_sum(total, red);
-  if (threadIdx.x == 0) a.dist_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sum;
+  if (threadIdx.x == 0) a.dist_part[(size_t)by * gridDim.x + bx] = sum;
 }
 
 template <int NST>
@@ -1736,10 +1819,9 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
     const int64_t t256 = ceil_div(nx + ny, 256);
     p.d256 = p.pm1_ok && env != 0 && d % 128 == 0 && d <= 512 && (t256 >= 32 || env == 1) && (nx + ny) * (int64_t)d < 2147483647LL;
   }
-  if (p.d256) {  // 256-row blocks: ceil(T/2) x S1 blocks, two resident per CU
-    p.GX1 = (ceil_div(nx + ny, 256) + 1) / 2;
-    S1 = ceil_div(512, p.GX1);
-    if (S1 > 32) S1 = 32;
+  if (p.d256) {  // 256-row blocks
+    p.GX1 = 64;  // 8 chunk streams (one per XCD) x 64 blocks of equal work: exactly two resident blocks per CU
+    S1 = 8;
   } else if (p.pm1_ok) {
     p.GX1 = (tiles + 1) / 2;
     S1 = ceil_div(512, p.GX1);

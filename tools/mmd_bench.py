@@ -12,12 +12,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-if "--w128" in sys.argv:
-    _lib.set_option("mmd_w128", int(sys.argv[sys.argv.index("--w128") + 1]))
 import torch  # noqa: E402
 
 import image_generation_amd  # noqa: E402,F401
 from image_generation_amd import _lib, functional as F  # noqa: E402
+
+if "--w128" in sys.argv:
+    _lib.set_option("mmd_w128", int(sys.argv[sys.argv.index("--w128") + 1]))
 
 nx, ny, d = (int(v) for v in args[:3]) if len(args) >= 3 else (32768, 256, 512)
 g = torch.Generator().manual_seed(0)
