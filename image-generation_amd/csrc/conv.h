@@ -141,6 +141,12 @@ bool plan_matches_forward(const void* ws, uint32_t signature);   // backward cal
 void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
 bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+// Winograd F(2x2,3x3) form of a stride-1 3x3 layer (conv_wino.hip): same ConvArgs, `wp` = the transformed pack of
+// launch_wino_weight_pack ([Cin][Cout][16] floats), stats rows = conv_wino_stats_blocks
+bool conv_wino_ok(int64_t M, int Cin, int Cout, int L);
+int conv_wino_stats_blocks(int64_t M, int Cout);
+int launch_conv_wino(const ConvArgs& a, hipStream_t s);
+int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);
 // fold = 1 launches: M source pixels; usable when conv_fold_ok (whole row blocks per class)
 bool conv_fold_ok(int64_t Msrc);

@@ -1,0 +1,393 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 convolutions of the encoder (forward of layers 1-3 and their data
+// gradients: /root/reference/src/encoder.py:28-36), float32 on v_mfma_f32_32x32x2_f32.
+//
+// Why: the float32 MFMA is the slow matrix instruction of the chip (157 TFLOP/s: 1/16 of the bf16 rate), the strict-f32
+// step spends its matrix time in these layers, and the minimal-filtering form needs 16 multiplies per 2x2 output quad and
+// channel pair where the direct form needs 36: 2.25x fewer MFMAs for the same float32 convolution (the transforms only
+// add and halve).  Morton-ordered activations (conv.h) make it cheap: a 2x2 output quad IS four consecutive rows, a run
+// of 64 or 128 quads is a whole number of images (no halo between workgroups), and a lane's MFMA accumulator registers
+// hold all 16 transform-domain values of a (quad, output channel) pair, so the output transform is lane-local.
+//
+//   U[xi][nu][ci][co] = (G g G^T)          weights, once per step (wino_weight_pack_kernel), G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//   V[xi][nu][quad][ci] = (B^T d B)        4x4 input patch d of the quad (zero padded), B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//   M[xi][nu][quad][co] = sum_ci V U       16 independent GEMMs: the MFMA work
+//   Y[quad][2x2][co]    = A^T M A (+bias)  A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// One workgroup = 4 waves, ONE per SIMD with the whole register file (16 accumulator tiles of 32 quads x 32 channels =
+// 256 AGPRs per wave).  Channels are walked in chunks of KC; per chunk three LDS images: the raw input pixels of the
+// block's images [pixel][KC] and the transformed weights [k][co][16] arrive by LDS-DMA, the transformed input
+// [k][quad][16] is written by the block itself (each thread transforms TBLK KC / 256 patches per chunk, under the
+// previous chunk's MFMAs).  Two stages of each, one barrier per chunk, and the chunk sequence runs on across the tile
+// blocks a workgroup owns (persistent grid), so the staging pipeline is filled once per workgroup, not once per tile.
+// A 64-byte entry (16 transform positions of one (k, row)) is read as four ds_read_b128 whose 16-byte slots are XOR-ed
+// with bits 2-3 of the row: conflict-free for the 16 lanes of a read pass.
+#include "conv.h"
+#include "conv_tile.h"
+
+namespace dvg {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+
+struct WinoArgs {
+  const float* in;    // [4 tiles][Cin]  (Morton pixel order: quad t = rows 4t .. 4t+3)
+  const float* u;     // [Cin][Cout][16] transformed weights, 16-byte slots swizzled by (co >> 2) & 3
+  const float* bias;  // [Cout] or null
+  float* out;         // [4 tiles][Cout]
+  float* stats;       // [nblk][Cout][2] per tile block (sum, sum of squares) of the output, or null
+  int Cin, Cout, L;   // L = log2 of the image side
+  int nblk;           // tile blocks (of 32 WM quads)
+};
+
+template <int WM, int WN, int KC>
+struct WinoCfg {
+  static constexpr int TBLK = 32 * WM, CB = 32 * WN, KS = KC / 2;
+  static constexpr int RAW_PIX = TBLK * 4 * KC * 4;          // bytes of raw pixels per stage
+  static constexpr int RAW_B = 64 + RAW_PIX;                 // + the zero entry padding taps read
+  static constexpr int V_B = KC * TBLK * 64, U_B = KC * CB * 64;
+  static constexpr int OFF_RAW = 0, OFF_V = OFF_RAW + 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B;
+  static constexpr int LDS_BYTES = OFF_RED + WM * CB * 2 * 4;
+  static constexpr int NI = TBLK * KC / 256;                 // patches a thread transforms per chunk
+  static constexpr int RR = RAW_PIX / 4096, UR = U_B / 4096; // 4 KiB DMA rounds (256 lanes x 16 bytes) per chunk
+};
+
+template <int WM, int WN, int KC>
+__device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char* wsm) {
+  using C = WinoCfg<WM, WN, KC>;
+  constexpr int TBLK = C::TBLK, CB = C::CB, KS = C::KS, NI = C::NI;
+  static_assert(WM * WN == 4 && KC % 2 == 0 && C::RR >= 1 && C::UR >= 1 && NI >= 1, "unsupported shape");
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.y * CB;
+  const int H = 1 << a.L, HW = H * H;
+
+  // ---- per-thread constants of the input transform: LDS offsets (inside a raw stage) of the 4x4 patch of quad `tl`
+  // (the thread's NI patches are that quad at channels k0 + j * 256 / TBLK); a padding tap reads the stage's zero entry
+  // Raw stage layout: pixel px of the block sits at position (px & 3) TBLK + (px >> 2) (quad-position-major: the DMA's
+  // per-lane SOURCE picks the pixel), KC floats each; the 64 lanes of a wave read the same tap of 64 consecutive quads,
+  // and a lane's channel is rotated by its quad index, so that a read spreads over 32 banks (pixel-major order with one
+  // channel per wave put all 64 lanes on 2 banks: the kernel ran at a third of its MFMA time).
+  constexpr int KG = 256 / TBLK;  // channel groups: the thread's NI patches are channels kb, kb + KG, ...
+  const int tl = tid % TBLK, k0 = ((tid / TBLK) + tl / (64 / KC)) % KG;
+  int poff[16];
+  {
+    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4);  // quad index inside its image = Morton index of (ty, tx)
+    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
+        const int px = img * HW + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
+        const int pos = (px & 3) * TBLK + (px >> 2);
+        poff[i * 4 + j] = ok ? 64 + (pos * KC + k0) * 4 : 0;
+      }
+  }
+  // where the thread's transformed patches go / where the wave's MFMA operands come from (absolute LDS addresses, stage 0)
+  const uint32_t vst = lds0 + C::OFF_V + (uint32_t)((k0 * TBLK + tl) * 64);
+  const int swt = (tl >> 2) & 3;
+  const int rowA = wm * 32 + c, colB = wn * 32 + c;
+  uint32_t aaddr[2][4], baddr[2][4];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      aaddr[st][i] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)((hh * TBLK + rowA) * 64 + ((i ^ ((rowA >> 2) & 3)) << 4));
+      baddr[st][i] = lds0 + C::OFF_U + st * C::U_B + (uint32_t)((hh * CB + colB) * 64 + ((i ^ ((colB >> 2) & 3)) << 4));
+    }
+  // the zero entries
+  if (tid < 32) *reinterpret_cast<float*>(wsm + C::OFF_RAW + (tid >> 4) * C::RAW_B + (tid & 15) * 4) = 0.f;
+
+  // ---- DMA of one chunk's images
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cin * 4), 0x00020000);
+  int rvoff[C::RR];
+#pragma unroll
+  for (int q = 0; q < C::RR; ++q) {
+    const int byte = (q * 256 + tid) * 16, pos = byte / (KC * 4);
+    rvoff[q] = (4 * (pos % TBLK) + pos / TBLK) * a.Cin * 4 + byte % (KC * 4);
+  }
+  const int nch = a.Cin / KC;
+  auto issue_raw = [&](int blk, int ch, int st) {
+    const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK * 4 * a.Cin + ch * KC) * 4);
+#pragma unroll
+    for (int q = 0; q < C::RR; ++q) {
+      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + st * C::RAW_B + 64 + q * 4096 + wave * 1024));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
+    }
+  };
+  auto issue_u = [&](int ch, int st) {
+#pragma unroll
+    for (int q = 0; q < C::UR; ++q) {
+      const int off = q * 4096 + wave * 1024;               // position in the chunk image [KC][CB][64 bytes]
+      const int kk = off / (CB * 64), within = off % (CB * 64);
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.u) +
+                                 ((size_t)(ch * KC + kk) * a.Cout + n0) * 64 + within + lane * 16;
+      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + off));
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (lds_void_t*)(uintptr_t)dst, 16, 0, 0);
+    }
+  };
+
+  // ---- input transform of the thread's NI patches: raw stage `rs` -> transformed stage `vs`
+  auto load_patch = [&](int rs, int j, float (&d)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      d[e] = *reinterpret_cast<lds_cf32*>((uintptr_t)(lds0 + C::OFF_RAW + rs * C::RAW_B + j * (256 / TBLK) * 4 + (uint32_t)poff[e]));
+  };
+  auto store_patch = [&](int vs, int j, const float (&d)[16]) {
+    float t[16], v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // B^T d
+      t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
+      t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
+      t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
+      t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {  // (.) B
+      v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
+      v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
+      v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
+      v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + j * (256 / TBLK) * TBLK * 64 + (uint32_t)((x ^ swt) << 4))) = o;
+    }
+  };
+
+  f32x16 acc[16];
+
+  // ---- the workgroup's sequence of chunks: tile blocks blockIdx.x, + gridDim.x, ... x (Cin / KC) chunks each
+  const int nmine = ((int)a.nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int VT = nmine * nch;
+  auto blk_of = [&](int v) { return (int)blockIdx.x + (v / nch) * (int)gridDim.x; };
+  if (VT <= 0) return;
+  issue_raw(blk_of(0), 0, 0);
+  issue_u(0, 0);
+  if (VT > 1) issue_raw(blk_of(1), 1 % nch, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float d[16];
+      load_patch(0, j, d);
+      store_patch(0, j, d);
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+      a.out, 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cout * 4), 0x00020000);
+  const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;
+  auto epilogue = [&](int blk) {
+    float s1 = 0.f, s2 = 0.f;
+    const int col = n0 + wn * 32 + c;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    // A^T M A on whole accumulator tiles (the transform is elementwise in the 16 rows a lane holds): element-by-element
+    // access would make the compiler copy every 16-register accumulator tuple out of the AGPRs at once
+    f32x16 y[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      const f32x16 t0 = (acc[0 + nu] + acc[4 + nu]) + acc[8 + nu];
+      const f32x16 t1 = (acc[4 + nu] - acc[8 + nu]) - acc[12 + nu];
+      if (nu == 0) { y[0] = t0; y[2] = t1; }
+      if (nu == 1) { y[0] = y[0] + t0; y[1] = t0; y[2] = y[2] + t1; y[3] = t1; }
+      if (nu == 2) { y[0] = y[0] + t0; y[1] = y[1] - t0; y[2] = y[2] + t1; y[3] = y[3] - t1; }
+      if (nu == 3) { y[1] = y[1] - t0; y[3] = y[3] - t1; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // quad gt = blk TBLK + 32 wm + crow(r, hh), rows 4 gt + q: one per-lane offset for the whole kernel, the rest scalar
+      const int rq = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = y[q][r] + bias;
+        const int soff = __builtin_amdgcn_readfirstlane(((blk * TBLK + wm * 32) * 4 + rq + q) * a.Cout * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_out, ovoff, soff, 0);
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+    if (a.stats) {
+      float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hh == 0) { red[(wm * CB + wn * 32 + c) * 2] = s1; red[(wm * CB + wn * 32 + c) * 2 + 1] = s2; }
+      __syncthreads();
+      if (tid < CB) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += red[(w * CB + tid) * 2]; t2 += red[(w * CB + tid) * 2 + 1]; }
+        float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
+        dst[0] = t1; dst[1] = t2;
+      }
+    }
+  };
+
+  // One chunk = KS k-steps x 4 operand groups x 4 MFMAs, written as ONE pinned instruction stream (a fence after every
+  // piece): left to itself the compiler loads each group's operands right before its MFMAs and waits for them with the
+  // matrix pipe draining, and puts a whole patch transform (16 LDS reads, a wait, ~50 VALU) between two MFMAs.  Here the
+  // operands of group g + 1 are requested before the MFMAs of group g, and the next chunk's input transform rides in the
+  // shadows of the MFMAs a few instructions at a time: patch j is read at the start of k-step j, its B^T d columns follow
+  // beside the MFMAs of group 1, its (.) B rows and their stores beside those of group 2.
+  auto chunk = [&](int v, auto stc) {
+    constexpr int st = decltype(stc)::value;
+    // (branch-free: past the end of the sequence the last chunk is fetched and transformed again, into stages nobody reads)
+    const int v1 = v + 1 < VT ? v + 1 : VT - 1, v2 = v + 2 < VT ? v + 2 : VT - 1;
+    issue_u(v1 % nch, st ^ 1);
+    issue_raw(blk_of(v2), v2 % nch, st);
+    f32x4 ca, cb, na, nb;
+    auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 4 ks + i: positions 4 i .. 4 i + 3 of k-step ks
+      x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st][g & 3] + (g >> 2) * 2 * TBLK * 64));
+      y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st][g & 3] + (g >> 2) * 2 * CB * 64));
+    };
+    load_grp(0, ca, cb);
+    float d[16], t[16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4 * KS; ++g) {
+      const int ks = g >> 2, i = g & 3;
+      if (g + 1 < 4 * KS) load_grp(g + 1, na, nb);
+      if (ks < NI && i == 0) load_patch(st ^ 1, ks, d);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (ks < NI && i == 1) {  // B^T d, column m
+          t[0 * 4 + m] = d[0 * 4 + m] - d[2 * 4 + m];
+          t[1 * 4 + m] = d[1 * 4 + m] + d[2 * 4 + m];
+          t[2 * 4 + m] = d[2 * 4 + m] - d[1 * 4 + m];
+          t[3 * 4 + m] = d[1 * 4 + m] - d[3 * 4 + m];
+        }
+        if (ks < NI && i == 2) {  // (.) B, row m, and its store
+          const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], t[m * 4 + 2] - t[m * 4 + 1],
+                           t[m * 4 + 1] - t[m * 4 + 3]};
+          *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[4 * i + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * i + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ca = na; cb = nb;
+    }
+    static_assert(NI <= KS, "one patch per k-step");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // (nested on purpose: the accumulators are zeroed and consumed in straight-line code of the outer loop.  A flat chunk
+  // loop with a conditional epilogue made every chunk end in a merge of "old" and "zeroed" accumulators, which the compiler
+  // implements by moving all 256 of them through VGPRs; an even chunk count keeps the stage parity per tile block)
+  int v = 0;
+  for (int bi = 0; bi < nmine; ++bi) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+    for (int ch = 0; ch < nch; ch += 2) {
+      chunk(v, std::integral_constant<int, 0>{});
+      chunk(v + 1, std::integral_constant<int, 1>{});
+      v += 2;
+    }
+    epilogue((int)blockIdx.x + bi * (int)gridDim.x);
+  }
+}
+
+template <int WM, int WN, int KC>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
+  extern __shared__ __align__(16) unsigned char wino_smem[];
+  conv_wino_body<WM, WN, KC>(a, wino_smem);
+}
+
+// U = G g G^T of every (reduction channel a, output channel b) pair, in the layout the kernel's DMA copies verbatim
+__global__ __launch_bounds__(256) void wino_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u) {
+  const int64_t total = (int64_t)map.Ca * map.Cb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e % map.Cb), av = (int)(e / map.Cb);
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = packed_weight(w, map, t, av, b);
+    float tg[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      tg[0][s] = g[s];
+      tg[1][s] = 0.5f * ((g[s] + g[3 + s]) + g[6 + s]);
+      tg[2][s] = 0.5f * ((g[s] - g[3 + s]) + g[6 + s]);
+      tg[3][s] = g[6 + s];
+    }
+    const int sw = (b >> 2) & 3;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      f32x4 o;
+      o[0] = tg[x][0];
+      o[1] = 0.5f * ((tg[x][0] + tg[x][1]) + tg[x][2]);
+      o[2] = 0.5f * ((tg[x][0] - tg[x][1]) + tg[x][2]);
+      o[3] = tg[x][2];
+      *reinterpret_cast<f32x4*>(u + e * 16 + ((x ^ sw) << 2)) = o;
+    }
+  }
+}
+
+int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s) {
+  int64_t gx = ceil_div((int64_t)map.Ca * map.Cb, 256);
+  if (gx > 1024) gx = 1024;
+  DVG_LAUNCH(K_WEIGHT_PACK, wino_weight_pack_kernel, dim3((unsigned)gx), dim3(256), 0, s, w, map, u);
+  return DVG_OK;
+}
+
+// Which tile shape serves a layer: 64 quads x 64 channels (8-channel chunks) or 128 quads x 32 channels (4-channel chunks)
+static int wino_cfg(int Cout) { return Cout % 64 == 0 ? 0 : 1; }
+static int wino_tblk(int cfg) { return cfg == 0 ? 64 : 128; }
+
+bool conv_wino_ok(int64_t M, int Cin, int Cout, int L) {
+  if (opt(OPT_ENC_WINO) == 0) return false;
+  if (L < 1 || L > 4 || Cout % 32 || Cin % (Cout % 64 == 0 ? 16 : 8) || M % 4) return false;  // (an even number of chunks)
+  const int cfg = wino_cfg(Cout);
+  const int64_t tiles = M / 4;
+  if (tiles % wino_tblk(cfg)) return false;                      // whole tile blocks ...
+  if ((wino_tblk(cfg) * 4) % (1 << (2 * L))) return false;       // ... of whole images
+  if (M * (int64_t)(Cin > Cout ? Cin : Cout) * 4 >= 2147483647LL) return false;  // (32-bit buffer offsets)
+  const int64_t blocks = tiles / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
+  return opt(OPT_ENC_WINO) == 1 || blocks >= 256;               // small launches: the direct form's finer tiles
+}
+
+int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
+
+template <int WM, int WN, int KC>
+static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
+  using C = WinoCfg<WM, WN, KC>;
+  auto kern = conv_wino_kernel<WM, WN, KC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  const int ny = a.Cout / C::CB;
+  int gx = 256 / ny;  // one workgroup per CU: persistent over its tile blocks
+  if (gx < 1) gx = 1;
+  if (gx > a.nblk) gx = a.nblk;
+  DVG_LAUNCH_WORK(K_IGEMM_WINO, flops, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, a);
+  return DVG_OK;
+}
+
+// a.wp must be the transformed pack of launch_wino_weight_pack; a.M, Cin, Cout, L, bias, out, stats as for launch_conv_igemm
+int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
+  DVG_REQUIRE(conv_wino_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold,
+              "conv_wino: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
+  WinoArgs w;
+  w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
+  w.Cin = a.Cin; w.Cout = a.Cout; w.L = a.L;
+  const int cfg = wino_cfg(a.Cout);
+  w.nblk = (int)(a.M / 4 / wino_tblk(cfg));
+  const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * 9;  // algorithmic (direct-form) FLOPs of the layer
+  if (cfg == 0) return launch_wino_cfg<2, 2, 8>(w, flops, s);
+  return launch_wino_cfg<4, 1, 4>(w, flops, s);
+}
+
+}  // namespace dvg

@@ -16,6 +16,22 @@ extern "C" int dvg_dev_conv_igemm(const float* in, const float* w, int mode, flo
   return launch_conv_igemm(a, s);
 }
 
+// The same layer in the Winograd F(2x2,3x3) form (conv_wino.hip): `u` takes the 16 Cin Cout transformed weights; stats rows =
+// dvg_dev_conv_wino_stats_blocks.  DVG_E_INVALID when the shape does not qualify (dvg_dev_conv_wino_ok).
+extern "C" int dvg_dev_conv_wino(const float* in, const float* w, int mode, float* u, const float* bias, float* out,
+                                 float* stats, int64_t M, int Cin, int Cout, int L, dvg_stream_t stream) {
+  DVG_REQUIRE(in && w && u && out, "dev_conv_wino: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  DVG_TRY(launch_wino_weight_pack(w, WeightMap{mode, Cin, Cout, 9}, u, s));
+  ConvArgs a;
+  a.in = in; a.wp = u; a.bias = bias; a.out = out; a.stats = stats;
+  a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
+  a.splitk_ws = nullptr;
+  return launch_conv_wino(a, s);
+}
+extern "C" int dvg_dev_conv_wino_ok(int64_t M, int Cin, int Cout, int L) { return conv_wino_ok(M, Cin, Cout, L) ? 1 : 0; }
+extern "C" int dvg_dev_conv_wino_stats_blocks(int64_t M, int Cout) { return conv_wino_stats_blocks(M, Cout); }
+
 extern "C" size_t dvg_dev_conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum) {
   return conv_splitk_floats(M, Cin, Cout, ntaps, poolsum);
 }

@@ -19,6 +19,7 @@ struct EncPlan {
   int nblk[4];
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
+  bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, splitk;
   int ksplit[4];
   size_t total_floats;
@@ -44,7 +45,9 @@ EncPlan enc_plan(int64_t B, int n) {
     p.Q[l] = p.M[l] / 4;
     const int C = ch[l + 1];
     if (C > cmax) cmax = C;
-    p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : conv_stats_blocks(p.M[l], C);
+    p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l]);
+    p.wino_d[l] = l > 0 && conv_wino_ok(p.M[l], C, ch[l], p.L[l]);
+    p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
     p.mean[l] = bump(o, C);
@@ -53,8 +56,8 @@ EncPlan enc_plan(int64_t B, int n) {
     p.wp[l] = p.wpd[l] = 0;
     p.ksplit[l] = 0;
     if (l > 0) {
-      p.wp[l] = bump(o, conv_pack_floats((size_t)9 * ch[l] * C));
-      p.wpd[l] = bump(o, conv_pack_floats((size_t)9 * ch[l] * C));
+      p.wp[l] = bump(o, conv_pack_floats((size_t)(p.wino_f[l] ? 16 : 9) * ch[l] * C));
+      p.wpd[l] = bump(o, conv_pack_floats((size_t)(p.wino_d[l] ? 16 : 9) * ch[l] * C));
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
@@ -79,6 +82,13 @@ EncPlan enc_plan(int64_t B, int n) {
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
+}
+
+// what shapes the workspace's contents: the pack format of the direct GEMMs and which layers run in the Winograd form
+uint32_t enc_plan_signature(const EncPlan& pl) {
+  uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64);
+  for (int l = 1; l < 4; ++l) sig |= (pl.wino_f[l] ? 1u : 0u) << (8 + 2 * l) | (pl.wino_d[l] ? 1u : 0u) << (9 + 2 * l);
+  return sig;
 }
 
 int check_common(const dvg_encoder_params_t* p, int n, int64_t B, const void* ws, size_t ws_bytes, const EncPlan& pl) {
@@ -116,18 +126,22 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
-  plan_note_forward(ws, (uint32_t)conv_launch_mode(B, 64));  // (the pack format the backward will read)
+  plan_note_forward(ws, enc_plan_signature(pl));  // (the pack formats the backward will read)
   DVG_REQUIRE(images && logits, "encoder_fwd: null images/logits");
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
   const float* x = images;
   {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
     PackJob jobs[6];
+    int nj = 0;
     for (int l = 1; l < 4; ++l) {
-      jobs[2 * (l - 1)] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l]};
-      jobs[2 * (l - 1) + 1] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l]};
+      const WeightMap mf{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}, md{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9};
+      if (pl.wino_f[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], mf, W + pl.wp[l], s));
+      else jobs[nj++] = PackJob{p->conv_w[l], W + pl.wp[l], mf, 0, pl.M[l]};
+      if (pl.wino_d[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], md, W + pl.wpd[l], s));
+      else jobs[nj++] = PackJob{p->conv_w[l], W + pl.wpd[l], md, 0, pl.M[l]};
     }
-    DVG_TRY(launch_weight_pack_multi(jobs, 6, s));
+    if (nj > 0) DVG_TRY(launch_weight_pack_multi(jobs, nj, s));
   }
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
@@ -139,7 +153,8 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
       a.splitk_ws = W + pl.splitk;
-      DVG_TRY(launch_conv_igemm(a, s));
+      if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
+      else DVG_TRY(launch_conv_igemm(a, s));
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
                                p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
@@ -157,7 +172,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "encoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
-  DVG_REQUIRE(plan_matches_forward(ws, (uint32_t)conv_launch_mode(B, 64)), "encoder_bwd: option igemm_dma changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl)), "encoder_bwd: option igemm_dma / enc_wino changed since the forward call on this workspace");
   DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
   for (int l = 0; l < 4; ++l)
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);
@@ -197,7 +212,8 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
-    DVG_TRY(launch_conv_igemm(a, s));
+    if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
+    else DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
     if (proj_pending) {
       DVG_REQUIRE(sums.add2(W + pl.partP, EW_BLOCKS, 5, 4, g->proj_w, 1, g->proj_b), "encoder_bwd: column-sum batch full");

@@ -12,6 +12,10 @@ _SIGS = {
                            [ctypes.c_int64] + [ctypes.c_int] * 7 + [ctypes.c_void_p, ctypes.c_void_p]),
     "dvg_dev_conv_splitk_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
+    "dvg_dev_conv_wino": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
+                          [ctypes.c_int64] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "dvg_dev_conv_wino_ok": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dvg_dev_conv_wino_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
     "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 5 +
                            [ctypes.c_void_p]),
@@ -69,6 +73,22 @@ def conv_igemm(x_m, w, mode, M, Cin, Cout, L, ntaps=9, ups=0, poolsum=0, bias=No
     _lib.check(Lb.dvg_dev_conv_igemm(x_m.data_ptr(), w.data_ptr(), mode, wp.data_ptr(), _lib.ptr(bias), out.data_ptr(),
                                      _lib.ptr(st), M, Cin, Cout, L, ntaps, ups, poolsum, int(repack), _lib.ptr(sk),
                                      _lib.stream_ptr(dev)))
+    return (out, st) if stats else out
+
+
+def conv_wino_ok(M, Cin, Cout, L):
+    return bool(lib().dvg_dev_conv_wino_ok(M, Cin, Cout, L))
+
+
+def conv_wino(x_m, w, mode, M, Cin, Cout, L, bias=None, stats=False):
+    """The stride-1 3x3 layer of conv_igemm (modes 0 / 1) in the Winograd F(2x2,3x3) form (csrc/conv_wino.hip)."""
+    Lb = lib()
+    dev = x_m.device
+    u = torch.empty(16 * Cin * Cout, device=dev)
+    out = torch.empty((M, Cout), device=dev)
+    st = torch.empty((Lb.dvg_dev_conv_wino_stats_blocks(M, Cout), Cout, 2), device=dev) if stats else None
+    _lib.check(Lb.dvg_dev_conv_wino(x_m.data_ptr(), w.data_ptr(), mode, u.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                    _lib.ptr(st), M, Cin, Cout, L, _lib.stream_ptr(dev)))
     return (out, st) if stats else out
 
 

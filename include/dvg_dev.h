@@ -15,6 +15,13 @@ int dvg_dev_conv_igemm(const float *in, const float *w, int mode, float *wp, con
                        float *stats, int64_t M, int Cin, int Cout, int L, int ntaps, int ups, int poolsum,
                        int repack, float *splitk_ws, dvg_stream_t stream);
 size_t dvg_dev_conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int poolsum);
+/* The same stride-1 3x3 layer in the Winograd F(2x2,3x3) form the encoder uses from 256 workgroups up (option enc_wino):
+ * `u` = scratch of 16*Cin*Cout floats (transformed weights), `stats` rows = dvg_dev_conv_wino_stats_blocks(M, Cout).
+ * Replaces (with the implicit GEMM above) /root/reference/src/encoder.py:28-36's nn.Conv2d calls. */
+int dvg_dev_conv_wino(const float *in, const float *w, int mode, float *u, const float *bias, float *out, float *stats,
+                      int64_t M, int Cin, int Cout, int L, dvg_stream_t stream);
+int dvg_dev_conv_wino_ok(int64_t M, int Cin, int Cout, int L);
+int dvg_dev_conv_wino_stats_blocks(int64_t M, int Cout);
 int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
 /* grad_w (checkpoint layout, `mode` = the layer's FORWARD mode) = sum_m in[nbr(m,tap)] (x) dy[m]; slabs: scratch of
  * dvg_dev_wgrad_slab_floats() floats. */

@@ -48,6 +48,36 @@ def test_conv2d_fwd_dgrad_wgrad(N, Cin, Cout, side, staging):
     assert _rel(gw.cpu(), w.grad) < 3e-6
 
 
+@pytest.mark.parametrize("N,Cin,Cout,side", [(64, 32, 64, 16), (256, 64, 128, 8), (512, 128, 512, 4), (512, 512, 128, 4),
+                                             (128, 128, 64, 8), (64, 64, 32, 16), (2, 32, 64, 16), (32, 32, 32, 4)])
+def test_winograd_form_of_the_3x3_layers(N, Cin, Cout, side):
+    """The Winograd F(2x2,3x3) form (csrc/conv_wino.hip; the encoder's layers 1-3 from 256 workgroups up) against float64
+    convolutions: outputs and data gradients within 3x the direct float32 kernel's own bar (its transforms add a few
+    roundings per product sum), BatchNorm partial sums as the direct kernel's; and against the direct kernel itself."""
+    from image_generation_amd import _lib
+    torch.manual_seed(N + Cin)
+    x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    dx64 = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+    L, M = side.bit_length() - 1, N * side * side
+    with _lib.option_scope(enc_wino=1):
+        assert dev.conv_wino_ok(M, Cin, Cout, L) and dev.conv_wino_ok(M, Cout, Cin, L)
+        xm, gym = dev.nchw_to_morton(x).cuda(), dev.nchw_to_morton(gy).cuda()
+        out, st = dev.conv_wino(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+        dx = dev.conv_wino(gym, w.cuda(), 1, M, Cout, Cin, L)
+    out_d = dev.conv_igemm(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda())
+    e_w = _rel(dev.morton_to_nchw(out.cpu(), N, Cout, side).double(), y64)
+    e_d = _rel(dev.morton_to_nchw(out_d.cpu(), N, Cout, side).double(), y64)
+    assert e_w < 2e-6 and e_w < 4 * e_d + 1e-8, (e_w, e_d)
+    dx_d = dev.conv_igemm(gym, w.cuda(), 1, M, Cout, Cin, L)
+    g_w = _rel(dev.morton_to_nchw(dx.cpu(), N, Cin, side).double(), dx64)
+    g_d = _rel(dev.morton_to_nchw(dx_d.cpu(), N, Cin, side).double(), dx64)
+    assert g_w < 2e-6 and g_w < 4 * g_d + 1e-8, (g_w, g_d)
+    s = st.sum(0).cpu().double()
+    assert _rel(s[:, 0], y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y64 ** 2).sum((0, 2, 3))) < 1e-5
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side", [(1024, 32, 64, 4), (8192, 32, 64, 2), (1024, 128, 128, 8)])
 def test_position_major_tiles_are_bit_identical_to_pixel_major_tiles(N, Cin, Cout, side):
     """Position-major tiles (conv.h: ConvArgs.posmajor) skip the taps that fall outside the image -- multiplications by
