@@ -143,7 +143,7 @@ bool conv_precision_matches_forward(const void* ws);   // backward calls: same m
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) form of a stride-1 3x3 layer (conv_wino.hip): same ConvArgs, `wp` = the transformed pack of
 // launch_wino_weight_pack ([Cin][Cout][16] floats), stats rows = conv_wino_stats_blocks
-bool conv_wino_ok(int64_t M, int Cin, int Cout, int L);
+bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind = 0);  // kind: 0 training forward, 1 data gradient, 2 evaluation forward
 int conv_wino_stats_blocks(int64_t M, int Cout);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);

@@ -345,16 +345,28 @@ int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipS
 static int wino_cfg(int Cout) { return Cout % 64 == 0 ? 0 : 1; }
 static int wino_tblk(int cfg) { return cfg == 0 ? 64 : 128; }
 
-bool conv_wino_ok(int64_t M, int Cin, int Cout, int L) {
-  if (opt(OPT_ENC_WINO) == 0) return false;
+static bool wino_shape_ok(int64_t M, int Cin, int Cout, int L) {
   if (L < 1 || L > 4 || Cout % 32 || Cin % (Cout % 64 == 0 ? 16 : 8) || M % 4) return false;  // (an even number of chunks)
   const int cfg = wino_cfg(Cout);
   const int64_t tiles = M / 4;
   if (tiles % wino_tblk(cfg)) return false;                      // whole tile blocks ...
   if ((wino_tblk(cfg) * 4) % (1 << (2 * L))) return false;       // ... of whole images
   if (M * (int64_t)(Cin > Cout ? Cin : Cout) * 4 >= 2147483647LL) return false;  // (32-bit buffer offsets)
-  const int64_t blocks = tiles / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
-  return opt(OPT_ENC_WINO) == 1 || blocks >= 256;               // small launches: the direct form's finer tiles
+  return true;
+}
+
+// kind: 0 forward launch of a training call, 1 data-gradient launch, 2 forward launch of an evaluation call.
+// option enc_wino: -1 (default) evaluation-mode forward launches of 256 workgroups or more -- inside a training step the
+// form measured neutral to slower (its workgroups need whole CUs: the sampler, the weight-gradient GEMMs and the elementwise
+// kernels that the direct form shares CUs with wait for it) --, 0 never, 1 every launch the shape allows,
+// 2 / 3 like 1 for the forward / the data-gradient launches only (A/B measurements)
+bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
+  const int64_t o = opt(OPT_ENC_WINO);
+  if (o == 0 || (o == 2 && kind == 1) || (o == 3 && kind != 1) || !wino_shape_ok(M, Cin, Cout, L)) return false;
+  if (o >= 1) return true;
+  const int cfg = wino_cfg(Cout);
+  const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
+  return kind == 2 && blocks >= 256;            // small launches: the direct form's finer tiles
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
@@ -378,7 +390,7 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
 
 // a.wp must be the transformed pack of launch_wino_weight_pack; a.M, Cin, Cout, L, bias, out, stats as for launch_conv_igemm
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
-  DVG_REQUIRE(conv_wino_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold,
+  DVG_REQUIRE(wino_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold,
               "conv_wino: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
   WinoArgs w;
   w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;

@@ -31,7 +31,9 @@ size_t bump(size_t& o, size_t count) {
   return r;
 }
 
-EncPlan enc_plan(int64_t B, int n) {
+// `training` = 0 plans an evaluation-mode forward call (no backward follows; nothing else runs beside it): by default
+// only those calls use the Winograd form (conv_wino_ok)
+EncPlan enc_plan(int64_t B, int n, int training = 1) {
   EncPlan p;
   p.B = B; p.n = n;
   const int ch[5] = {1, 32, 64, 128, n};
@@ -45,8 +47,12 @@ EncPlan enc_plan(int64_t B, int n) {
     p.Q[l] = p.M[l] / 4;
     const int C = ch[l + 1];
     if (C > cmax) cmax = C;
-    p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l]);
-    p.wino_d[l] = l > 0 && conv_wino_ok(p.M[l], C, ch[l], p.L[l]);
+    p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l], training ? 0 : 2);
+    p.wino_d[l] = l > 0 && training && conv_wino_ok(p.M[l], C, ch[l], p.L[l], 1);
+    if (const int64_t mask = opt(OPT_ENC_WINO_MASK); mask != 0 && l > 0) {
+      p.wino_f[l] = p.wino_f[l] && ((mask >> (l - 1)) & 1);
+      p.wino_d[l] = p.wino_d[l] && ((mask >> (2 + l)) & 1);
+    }
     p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
@@ -118,12 +124,13 @@ extern "C" int dvg_dev_encoder_layout(int64_t B, int n_latents, size_t out[16]) 
 extern "C" size_t dvg_encoder_workspace_bytes(int64_t B, int n_latents) {
   dvg::side_stream_warm();  // the backward's fork/join context exists before any step is captured
   if (B < 1 || n_latents < 32 || n_latents % 32) return 0;
-  return enc_plan(B, n_latents).total_floats * sizeof(float);
+  const size_t t1 = enc_plan(B, n_latents, 1).total_floats, t0 = enc_plan(B, n_latents, 0).total_floats;
+  return (t1 > t0 ? t1 : t0) * sizeof(float);
 }
 
 extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float* images, int64_t B, int training,
                                float* logits, void* ws, size_t ws_bytes, dvg_stream_t stream) {
-  const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32, training ? 1 : 0);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
   plan_note_forward(ws, enc_plan_signature(pl));  // (the pack formats the backward will read)

@@ -33,7 +33,8 @@ const OptDef kDefs[OPT_COUNT] = {
     {"gibbs_bigfast", 0, "sampler: 1 = 8-wave unrolled form for graphs above 72 KB of tables (faster alone, slower in a step)"},
     {"gibbs_waves_per_chain", 1, "sampler: 2 = two waves per chain where colour classes hold 65..128 spins and chains are few (the faster draw ALONE: generation; neutral inside a training step), 1 = one (default)"},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
-    {"enc_wino", -1, "encoder 3x3 layers (forward and data gradient) in the Winograd F(2x2,3x3) form: -1 from 256 workgroups up (default), 0 never (direct implicit GEMM), 1 whenever the shape allows"},
+    {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form: -1 evaluation-mode forward calls of 256 workgroups or more (default: 1.5x faster alone, neutral to slower inside a training step), 0 never, 1 every launch the shape allows, 2 / 3 forward / data-gradient launches only"},
+    {"enc_wino_mask", 0, "A/B: when non-zero, picks the Winograd form per launch instead of enc_wino: bit l-1 = forward of layer l (1..3), bit 2+l = its data gradient"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::atomic<bool> g_init{false};

@@ -64,6 +64,37 @@ def test_encoder_matches_reference_fixture(fx):
     _close(enc(x).detach().cpu(), fx["enc_eval_logits"], 2e-5, "eval logits")
 
 
+def test_encoder_winograd_form_matches_direct_form():
+    """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip) against the direct implicit GEMM, on whole
+    networks: evaluation-mode forward (the default use: option enc_wino = -1 picks it for evaluation calls of this size),
+    and a training-mode forward + backward with every launch switched (enc_wino = 1)."""
+    from image_generation_amd import _lib
+    n, B = 128, 1024
+    params = gen.make_params(n, "encoder", 111)
+    x = torch.from_numpy(gen.make_images(B, 222)).cuda()
+    gl = torch.from_numpy(np.random.default_rng(333).standard_normal((B, n)).astype(np.float32)).cuda()
+    out = {}
+    for mode in (0, -1, 1):
+        with _lib.option_scope(enc_wino=mode):
+            enc = _load(Encoder(n), params).eval()
+            ev = enc(x).detach().cpu()
+            enc = _load(Encoder(n), params).train()
+            lg = enc(x)
+            (lg * gl).sum().backward()
+            out[mode] = (ev, lg.detach().cpu(), {k: v.grad.detach().cpu() for k, v in enc.named_parameters()})
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(out[-1][0], out[0][0]) < 2e-6 and rel(out[1][0], out[0][0]) < 2e-6
+    assert not torch.equal(out[-1][0], out[0][0])            # (the default DID take the other kernel for the evaluation call)
+    assert torch.equal(out[-1][1], out[0][1])                # ... and not for the training call
+    assert rel(out[1][1], out[0][1]) < 5e-6
+    for k, g in out[0][2].items():
+        if k.startswith("conv") and k.endswith("bias") or ".bias" in k and "conv" in k:
+            continue  # conv biases in front of a BatchNorm: zero true gradient, rounding noise only
+        # (5e-3: the bar of the full-size step test against float64 -- the first layers' gradients pass through three
+        # BatchNorm backward passes, whose cancellations amplify any float32 rounding difference to ~1e-3)
+        assert rel(out[1][2][k], g) < 5e-3, (k, rel(out[1][2][k], g))
+
+
 def test_decoder_matches_reference_fixture(fx):
     n, B, R = int(fx["n"]), int(fx["B"]), int(fx["R"])
     dec = _load(Decoder(n), gen.make_params(n, "decoder", 404)).train()
