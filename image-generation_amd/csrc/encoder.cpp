@@ -92,7 +92,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
 
 // what shapes the workspace's contents: the pack format of the direct GEMMs and which layers run in the Winograd form
 uint32_t enc_plan_signature(const EncPlan& pl) {
-  uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64);
+  uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64) | (opt(OPT_ENC_L0_FUSED) != 0 ? 1u << 30 : 0u);
   for (int l = 1; l < 4; ++l) sig |= (pl.wino_f[l] ? 1u : 0u) << (8 + 2 * l) | (pl.wino_d[l] ? 1u : 0u) << (9 + 2 * l);
   return sig;
 }
@@ -152,6 +152,21 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   }
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
+    if (l == 0 && opt(OPT_ENC_L0_FUSED) != 0) {
+      // layer 0 recomputed (special.hip, enc_l0_kernel): statistics pass, finaliser, then BN -> pool -> LeakyReLU from
+      // the images; Y0 is never written
+      EncL0Args a0{};
+      a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
+      a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
+      a0.Xp = W + pl.Xp[0];
+      a0.part = W + pl.stats[0];
+      if (training) DVG_TRY(launch_enc_l0(0, a0, s));
+      DVG_TRY(launch_bn_finalize(W + pl.stats[0], pl.nblk[0], C, pl.M[0], training, W + pl.mean[0], W + pl.invstd[0],
+                                 p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
+      DVG_TRY(launch_enc_l0(1, a0, s));
+      x = W + pl.Xp[0];
+      continue;
+    }
     if (l == 0) {
       DVG_TRY(launch_enc_conv0_fwd(images, B, p->conv_w[0], p->conv_b[0], W + pl.Y[0], W + pl.stats[0], s));
     } else {
@@ -199,6 +214,22 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     const float* Y = W + pl.Y[l];
     float* dY = W + pl.dYl[l];
+    if (l == 0 && opt(OPT_ENC_L0_FUSED) != 0) {
+      // layer 0 recomputed: (sum dz, sum dz zhat) from the images and the pooled gradient, then the weight gradient with dY0
+      // formed in registers -- neither Y0 nor dY0 exists
+      EncL0Args a0{};
+      a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
+      a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
+      a0.dXp = dX;
+      a0.part = partA;
+      DVG_TRY(launch_enc_l0(2, a0, s));
+      DVG_TRY(launch_colsum2(partA, enc_l0_blocks(B), 2 * C, C, g->bn_b[0], C, g->bn_g[0], s));
+      a0.sum_dz = g->bn_b[0]; a0.sum_dzzh = g->bn_g[0]; a0.inv_m = (float)(1.0 / ((double)B * 1024.0));
+      a0.part = W + pl.part320;
+      DVG_TRY(launch_enc_l0(3, a0, s));
+      DVG_TRY(launch_colsum2(W + pl.part320, enc_l0_blocks(B), 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
+      break;
+    }
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
     DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                           dX, partA, s));

@@ -82,6 +82,18 @@ int launch_dec_bn_act_bwd_apply(const float* Y, const float* X, int64_t M, int C
 int enc_conv0_blocks(int64_t B);
 int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s);
+// encoder layer 0 with its output recomputed instead of stored (special.hip: enc_l0_kernel<MODE>)
+struct EncL0Args {
+  const float* img; int64_t B;
+  const float* w; const float* bias;                       // conv weight (32,1,3,3), bias (32)
+  const float* mean; const float* invstd; const float* gamma; const float* beta;
+  const float* dXp;                                        // gradient wrt the pooled map [B*256][32]          (MODE 2, 3)
+  const float* sum_dz; const float* sum_dzzh; float inv_m; // BatchNorm backward sums over the batch, 1 / (B*1024) (MODE 3)
+  float* Xp;                                               // [B*256][32]                                     (MODE 1)
+  float* part;                                             // MODE 0: [blocks][32][2], MODE 2: [blocks][64], MODE 3: [blocks][320]
+};
+int enc_l0_blocks(int64_t B);
+int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s);
 // part: [EW_BLOCKS][320]: 288 weight-gradient entries in checkpoint order, then 32 bias-gradient entries
 int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s);
 // Linear(4,1) over the 2x2 pooled map: P (B,4,n) -> logits (B,n)

@@ -95,6 +95,185 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
   return DVG_OK;
 }
 
+// ------------------------------------------------------------------------------ encoder layer 0, recomputed
+// The layer's output Y0 is the largest tensor of the network (c3: 537 MB) and the cheapest to make (nine taps of ONE input
+// channel: five MFMAs per 32 pixels from a 4 KB image that sits in cache).  Round 3: nothing stores or reads it any more.
+// Every pass that needed it -- the BatchNorm statistics, BN -> MaxPool -> LeakyReLU, the two backward passes of that stage,
+// the weight gradient -- recomputes the 32-pixel tile with the same five MFMAs (bit-identical every time) and works on
+// the accumulator registers: a lane holds channel c of pixels crow(r, hh), i.e. FOUR WHOLE pooling quads (r = 4g .. 4g+3),
+// so pooling, arg-max and the BatchNorm backward are lane-local.  HBM traffic of the stage at c3: 2.9 GB -> 0.45 GB.
+//   MODE 0  per-block (sum, sum of squares) partials for BatchNorm           (replaces the store of Y0)
+//   MODE 1  Xp = LeakyReLU(MaxPool(BN(y)))                                    (replaces enc_bn_pool_fwd's read of Y0)
+//   MODE 2  per-block (sum dz, sum dz zhat) partials                          (replaces enc_bn_pool_bwd reduce)
+//   MODE 3  dW[co][t] = sum_m dY[m][co] in_t[m], db = sum_m dY: dY formed in registers and fed to the MFMA as the A
+//           operand of the pixel pair (crow(r,0), crow(r,1))                  (replaces the apply pass, dY0 and the wgrad's reads)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
+  __shared__ double redd[MODE == 0 ? 2 * 4 * 32 : 1];
+  __shared__ float redf[MODE == 3 ? 4 * 32 * 33 : (MODE == 2 ? 2 * 4 * 32 : 1)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  float bw[5];
+  int dy[5], dx[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int t = 2 * j + hh;
+    bw[j] = t < 9 ? a.w[c * 9 + t] : a.bias[c];
+    dy[j] = t < 9 ? t / 3 - 1 : 0;
+    dx[j] = t < 9 ? t % 3 - 1 : 0;
+  }
+  float mu = 0.f, is = 0.f, gm = 0.f, bt = 0.f, m1 = 0.f, m2 = 0.f, gi = 0.f;
+  if (MODE >= 1) { mu = a.mean[c]; is = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
+  if (MODE == 3) { m1 = a.sum_dz[c] * a.inv_m; m2 = a.sum_dzzh[c] * a.inv_m; gi = gm * is; }
+  const int tdy = c < 9 ? c / 3 - 1 : 0, tdx = c < 9 ? c % 3 - 1 : 0;  // MODE 3: this lane's tap column of the B operand
+  const int cy = (int)morton_y((uint32_t)c), cx = (int)morton_x((uint32_t)c);  // pixel c of a tile, inside the tile
+  const int64_t tiles = a.B * 32;
+  double s1 = 0.0, s2 = 0.0;
+  float r1 = 0.f, r2 = 0.f;
+  f32x16c wacc = {0};
+  constexpr int TU = 2;
+  for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
+    float av[TU][5], gov[TU][4];
+    bool ok[TU][5];
+    // every load of the TU tiles goes out before the first MFMA needs one (clamped, always-valid addresses)
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int64_t tile = t0 + u < tiles ? t0 + u : tiles - 1;
+      // a tile = 32 consecutive Morton indices = an 8 (x) by 4 (y) block of its image: corner from the tile index
+      // (wave-uniform scalar work), the pixel's place inside from the lane (constants)
+      const int ti = (int)(tile & 31);
+      const int y = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)) + cy;
+      const int x = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1)) + cx;
+      const float* im = a.img + (tile >> 5) * 1024;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int yy = y + dy[j], xx = x + dx[j];
+        ok[u][j] = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+        av[u][j] = im[ok[u][j] ? yy * 32 + xx : 0];
+      }
+      if (MODE >= 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gov[u][g] = a.dXp[(tile * 8 + 2 * g + hh) * 32 + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      if (t0 + u >= tiles) continue;  // wave-uniform
+      const int64_t tile = t0 + u;
+      f32x16c acc = {0};
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float av_ = (2 * j + hh == 9) ? 1.0f : (ok[u][j] ? av[u][j] : 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bw[j], acc, 0, 0, 0);
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s1 += (double)acc[r];
+          s2 = fma((double)acc[r], (double)acc[r], s2);
+        }
+        continue;
+      }
+      float go[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE >= 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) go[g] = gov[u][g];
+      }
+      float bimg[16];
+      if (MODE == 3) {  // B operand of the weight-gradient MFMA r: in_t[pixel crow(r, hh)], t = this lane's column
+        const int ti = (int)(tile & 31);
+        const int y0 = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)) + tdy;
+        const int x0 = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1)) + tdx + 2 * hh;
+        const float* im = a.img + (tile >> 5) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // pixel crow(r, hh) = (r & 3) + 4 hh + 8 (r >> 2) of the tile: x = (r & 1) + 2 hh + 4 (r >> 3), y = ((r >> 1) & 1) + 2 ((r >> 2) & 1)
+          const int yy = y0 + ((r >> 1) & 1) + 2 * ((r >> 2) & 1), xx = x0 + (r & 1) + 4 * (r >> 3);
+          const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+          const float v = im[inb ? yy * 32 + xx : 0];
+          bimg[r] = c == 9 ? 1.0f : ((c < 9 && inb) ? v : 0.f);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // the window of enc_bn_pool_*: zhat, arg-max (first maximum wins), LeakyReLU slope at the pooled value
+        float zh[4], best = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+          zh[sq] = (acc[4 * g + sq] - mu) * is;
+          const float z = fmaf(zh[sq], gm, bt);
+          if (sq == 0 || z > best) { best = z; arg = sq; }
+        }
+        if (MODE == 1) {
+          a.Xp[(tile * 8 + 2 * g + hh) * 32 + c] = best < 0.f ? best * LRELU_SLOPE : best;
+        } else {
+          const float slope = !(best > 0.f) ? LRELU_SLOPE : 1.0f;
+          const float dz = go[g] * slope;
+          if (MODE == 2) {
+            r1 += dz;
+            r2 = fmaf(dz, zh[arg], r2);
+          } else {
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+              const float dyv = gi * (((sq == arg) ? dz : 0.f) - m1 - zh[sq] * m2);
+              wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, bimg[4 * g + sq], wacc, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hh == 0) { redd[wave * 32 + c] = s1; redd[128 + wave * 32 + c] = s2; }
+    __syncthreads();
+    if (tid < 32) {
+      a.part[((size_t)blockIdx.x * 32 + tid) * 2] = (float)((redd[tid] + redd[32 + tid]) + (redd[64 + tid] + redd[96 + tid]));
+      a.part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] =
+          (float)((redd[128 + tid] + redd[160 + tid]) + (redd[192 + tid] + redd[224 + tid]));
+    }
+  }
+  if (MODE == 2) {
+    r1 += __shfl_xor(r1, 32, 64);
+    r2 += __shfl_xor(r2, 32, 64);
+    if (hh == 0) { redf[wave * 32 + c] = r1; redf[128 + wave * 32 + c] = r2; }
+    __syncthreads();
+    if (tid < 64) {
+      const int k = tid >> 5, cc = tid & 31;
+      a.part[(size_t)blockIdx.x * 64 + tid] =
+          (redf[k * 128 + cc] + redf[k * 128 + 32 + cc]) + (redf[k * 128 + 64 + cc] + redf[k * 128 + 96 + cc]);
+    }
+  }
+  if (MODE == 3) {
+    // D[row = co][col = t]: lane holds column c, rows crow(r, hh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) redf[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = wacc[r];
+    __syncthreads();
+    for (int w = tid; w < 320; w += 256) {
+      const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
+      a.part[(size_t)blockIdx.x * 320 + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
+                                             (redf[(2 * 32 + co) * 33 + t] + redf[(3 * 32 + co) * 33 + t]);
+    }
+  }
+}
+
+// blocks: MODE 0 enc_conv0_blocks(B) (the BatchNorm partial rows); MODE 2, 3: enc_l0_blocks(B) rows of `part`
+// (2048 rows: the passes are bound by load latency, and 512 blocks are two per CU)
+int enc_l0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > STREAM_BLOCKS ? STREAM_BLOCKS : b); }
+
+int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
+  const dim3 g0((unsigned)enc_conv0_blocks(a.B)), g((unsigned)enc_l0_blocks(a.B));
+  switch (mode) {
+    case 0: DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_kernel<0>, g0, dim3(256), 0, s, a); break;
+    case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
+    case 2: DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_l0_kernel<2>, g, dim3(256), 0, s, a); break;
+    default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<3>, g, dim3(256), 0, s, a); break;
+  }
+  return DVG_OK;
+}
+
 // dW[co][t] = sum_m dY[m][co] * in_t[m];  db[co] = sum_m dY[m][co];  part [stream_blocks(B)][320]
 // A (32 x K) x (K x 10) GEMM with K = B*1024 pixels: one f32 MFMA per two pixels.  The A operand (dY rows, 32
 // channels = 128 B) and the B operand (the 9 shifted input pixels + a column of ones for the bias, rest zero) go
