@@ -64,6 +64,34 @@ def test_encoder_matches_reference_fixture(fx):
     _close(enc(x).detach().cpu(), fx["enc_eval_logits"], 2e-5, "eval logits")
 
 
+def test_encoder_layer0_recomputed_equals_stored():
+    """Layer 0 recomputed by every pass (option enc_l0_fused = 1, the default: csrc/special.hip enc_l0_kernel) against the
+    stored form of rounds 1-2: the forward is the same arithmetic in the same order (bit-identical logits, training and
+    evaluation mode, and the same running statistics); the backward sums run over another partition of the pixels."""
+    n, B = 64, 96
+    params = gen.make_params(n, "encoder", 121)
+    x = torch.from_numpy(gen.make_images(B, 232)).cuda()
+    gl = torch.from_numpy(np.random.default_rng(343).standard_normal((B, n)).astype(np.float32)).cuda()
+    out = {}
+    for fused in (0, 1):
+        with _lib.option_scope(enc_l0_fused=fused):
+            enc = _load(Encoder(n), params).eval()
+            ev = enc(x).detach().cpu()
+            enc = _load(Encoder(n), params).train()
+            lg = enc(x)
+            (lg * gl).sum().backward()
+            out[fused] = (ev, lg.detach().cpu(), {k: v.grad.detach().cpu() for k, v in enc.named_parameters()},
+                          {k: v.detach().cpu() for k, v in enc.state_dict().items() if "running" in k})
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for k, v in out[0][3].items():
+        assert torch.equal(v, out[1][3][k]), k
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for k, g in out[0][2].items():
+        if k == "conv.0.bias":
+            continue  # a conv bias in front of a BatchNorm: zero true gradient, rounding noise only
+        assert rel(out[1][2][k], g) < 2e-5, (k, rel(out[1][2][k], g))
+
+
 def test_encoder_winograd_form_matches_direct_form():
     """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip) against the direct implicit GEMM, on whole
     networks: evaluation-mode forward (the default use: option enc_wino = -1 picks it for evaluation calls of this size),
