@@ -30,6 +30,7 @@ struct DecPlan {
   // 3 x 2 N (n 4n + 4n 512); the gradients of BOTH original parameter tensors follow by the chain rule in weight space
   // (dWlin = dWc . Weff^T, dWeff = Wlin^T . dWc + blin (x) dbc).  X0 is never materialised.
   bool lc0;
+  bool tail;  // layer 2's BN/Dropout/LeakyReLU folded into layer 3's kernels (special.hip: DecActIn)
   size_t WcT, Wc, bc, dbc, dWc, dWcT, T1, dWeff, partC;
   int ksplit_c;
   size_t total_floats;
@@ -108,6 +109,7 @@ DecPlan dec_plan(int64_t N, int n) {
     // composed form: the LDS-DMA GEMMs only (their K-major float32 packs double as plain row-major matrices); every
     // operand mode has them (conv_launch_mode: 3 float32, 4 f32x3, 5 bf16 inputs), the register-staged A/B form does not
     p.lc0 = p.d22 && env != 0 && (N >= 4096 || env == 1) && conv_pack_is_f32_kmajor(conv_launch_mode(N, 4 * C));
+    p.tail = opt(OPT_DEC_TAIL_FUSED) != 0;
     if (p.lc0) {
       p.WcT = bump(o, (size_t)4 * C * n);
       p.Wc = bump(o, (size_t)n * 4 * C);
@@ -135,7 +137,7 @@ DecPlan dec_plan(int64_t N, int n) {
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   // one bias-gradient partial buffer per layer: their column sums run on the side stream, behind the main chain
-  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);
+  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)(l == 2 ? STREAM_BLOCKS : EW_BLOCKS) * ch[l + 1]);  // (l = 2: rows of the fused tail)
   p.partL = bump(o, (size_t)EW_BLOCKS * cmax);
   p.partF = bump(o, (size_t)EW_BLOCKS * 10);
   p.partW = bump(o, (size_t)STREAM_BLOCKS * 288);
@@ -147,7 +149,7 @@ DecPlan dec_plan(int64_t N, int n) {
 // what of the plan the backward relies on the forward having done (which buffers hold what, in which pack format)
 uint32_t plan_signature(const DecPlan& pl) {
   return (uint32_t)pl.d22 | (uint32_t)pl.lc0 << 1 | (uint32_t)pl.fold[1] << 2 | (uint32_t)pl.fold[2] << 3 |
-         (uint32_t)conv_launch_mode(pl.N, 128) << 4;
+         (uint32_t)conv_launch_mode(pl.N, 128) << 4 | (uint32_t)pl.tail << 12;
 }
 
 int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws, size_t ws_bytes, const DecPlan& pl) {
@@ -257,12 +259,16 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       }
       a.splitk_ws = W + pl.splitk;
       DVG_TRY(launch_conv_igemm(a, s));
+    } else if (pl.tail) {  // layer 2's activation happens while layer 3 stages its input (Xs[2] is never written)
+      const DecActIn in{W + pl.Y[2], W + pl.mean[2], W + pl.invstd[2], p->bn_g[2], p->bn_b[2], training ? W + pl.mask[2] : nullptr};
+      DVG_TRY(launch_dec_conv3_fwd_act(in, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
     } else {
       DVG_TRY(launch_dec_conv3_fwd(x, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
                                p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
     const float* mask = training ? W + pl.mask[l] : nullptr;
+    if (l == 2 && pl.tail) continue;
     DVG_TRY(launch_dec_bn_act_fwd(W + pl.Y[l], pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                   p->bn_b[l], mask, W + pl.Xs[l], s));
     x = W + pl.Xs[l];
@@ -320,11 +326,18 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     const float* Xs = W + pl.Xs[l];
     const float* mask = W + pl.mask[l];  // backward only exists for a training-mode forward
     float* dY = W + pl.dYl[l];
-    DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
-                                         partA, s));
-    DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
-    DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
-                                        mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+    const DecActIn in2{W + pl.Y[2], W + pl.mean[2], W + pl.invstd[2], p->bn_g[2], p->bn_b[2], W + pl.mask[2]};
+    if (l == 2 && pl.tail) {
+      // the (sum dz, sum dz zhat) partials came out of layer 3's fused backward below; dY2 = its second pass
+      DVG_TRY(launch_colsum2(partA, dec_tail_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      DVG_TRY(launch_dec_conv3_bwd_apply(in2, N, W + pl.dYl[3], p->conv_w[3], g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+    } else {
+      DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
+                                           partA, s));
+      DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                          mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+    }
     // Fork: dY is ready.  The caller's-stream kernel is enqueued BEFORE the side-stream ones: when the call is being
     // captured into a hipGraph, the first child captured after a fork inherits the parent's hardware queue, and a
     // data-gradient chain that changes queue at every layer pays a cross-queue signal (~10-15 us) per hop.
@@ -373,7 +386,8 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       // the column sums go to the side stream (no fork here: they are in the batch at the end of the side chain).  (The two
       // separate kernels this replaced were retired in round 3.)
       const int w3_blocks = stream_blocks(N);  // partial rows of the weight gradient
-      DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
+      if (pl.tail) DVG_TRY(launch_dec_conv3_bwd_reduce(in2, N, dY, p->conv_w[3], partW, partA, s));
+      else DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
       DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
                   sums.add(partW, w3_blocks, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
                   "decoder_bwd: column-sum batch full");
@@ -388,7 +402,8 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     a.splitk_ws = W + pl.splitk;
     DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
-    DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0), "decoder_bwd: column-sum batch full");
+    DVG_REQUIRE(sums.add(W + pl.partB[l], (l == 2 && pl.tail) ? dec_tail_blocks(N) : EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0),
+                "decoder_bwd: column-sum batch full");
     WgradArgs wa;
     wa.in = xin; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = l > 0; wa.ksplit = pl.ksplit[l];

@@ -102,6 +102,22 @@ int launch_enc_proj_fwd(const float* P, int64_t B, int n, const float* w, const 
 int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const float* dlogits, float* dP, float* part,
                         hipStream_t s);
 // decoder conv3 (32 -> 1 channel, 16x16, input upsampled from 8x8)
+// The layer's input given as the PREVIOUS layer's pre-BatchNorm output: the kernels apply BN -> Dropout2d -> LeakyReLU
+// while they stage an image (decoder layer 2's activated map, 268 MB at c3, is then never written or read).  `mask`:
+// Dropout2d keep-mask [N][32] or null (evaluation).  Null `y`: the input is the activated map itself.
+struct DecActIn {
+  const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; const float* mask;
+};
+int launch_dec_conv3_fwd_act(const DecActIn& in, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
+                             hipStream_t s);
+// backward of conv3 fused with the BatchNorm/Dropout/LeakyReLU backward of the layer in front of it: pass 1 = conv3's weight
+// gradient partials part_w [blocks][288] + that layer's (sum dz, sum dz zhat) partials part_bn [blocks][64] (no dX);
+// pass 2 = that layer's dY [N*64][32] + its column-sum partials part_db [blocks][32]
+int dec_tail_blocks(int64_t N);
+int launch_dec_conv3_bwd_reduce(const DecActIn& in, int64_t N, const float* dY3, const float* w, float* part_w, float* part_bn,
+                                hipStream_t s);
+int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, const float* w, const float* sum_dz,
+                               const float* sum_dzzh, float* dY2, float* part_db, hipStream_t s);
 int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s);
 int dec_conv3_blocks(int64_t N);

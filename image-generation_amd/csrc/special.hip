@@ -396,7 +396,8 @@ int launch_enc_proj_bwd(const float* P, int64_t B, int n, const float* w, const 
 // (i-1+pa+dr, j-1+pb+dc) with the 9 kernel taps pre-summed onto them.  One image per block iteration: its 8x8x32 source
 // map is staged in LDS once (the old gather re-read every source row 36 times through L1); wave w computes the 64
 // outputs of class w with its 4x32 folded weights in registers; the 256 outputs leave through LDS as one contiguous row.
-__global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restrict__ X, int64_t N,
+template <bool ACT>  // ACT: X is the previous layer's pre-BatchNorm output, activated on the way into LDS (DecActIn)
+__global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restrict__ X, DecActIn in, int64_t N,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ Y, float* __restrict__ stats_part) {
   constexpr int XP = 36;  // row pitch in floats: 16-byte aligned rows, conflict-free b128 reads across source rows
@@ -437,14 +438,34 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
     src[t] = (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) ? (int)morton((uint32_t)yy, (uint32_t)xx) : -1;
   }
   double s1 = 0.0, s2 = 0.0;  // (BatchNorm partials in double: see enc_conv0_fwd_kernel)
+  const int cg4 = (tid & 7) * 4;  // the channel quad this thread stages (the same for both of its float4s)
+  float4 amu = {0.f, 0.f, 0.f, 0.f}, ais = amu, agm = amu, abt = amu;
+  if (ACT) {
+    amu = *reinterpret_cast<const float4*>(in.mean + cg4); ais = *reinterpret_cast<const float4*>(in.invstd + cg4);
+    agm = *reinterpret_cast<const float4*>(in.gamma + cg4); abt = *reinterpret_cast<const float4*>(in.beta + cg4);
+  }
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();  // previous image's xs / outs readers are done
     {  // 64 rows x 32 floats = 512 float4: two per thread, coalesced
-      const float4* g = reinterpret_cast<const float4*>(X + img * 64 * 32);
+      const float4* g = reinterpret_cast<const float4*>((ACT ? in.y : X) + img * 64 * 32);
+      float4 mk = {1.f, 1.f, 1.f, 1.f};
+      if (ACT && in.mask) {
+        mk = *reinterpret_cast<const float4*>(in.mask + img * 32 + cg4);
+        const float ks = 1.0f / DROPOUT_KEEP;
+        mk.x *= ks; mk.y *= ks; mk.z *= ks; mk.w *= ks;
+      }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int e = tid + 256 * k;
-        *reinterpret_cast<float4*>(xs + (e >> 3) * XP + (e & 7) * 4) = g[e];
+        float4 v = g[e];
+        if (ACT) {  // dec_bn_act_fwd's arithmetic, element for element
+          float z;
+          z = fmaf((v.x - amu.x) * ais.x, agm.x, abt.x); if (in.mask) z *= mk.x; v.x = z < 0.f ? z * LRELU_SLOPE : z;
+          z = fmaf((v.y - amu.y) * ais.y, agm.y, abt.y); if (in.mask) z *= mk.y; v.y = z < 0.f ? z * LRELU_SLOPE : z;
+          z = fmaf((v.z - amu.z) * ais.z, agm.z, abt.z); if (in.mask) z *= mk.z; v.z = z < 0.f ? z * LRELU_SLOPE : z;
+          z = fmaf((v.w - amu.w) * ais.w, agm.w, abt.w); if (in.mask) z *= mk.w; v.w = z < 0.f ? z * LRELU_SLOPE : z;
+        }
+        *reinterpret_cast<float4*>(xs + (e >> 3) * XP + (e & 7) * 4) = v;
       }
     }
     __syncthreads();
@@ -483,8 +504,15 @@ int dec_conv3_blocks(int64_t N) { return (int)(N < special_block_cap() ? N : spe
 
 int launch_dec_conv3_fwd(const float* X, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
                          hipStream_t s) {
-  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel, dim3((unsigned)dec_conv3_blocks(N)), dim3(256), 0, s, X, N, w, b, Y,
-             stats_part);
+  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel<false>, dim3((unsigned)dec_conv3_blocks(N)), dim3(256), 0, s, X, DecActIn{}, N,
+             w, b, Y, stats_part);
+  return DVG_OK;
+}
+
+int launch_dec_conv3_fwd_act(const DecActIn& in, int64_t N, const float* w, const float* b, float* Y, float* stats_part,
+                             hipStream_t s) {
+  DVG_LAUNCH(K_DEC_CONV3_FWD, dec_conv3_fwd_kernel<true>, dim3((unsigned)dec_conv3_blocks(N)), dim3(256), 0, s, nullptr, in, N,
+             w, b, Y, stats_part);
   return DVG_OK;
 }
 
@@ -563,6 +591,175 @@ int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float
   return DVG_OK;
 }
 
+
+// The same pass with the layer in front of conv3 folded in (round 3).  The image's source map arrives as that layer's
+// pre-BatchNorm output y (DecActIn): zhat and the activated value x are formed while it is staged; the gradient wrt x
+// (what dec_conv3_bwd_kernel writes as dX) stays in registers and goes straight through the LeakyReLU / Dropout2d backward:
+//   APPLY = false: (sum dz, sum dz zhat) partials of that layer + conv3's weight-gradient partials   (x, dX never stored)
+//   APPLY = true:  that layer's dY = gamma invstd (dz - mean(dz) - zhat mean(dz zhat)) and its column-sum partials
+// Together they replace dec_conv3_bwd + dec_bn_act_bwd reduce + apply of the 8x8x32 stage: 2.4 GB -> 0.9 GB at c3.
+template <bool APPLY>
+__global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, int64_t N, const float* __restrict__ dY3,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ sum_dz,
+                                                                  const float* __restrict__ sum_dzzh, float inv_m,
+                                                                  float* __restrict__ dY2, float* __restrict__ part_w,
+                                                                  float* __restrict__ part_bn) {
+  __shared__ float dys[256];
+  __shared__ float G[64 * 9];
+  __shared__ __align__(16) float xs[APPLY ? 4 : 64 * 32];  // activated input, for the weight-gradient role
+  __shared__ float ws[9 * 32];  // [tap][ci]
+  __shared__ float red[8 * 32 * (APPLY ? 1 : 2)];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 288; i += 288) ws[(i % 9) * 32 + i / 9] = w[i];
+  int gsrc[2][4];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 288 * k, q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
+    const int ys = (int)morton_y((uint32_t)q), xq = (int)morton_x((uint32_t)q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int y = 2 * ys + (u >> 1) - 1 + kh, x = 2 * xq + (u & 1) - 1 + kw;
+      gsrc[k][u] = (y >= 0 && y < 16 && x >= 0 && x < 16) ? (int)morton((uint32_t)y, (uint32_t)x) : -1;
+    }
+  }
+  const int tap = tid >> 5, ci = tid & 31;      // weight-gradient role
+  const int q = tid >> 2, cg = (tid & 3) * 8;   // data-gradient role (tid < 256): source pixel q, channels cg .. cg + 7
+  const bool dg = tid < 256;
+  // per-channel constants in LDS (read as broadcast float4s where they are used: in registers they made this a 170-VGPR
+  // kernel, two waves per SIMD, bound by the latency of its own loads)
+  __shared__ __align__(16) float cst[7][32];  // mean, invstd, gamma, beta, gamma invstd, mean(dz), mean(dz zhat)
+  if (tid < 32) {
+    cst[0][tid] = in.mean[tid]; cst[1][tid] = in.invstd[tid]; cst[2][tid] = in.gamma[tid]; cst[3][tid] = in.beta[tid];
+    cst[4][tid] = in.gamma[tid] * in.invstd[tid];
+    cst[5][tid] = APPLY ? sum_dz[tid] * inv_m : 0.f;
+    cst[6][tid] = APPLY ? sum_dzzh[tid] * inv_m : 0.f;
+  }
+  float acc = 0.f;
+  float a1[8], a2[8];  // APPLY: a1 = column sums of dY; else (sum dz, sum dz zhat)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
+  const float ks = 1.0f / DROPOUT_KEEP;
+  __syncthreads();
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();  // the previous image's readers of dys / G / xs are done
+    if (dg) dys[tid] = dY3[img * 256 + tid];
+    // this thread's 8 values of the layer's pre-BatchNorm output: zhat, the slope of the LeakyReLU at the activated value
+    // and the keep-mask stay in registers; the activated values go to LDS for the weight-gradient role
+    float zh[8], sl[8];
+    if (dg) {
+      const float4* yp = reinterpret_cast<const float4*>(in.y + (img * 64 + q) * 32 + cg);
+      const float4 y0 = yp[0], y1 = yp[1];
+      float4 k0 = {1.f, 1.f, 1.f, 1.f}, k1 = k0;
+      if (in.mask) {
+        const float4* mp = reinterpret_cast<const float4*>(in.mask + img * 32 + cg);
+        k0 = mp[0]; k1 = mp[1];
+      }
+      const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+      const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+      float xv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        zh[k] = (yv[k] - cst[0][cg + k]) * cst[1][cg + k];
+        float z = fmaf(zh[k], cst[2][cg + k], cst[3][cg + k]);
+        const float mk = in.mask ? kv[k] * ks : 1.0f;
+        if (in.mask) z *= mk;
+        xv[k] = z < 0.f ? z * LRELU_SLOPE : z;
+        sl[k] = ((xv[k] > 0.f) ? 1.0f : LRELU_SLOPE) * mk;  // dec_dz of elementwise.hip: LeakyReLU'(x) * keep-mask
+      }
+      if (!APPLY) {
+        float4* xd = reinterpret_cast<float4*>(xs + q * 32 + cg);
+        xd[0] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        xd[1] = make_float4(xv[4], xv[5], xv[6], xv[7]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float g = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g += gsrc[k][u] >= 0 ? dys[gsrc[k][u]] : 0.f;
+      G[tid + 288 * k] = g;
+    }
+    __syncthreads();
+    if (dg) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float g = G[q * 9 + t];
+        const float* wr = ws + t * 32 + cg;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaf(g, wr[k], o[k]);
+      }
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dz = o[k] * sl[k];
+        if (APPLY) {
+          v[k] = cst[4][cg + k] * (dz - cst[5][cg + k] - zh[k] * cst[6][cg + k]);
+          a1[k] += v[k];
+        } else {
+          a1[k] += dz;
+          a2[k] = fmaf(dz, zh[k], a2[k]);
+        }
+      }
+      if (APPLY) {
+        float4* dst = reinterpret_cast<float4*>(dY2 + (img * 64 + q) * 32 + cg);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    if (!APPLY) {
+#pragma unroll 8
+      for (int qq = 0; qq < 64; ++qq) acc = fmaf(G[qq * 9 + tap], xs[qq * 32 + ci], acc);
+    }
+  }
+  if (!APPLY) part_w[(size_t)blockIdx.x * 288 + tid] = acc;
+  // per-block column sums over the 64 source-pixel threads of each 8-channel group: waves 0-3 hold 16 pixels x 4 groups
+  // each; lanes with the same (tid & 3) share a group
+  if (dg) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int off = 4; off < 64; off <<= 1) {
+        a1[k] += __shfl_xor(a1[k], off, 64);
+        if (!APPLY) a2[k] += __shfl_xor(a2[k], off, 64);
+      }
+    }
+    if ((tid & 63) < 4) {
+      const int wv = tid >> 6;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(wv * 32 + cg + k) * (APPLY ? 1 : 2)] = a1[k];
+        if (!APPLY) red[(wv * 32 + cg + k) * 2 + 1] = a2[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (APPLY) {
+    if (tid < 32) part_bn[(size_t)blockIdx.x * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+  } else if (tid < 64) {
+    const int k = tid >> 5, cc = tid & 31;  // [2][32]: sums of dz, then sums of dz zhat
+    part_bn[(size_t)blockIdx.x * 64 + tid] =
+        (red[(0 * 32 + cc) * 2 + k] + red[(1 * 32 + cc) * 2 + k]) + (red[(2 * 32 + cc) * 2 + k] + red[(3 * 32 + cc) * 2 + k]);
+  }
+}
+
+int dec_tail_blocks(int64_t N) { return stream_blocks(N); }
+
+int launch_dec_conv3_bwd_reduce(const DecActIn& in, int64_t N, const float* dY3, const float* w, float* part_w, float* part_bn,
+                                hipStream_t s) {
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_fused_kernel<false>, dim3((unsigned)dec_tail_blocks(N)), dim3(288), 0, s, in, N, dY3,
+             w, nullptr, nullptr, 0.f, nullptr, part_w, part_bn);
+  return DVG_OK;
+}
+
+int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, const float* w, const float* sum_dz,
+                               const float* sum_dzzh, float* dY2, float* part_db, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_conv3_bwd_fused_kernel<true>, dim3((unsigned)dec_tail_blocks(N)), dim3(288), 0, s, in, N,
+             dY3, w, sum_dz, sum_dzzh, (float)(1.0 / ((double)N * 64.0)), dY2, nullptr, part_db);
+  return DVG_OK;
+}
 
 // ------------------------------------------------------------------------------ decoder final conv (1 -> 1)
 // X [N*256 (16x16 Morton)] upsampled to 32x32; out (N,32,32) row-major

@@ -92,6 +92,36 @@ def test_encoder_layer0_recomputed_equals_stored():
         assert rel(out[1][2][k], g) < 2e-5, (k, rel(out[1][2][k], g))
 
 
+def test_decoder_tail_fused_equals_separate_passes():
+    """The 8x8x32 stage's BatchNorm / Dropout2d / LeakyReLU inside the 32 -> 1 layer's kernels (option dec_tail_fused = 1,
+    the default: csrc/special.hip DecActIn) against the separate passes of rounds 1-2: the forward is the same arithmetic
+    element for element (bit-identical outputs, training with injected masks and evaluation); the backward sums run over
+    another partition of the pixels."""
+    n, B, R = 64, 12, 4
+    params = gen.make_params(n, "decoder", 414)
+    spins0 = torch.from_numpy(gen.make_spins(B, R, n, 515)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 616)]
+    go = torch.from_numpy(np.random.default_rng(717).standard_normal((B, R, 1, 32, 32)).astype(np.float32)).cuda()
+    out = {}
+    for fused in (0, 1):
+        with _lib.option_scope(dec_tail_fused=fused):
+            dec = _load(Decoder(n), params).eval()
+            ev = dec(spins0).detach().cpu()
+            dec = _load(Decoder(n), params).train()
+            dec.inject_dropout_masks(masks)
+            sp = spins0.clone().requires_grad_(True)
+            y = dec(sp)
+            (y * go).sum().backward()
+            out[fused] = (ev, y.detach().cpu(), sp.grad.detach().cpu(), {k: v.grad.detach().cpu() for k, v in dec.named_parameters()})
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(out[1][2], out[0][2]) < 2e-5
+    for k, g in out[0][3].items():
+        if k.startswith("conv") and k.endswith(".bias") and not k.startswith("conv.4"):
+            continue  # conv biases in front of a BatchNorm: zero true gradient, rounding noise only
+        assert rel(out[1][3][k], g) < 5e-5, (k, rel(out[1][3][k], g))
+
+
 def test_encoder_winograd_form_matches_direct_form():
     """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip) against the direct implicit GEMM, on whole
     networks: evaluation-mode forward (the default use: option enc_wino = -1 picks it for evaluation calls of this size),
