@@ -444,20 +444,30 @@ __global__ __launch_bounds__(256) void dec_conv3_fwd_kernel(const float* __restr
     amu = *reinterpret_cast<const float4*>(in.mean + cg4); ais = *reinterpret_cast<const float4*>(in.invstd + cg4);
     agm = *reinterpret_cast<const float4*>(in.gamma + cg4); abt = *reinterpret_cast<const float4*>(in.beta + cg4);
   }
+  // the next image's rows are requested before this image is computed (registers): one block iteration is three barriers
+  // long and would otherwise start with a full global-load latency
+  float4 nv[2], nmk = {1.f, 1.f, 1.f, 1.f};
+  auto fetch = [&](int64_t img) {
+    const int64_t im = img < N ? img : N - 1;
+    const float4* g = reinterpret_cast<const float4*>((ACT ? in.y : X) + im * 64 * 32);
+    nv[0] = g[tid]; nv[1] = g[tid + 256];
+    if (ACT && in.mask) nmk = *reinterpret_cast<const float4*>(in.mask + im * 32 + cg4);
+  };
+  fetch(blockIdx.x);
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();  // previous image's xs / outs readers are done
     {  // 64 rows x 32 floats = 512 float4: two per thread, coalesced
-      const float4* g = reinterpret_cast<const float4*>((ACT ? in.y : X) + img * 64 * 32);
-      float4 mk = {1.f, 1.f, 1.f, 1.f};
+      float4 mk = nmk;
+      const float4 cv[2] = {nv[0], nv[1]};
       if (ACT && in.mask) {
-        mk = *reinterpret_cast<const float4*>(in.mask + img * 32 + cg4);
         const float ks = 1.0f / DROPOUT_KEEP;
         mk.x *= ks; mk.y *= ks; mk.z *= ks; mk.w *= ks;
       }
+      fetch(img + gridDim.x);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int e = tid + 256 * k;
-        float4 v = g[e];
+        float4 v = cv[k];
         if (ACT) {  // dec_bn_act_fwd's arithmetic, element for element
           float z;
           z = fmaf((v.x - amu.x) * ais.x, agm.x, abt.x); if (in.mask) z *= mk.x; v.x = z < 0.f ? z * LRELU_SLOPE : z;
@@ -641,20 +651,30 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
   for (int k = 0; k < 8; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
   const float ks = 1.0f / DROPOUT_KEEP;
   __syncthreads();
+  // (the next image's values are requested before this image is computed, as in the forward kernel)
+  float4 ny0 = {0.f, 0.f, 0.f, 0.f}, ny1 = ny0, nk0 = {1.f, 1.f, 1.f, 1.f}, nk1 = nk0;
+  float ndy = 0.f;
+  auto fetch = [&](int64_t img) {
+    if (!dg) return;
+    const int64_t im = img < N ? img : N - 1;
+    const float4* yp = reinterpret_cast<const float4*>(in.y + (im * 64 + q) * 32 + cg);
+    ny0 = yp[0]; ny1 = yp[1];
+    if (in.mask) {
+      const float4* mp = reinterpret_cast<const float4*>(in.mask + im * 32 + cg);
+      nk0 = mp[0]; nk1 = mp[1];
+    }
+    ndy = dY3[im * 256 + tid];
+  };
+  fetch(blockIdx.x);
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();  // the previous image's readers of dys / G / xs are done
-    if (dg) dys[tid] = dY3[img * 256 + tid];
+    if (dg) dys[tid] = ndy;
     // this thread's 8 values of the layer's pre-BatchNorm output: zhat, the slope of the LeakyReLU at the activated value
     // and the keep-mask stay in registers; the activated values go to LDS for the weight-gradient role
     float zh[8], sl[8];
+    const float4 y0 = ny0, y1 = ny1, k0 = nk0, k1 = nk1;
+    fetch(img + gridDim.x);
     if (dg) {
-      const float4* yp = reinterpret_cast<const float4*>(in.y + (img * 64 + q) * 32 + cg);
-      const float4 y0 = yp[0], y1 = yp[1];
-      float4 k0 = {1.f, 1.f, 1.f, 1.f}, k1 = k0;
-      if (in.mask) {
-        const float4* mp = reinterpret_cast<const float4*>(in.mask + img * 32 + cg);
-        k0 = mp[0]; k1 = mp[1];
-      }
       const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
       const float kv[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
       float xv[8];
