@@ -332,11 +332,11 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       DVG_TRY(launch_colsum2(partA, dec_tail_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_conv3_bwd_apply(in2, N, W + pl.dYl[3], p->conv_w[3], g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     } else {
-      DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], mask, dX,
-                                           partA, s));
+      DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                           p->bn_b[l], mask, dX, partA, s));
       DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
-                                          mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+                                          p->bn_b[l], mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     }
     // Fork: dY is ready.  The caller's-stream kernel is enqueued BEFORE the side-stream ones: when the call is being
     // captured into a hipGraph, the first child captured after a fork inherits the parent's hardware queue, and a

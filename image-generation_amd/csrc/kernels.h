@@ -71,10 +71,13 @@ int launch_dropout_masks(int64_t N, const int C[4], float* const mask[4], uint64
                          const uint64_t* offset_dev, hipStream_t s);
 int launch_dec_bn_act_fwd(const float* Y, int64_t M, int C, int logHW, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, const float* mask, float* X, hipStream_t s);
+// (gamma / beta: the float4-of-channels kernels take the LeakyReLU slope from the sign of z = fma(zhat, gamma, beta) and do
+// not read X; the scalar kernels of the 1-channel stage read X)
 int launch_dec_bn_act_bwd_reduce(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
-                                 const float* invstd, const float* mask, const float* dX, float* part, hipStream_t s);
+                                 const float* invstd, const float* gamma, const float* beta, const float* mask,
+                                 const float* dX, float* part, hipStream_t s);
 int launch_dec_bn_act_bwd_apply(const float* Y, const float* X, int64_t M, int C, int logHW, const float* mean,
-                                const float* invstd, const float* gamma, const float* mask, const float* dX,
+                                const float* invstd, const float* gamma, const float* beta, const float* mask, const float* dX,
                                 const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);
 
 // ---- special-case layers
