@@ -313,7 +313,12 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
   {
     hipEvent_t start = nullptr;
     if (s2 != s) DVG_TRY(stream_mark(s, &start));
-    DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
+    if (pl.tail) {  // ... with the 1-channel stage's BatchNorm-backward sums formed on the way (no reduce pass below)
+      const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
+      DVG_TRY(launch_dec_final_dgrad_bn(grad_out, N, p->conv_w[4], dX, in3, partA, s));
+    } else {
+      DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
+    }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, start));
     DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
     DVG_REQUIRE(sums.add2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4]), "decoder_bwd: column-sum batch full");
@@ -332,9 +337,10 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       DVG_TRY(launch_colsum2(partA, dec_tail_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_conv3_bwd_apply(in2, N, W + pl.dYl[3], p->conv_w[3], g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     } else {
-      DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
-                                           p->bn_b[l], mask, dX, partA, s));
-      DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      if (!(l == 3 && pl.tail))
+        DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                             p->bn_b[l], mask, dX, partA, s));
+      DVG_TRY(launch_colsum2(partA, (l == 3 && pl.tail) ? dec_final_dgrad_blocks(N) : EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                           p->bn_b[l], mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     }

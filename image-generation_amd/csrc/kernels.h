@@ -117,6 +117,10 @@ int launch_dec_conv3_fwd_act(const DecActIn& in, int64_t N, const float* w, cons
 // gradient partials part_w [blocks][288] + that layer's (sum dz, sum dz zhat) partials part_bn [blocks][64] (no dX);
 // pass 2 = that layer's dY [N*64][32] + its column-sum partials part_db [blocks][32]
 int dec_tail_blocks(int64_t N);
+// the final layer's data gradient with the 1-channel stage's (sum dz, sum dz zhat) partials [dec_final_dgrad_blocks][2]
+int dec_final_dgrad_blocks(int64_t N);
+int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, float* dX, const DecActIn& in, float* part,
+                              hipStream_t s);
 int launch_dec_conv3_bwd_reduce(const DecActIn& in, int64_t N, const float* dY3, const float* w, float* part_w, float* part_bn,
                                 hipStream_t s);
 int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, const float* w, const float* sum_dz,

@@ -826,9 +826,17 @@ int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float*
 // dX[q] = sum over the quad's 4 pixels and taps of dOut(y+kh-1, x+kw-1) w[kh][kw]: a 4x4 stencil on dOut around the
 // quad with the taps pre-summed per offset (rows {w0}, {w0+w1}, {w1+w2}, {w2}, same for columns).  The image's dOut sits
 // in LDS with a zero halo (34x34); thread = source pixel.
+// BN = true (round 3): the thread that forms dX[img][q] also takes it through the 1-channel stage's Dropout / LeakyReLU
+// backward and adds its (dz, dz zhat) to the block's partials -- dec_bn_act_bwd_reduce's pass over Y, X and dX is gone
+// (the slope from the sign of the recomputed z, as in elementwise.hip).  part [blocks][2].
+template <bool BN>
 __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __restrict__ dOut, int64_t N,
-                                                              const float* __restrict__ w, float* __restrict__ dX) {
+                                                              const float* __restrict__ w, float* __restrict__ dX,
+                                                              DecActIn in, float* __restrict__ part) {
   __shared__ float gs[34 * 34];
+  __shared__ float red[2 * 4];
+  float r1 = 0.f, r2 = 0.f;
+  const float mu = BN ? in.mean[0] : 0.f, is = BN ? in.invstd[0] : 0.f, gm = BN ? in.gamma[0] : 0.f, bt = BN ? in.beta[0] : 0.f;
   const int tid = threadIdx.x;
   float wf[4][4];  // wf[u+1][v+1], u, v in -1..2: offset of the dOut pixel from the quad's top-left pixel
 #pragma unroll
@@ -863,11 +871,35 @@ __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __res
       for (int v = 0; v < 4; ++v) acc = fmaf(row[v], wf[u][v], acc);
     }
     dX[img * 256 + tid] = acc;
+    if (BN) {
+      const float zh = (in.y[img * 256 + tid] - mu) * is;
+      const float mk = in.mask ? in.mask[img] * (1.0f / DROPOUT_KEEP) : 1.0f;
+      const float dz = acc * ((fmaf(zh, gm, bt) > 0.f) ? 1.0f : LRELU_SLOPE) * mk;
+      r1 += dz;
+      r2 = fmaf(dz, zh, r2);
+    }
+  }
+  if (BN) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64); }
+    if ((tid & 63) == 0) { red[tid >> 6] = r1; red[4 + (tid >> 6)] = r2; }
+    __syncthreads();
+    if (tid < 2) part[(size_t)blockIdx.x * 2 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
   }
 }
 
+int dec_final_dgrad_blocks(int64_t N) { return (int)(N > 2048 ? 2048 : N); }
+
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, dOut, N, w, dX);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<false>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
+             dX, DecActIn{}, nullptr);
+  return DVG_OK;
+}
+
+int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, float* dX, const DecActIn& in, float* part,
+                              hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<true>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
+             dX, in, part);
   return DVG_OK;
 }
 
