@@ -41,5 +41,5 @@ for name, Cin, Cout, side, mode in shapes:
     w = torch.randn((Cout, Cin, 3, 3) if mode == 0 else (Cin, Cout, 3, 3), device="cuda") / 30
     t_w = timeit(lambda: dev.conv_wino(x, w, mode, M, Cin, Cout, L))
     t_d = timeit(lambda: dev.conv_igemm(x, w, mode, M, Cin, Cout, L))
-    gf = 2.0 * M * Cin * Cout * 9 / 1e9
-    print(f"{name:9s} M={M:8d} {Cin:4d}->{Cout:4d}  wino {t_w:8.1f} us ({gf / t_w * 1e-3:6.1f} TFLOP/s algorithmic)   direct {t_d:8.1f} us ({gf / t_d * 1e-3:6.1f})")
+    gf = 2.0 * M * Cin * Cout * 9 / 1e9  # direct-form GFLOP of the launch
+    print(f"{name:9s} M={M:8d} {Cin:4d}->{Cout:4d}  wino {t_w:8.1f} us ({gf / t_w * 1e3:6.1f} TFLOP/s of direct-form FLOPs)   direct {t_d:8.1f} us ({gf / t_d * 1e3:6.1f})")
