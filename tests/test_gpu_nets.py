@@ -628,3 +628,21 @@ def test_wide_tile_configuration_in_a_child_process():
                         "decoder_matches_oracle_full_gradients or matches_reference_fixture or bf16 or conv2d_fwd_dgrad_wgrad"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=1200)  # (f32 and bf16-input forms)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("options", ["enc_l0_fused=0,dec_tail_fused=0", "enc_wino=1"])
+def test_alternative_layer_forms_in_a_child_process(options):
+    """The forms round 3 replaced or made optional stay correct: encoder layer 0 and the decoder's 8x8x32 stage as stored
+    tensors with separate passes (rounds 1-2), and the Winograd form of the encoder's 3x3 layers on every launch.  The
+    fixture / oracle tests of both networks re-run under the options in a child."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DVG_TEST_OPTIONS"):
+        pytest.skip("already inside the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DVG_TEST_OPTIONS=options)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_nets.py"), "-q", "-m", "gpu", "-k",
+                        "matches_oracle_full_gradients or matches_reference_fixture"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
