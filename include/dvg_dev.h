@@ -30,7 +30,8 @@ int dvg_dev_conv_wgrad(const float *in, const float *dy, float *slabs, float *gr
                        int Cout, int L, int ntaps, int ups, dvg_stream_t stream);
 /* Where the encoder's workspace (dvg_encoder_workspace_bytes) keeps what a forward call saved, as FLOAT offsets:
  * out[0..3] = pre-BatchNorm convolution outputs Y[l] ([B * HW_l][C_l], Morton NHWC), out[4..7] = pooled stage outputs
- * Xp[l], out[8..11] = batch means, out[12..15] = batch inverse standard deviations.  Diagnostics only. */
+ * Xp[l], out[8..11] = batch means, out[12..15] = batch inverse standard deviations.  Diagnostics only.  (Y[0] is only
+ * written under option enc_l0_fused = 0: the default recomputes layer 0 wherever its output is needed.) */
 int dvg_dev_encoder_layout(int64_t B, int n_latents, size_t out[16]);
 #ifdef __cplusplus
 }
