@@ -84,7 +84,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);  // per layer: reduced on the side stream
   p.partP = bump(o, (size_t)EW_BLOCKS * 8);
-  p.part320 = bump(o, (size_t)STREAM_BLOCKS * 320);
+  p.part320 = bump(o, (size_t)STREAM_BLOCKS * ENC_L0_ROW_FLOATS);  // (rows of the one-pass layer-0 backward)
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -221,13 +221,21 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.dXp = dX;
-      a0.part = partA;
-      DVG_TRY(launch_enc_l0(2, a0, s));
-      DVG_TRY(launch_colsum2(partA, enc_l0_blocks(B), 2 * C, C, g->bn_b[0], C, g->bn_g[0], s));
-      a0.sum_dz = g->bn_b[0]; a0.sum_dzzh = g->bn_g[0]; a0.inv_m = (float)(1.0 / ((double)B * 1024.0));
+      if (opt(OPT_ENC_L0_FUSED) == 2) {  // two passes (A/B reference of the one-pass form)
+        a0.part = partA;
+        DVG_TRY(launch_enc_l0(2, a0, s));
+        DVG_TRY(launch_colsum2(partA, enc_l0_blocks(B), 2 * C, C, g->bn_b[0], C, g->bn_g[0], s));
+        a0.sum_dz = g->bn_b[0]; a0.sum_dzzh = g->bn_g[0]; a0.inv_m = (float)(1.0 / ((double)B * 1024.0));
+        a0.part = W + pl.part320;
+        DVG_TRY(launch_enc_l0(3, a0, s));
+        DVG_TRY(launch_colsum2(W + pl.part320, enc_l0_blocks(B), 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
+        break;
+      }
+      // one pass: S, T2, T1 and sum dz zhat per block, their column sums, then every gradient of the stage from the sums
       a0.part = W + pl.part320;
-      DVG_TRY(launch_enc_l0(3, a0, s));
-      DVG_TRY(launch_colsum2(W + pl.part320, enc_l0_blocks(B), 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
+      DVG_TRY(launch_enc_l0(4, a0, s));
+      DVG_TRY(launch_colsum(W + pl.part320, enc_l0_blocks(B), ENC_L0_ROW_FLOATS, 682, 1.0f, partA, 0, 0, s));
+      DVG_TRY(launch_enc_l0_combine(partA, p->bn_g[0], W + pl.invstd[0], B, g->conv_w[0], g->conv_b[0], g->bn_b[0], g->bn_g[0], s));
       break;
     }
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY

@@ -97,6 +97,11 @@ struct EncL0Args {
 };
 int enc_l0_blocks(int64_t B);
 int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s);
+// mode 4 (both backward passes in one): partial rows of ENC_L0_ROW_FLOATS floats; their column sums `tot` go through
+// launch_enc_l0_combine, which writes the four gradients of the stage
+constexpr int ENC_L0_ROW_FLOATS = 704;
+int launch_enc_l0_combine(const float* tot, const float* gamma, const float* invstd, int64_t B, float* gw, float* gb,
+                          float* g_bn_b, float* g_bn_g, hipStream_t s);
 // part: [EW_BLOCKS][320]: 288 weight-gradient entries in checkpoint order, then 32 bias-gradient entries
 int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s);
 // Linear(4,1) over the 2x2 pooled map: P (B,4,n) -> logits (B,n)

@@ -35,7 +35,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
     {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form: -1 evaluation-mode forward calls of 256 workgroups or more (default: 1.5x faster alone, neutral to slower inside a training step), 0 never, 1 every launch the shape allows, 2 / 3 forward / data-gradient launches only"},
     {"enc_wino_mask", 0, "A/B: when non-zero, picks the Winograd form per launch instead of enc_wino: bit l-1 = forward of layer l (1..3), bit 2+l = its data gradient"},
-    {"enc_l0_fused", 1, "encoder layer 0: 1 = its output is recomputed by every pass that needs it (BatchNorm statistics, BN/pool/LeakyReLU, both backward passes, the weight gradient) and never stored (default), 0 = stored and re-read (rounds 1-2)"},
+    {"enc_l0_fused", 1, "encoder layer 0: 1 = its output is recomputed by every pass that needs it (BatchNorm statistics, BN/pool/LeakyReLU, both backward passes, the weight gradient) and never stored (default; 2 = the same with the backward in two passes), 0 = stored and re-read (rounds 1-2)"},
     {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];

@@ -107,11 +107,19 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
 //   MODE 2  per-block (sum dz, sum dz zhat) partials                          (replaces enc_bn_pool_bwd reduce)
 //   MODE 3  dW[co][t] = sum_m dY[m][co] in_t[m], db = sum_m dY: dY formed in registers and fed to the MFMA as the A
 //           operand of the pixel pair (crow(r,0), crow(r,1))                  (replaces the apply pass, dY0 and the wgrad's reads)
+//   MODE 4  modes 2 and 3 in ONE pass.  dY = gi (delta dz - m1 - zhat m2) is linear in the two batch means m1, m2, so the
+//           weight gradient is gi (S - m1 T1 - m2 T2) with S = sum delta dz (x) in_t, T2 = sum zhat (x) in_t (two MFMA
+//           accumulations over the same B operand) and T1 = sum in_t: none of the three needs m1 or m2, which enter in
+//           enc_l0_combine_kernel after the partials are summed.  part [blocks][ENC_L0_ROW]: S (320), T2 (320), T1 (10),
+//           sum dz zhat (32).
 
+constexpr int ENC_L0_ROW = 704;  // floats per block of MODE 4's partials: S [0, 320), T2 [320, 640), T1 [640, 650), sum dz zhat [650, 682)
 template <int MODE>
 __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
   __shared__ double redd[MODE == 0 ? 2 * 4 * 32 : 1];
-  __shared__ float redf[MODE == 3 ? 4 * 32 * 33 : (MODE == 2 ? 2 * 4 * 32 : 1)];
+  __shared__ float redf[MODE >= 3 ? 4 * 32 * 33 : (MODE == 2 ? 2 * 4 * 32 : 1)];
+  __shared__ float redg[MODE == 4 ? 4 * 32 * 33 : 1];
+  __shared__ float redh[MODE == 4 ? 2 * 4 * 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
   float bw[5];
   int dy[5], dx[5];
@@ -125,7 +133,9 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
   float mu = 0.f, is = 0.f, gm = 0.f, bt = 0.f, m1 = 0.f, m2 = 0.f, gi = 0.f;
   if (MODE >= 1) { mu = a.mean[c]; is = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
   if (MODE == 3) { m1 = a.sum_dz[c] * a.inv_m; m2 = a.sum_dzzh[c] * a.inv_m; gi = gm * is; }
-  const int tdy = c < 9 ? c / 3 - 1 : 0, tdx = c < 9 ? c % 3 - 1 : 0;  // MODE 3: this lane's tap column of the B operand
+  const int tdy = c < 9 ? c / 3 - 1 : 0, tdx = c < 9 ? c % 3 - 1 : 0;  // MODE 3, 4: this lane's tap column of the B operand
+  f32x16c tacc = {0};  // MODE 4: T2
+  float t1 = 0.f;      // MODE 4: this lane's share of T1[c]
   const int cy = (int)morton_y((uint32_t)c), cx = (int)morton_x((uint32_t)c);  // pixel c of a tile, inside the tile
   const int64_t tiles = a.B * 32;
   double s1 = 0.0, s2 = 0.0;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
         for (int g = 0; g < 4; ++g) go[g] = gov[u][g];
       }
       float bimg[16];
-      if (MODE == 3) {  // B operand of the weight-gradient MFMA r: in_t[pixel crow(r, hh)], t = this lane's column
+      if (MODE >= 3) {  // B operand of the weight-gradient MFMA r: in_t[pixel crow(r, hh)], t = this lane's column
         const int ti = (int)(tile & 31);
         const int y0 = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)) + tdy;
         const int x0 = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1)) + tdx + 2 * hh;
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
           const float v = im[inb ? yy * 32 + xx : 0];
           bimg[r] = c == 9 ? 1.0f : ((c < 9 && inb) ? v : 0.f);
+          if (MODE == 4) t1 += bimg[r];
         }
       }
 #pragma unroll
@@ -213,11 +224,18 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           if (MODE == 2) {
             r1 += dz;
             r2 = fmaf(dz, zh[arg], r2);
-          } else {
+          } else if (MODE == 3) {
 #pragma unroll
             for (int sq = 0; sq < 4; ++sq) {
               const float dyv = gi * (((sq == arg) ? dz : 0.f) - m1 - zh[sq] * m2);
               wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, bimg[4 * g + sq], wacc, 0, 0, 0);
+            }
+          } else {
+            r2 = fmaf(dz, zh[arg], r2);
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+              wacc = __builtin_amdgcn_mfma_f32_32x32x2f32((sq == arg) ? dz : 0.f, bimg[4 * g + sq], wacc, 0, 0, 0);
+              tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(zh[sq], bimg[4 * g + sq], tacc, 0, 0, 0);
             }
           }
         }
@@ -246,15 +264,32 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           (redf[k * 128 + cc] + redf[k * 128 + 32 + cc]) + (redf[k * 128 + 64 + cc] + redf[k * 128 + 96 + cc]);
     }
   }
-  if (MODE == 3) {
+  if (MODE >= 3) {
     // D[row = co][col = t]: lane holds column c, rows crow(r, hh)
+    constexpr int ROW = MODE == 4 ? ENC_L0_ROW : 320;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) redf[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = wacc[r];
+    for (int r = 0; r < 16; ++r) {
+      redf[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = wacc[r];
+      if (MODE == 4) redg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = tacc[r];
+    }
+    if (MODE == 4) {
+      t1 += __shfl_xor(t1, 32, 64);
+      r2 += __shfl_xor(r2, 32, 64);
+      if (hh == 0) { redh[wave * 32 + c] = t1; redh[128 + wave * 32 + c] = r2; }
+    }
     __syncthreads();
     for (int w = tid; w < 320; w += 256) {
       const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
-      a.part[(size_t)blockIdx.x * 320 + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
+      a.part[(size_t)blockIdx.x * ROW + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
                                              (redf[(2 * 32 + co) * 33 + t] + redf[(3 * 32 + co) * 33 + t]);
+      if (MODE == 4)
+        a.part[(size_t)blockIdx.x * ROW + 320 + w] = (redg[(0 * 32 + co) * 33 + t] + redg[(1 * 32 + co) * 33 + t]) +
+                                                     (redg[(2 * 32 + co) * 33 + t] + redg[(3 * 32 + co) * 33 + t]);
+    }
+    if (MODE == 4 && tid < 42) {
+      const int k = tid < 10 ? 0 : 1, cc = tid < 10 ? tid : tid - 10;  // T1[0..9], then sum dz zhat [0..31]
+      a.part[(size_t)blockIdx.x * ROW + (k ? 650 : 640) + cc] =
+          (redh[k * 128 + cc] + redh[k * 128 + 32 + cc]) + (redh[k * 128 + 64 + cc] + redh[k * 128 + 96 + cc]);
     }
   }
 }
@@ -269,8 +304,30 @@ int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
     case 0: DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_kernel<0>, g0, dim3(256), 0, s, a); break;
     case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
     case 2: DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_l0_kernel<2>, g, dim3(256), 0, s, a); break;
-    default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<3>, g, dim3(256), 0, s, a); break;
+    case 3: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<3>, g, dim3(256), 0, s, a); break;
+    default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
   }
+  return DVG_OK;
+}
+
+// tot [ENC_L0_ROW]: the column sums of MODE 4's partials.  One block: every gradient of the stage.
+__global__ __launch_bounds__(320) void enc_l0_combine_kernel(const float* __restrict__ tot, const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, float inv_m,
+                                                             float* __restrict__ gw, float* __restrict__ gb,
+                                                             float* __restrict__ g_bn_b, float* __restrict__ g_bn_g) {
+  const int w = threadIdx.x;  // [0, 288): weight (co, t) = (w / 9, w % 9); [288, 320): bias of co = w - 288 (column 9)
+  const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
+  const float sum_dz = tot[288 + co], sum_dzzh = tot[650 + co];
+  const float m1 = sum_dz * inv_m, m2 = sum_dzzh * inv_m, gi = gamma[co] * invstd[co];
+  const float v = gi * (tot[w] - m1 * tot[640 + t] - m2 * tot[320 + w]);
+  if (w < 288) gw[w] = v;
+  else { gb[co] = v; g_bn_b[co] = sum_dz; g_bn_g[co] = sum_dzzh; }
+}
+
+int launch_enc_l0_combine(const float* tot, const float* gamma, const float* invstd, int64_t B, float* gw, float* gb,
+                          float* g_bn_b, float* g_bn_g, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, enc_l0_combine_kernel, dim3(1), dim3(320), 0, s, tot, gamma, invstd, (float)(1.0 / ((double)B * 1024.0)), gw,
+             gb, g_bn_b, g_bn_g);
   return DVG_OK;
 }
 
