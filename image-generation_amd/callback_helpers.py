@@ -69,7 +69,13 @@ def execute_training(set_progress: Optional[Callable], model, n_epochs: int, qpu
     figs = [None]
 
     def end_of_epoch(epoch: int, report: dict) -> None:
-        if not _is_main(model):  # data-parallel: rank 0 writes the side files and draws the figures (rank-local calls)
+        if not _is_main(model):
+            # data-parallel: rank 0 writes the side files and draws the figures.  The other ranks still make the
+            # generation DRAW (rank-local, no files): every rank's sampler counters -- the Philox sweep index of its
+            # globally numbered chains -- then advance together, so W ranks keep sampling what one GPU with W x C
+            # chains would.  The reconstruction preview consumes nothing (data.preview_batch).
+            if hasattr(model, "generate_images"):
+                model.generate_images(sharpen=sharpen)
             return
         with open(PROBLEM_DETAILS_PATH, "w") as f:
             json.dump(report, f)
@@ -84,4 +90,4 @@ def execute_training(set_progress: Optional[Callable], model, n_epochs: int, qpu
 
     training.execute_training(model, n_epochs, qpu=qpu, n_latents=n_latents, set_progress=set_progress,
                               on_epoch_end=end_of_epoch)
-    return figs[0]
+    return figs[0] if figs[0] is not None else (None, None, None, None)  # non-main ranks: unpackable

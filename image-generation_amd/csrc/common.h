@@ -90,7 +90,7 @@ enum Opt : int {
 int64_t opt(Opt id);
 
 // Fork/join helpers (streams.cpp).  side_stream(s) is the library's side stream of the current device (or `s` itself
-// when DVG_NO_SIDE_STREAM is set); stream_order_after(w, p) makes everything enqueued on `w` from now on wait for what
+// when option side_stream = 0: dvg_set_option("side_stream", 0)); stream_order_after(w, p) makes everything enqueued on `w` from now on wait for what
 // has been enqueued on `p` so far (no-op when w == p).  Capture-safe.
 bool side_enabled();
 void side_stream_warm();  // create the current device's side stream + event ring now (outside any capture)

@@ -131,12 +131,13 @@ struct ConvArgs {
   // are never staged or multiplied.  Same outputs, same number of BatchNorm partial rows.
   int posmajor = 0;
 };
-// process-wide precision of the forward / data-gradient GEMMs (dvg_set_conv_precision, env DVG_CONV_BF16=1)
+// process-wide precision of the forward / data-gradient GEMMs (set through the ABI only: dvg_set_conv_precision; the library reads no environment variable)
 bool conv_precision_bf16();
 int conv_precision_mode();  // 0 f32, 1 bf16 inputs, 2 f32 as three bf16 pieces
 // packed-weight buffers: one float32 per entry (every operand form reads a float32 pack)
 static inline size_t conv_pack_floats(size_t entries) { return entries; }
 void plan_note_forward(const void* ws, uint32_t signature);      // forward calls: what shaped the workspace's contents
+bool plan_forward_flag(const void* ws, uint32_t bit);   // the forward noted on `ws` had this signature bit (or none was noted)
 bool plan_matches_forward(const void* ws, uint32_t signature);   // backward calls: the same plan as the forward's?
 void conv_precision_note_forward(const void* ws);      // forward calls: remember the mode that wrote the packs
 bool conv_precision_matches_forward(const void* ws);   // backward calls: same mode as the forward on this workspace?

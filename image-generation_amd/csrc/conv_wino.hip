@@ -21,6 +21,8 @@
 // blocks a workgroup owns (persistent grid), so the staging pipeline is filled once per workgroup, not once per tile.
 // A 64-byte entry (16 transform positions of one (k, row)) is read as four ds_read_b128 whose 16-byte slots are XOR-ed
 // with bits 2-3 of the row: conflict-free for the 16 lanes of a read pass.
+#include <atomic>
+
 #include "conv.h"
 #include "conv_tile.h"
 
@@ -375,10 +377,14 @@ template <int WM, int WN, int KC>
 static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   using C = WinoCfg<WM, WN, KC>;
   auto kern = conv_wino_kernel<WM, WN, KC>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the raised dynamic-LDS limit is a per-DEVICE function attribute: once per device (bit per ordinal), not per process
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  DVG_CHECK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int ny = a.Cout / C::CB;
   int gx = 256 / ny;  // one workgroup per CU: persistent over its tile blocks

@@ -91,8 +91,9 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
 }
 
 // what shapes the workspace's contents: the pack format of the direct GEMMs and which layers run in the Winograd form
-uint32_t enc_plan_signature(const EncPlan& pl) {
-  uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64) | (opt(OPT_ENC_L0_FUSED) != 0 ? 1u << 30 : 0u);
+// (bit 31: the forward ran in training mode -- the only kind a backward call may follow)
+uint32_t enc_plan_signature(const EncPlan& pl, int training) {
+  uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64) | (opt(OPT_ENC_L0_FUSED) != 0 ? 1u << 30 : 0u) | (training ? 1u << 31 : 0u);
   for (int l = 1; l < 4; ++l) sig |= (pl.wino_f[l] ? 1u : 0u) << (8 + 2 * l) | (pl.wino_d[l] ? 1u : 0u) << (9 + 2 * l);
   return sig;
 }
@@ -133,7 +134,7 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32, training ? 1 : 0);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
-  plan_note_forward(ws, enc_plan_signature(pl));  // (the pack formats the backward will read)
+  plan_note_forward(ws, enc_plan_signature(pl, training));  // (the pack formats the backward will read)
   DVG_REQUIRE(images && logits, "encoder_fwd: null images/logits");
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
@@ -194,7 +195,8 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   const EncPlan pl = enc_plan(B > 0 ? B : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "encoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
-  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl)), "encoder_bwd: option igemm_dma / enc_wino changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_forward_flag(ws, 1u << 31), "encoder_bwd: backward requires a training-mode forward on this workspace (the last forward call here ran in evaluation mode: running statistics, no saved batch statistics)");
+  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl, 1)), "encoder_bwd: a kernel-form option (dvg_set_option: igemm_dma / enc_wino / enc_wino_mask / enc_l0_fused) changed since the forward call on this workspace");
   DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
   for (int l = 0; l < 4; ++l)
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);

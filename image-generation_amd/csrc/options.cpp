@@ -7,6 +7,7 @@
 // not silent garbage.
 #include <atomic>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -39,11 +40,11 @@ const OptDef kDefs[OPT_COUNT] = {
     {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
-std::atomic<bool> g_init{false};
-void init_once() {
-  if (g_init.load(std::memory_order_acquire)) return;
-  for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
-  g_init.store(true, std::memory_order_release);
+std::once_flag g_once;
+void init_once() {  // a real once: a racing dvg_set_option can no longer be overwritten by a late default store
+  std::call_once(g_once, [] {
+    for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
+  });
 }
 }  // namespace
 

@@ -39,6 +39,13 @@ bool plan_matches_forward(const void* ws, uint32_t signature) {
   return it == g_ws_plan.end() || it->second == signature;
 }
 
+// true when no forward was noted for `ws` (nothing to contradict) or the noted signature has `bit` set
+bool plan_forward_flag(const void* ws, uint32_t bit) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  auto it = g_ws_plan.find(ws);
+  return it == g_ws_plan.end() || (it->second & bit) != 0;
+}
+
 // A backward call reuses the weight packs its forward call left in the workspace, so it must run in the mode that wrote
 // them: the forward notes its mode per workspace pointer, the backward checks it (host-side bookkeeping only).
 void conv_precision_note_forward(const void* ws) {

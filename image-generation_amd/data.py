@@ -35,14 +35,35 @@ class TensorBatches:
     def __len__(self):
         return (self.images.shape[0] // self.world_size) // self.batch_size
 
-    def __iter__(self):
+    def _shard_order(self, gen):
         n = self.images.shape[0]
-        order = torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)
+        order = torch.randperm(n, generator=gen) if self.shuffle else torch.arange(n)
         order = order[self.rank::self.world_size][: (n // self.world_size)]
-        order = order.to(self.images.device)
+        return order.to(self.images.device)
+
+    def __iter__(self):
+        order = self._shard_order(self._gen)
         for k in range(len(self)):
             idx = order[k * self.batch_size: (k + 1) * self.batch_size]
             yield gather_rows(self.images, idx), self.labels[idx]
+
+    def preview_batch(self):
+        """The first batch the NEXT ``iter()`` of this rank will yield, drawn from a CLONE of the permutation generator:
+        the training iterator's stream is not advanced.  (The reference previews with ``next(iter(dataloader))``,
+        /root/reference/src/model_wrapper.py:459; here the epoch-end preview runs on rank 0 only, and a permutation
+        consumed by one rank alone would leave the ranks sharding DIFFERENT permutations from the next epoch on.)"""
+        gen = torch.Generator()
+        gen.set_state(self._gen.get_state())
+        idx = self._shard_order(gen)[: self.batch_size]
+        return gather_rows(self.images, idx), self.labels[idx]
+
+
+def preview_batch(dataloader):
+    """First batch of ``dataloader`` for the epoch-end reconstruction figure, without side effects on a
+    :class:`TensorBatches` (any other iterable: ``next(iter(...))`` as the reference does)."""
+    if isinstance(dataloader, TensorBatches):
+        return dataloader.preview_batch()
+    return next(iter(dataloader))
 
 
 def gather_rows(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -104,7 +104,9 @@ def conv_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ntaps=9, ups=0):
 
 def encoder_saved(ws: torch.Tensor, B: int, n: int):
     """Views into an encoder workspace after a forward call: per layer the pre-BatchNorm convolution output as NCHW, the
-    batch mean and the batch inverse standard deviation (diagnostics)."""
+    batch mean and the batch inverse standard deviation (diagnostics).  The offsets are the TRAINING plan's (an evaluation-
+    mode forward may plan its packs differently: do not use this after one).  Layer 0's ``Y`` is ``None`` under the
+    default ``enc_l0_fused`` != 0: that output is recomputed by every pass that needs it and never written."""
     off = (ctypes.c_size_t * 16)()
     _lib.check(lib().dvg_dev_encoder_layout(B, n, off), "dvg_dev_encoder_layout")
     f = ws.view(torch.float32)
@@ -113,5 +115,6 @@ def encoder_saved(ws: torch.Tensor, B: int, n: int):
     for l in range(4):
         side, C = 32 >> l, ch[l]
         y = f[off[l]: off[l] + B * side * side * C]
-        out.append(dict(Y=morton_to_nchw(y, B, C, side), mean=f[off[8 + l]: off[8 + l] + C], invstd=f[off[12 + l]: off[12 + l] + C]))
+        stored = l > 0 or _lib.get_option("enc_l0_fused") == 0
+        out.append(dict(Y=morton_to_nchw(y, B, C, side) if stored else None, mean=f[off[8 + l]: off[8 + l] + C], invstd=f[off[12 + l]: off[12 + l] + C]))
     return out

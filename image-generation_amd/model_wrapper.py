@@ -19,7 +19,7 @@ import yaml
 
 from . import functional as F
 from .losses import nll_loss
-from .modules import Decoder, Encoder
+from .modules import Decoder, Encoder, writes_grads_direct
 from .optim import FlatAdam
 from .persistent_sampler import PersistentQPUSampleHelper
 from .plugin import (DiscreteVariationalAutoencoder, GaussianKernel, GraphRestrictedBoltzmannMachine,
@@ -487,8 +487,9 @@ class ModelWrapper:
             # chain).  The decoder's parameter gradients do not travel through autograd at all here: its backward writes
             # them into the optimizer's flat buffer and sets .grad itself (modules._grad_targets).
             dec = self._dvae.decoder
-            if getattr(dec, "_grad_sink", None) is not None and all(p.grad is None for p in dec._trainable()):
+            if writes_grads_direct(dec):
                 (g_dec,) = torch.autograd.grad([reconstructed_images], [spins_cut], [g_recon])
+                assert all(p.grad is not None for p in dec._trainable()), "decoder backward did not take the direct path"
             else:
                 torch.autograd.backward([reconstructed_images], [g_recon])
                 g_dec = spins_cut.grad
@@ -720,7 +721,9 @@ class ModelWrapper:
         if batch is None:
             if self._dataloader is None:
                 self._load_dataset(batch_size=self.BATCH_SIZE, dataset_size=self.DATASET_SIZE)
-            batch = next(iter(self._dataloader))[0]
+            from .data import preview_batch
+
+            batch = preview_batch(self._dataloader)[0]  # never advances the training permutation stream
         batch = batch.to(self._device)
         self._dvae.eval()
         self._grbm.eval()

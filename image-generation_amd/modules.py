@@ -43,10 +43,20 @@ def _grad_targets(module, params):
     no parameter holds a gradient yet, the kernels write straight into those views: the flat buffer is then already
     packed when the backward pass ends -- no per-tensor allocations, no concatenation launch in front of Adam / the
     all-reduce."""
-    sink = getattr(module, "_grad_sink", None)
-    if sink is not None and len(sink) == len(params) and all(p.grad is None for p in module._trainable()):
-        return sink, True
+    if writes_grads_direct(module, len(params)):
+        return module._grad_sink, True
     return [torch.empty_like(p) for p in params], False
+
+
+def writes_grads_direct(module, n_params=None) -> bool:
+    """THE predicate for "this module's backward writes its parameter gradients into the gradient sink and sets
+    ``.grad`` itself" -- used by :func:`_grad_targets` and by callers that bypass autograd's accumulation for the
+    module's parameters (``ModelWrapper`` takes the decoder's spin gradient through ``torch.autograd.grad``, which
+    DISCARDS whatever the backward returns for the parameters: correct only on this path)."""
+    sink = getattr(module, "_grad_sink", None)
+    trainable = module._trainable()
+    n_params = len(trainable) if n_params is None else n_params
+    return sink is not None and len(sink) == n_params and all(p.grad is None for p in trainable)
 
 
 def _grad_returns(module, grads, direct):

@@ -23,12 +23,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C3 = dict(B=4096, n=512, R=8, C=256, sweeps=200, qpu="Advantage2_system1")
 C5 = dict(B=256, n=1024, R=8, C=2048, sweeps=50, qpu="Advantage2_system1")
+STOCK_CAP = 1.5e-2
 
 
 def _yaml(tmp_path, cfg, name="p.yaml"):
     base = yaml.safe_load(open(os.path.join(ROOT, "image-generation_amd", "training_parameters.yaml")))
     base.update(BATCH_SIZE=cfg["B"], N_REPLICAS=cfg["R"], NUM_READS=cfg["C"], GIBBS_SWEEPS=cfg["sweeps"],
-                GIBBS_PERSISTENT=True, CONV_PRECISION="f32")
+                GIBBS_PERSISTENT=True, CONV_PRECISION=cfg.get("precision", "f32"))
     path = tmp_path / name
     with open(path, "w") as f:
         yaml.safe_dump(base, f)
@@ -98,8 +99,12 @@ def _check_step_against_float64(tmp_path, cfg, grad_bar):
             continue
         worst[name] = _rel_l2(g, w["grads"][name])
         stock[name] = _rel_l2(w32["grads"][name], w["grads"][name])
-    bad = {k: (v, stock[k]) for k, v in worst.items() if not v < max(grad_bar, stock[k])}
+    # (the stock-float32 allowance is itself capped: STOCK_CAP is ~1.5x the farthest stock float32 has been measured from
+    # float64 on any tensor here, so the relative bar cannot pass a multiple-x regression on the tensors that use it)
+    bad = {k: (v, stock[k]) for k, v in worst.items() if not v < max(grad_bar, min(stock[k], STOCK_CAP))}
     assert not bad, bad
+    used_allowance = {k: (f"{v:.2e}", f"{stock[k]:.2e}") for k, v in worst.items() if v >= grad_bar}
+    print(f"parameters above the {grad_bar:g} bar that passed on the stock-float32 allowance (HIP, stock):", used_allowance or "none")
     print("gradient rel-L2 vs float64, HIP / stock float32 (worst 6):",
           [(k, f"{v:.2e}", f"{stock[k]:.2e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]])
     # GRBM sufficient statistics: means of +-1 products, exact in either arithmetic -- on the same spins.  A handful of the
@@ -110,11 +115,28 @@ def _check_step_against_float64(tmp_path, cfg, grad_bar):
     return worst
 
 
-def test_c3_step_matches_float64_oracle_on_device(tmp_path):
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_c3_step_matches_float64_oracle_on_device(tmp_path, precision):
     """mse, mse + mmd, nll <= 1e-5 relative; every parameter gradient's relative L2 <= 5e-3 (the bar of
-    tests/test_gpu_fullsize.py: float32 LeakyReLU kinks / pooling near-ties route a few elements differently)."""
-    worst = _check_step_against_float64(tmp_path, C3, 5e-3)
-    print("c3 gradient rel-L2 (worst 5):", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+    tests/test_gpu_fullsize.py: float32 LeakyReLU kinks / pooling near-ties route a few elements differently).  Under
+    the headline's strict float32 operands AND under the f32x3 side mode (float32 operands as three bf16 pieces on the
+    bf16 MFMA, reported beside the headline): same bars."""
+    from image_generation_amd import _lib
+
+    try:
+        worst = _check_step_against_float64(tmp_path, dict(C3, precision=precision), 5e-3)
+    finally:
+        _lib.set_conv_precision("f32")  # (process-wide mode: the YAML key set it)
+    print(f"c3 [{precision}] gradient rel-L2 (worst 5):", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+
+
+@pytest.mark.parametrize("n,qpu", [(192, "Advantage_system4"), (320, "Advantage2_system1"), (448, "Advantage_system6")])
+def test_ui_selectable_latent_sizes_step_matches_float64_oracle(tmp_path, n, qpu):
+    """The latent sizes the reference's UI offers besides the powers of two (/root/reference/demo_configs.py:47-52:
+    128...512 in steps of 64): one whole training step -- networks at n channels, discretisation, MMD at d = n, sampler
+    on an n-spin Pegasus / Zephyr sub-graph, NLL -- against the float64 oracle, same bars as the headline shape."""
+    worst = _check_step_against_float64(tmp_path, dict(B=96, n=n, R=8, C=128, sweeps=20, qpu=qpu), 5e-3)
+    print(f"n={n} gradient rel-L2 (worst 5):", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
 
 
 def test_c5_slice_step_matches_float64_oracle_on_device(tmp_path):

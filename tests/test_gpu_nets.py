@@ -191,7 +191,7 @@ def _tie_free_images(params, n, B, min_gap=3e-6):
     raise RuntimeError("no tie-free batch found")
 
 
-@pytest.mark.parametrize("n,B", [(128, 32), (256, 9), (64, 130)])
+@pytest.mark.parametrize("n,B", [(128, 32), (256, 9), (64, 130), (192, 16), (320, 12), (448, 8)])  # last three: UI sizes
 def test_encoder_matches_oracle_full_gradients(n, B):
     params = gen.make_params(n, "encoder", 11 + n)
     enc = _load(Encoder(n), params).train()
@@ -252,7 +252,7 @@ def test_encoder_maxpool_exact_ties_route_to_first_element():
         _close(dict(enc.named_parameters())[name].grad.cpu(), p[name].grad, 2e-3, name)
 
 
-@pytest.mark.parametrize("n,B,R", [(128, 8, 8), (64, 3, 1), (256, 5, 2)])
+@pytest.mark.parametrize("n,B,R", [(128, 8, 8), (64, 3, 1), (256, 5, 2), (192, 6, 2), (320, 4, 4), (448, 3, 2)])  # last three: UI sizes
 def test_decoder_matches_oracle_full_gradients(n, B, R):
     params = gen.make_params(n, "decoder", 21 + n)
     dec = _load(Decoder(n), params).train()

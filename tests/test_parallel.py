@@ -96,3 +96,65 @@ def test_model_wrapper_rank_offsets():
         assert m.local_num_reads() == m.NUM_READS
         offs.append((m.sampler.chain_offset, m._dvae.gumbel_seed, m._dvae.decoder.dropout_seed))
     assert offs[0][0] == 0 and offs[1][0] == 16 and offs[0][1] != offs[1][1] and offs[0][2] != offs[1][2]
+
+
+def test_two_epochs_through_the_epoch_driver_keep_rank_shards_disjoint(tmp_path, monkeypatch):
+    """the epoch-end preview runs on rank 0 only; it must not advance the shared-seed permutation
+    stream of the training iterator, or rank 0 shards a different permutation than the others from epoch 2 on.  Two
+    ranks (simulated in-process: the sharding is host logic without a collective) run two epochs through
+    callback_helpers.execute_training; every epoch the two shards are disjoint and their union is one permutation."""
+    import inspect
+
+    from image_generation_amd import callback_helpers, data
+    from image_generation_amd.model_wrapper import ModelWrapper
+
+    assert "preview_batch(self._dataloader)" in inspect.getsource(ModelWrapper.reconstruct_images)
+    monkeypatch.chdir(tmp_path)
+    n, B, W = 64, 4, 2
+    images = torch.arange(n, dtype=torch.float32).reshape(n, 1, 1, 1).expand(n, 1, 2, 2).contiguous()
+
+    class Rank:
+        BATCH_SIZE = B
+        qpu, n_latents = "x", 8
+
+        def __init__(self, rank):
+            self.rank = rank
+            self._dataloader = data.TensorBatches(images, torch.zeros(n, dtype=torch.int64), B, seed=5, rank=rank, world_size=W)
+            self._device = torch.device("cpu")
+            self._tpar = {"dvae_lr_schedule": np.ones(100), "grbm_lr_schedule": np.ones(100), "opt_step": 0}
+            self.seen, self.draws, self.previews = [[]], 0, []
+
+        def is_main_rank(self):
+            return self.rank == 0
+
+        def step(self, batch, epoch):
+            while len(self.seen) <= epoch:
+                self.seen.append([])
+            self.seen[epoch] += batch[0][:, 0, 0, 0].to(torch.int64).tolist()
+            return torch.tensor(0.5)
+
+        def generate_images(self, sharpen=False):
+            self.draws += 1
+
+        def generate_output(self, **k):
+            self.generate_images()
+            return "out"
+
+        def generate_reconstucted_samples(self, **k):  # what ModelWrapper.reconstruct_images(None) does to the loader
+            self.previews.append(data.preview_batch(self._dataloader)[0][:, 0, 0, 0].tolist())
+            return "rec"
+
+        def generate_loss_plot(self, **k):
+            return "mse", "total"
+
+    ranks = [Rank(0), Rank(1)]
+    figs = [callback_helpers.execute_training(None, m, 2, "x", 8) for m in ranks]
+    assert figs[0] == ("out", "rec", "mse", "total") and figs[1] == (None, None, None, None)
+    per_rank = (n // W) // B * B
+    for epoch in range(2):
+        a, b = ranks[0].seen[epoch], ranks[1].seen[epoch]
+        assert len(a) == len(b) == per_rank and not set(a) & set(b) and len(set(a) | set(b)) == 2 * per_rank, epoch
+    assert ranks[0].seen[0] != ranks[0].seen[1]                     # a fresh permutation per epoch
+    assert ranks[0].draws == ranks[1].draws == 2                    # sampler counters advance together
+    # the preview is the first batch of the NEXT epoch's shard and consumed nothing
+    assert ranks[0].previews[0] == [float(v) for v in ranks[0].seen[1][:B]]
