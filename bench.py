@@ -134,7 +134,40 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, seconds=20.0, sweep=(8, 16, 32, 64)):
+def _cpu_leg(config, threads, warm, min_steps, seconds, natural_grbm):
+    """(child process of cpu_baseline: `bench.py --cpu-leg CONFIG --threads T ...`)  Times the CPU oracle on `threads`
+    threads of a FRESH process -- stock PyTorch's OpenMP pool does not shrink cleanly inside one process (measured on the
+    GPU box: after a 64-thread point the 32-thread steps ran 3x slower than in a process that only ever had 32) -- and
+    prints one JSON object."""
+    from image_generation_amd import graphs
+    from oracle.step import OracleTrainer
+
+    cfg = CONFIGS[config]
+    torch.set_num_threads(threads)
+    make, h_range, j_range = graphs.LOCAL_SOLVERS[cfg["qpu"]]
+    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(cfg["n"], 775321899904, make()))
+    _, ei, ej = graphs.edges_of(mg)
+    plan = graphs.build_plan(cfg["n"], ei, ej)
+    tr = OracleTrainer(plan, cfg["n"], cfg["R"], cfg["C"], cfg["sweeps"], 0.05, seed=1, h_range=h_range, j_range=j_range)
+    Bc = min(cfg["B"], 512)
+    g = torch.Generator().manual_seed(3)
+    batch = lambda: (torch.rand((Bc, 1, 32, 32), generator=g) < 0.13).float()  # noqa: E731
+    for _ in range(warm):
+        tr.step(batch(), force_grbm=False)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < min_steps or (time.perf_counter() - t_all < seconds and len(times) < 40):
+        t0 = time.perf_counter()
+        if natural_grbm:
+            tr.step(batch())  # GRBM branch at its natural duty (step 10k)
+        else:
+            tr.step(batch(), force_grbm=False)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    print(json.dumps({"threads": threads, "batch": Bc, "times_ms": [t * 1e3 for t in times]}), flush=True)
+
+
+def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
     """The CPU oracle (a port: stock PyTorch CPU ops + the C Gibbs restatement) on this box's host cores, on a BOUNDED
     sample of the workload: the same model, sampler and replica count at a batch of at most 512 images per step (a c3
     step is 4096; the oracle's MMD materialises the (B R + C)^2 kernel matrix as the reference does, 4.4 GB per
@@ -144,58 +177,39 @@ def cpu_baseline(cfg, seconds=20.0, sweep=(8, 16, 32, 64)):
     `comparable_to_value` say so in the line (c1, B = 64, runs at its own size: comparable).
 
     `cores`: stock PyTorch's intra-op pool does not scale on these layer sizes, so the thread count is MEASURED: a short
-    sweep (1 warm-up + 2 timed steps per point) over `sweep`, capped at the host's core count; the fastest point runs
-    the baseline proper and the sweep is recorded in the line (`thread_sweep`)."""
-    from image_generation_amd import graphs
-    from oracle.step import OracleTrainer
+    sweep (1 warm-up + 3 timed steps per point, each point a fresh process) over `sweep`, capped at the host's core
+    count; the fastest point's thread count runs the baseline proper (again a fresh process) and the sweep is recorded in
+    the line (`thread_sweep`)."""
+    import subprocess
 
+    cfg = CONFIGS[config]
     host = os.cpu_count() or 1
-    make, h_range, j_range = graphs.LOCAL_SOLVERS[cfg["qpu"]]
-    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(cfg["n"], 775321899904, make()))
-    _, ei, ej = graphs.edges_of(mg)
-    plan = graphs.build_plan(cfg["n"], ei, ej)
-    tr = OracleTrainer(plan, cfg["n"], cfg["R"], cfg["C"], cfg["sweeps"], 0.05, seed=1, h_range=h_range, j_range=j_range)
-    Bc = min(cfg["B"], 512)
-    g = torch.Generator().manual_seed(3)
-    batch = lambda: (torch.rand((Bc, 1, 32, 32), generator=g) < 0.13).float()  # noqa: E731
     points = sorted({min(t, host) for t in sweep}) or [min(host, 16)]
-    torch.set_num_threads(points[0])
-    t0 = time.perf_counter()
-    tr.step(batch(), force_grbm=False)  # first step: allocator / thread-pool warm-up
-    first = time.perf_counter() - t0
+
+    def leg(threads, warm, min_steps, secs, natural):
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", config, "--threads", str(threads), "--leg-warm", str(warm),
+               "--leg-steps", str(min_steps), "--leg-seconds", str(secs)] + (["--leg-natural"] if natural else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"threads"')][-1])
+
     thread_sweep = {}
     for t in points:
-        torch.set_num_threads(t)
-        tr.step(batch(), force_grbm=False)
-        ts = []
-        for _ in range(2):
-            t0 = time.perf_counter()
-            tr.step(batch(), force_grbm=False)
-            ts.append(time.perf_counter() - t0)
-        thread_sweep[str(t)] = {"ms_per_step": min(ts) * 1e3, "images_per_s": Bc / min(ts)}
+        d = leg(t, 1, 3, 0.0, False)
+        thread_sweep[str(t)] = {"ms_per_step": d["times_ms"][len(d["times_ms"]) // 2], "images_per_s": d["batch"] / (d["times_ms"][len(d["times_ms"]) // 2] * 1e-3)}
     cores = int(min(thread_sweep, key=lambda k: thread_sweep[k]["ms_per_step"]))
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    warm = 1 + 3 * len(points)
-    tr.step(batch(), force_grbm=False)
-    warm += 1
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 10 or (time.perf_counter() - t_all < seconds and len(times) < 40):
-        t0 = time.perf_counter()
-        tr.step(batch())  # GRBM branch at its natural duty (step 10k)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+    d = leg(cores, 3, 10, seconds, True)
+    times, Bc = d["times_ms"], d["batch"]
+    med = times[len(times) // 2] * 1e-3
     return {"value": Bc / med, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "host_cores": host, "batch": Bc, "workload_batch": cfg["B"], "timed_steps": len(times),
             "comparable_to_value": bool(Bc == cfg["B"]),
-            "thread_sweep": thread_sweep, "first_step_ms": first * 1e3,
+            "thread_sweep": thread_sweep,
             "sample": f"{len(times)} train steps of the {cfg['B']}-image workload's model (n={cfg['n']}, R={cfg['R']}, "
-                      f"{cfg['C']} chains x {cfg['sweeps']} sweeps) at B={Bc} images per step on the CPU oracle after {warm} "
-                      f"warm-up / sweep steps on {cores} threads (the fastest of {points}); median {med * 1e3:.0f} ms/step, "
-                      f"min {times[0] * 1e3:.0f} ms",
-            "ms_per_step_median": med * 1e3, "ms_per_step_min": times[0] * 1e3}
+                      f"{cfg['C']} chains x {cfg['sweeps']} sweeps) at B={Bc} images per step on the CPU oracle after 3 "
+                      f"warm-up steps, {cores} threads in a fresh process (the fastest of {points}, each measured in its own "
+                      f"process); median {med * 1e3:.0f} ms/step, min {times[0]:.0f} ms",
+            "ms_per_step_median": med * 1e3, "ms_per_step_min": times[0]}
 
 
 def loss_parity():
@@ -336,7 +350,16 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="operands of the forward / data-gradient convolution GEMMs: f32 (the 1e-5 loss parity; the bench "
                          "line) or bf16 inputs with f32 accumulate (BASELINE.json configs[1] names bf16; reported beside it)")
+    ap.add_argument("--cpu-leg", default="", help="(internal) time the CPU oracle on CONFIG in this process and print JSON")
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--leg-warm", type=int, default=3)
+    ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--leg-seconds", type=float, default=20.0)
+    ap.add_argument("--leg-natural", action="store_true")
     args = ap.parse_args()
+    if args.cpu_leg:
+        _cpu_leg(args.cpu_leg, args.threads, args.leg_warm, args.leg_steps, args.leg_seconds, args.leg_natural)
+        return
     cfg = CONFIGS[args.config]
 
     from image_generation_amd import _lib
@@ -535,7 +558,7 @@ def main():
             "roofline": roofline,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(args.config)
             out["loss_parity"] = loss_parity()
         if args.parity and args.gpus == 1:
             out["loss_parity"] = dict(loss_parity(), note="12 fixture steps in this arithmetic mode (every forward / data-gradient launch)")
@@ -548,7 +571,7 @@ def main():
                 # pair of this line where the CPU and the GPU ran the same workload at the same size
                 if "error" not in out["extra"]["c1"]:
                     try:
-                        out["extra"]["c1"]["cpu_baseline"] = cpu_baseline(CONFIGS["c1"], seconds=8.0)
+                        out["extra"]["c1"]["cpu_baseline"] = cpu_baseline("c1", seconds=8.0)
                         out["extra"]["c1"]["gpu_over_cpu"] = out["extra"]["c1"]["value"] / out["extra"]["c1"]["cpu_baseline"]["value"]
                     except Exception as exc:
                         out["extra"]["c1"]["cpu_baseline"] = {"error": repr(exc)}
