@@ -1271,11 +1271,15 @@ template <int NST, int NFT>
 __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned char* smem) {
   using L = W128<NST, NFT>;
   constexpr int D = L::D;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
   double* red = reinterpret_cast<double*>(smem + L::OFF_RED);
   unsigned char* z8buf = smem + L::OFF_Z8;
   unsigned char* ztbuf = smem + L::OFF_ZT;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
+  // (wave: uniform by construction; readfirstlane tells the compiler so -- the LDS-DMA destinations derived from it are
+  // then scalar, no readfirstlane per piece)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5, c = lane & 31;
   const int64_t rbx = (a.nx + 127) / 128;
   const int64_t rb = blockIdx.x;
   const bool rows_x = rb < rbx;
@@ -1372,28 +1376,33 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // The same transfers one 1 KiB piece at a time and without branches, for issue from inside the MFMA stream of the
   // steady-state loop: `i` < NZ8 is a piece of the int8 rows of chunk tz8 (rows clamped to `last8`), the others are
   // pieces of the transposed copy of chunk tzt.  The bases are wave-uniform and computed once per iteration.
+  // In the steady-state loop every piece is ONE instruction, buffer_load_dwordx4 ... lds: the per-lane offset inside the
+  // chunk (z8off / ztoff: constant over the kernel) is the vector offset, the chunk's position the SCALAR offset, the LDS
+  // destination a scalar too -- no per-piece vector arithmetic (the global_load_lds form of round 3 cost 6 vector
+  // instructions per piece for its 64-bit per-lane pointer, its row clamp and the readfirstlane of its destination:
+  // 72 of the ~280 vector instructions of a chunk).  Rows past the end of x read the first rows of y, rows past the end
+  // of y are out of the buffer's range and arrive as zeros: either way those pairs are masked in the lookups.
   constexpr int NZ8 = NST / 4, NZT = NFT / 2;
-  struct DmaPlan { const int8_t* z8base; int last8; unsigned char* z8dst; const unsigned char* ztbase; unsigned char* ztdst; };
+  const __amdgpu_buffer_rsrc_t rsrc8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.zi8), 0, (int)((a.nx + a.ny) * D), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrct = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.zt), 0, (int)((a.ztb_y + (a.ny + 127) / 128 * 4) * (int64_t)D * 64), 0x00020000);
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_byte*)smem);
+  struct DmaPlan { int z8soff, ztsoff; uint32_t z8dst, ztdst; };
   auto dma_plan = [&](int tz8, int buf8, int tzt, int buft) -> DmaPlan {
     DmaPlan pl;
     const bool cx8 = tz8 < ncx_i;
-    const int jrow0 = (cx8 ? tz8 : tz8 - ncx_i) * 32, cnt_j = cx8 ? nx_i : ny_i;
-    pl.z8base = a.zi8 + ((int64_t)(cx8 ? 0 : nx_i) + jrow0) * D;
-    pl.last8 = cnt_j - 1 - jrow0;  // (>= 31 for a whole chunk: no row is clamped)
-    pl.z8dst = z8buf + buf8 * L::Z8_BYTES + wave * NZ8 * 1024;
+    pl.z8soff = __builtin_amdgcn_readfirstlane(((cx8 ? 0 : nx_i) + (cx8 ? tz8 : tz8 - ncx_i) * 32) * D);
+    pl.z8dst = lds0 + (uint32_t)(L::OFF_Z8 + buf8 * L::Z8_BYTES + wave * NZ8 * 1024);
     const bool cxt = tzt < ncx_i;
-    pl.ztbase = reinterpret_cast<const unsigned char*>(a.zt) +
-                (((cxt ? 0 : a.ztb_y) + (int64_t)(cxt ? tzt : tzt - ncx_i)) * (int64_t)D + f0) * 64;
-    pl.ztdst = ztbuf + buft * L::ZT_BYTES + wave * NZT * 1024;
+    pl.ztsoff = __builtin_amdgcn_readfirstlane((((cxt ? 0 : (int)a.ztb_y) + (cxt ? tzt : tzt - ncx_i)) * D + f0) * 64);
+    pl.ztdst = lds0 + (uint32_t)(L::OFF_ZT + buft * L::ZT_BYTES + wave * NZT * 1024);
     return pl;
   };
   auto dma_piece = [&](const DmaPlan& pl, int i) {
-    if (i < NZ8) {
-      const int r = z8row[i] < pl.last8 ? z8row[i] : pl.last8;
-      dma16(pl.z8base + (r * D + z8col[i]), pl.z8dst + i * 1024);
-    } else {
-      dma16(pl.ztbase + ztoff[i - NZ8], pl.ztdst + (i - NZ8) * 1024);
-    }
+    if (i < NZ8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc8, (lds_void*)(uintptr_t)(pl.z8dst + i * 1024), 16, z8off[i], pl.z8soff, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrct, (lds_void*)(uintptr_t)(pl.ztdst + (i - NZ8) * 1024), 16, ztoff[i - NZ8], pl.ztsoff, 0, 0);
   };
   auto issue_zt = [&](int64_t t, int buf) {
     const bool cx = t < ncx;
@@ -1409,6 +1418,14 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   const int sw_c = (c >> 2) & 3;
   const int aoff0 = c * 64 + ((hh ^ sw_c) << 4), aoff1 = c * 64 + (((2 + hh) ^ sw_c) << 4);
 
+  // Byte offset of k-step s inside this lane's LDS row: ((2 s + hh) ^ fz_c) << 4.  The swizzle touches the low ZSW slots
+  // only, so steps s and s + ZSW / 2 differ by a CONSTANT ZSW * 16 bytes: ZSW / 2 per-lane registers + immediates
+  // instead of one register per k-step.
+  constexpr int ZSW = (D % 256 == 0) ? 16 : 8;
+  int zlow[ZSW / 2];
+#pragma unroll
+  for (int m = 0; m < ZSW / 2; ++m) zlow[m] = ((2 * m + hh) ^ fz_c) << 4;
+  auto zslot = [&](int s_) -> int { return zlow[s_ % (ZSW / 2)] + (s_ / (ZSW / 2)) * (ZSW * 16); };
   auto gram = [&](int buf) -> i32x16 {
     const unsigned char* zrow = z8buf + buf * L::Z8_BYTES + c * D;
     i32x16 acc = {0};
@@ -1450,9 +1467,13 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     return m;
   };
   auto fixup = [&](i32x16& S, const ChunkMeta& m) {
+    // (rare and block-uniform: a real branch.  The empty asm keeps the compiler from if-converting it into 32 selects per
+    // chunk, and from hoisting the 16 row indices into registers that would be live across the whole loop.)
+    int hho = hh;
+    asm volatile("" : "+v"(hho));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int jl = crow(r, hh);
+      const int jl = crow(r, hho);
       int v = S[r];
       v = jl == m.dloc ? -(D + 4) : v;
       v = jl < m.nj ? v : -(D + 2);
@@ -1525,6 +1546,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     }
     if (want_grad) {
       i32x16 Sa = gram(1), Sb = {0};  // Sa: Gram tile of chunk t0+1 (stale bytes if T == 1: masked by its fixup)
+      asm volatile("" : "+v"(Sa), "+v"(Sb));  // both Gram tiles live in vector registers from here on (see the loop)
       __builtin_amdgcn_s_barrier();   // every wave is done with z8buf[0]: chunk t0+2 may land there
       if (T > 2) issue_z8(t0 + 2, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1536,27 +1558,33 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       // Iteration k: gradient GEMM of chunk t = t0+k (weights Bw, transposed copy in ztbuf[k&1]) || lookups of chunk t+1
       // (its Gram tile Scur, fixed up first if need be) -> next weights || Gram of chunk t+2 (int8 rows in z8buf[k&1])
       // -> Snext.  Chunks past t1 are dummies: no DMA, every pair masked, zero weights.
-      auto iteration = [&](int k, i32x16& Scur, i32x16& Snext) {
+      // (P = k & 1 as a compile-time constant: the trip below runs k = 0, 2, 4, ... through P = 0 and k + 1 through
+      // P = 1, so every LDS stage address is a per-lane base register plus an IMMEDIATE offset -- no address arithmetic)
+      auto iteration = [&](int k, auto parity, i32x16& Scur, i32x16& Snext) {
+        constexpr int P = decltype(parity)::value;
+        asm volatile("" : "+v"(Scur));
         const int t = (int)t0 + k, tl = (int)t1 - 1;
         // next transfers: transposed copy of chunk t+1 -> ztbuf[(k+1)&1] (last read in iteration k-1), int8 rows of chunk
         // t+3 -> z8buf[(k+1)&1] (ditto: the Gram of chunk t+1 ran in iteration k-1).  Past the last chunk the last one
         // is fetched again (harmless, and it keeps the issue free of branches): the pieces go out from inside the first
         // tiles of the MFMA stream below.
-        const DmaPlan pl = dma_plan(t + 3 < tl ? t + 3 : tl, (k + 1) & 1, t + 1 < tl ? t + 1 : tl, (k + 1) & 1);
+        const DmaPlan pl = dma_plan(t + 3 < tl ? t + 3 : tl, 1 - P, t + 1 < tl ? t + 1 : tl, 1 - P);
         const bool more = k + 1 < T;
         const ChunkMeta m = chunk_meta(more ? t + 1 : t, more);
-        if (m.fix) fixup(Scur, m);
+        if (m.fix) {
+          asm volatile("" ::: "memory");
+          fixup(Scur, m);
+        }
         const unsigned char* tb = table_base(m);
-        const unsigned char* zt0 = ztbuf + (k & 1) * L::ZT_BYTES;
-        const unsigned char* zrow = z8buf + (k & 1) * L::Z8_BYTES + c * D;
+        const unsigned char* zt0 = ztbuf + P * L::ZT_BYTES;
+        const unsigned char* zrow = z8buf + P * L::Z8_BYTES + c * D;
         i32x4 Bn[2][NTERM];
         i32x4 ent[RMAX];   // table entries requested beside tile ft, consumed beside tile ft + 1
         i32x4 an[2], ac[2], zn[GPT], zc[GPT];
         ac[0] = *reinterpret_cast<const i32x4*>(zt0 + aoff0);
         ac[1] = *reinterpret_cast<const i32x4*>(zt0 + aoff1);
 #pragma unroll
-        for (int u = 0; u < GPT; ++u) zc[u] = *reinterpret_cast<const i32x4*>(zrow + (((2 * u + hh) ^ fz_c) << 4));
-        Snext = (i32x16){0};
+        for (int u = 0; u < GPT; ++u) zc[u] = *reinterpret_cast<const i32x4*>(zrow + zslot(u));
 #pragma unroll
         for (int ft = 0; ft < NFT; ++ft) {
           // Everything this tile consumes was requested a tile ago: wait for it HERE, before the next tile's requests go
@@ -1576,7 +1604,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
             an[1] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff1);
 #pragma unroll
             for (int u = 0; u < GPT; ++u)
-              zn[u] = *reinterpret_cast<const i32x4*>(zrow + (((2 * ((ft + 1) * GPT + u) + hh) ^ fz_c) << 4));
+              zn[u] = *reinterpret_cast<const i32x4*>(zrow + zslot((ft + 1) * GPT + u));
           }
           i32x4 enew[RMAX];
 #pragma unroll
@@ -1599,8 +1627,17 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
                                                             __builtin_bit_cast(bf16x8, Bw[1][term]), G[ft], 0, 0, 0);
           }
 #pragma unroll
-          for (int u = 0; u < GPT; ++u)
-            Snext = __builtin_amdgcn_mfma_i32_32x32x32_i8(zc[u], xb[ft * GPT + u], Snext, 0, 0, 0);
+          for (int u = 0; u < GPT; ++u) {
+            // The Gram tile lives in VECTOR registers (inline asm: "v" operands).  Left to the compiler it goes to the
+            // accumulator file, which G^T fills completely at d = 512: round 3's build moved one G^T tile out to vector
+            // registers and back around this tile every chunk (32 v_accvgpr moves + 16 zeroing writes + a 12-cycle
+            // hazard stall) and read the finished Gram tile back through 16 more.  The first k-step takes C = 0.
+            // (No hazard bookkeeping is lost: the next reader of Snext is an iteration away.)
+            if (ft == 0 && u == 0)
+              asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
+            else
+              asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
+          }
           if (ft > 0) {
 #pragma unroll
             for (int u = 0; u < RMAX; ++u)
@@ -1633,8 +1670,8 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       };
       // two chunks per trip, so that the two Gram tiles swap roles without register copies; an odd T runs one dummy chunk
       for (int k = 0; k < T; k += 2) {
-        iteration(k, Sa, Sb);
-        iteration(k + 1, Sb, Sa);
+        iteration(k, std::integral_constant<int, 0>{}, Sa, Sb);
+        iteration(k + 1, std::integral_constant<int, 1>{}, Sb, Sa);
       }
     } else {
       // loss only (y-row blocks, or no gradient asked for): Gram + lookups per chunk
