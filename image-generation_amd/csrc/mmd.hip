@@ -1254,12 +1254,16 @@ template <int NST, int NFT>  // d = 32 NST features; a block accumulates 32 NFT 
 struct W128 {
   static constexpr int D = 32 * NST;
   static constexpr int TABN = D + 3;  // entries per table: h = 0 .. D, the all-zero entry D+1, the diagonal entry D+2
-  static constexpr int TAB_BYTES = (2 * TABN * 16 + 1023) / 1024 * 1024;
+  // 8-byte entries {kernel sum (f32), weight as two bf16 terms hi | lo}: one ds_read_b64 per pair (round 3: 16 bytes with
+  // the float32 weight beside its two terms; the row sums now add the two terms themselves, which is also what G^T holds)
+  static constexpr int TAB_BYTES = (2 * TABN * 8 + 1023) / 1024 * 1024;
   static constexpr int RED_BYTES = 2048;
   static constexpr int Z8_BYTES = 32 * D;        // one chunk of int8 rows [32][D]
   static constexpr int ZT_BYTES = 64 * 32 * NFT; // one chunk of this block's slice of the transposed bf16 copy [32 NFT][32]
-  static constexpr int OFF_RED = TAB_BYTES, OFF_Z8 = OFF_RED + RED_BYTES, OFF_ZT = OFF_Z8 + 2 * Z8_BYTES;
-  static constexpr int LDS_BYTES = OFF_ZT + 2 * ZT_BYTES;
+  static constexpr int NSTG = 3;                 // ring depth of both images (see the loop)
+  static constexpr int OFF_RED = TAB_BYTES, OFF_Z8 = OFF_RED + RED_BYTES, OFF_ZT = OFF_Z8 + NSTG * Z8_BYTES;
+  static constexpr int LDS_BYTES = OFF_ZT + NSTG * ZT_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "w128: LDS image over the CU's 160 KiB");
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
@@ -1273,6 +1277,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   constexpr int D = L::D;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
   double* red = reinterpret_cast<double*>(smem + L::OFF_RED);
   unsigned char* z8buf = smem + L::OFF_Z8;
   unsigned char* ztbuf = smem + L::OFF_ZT;
@@ -1303,8 +1308,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   }
   const int T = t1 > t0 ? (int)(t1 - t0) : 0;
   // (32-bit copies for the block-uniform per-chunk arithmetic of the loop: chunk and row counts are far below 2^31)
-  const int ncx_i = (int)ncx, ncy_i = (int)ncy, nx_i = (int)a.nx, ny_i = (int)a.ny, gi_i = (int)gi, base_i_i = (int)base_i;
-  (void)ncy_i;
+  const int ncx_i = (int)ncx, nx_i = (int)a.nx, ny_i = (int)a.ny, gi_i = (int)gi, base_i_i = (int)base_i;
 
   // ---- one-time staging: pair table (+ the two masking entries per table) -> LDS, this wave's 32 rows -> B fragments
   constexpr int TABN = L::TABN;
@@ -1317,15 +1321,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     // |w - (hi + lo)| <= 2^-18 |w|, unbiased.  (The 32-row kernels' third, truncation-split term is below half an ulp
     // of a float32 accumulator that already holds a few hundred weights, i.e. it is rounded away add by add -- a
     // systematic loss of ~2^-17 of the sum -- and costs a third of the gradient GEMM)
-    {
-      const float w = __uint_as_float(v.y);
-      auto rn_bf16 = [](float f) { const uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; };
-      const uint32_t hi = rn_bf16(w);
-      const uint32_t lo = rn_bf16(w - __uint_as_float(hi));
-      v.z = hi | (lo >> 16);
-      v.w = 0u;
-    }
-    reinterpret_cast<uint4*>(smem)[e] = v;
+    const float w = __uint_as_float(v.y);
+    auto rn_bf16 = [](float f) { const uint32_t u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; };
+    const uint32_t hi = rn_bf16(w);
+    const uint32_t lo = rn_bf16(w - __uint_as_float(hi));
+    reinterpret_cast<uint2*>(smem)[e] = make_uint2(v.x, hi | (lo >> 16));
   }
   i32x4 xb[NST];
   {
@@ -1338,100 +1338,75 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // address carries the swizzle: 16-byte slot `sl` of row `r` is stored at slot sl ^ f(r).
   //   int8 rows [32][D]: f(r) = r & 15 when a row is a whole number of 256-byte bank rows, else (r >> 1) & 7;
   //   transposed bf16 [D][32] (64-byte rows): f(r) = (r >> 2) & 3.
-  // Per-lane pieces are constant over the kernel: (row, swizzled slot) -> a 32-bit source offset inside the chunk and the
-  // LDS piece; per chunk only a wave-uniform base pointer changes (scalar registers), plus a clamp on the last,
-  // partial chunk of x or y.
-  int z8off[NST / 4], z8row[NST / 4], z8col[NST / 4], ztoff[NFT / 2];
+  // Every piece is ONE instruction, buffer_load_dwordx4 ... lds: the per-lane offset inside the chunk (z8off / ztoff:
+  // constant over the kernel) is the vector offset, the chunk's position the SCALAR offset, the LDS destination a scalar
+  // too -- no per-piece vector arithmetic (the global_load_lds form of round 3 cost 6 vector instructions per piece for
+  // its 64-bit per-lane pointer, its row clamp and the readfirstlane of its destination).  Rows past the end of x read
+  // the first rows of y, rows past the end of y are out of the buffer's range and arrive as zeros: either way those
+  // pairs are masked in the lookups.
+  constexpr int NZ8 = NST / 4, NZT = NFT / 2;
+  int z8off[NZ8], ztoff0;  // (transposed copy: piece q of a wave = piece 0 + q KiB, the swizzle class does not change)
 #pragma unroll
-  for (int q = 0; q < NST / 4; ++q) {
-    const int byte = (wave * (NST / 4) + q) * 1024 + lane * 16;  // position in the [32][D] image
+  for (int q = 0; q < NZ8; ++q) {
+    const int byte = (wave * NZ8 + q) * 1024 + lane * 16;  // position in the [32][D] image
     const int r = byte / D, sl = (byte % D) >> 4;
     const int fz = (D % 256 == 0) ? (r & 15) : ((r >> 1) & 7);
-    z8row[q] = r;
     z8off[q] = r * D + ((sl ^ fz) << 4);
-    z8col[q] = (sl ^ fz) << 4;
   }
-#pragma unroll
-  for (int q = 0; q < NFT / 2; ++q) {
-    const int f = (wave * (NFT / 2) + q) * 16 + (lane >> 2), sl = lane & 3;  // 1 KiB piece = 16 feature rows of 64 bytes
-    ztoff[q] = f * 64 + ((sl ^ ((f >> 2) & 3)) << 4);
+  {
+    const int f = wave * NZT * 16 + (lane >> 2), sl = lane & 3;  // 1 KiB piece = 16 feature rows of 64 bytes
+    ztoff0 = f * 64 + ((sl ^ ((f >> 2) & 3)) << 4);
   }
-  auto issue_z8 = [&](int64_t t, int buf) {
-    const bool cx = t < ncx;
-    const int64_t jrow0 = (cx ? t : t - ncx) * 32, cnt_j = cx ? a.nx : a.ny;
-    const int8_t* base = a.zi8 + ((cx ? 0 : a.nx) + jrow0) * D;  // wave-uniform
-    unsigned char* dst = z8buf + buf * L::Z8_BYTES + wave * (NST / 4) * 1024;
-    if (jrow0 + 32 <= cnt_j) {
-#pragma unroll
-      for (int q = 0; q < NST / 4; ++q) dma16(base + z8off[q], dst + q * 1024);
-    } else {  // rows past the end re-read the last row (those pairs are masked in the lookups)
-      const int last = (int)(cnt_j - 1 - jrow0);
-#pragma unroll
-      for (int q = 0; q < NST / 4; ++q) {
-        const int r = z8row[q] < last ? z8row[q] : last;
-        dma16(base + (z8off[q] - z8row[q] * D + r * D), dst + q * 1024);
-      }
-    }
-  };
-  // The same transfers one 1 KiB piece at a time and without branches, for issue from inside the MFMA stream of the
-  // steady-state loop: `i` < NZ8 is a piece of the int8 rows of chunk tz8 (rows clamped to `last8`), the others are
-  // pieces of the transposed copy of chunk tzt.  The bases are wave-uniform and computed once per iteration.
-  // In the steady-state loop every piece is ONE instruction, buffer_load_dwordx4 ... lds: the per-lane offset inside the
-  // chunk (z8off / ztoff: constant over the kernel) is the vector offset, the chunk's position the SCALAR offset, the LDS
-  // destination a scalar too -- no per-piece vector arithmetic (the global_load_lds form of round 3 cost 6 vector
-  // instructions per piece for its 64-bit per-lane pointer, its row clamp and the readfirstlane of its destination:
-  // 72 of the ~280 vector instructions of a chunk).  Rows past the end of x read the first rows of y, rows past the end
-  // of y are out of the buffer's range and arrive as zeros: either way those pairs are masked in the lookups.
-  constexpr int NZ8 = NST / 4, NZT = NFT / 2;
   const __amdgpu_buffer_rsrc_t rsrc8 = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(a.zi8), 0, (int)((a.nx + a.ny) * D), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrct = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(a.zt), 0, (int)((a.ztb_y + (a.ny + 127) / 128 * 4) * (int64_t)D * 64), 0x00020000);
   const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_byte*)smem);
-  struct DmaPlan { int z8soff, ztsoff; uint32_t z8dst, ztdst; };
-  auto dma_plan = [&](int tz8, int buf8, int tzt, int buft) -> DmaPlan {
-    DmaPlan pl;
-    const bool cx8 = tz8 < ncx_i;
-    pl.z8soff = __builtin_amdgcn_readfirstlane(((cx8 ? 0 : nx_i) + (cx8 ? tz8 : tz8 - ncx_i) * 32) * D);
-    pl.z8dst = lds0 + (uint32_t)(L::OFF_Z8 + buf8 * L::Z8_BYTES + wave * NZ8 * 1024);
-    const bool cxt = tzt < ncx_i;
-    pl.ztsoff = __builtin_amdgcn_readfirstlane((((cxt ? 0 : (int)a.ztb_y) + (cxt ? tzt : tzt - ncx_i)) * D + f0) * 64);
-    pl.ztdst = lds0 + (uint32_t)(L::OFF_ZT + buft * L::ZT_BYTES + wave * NZT * 1024);
-    return pl;
+  // scalar source offsets of chunk t's images (chunks past the block's last one re-fetch the last: harmless, branch-free)
+  const int tl_i = (int)t1 - 1;
+  auto z8_soff = [&](int t) -> int {
+    t = t < tl_i ? t : tl_i;
+    const bool cx = t < ncx_i;
+    return ((cx ? 0 : nx_i) + (cx ? t : t - ncx_i) * 32) * D;
   };
-  auto dma_piece = [&](const DmaPlan& pl, int i) {
-    if (i < NZ8)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc8, (lds_void*)(uintptr_t)(pl.z8dst + i * 1024), 16, z8off[i], pl.z8soff, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrct, (lds_void*)(uintptr_t)(pl.ztdst + (i - NZ8) * 1024), 16, ztoff[i - NZ8], pl.ztsoff, 0, 0);
+  auto zt_soff = [&](int t) -> int {
+    t = t < tl_i ? t : tl_i;
+    const bool cx = t < ncx_i;
+    return (((cx ? 0 : (int)a.ztb_y) + (cx ? t : t - ncx_i)) * D + f0) * 64;
   };
-  auto issue_zt = [&](int64_t t, int buf) {
-    const bool cx = t < ncx;
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(a.zt) +
-                                (((cx ? 0 : a.ztb_y) + (cx ? t : t - ncx)) * (int64_t)D + f0) * 64;  // wave-uniform
-    unsigned char* dst = ztbuf + buf * L::ZT_BYTES + wave * (NFT / 2) * 1024;
+  auto issue_z8 = [&](int t, int stg) {
+    const int so = __builtin_amdgcn_readfirstlane(z8_soff(t));
+    const uint32_t dst = lds0 + (uint32_t)(L::OFF_Z8 + stg * L::Z8_BYTES + wave * NZ8 * 1024);
 #pragma unroll
-    for (int q = 0; q < NFT / 2; ++q) dma16(base + ztoff[q], dst + q * 1024);
+    for (int q = 0; q < NZ8; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc8, (lds_void*)(uintptr_t)(dst + q * 1024), 16, z8off[q], so, 0, 0);
+  };
+  auto issue_zt = [&](int t, int stg) {
+    const int so = __builtin_amdgcn_readfirstlane(zt_soff(t));
+    const uint32_t dst = lds0 + (uint32_t)(L::OFF_ZT + stg * L::ZT_BYTES + wave * NZT * 1024);
+#pragma unroll
+    for (int q = 0; q < NZT; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrct, (lds_void*)(uintptr_t)(dst + q * 1024), 16, ztoff0, so + q * 1024, 0, 0);
   };
 
   // per-lane LDS read offsets (constant over the kernel)
   const int fz_c = (D % 256 == 0) ? (c & 15) : ((c >> 1) & 7);
   const int sw_c = (c >> 2) & 3;
   const int aoff0 = c * 64 + ((hh ^ sw_c) << 4), aoff1 = c * 64 + (((2 + hh) ^ sw_c) << 4);
-
   // Byte offset of k-step s inside this lane's LDS row: ((2 s + hh) ^ fz_c) << 4.  The swizzle touches the low ZSW slots
   // only, so steps s and s + ZSW / 2 differ by a CONSTANT ZSW * 16 bytes: ZSW / 2 per-lane registers + immediates
   // instead of one register per k-step.
   constexpr int ZSW = (D % 256 == 0) ? 16 : 8;
-  int zlow[ZSW / 2];
+  constexpr int NZB = ZSW / 2 < NST ? ZSW / 2 : NST;
+  int zlow[NZB];
 #pragma unroll
-  for (int m = 0; m < ZSW / 2; ++m) zlow[m] = ((2 * m + hh) ^ fz_c) << 4;
-  auto zslot = [&](int s_) -> int { return zlow[s_ % (ZSW / 2)] + (s_ / (ZSW / 2)) * (ZSW * 16); };
-  auto gram = [&](int buf) -> i32x16 {
-    const unsigned char* zrow = z8buf + buf * L::Z8_BYTES + c * D;
+  for (int m = 0; m < NZB; ++m) zlow[m] = c * D + (((2 * m + hh) ^ fz_c) << 4);
+
+  auto gram = [&](int stg) -> i32x16 {
+    const unsigned char* z = z8buf + stg * L::Z8_BYTES;
     i32x16 acc = {0};
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
-      const i32x4 za = *reinterpret_cast<const i32x4*>(zrow + (((2 * s + hh) ^ fz_c) << 4));
+      const i32x4 za = *reinterpret_cast<const i32x4*>(z + zlow[s % NZB] + (s / NZB) * (ZSW * 16));
       acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(za, xb[s], acc, 0, 0, 0);
     }
     return acc;
@@ -1440,20 +1415,18 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   f32x16 G[NFT];
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) G[ft] = (f32x16){0};
-  float rowsum = 0.f;
-  double l_xx = 0.0, l_xy = 0.0, l_yy = 0.0;
 
   // Masking.  The steady-state iteration is ONE straight-line instruction stream with no per-pair masks (variants of
   // the loop body make the register allocator copy all of G^T between them every iteration; a branch inside the body
   // stops the scheduler from interleaving lookups with MFMAs; per-pair compare / select pairs made the loop
-  // issue-bound: the MFMAs leave room for ~6 other instructions each).  Instead:
+  // issue-bound).  Instead:
   //   * a row of x past the end: its lane's kernel sums are dropped when they are flushed (one select per chunk); its
   //     weights only reach columns of G^T that are never stored;
   //   * the rare chunks with invalid COLUMNS (the ragged last chunk of x or y, the dummy chunks that pad the pipeline)
   //     or with the diagonal pair of an unbiased estimate get their Gram tile rewritten before the lookups, in a
   //     block-uniform branch outside the MFMA stream: an invalid pair becomes S = -(D+2), i.e. "Hamming distance" D+1,
   //     whose table entry is all zero; the diagonal pair becomes S = -(D+4), entry D+2 = entry 0 with a zero kernel sum.
-  struct ChunkMeta { bool cols_x, fix; int nj, dloc; };
+  struct ChunkMeta { bool cols_x, fix; int nj, djrow; };  // djrow: first column row of a chunk that crosses the diagonal, else INT_MIN / 2
   const bool diag_kind = !a.biased;
   auto chunk_meta = [&](int t, bool exists) -> ChunkMeta {
     ChunkMeta m;
@@ -1462,7 +1435,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     const int left = cnt_j - jrow0;
     m.nj = exists ? (left < 32 ? left : 32) : 0;
     const bool diag_here = exists && diag_kind && rows_x == m.cols_x && jrow0 + 32 > base_i_i && jrow0 < base_i_i + 128;
-    m.dloc = diag_here ? gi_i - jrow0 : -1;  // (outside [0, 32) for the waves / lanes the chunk does not cross)
+    m.djrow = diag_here ? jrow0 : -(1 << 30);  // (gi - djrow is then outside [0, 32) for every lane)
     m.fix = m.nj < 32 || diag_here;
     return m;
   };
@@ -1471,34 +1444,37 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     // chunk, and from hoisting the 16 row indices into registers that would be live across the whole loop.)
     int hho = hh;
     asm volatile("" : "+v"(hho));
+    const int dloc = gi_i - m.djrow;  // this lane's diagonal pair, if the chunk holds it
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int jl = crow(r, hho);
       int v = S[r];
-      v = jl == m.dloc ? -(D + 4) : v;
+      v = jl == dloc ? -(D + 4) : v;
       v = jl < m.nj ? v : -(D + 2);
       S[r] = v;
     }
   };
 
-  // One pair-row r of the lookup phase: table read (byte offset 8 (D - S) = 16 h), then loss / row sums and -- every
+  // One pair-row r of the lookup phase: table read (byte offset 4 (D - S) = 8 h), then loss / row sums and -- every
   // second row -- the pair's weight pieces packed straight into the next chunk's B-operand registers (k-permuted layout
   // of the Gram accumulator: see the comment on the spin path above).  Split in two so that a row's table read is issued
-  // a feature tile -- six MFMAs -- ahead of its use.
-  float lsum = 0.f;
+  // a feature tile ahead of its use.  The row sum adds the two bf16 terms themselves (two running sums): exactly the
+  // weights the gradient GEMM multiplies with.
+  float lsum = 0.f, rs_hi = 0.f, rs_lo = 0.f;
   uint32_t hm_prev = 0;
   constexpr int NTERM = 2;  // bf16 terms of a weight
-  auto look_issue = [&](const i32x16& S, int r, const unsigned char* tb) -> i32x4 {
-    return *reinterpret_cast<const i32x4*>(tb + __mul24(S[r], -8));
+  auto look_issue = [&](const i32x16& S, int r, const unsigned char* tb) -> i32x2 {
+    return *reinterpret_cast<const i32x2*>(tb + __mul24(S[r], -4));
   };
   // (the empty asm statements pin each row's arithmetic to the tile it is written in: its results are only needed by the
-  // NEXT iteration, and left alone the compiler sinks all of it behind the barrier, into a VALU-only stretch of ~150
-  // instructions during which the matrix pipe idles -- with one wave per SIMD nothing else would fill it)
-  auto look_use = [&](const i32x4& e, int r, i32x4 (&Bn)[2][NTERM]) {
+  // NEXT iteration, and left alone the compiler sinks all of it into one VALU-only stretch during which the matrix pipe
+  // idles -- with one wave per SIMD nothing else would fill it)
+  auto look_use = [&](const i32x2& e, int r, i32x4 (&Bn)[2][NTERM]) {
     lsum += __int_as_float(e[0]);
-    rowsum += __int_as_float(e[1]);
-    asm volatile("" ::"v"(lsum), "v"(rowsum));
-    const uint32_t hm = (uint32_t)e[2];
+    const uint32_t hm = (uint32_t)e[1];
+    rs_hi += __uint_as_float(hm & 0xffff0000u);
+    rs_lo += __uint_as_float(hm << 16);
+    asm volatile("" ::"v"(lsum), "v"(rs_hi), "v"(rs_lo));
     if (r & 1) {
       const int s2 = r >> 3, q = (r & 7) >> 1;
       Bn[s2][0][q] = (int)__builtin_amdgcn_perm(hm, hm_prev, 0x07060302u);
@@ -1508,190 +1484,260 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
       hm_prev = hm;
     }
   };
-  // (tb = table base + 8 D: the byte offset of Gram value S is then -8 S)
-  auto table_base = [&](const ChunkMeta& m) -> const unsigned char* {
-    return smem + (m.cols_x ? 0 : TABN * 16) + 8 * D;
-  };
+  // (tb = table base + 4 D: the byte offset of Gram value S is then -4 S)
+  auto table_base = [&](bool cols_x) -> const unsigned char* { return smem + (cols_x ? 0 : TABN * 8) + 4 * D; };
   double l_cx = 0.0, l_cy = 0.0;  // kernel sums against x columns / y columns
-  // Per chunk the two float32 running sums of a lane (16 pairs each) move into double accumulators.  For the row sums
+  // Per chunk the float32 running sums of a lane (16 pairs each) move into double accumulators.  For the row sums
   // this is an accuracy matter, not a nicety: a lane adds ~N/2 table values -- a few dozen DISTINCT values, so the
   // rounding errors of a float32 chain do not average out -- and x_i * rowsum_i - G_i subtracts two nearly equal
   // numbers (measured at c3's size against float64: 1.3e-5 of the parts with a float32 chain of 16 k terms per lane).
   double rowsum_d = 0.0;
-  auto flush_lsum = [&](const ChunkMeta& m) {
+  auto flush_lsum = [&](bool cols_x) {
     const double dl = vi ? (double)lsum : 0.0;
-    l_cx += m.cols_x ? dl : 0.0;
-    l_cy += m.cols_x ? 0.0 : dl;
+    l_cx += cols_x ? dl : 0.0;
+    l_cy += cols_x ? 0.0 : dl;
     lsum = 0.f;
-    rowsum_d += (double)rowsum;
-    rowsum = 0.f;
+    rowsum_d += (double)rs_hi + (double)rs_lo;
+    rs_hi = 0.f; rs_lo = 0.f;
   };
 
   i32x4 Bw[2][NTERM];
-  if (T > 0) {
-    // ---- prologue: images of chunks t0 and t0+1, Gram + lookups of chunk t0, Gram of chunk t0+1
-    issue_z8(t0, 0);
-    if (want_grad) issue_zt(t0, 0);
-    if (T > 1) issue_z8(t0 + 1, 1);
+  if (T > 0 && want_grad) {
+    // ================================================================================================ gradient blocks
+    // Three-stage rings for both images; chunk u (counted from t0) lives in stage u % 3.  Iteration k (chunk t = t0 + k)
+    // runs   G^T += Z^T(t) W(t)           transposed copy of chunk t      from stage  k      % 3
+    //        lookups of chunk t+1          its Gram tile (registers) -> the next weights
+    //        Gram of chunk t+2             int8 rows of chunk t+2          from stage (k + 2) % 3
+    //        LDS-DMA: int8 rows of chunk t+4 -> stage (k+1) % 3,  transposed copy of chunk t+2 -> stage (k+2) % 3
+    // with ONE workgroup barrier, at the TOP of the iteration and in front of the DMA issue: the stages the DMA
+    // overwrites were last read in iteration k-1 (every wave is past it), and what it fetches is first read in
+    // iteration k+2, behind the next barrier, in front of which each wave has waited for its own pieces (a whole
+    // iteration after issuing them: that wait does not stall).  With two stages (round 3) the barrier had to sit
+    // BETWEEN an iteration's last reads and the next one's first, i.e. every chunk ended in
+    // `wait - barrier - first operand reads - wait`, a serial stretch with the matrix pipe empty; here the operand reads
+    // of the next chunk's first tile go out beside the last tile's MFMAs and the tile pipeline never drains.  The
+    // block-uniform bookkeeping of the NEXT iteration (chunk meta, DMA offsets, stage addresses: ~60 scalar and a dozen
+    // vector instructions) is computed in the middle of the current one, between MFMAs, for the same reason.
+    issue_z8((int)t0, 0);
+    issue_z8((int)t0 + 1, 1);
+    issue_z8((int)t0 + 2, 2);
+    issue_zt((int)t0, 0);
+    issue_zt((int)t0 + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // also publishes the pair table
     {
       const ChunkMeta m = chunk_meta((int)t0, true);
       i32x16 S = gram(0);
       if (m.fix) fixup(S, m);
-      const unsigned char* tb = table_base(m);
+      const unsigned char* tb = table_base(m.cols_x);
 #pragma unroll
       for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb), r, Bw);
-      flush_lsum(m);
+      flush_lsum(m.cols_x);
     }
-    if (want_grad) {
-      i32x16 Sa = gram(1), Sb = {0};  // Sa: Gram tile of chunk t0+1 (stale bytes if T == 1: masked by its fixup)
-      asm volatile("" : "+v"(Sa), "+v"(Sb));  // both Gram tiles live in vector registers from here on (see the loop)
-      __builtin_amdgcn_s_barrier();   // every wave is done with z8buf[0]: chunk t0+2 may land there
-      if (T > 2) issue_z8(t0 + 2, 0);
+    i32x16 Sa = gram(1), Sb = {0};  // Sa: Gram tile of chunk t0+1 (a repeat of chunk t0's rows if T == 1: masked by its fixup)
+    __builtin_amdgcn_s_barrier();   // every wave is done with stage 0 of the int8 ring: chunk t0+3 may land there
+    issue_z8((int)t0 + 3, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(Sa), "+v"(Sb));  // both Gram tiles live in vector registers from here on (see the tile loop)
+
+    // pair-rows [rb(ft), rb(ft+1)) are requested beside feature tile ft < NFT - 1 and consumed beside tile ft + 1
+    auto rb = [](int ft) { return ft >= NFT - 1 ? 16 : (16 * ft + NFT - 2) / (NFT - 1); };
+    constexpr int RMAX = (16 + NFT - 2) / (NFT - 1);
+    constexpr int GPT = NST / NFT;  // Gram k-steps (MFMAs) beside each feature tile
+    // what an iteration needs from the one before it (block-uniform unless said otherwise)
+    struct Carry {
+      int z8so, ztso;          // scalar source offsets of this iteration's DMA (int8 rows of chunk t+4, transposed copy of t+2)
+      uint32_t z8dst, ztdst;   // ... and their LDS destinations
+      bool fix, cols_x;        // lookups of this iteration (chunk t+1): Gram tile needs the fixup / which table
+      int nj, djrow;
+      bool prev_cols_x;        // the chunk whose sums this iteration flushes
+    };
+    auto carry_for = [&](int k, int stg) -> Carry {  // stg = k % 3
+      Carry cy;
+      const int t = (int)t0 + k;
+      const int s1 = stg == 2 ? 0 : stg + 1, s2 = stg == 0 ? 2 : stg - 1;  // (k+1) % 3, (k+2) % 3
+      cy.z8so = __builtin_amdgcn_readfirstlane(z8_soff(t + 4));
+      cy.ztso = __builtin_amdgcn_readfirstlane(zt_soff(t + 2));
+      cy.z8dst = lds0 + (uint32_t)(L::OFF_Z8 + s1 * L::Z8_BYTES + wave * NZ8 * 1024);
+      cy.ztdst = lds0 + (uint32_t)(L::OFF_ZT + s2 * L::ZT_BYTES + wave * NZT * 1024);
+      const bool more = k + 1 < T;
+      const ChunkMeta m = chunk_meta(more ? t + 1 : t, more);
+      cy.fix = m.fix; cy.cols_x = m.cols_x; cy.nj = m.nj; cy.djrow = m.djrow;
+      cy.prev_cols_x = t < ncx_i;  // chunk t's lookups ran in iteration k-1 (or the prologue)
+      return cy;
+    };
+    // per-lane LDS addresses of a stage's operands: [0], [1] the two halves of a transposed-copy row (+ 2048 per feature
+    // tile), [2 ...] the swizzle classes of the int8 row (+ ZSW * 16 per class repeat)
+    struct Addr { const unsigned char* a0; const unsigned char* a1; const unsigned char* z[NZB]; };
+    auto addr_for = [&](int stg_zt, int stg_z8) -> Addr {
+      Addr ad;
+      ad.a0 = ztbuf + stg_zt * L::ZT_BYTES + aoff0;
+      ad.a1 = ztbuf + stg_zt * L::ZT_BYTES + aoff1;
+#pragma unroll
+      for (int m = 0; m < NZB; ++m) ad.z[m] = z8buf + stg_z8 * L::Z8_BYTES + zlow[m];
+      return ad;
+    };
+    auto zread = [&](const Addr& ad, int s_) -> i32x4 {
+      return *reinterpret_cast<const i32x4*>(ad.z[s_ % NZB] + (s_ / NZB) * (ZSW * 16));
+    };
+
+    int stg = 0;  // k % 3
+    Carry cy = carry_for(0, 0);
+    Addr ad = addr_for(0, 2);  // ONE set of per-lane addresses, moved to the next stages in place at an iteration's last tile
+    // operands of the first tile of iteration 0 (from here on they are requested a tile ahead, across iterations too)
+    i32x4 ac[2], zc[GPT];
+    ac[0] = *reinterpret_cast<const i32x4*>(ad.a0);
+    ac[1] = *reinterpret_cast<const i32x4*>(ad.a1);
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) zc[u] = zread(ad, u);
+    i32x2 ent[RMAX];
+
+    auto iteration = [&](int k, auto parity, i32x16& Scur, i32x16& Snext) {
+      constexpr int P = decltype(parity)::value;
+      // ---- top: the one barrier (behind the wait for this wave's pieces of the previous iteration), the rare fixup
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // pair-rows [rb(ft), rb(ft+1)) are looked up beside feature tile ft: 16 rows spread evenly over the NFT tiles
-      auto rb = [](int ft) { return (16 * ft + NFT - 1) / NFT; };
-      constexpr int RMAX = (16 + NFT - 1) / NFT;
-      constexpr int GPT = NST / NFT;  // Gram k-steps (MFMAs) beside each feature tile
-      // Iteration k: gradient GEMM of chunk t = t0+k (weights Bw, transposed copy in ztbuf[k&1]) || lookups of chunk t+1
-      // (its Gram tile Scur, fixed up first if need be) -> next weights || Gram of chunk t+2 (int8 rows in z8buf[k&1])
-      // -> Snext.  Chunks past t1 are dummies: no DMA, every pair masked, zero weights.
-      // (P = k & 1 as a compile-time constant: the trip below runs k = 0, 2, 4, ... through P = 0 and k + 1 through
-      // P = 1, so every LDS stage address is a per-lane base register plus an IMMEDIATE offset -- no address arithmetic)
-      auto iteration = [&](int k, auto parity, i32x16& Scur, i32x16& Snext) {
-        constexpr int P = decltype(parity)::value;
-        asm volatile("" : "+v"(Scur));
-        const int t = (int)t0 + k, tl = (int)t1 - 1;
-        // next transfers: transposed copy of chunk t+1 -> ztbuf[(k+1)&1] (last read in iteration k-1), int8 rows of chunk
-        // t+3 -> z8buf[(k+1)&1] (ditto: the Gram of chunk t+1 ran in iteration k-1).  Past the last chunk the last one
-        // is fetched again (harmless, and it keeps the issue free of branches): the pieces go out from inside the first
-        // tiles of the MFMA stream below.
-        const DmaPlan pl = dma_plan(t + 3 < tl ? t + 3 : tl, 1 - P, t + 1 < tl ? t + 1 : tl, 1 - P);
-        const bool more = k + 1 < T;
-        const ChunkMeta m = chunk_meta(more ? t + 1 : t, more);
-        if (m.fix) {
-          asm volatile("" ::: "memory");
-          fixup(Scur, m);
-        }
-        const unsigned char* tb = table_base(m);
-        const unsigned char* zt0 = ztbuf + P * L::ZT_BYTES;
-        const unsigned char* zrow = z8buf + P * L::Z8_BYTES + c * D;
-        i32x4 Bn[2][NTERM];
-        i32x4 ent[RMAX];   // table entries requested beside tile ft, consumed beside tile ft + 1
-        i32x4 an[2], ac[2], zn[GPT], zc[GPT];
-        ac[0] = *reinterpret_cast<const i32x4*>(zt0 + aoff0);
-        ac[1] = *reinterpret_cast<const i32x4*>(zt0 + aoff1);
+      asm volatile("" : "+v"(Scur));
+      if (cy.fix) {
+        asm volatile("" ::: "memory");
+        ChunkMeta m;
+        m.cols_x = cy.cols_x; m.fix = true; m.nj = cy.nj; m.djrow = cy.djrow;
+        fixup(Scur, m);
+      }
+      const unsigned char* tb = table_base(cy.cols_x);
+      const Carry cur = cy;
+      const int stg_n = stg == 2 ? 0 : stg + 1;  // (k+1) % 3: the next iteration's transposed-copy stage; its int8 stage is stg
+      i32x4 Bn[2][NTERM];
+      i32x4 an[2], zn[GPT];
 #pragma unroll
-        for (int u = 0; u < GPT; ++u) zc[u] = *reinterpret_cast<const i32x4*>(zrow + zslot(u));
+      for (int ft = 0; ft < NFT; ++ft) {
+        // Everything this tile consumes was requested a tile ago: wait for it HERE, before the next tile's requests go
+        // out (the compiler waits with lgkmcnt(0) at the first use; placed behind fresh requests that wait would sit
+        // out their whole latency every tile).  The empty asm is that first use.
 #pragma unroll
-        for (int ft = 0; ft < NFT; ++ft) {
-          // Everything this tile consumes was requested a tile ago: wait for it HERE, before the next tile's requests go
-          // out (the compiler waits with lgkmcnt(0) at the first use; placed behind fresh requests that wait would sit
-          // out their whole latency every tile).  The empty asm is that first use.
-#pragma unroll
-          for (int u = 0; u < GPT; ++u) asm volatile("" ::"v"(zc[u]));
-          asm volatile("" ::"v"(ac[0]), "v"(ac[1]));
-          if (ft > 0) {
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u)
-              if (rb(ft - 1) + u < rb(ft)) asm volatile("" ::"v"(ent[u]));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (ft + 1 < NFT) {
-            an[0] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff0);
-            an[1] = *reinterpret_cast<const i32x4*>(zt0 + (ft + 1) * 2048 + aoff1);
-#pragma unroll
-            for (int u = 0; u < GPT; ++u)
-              zn[u] = *reinterpret_cast<const i32x4*>(zrow + zslot((ft + 1) * GPT + u));
-          }
-          i32x4 enew[RMAX];
+        for (int u = 0; u < GPT; ++u) asm volatile("" ::"v"(zc[u]));
+        asm volatile("" ::"v"(ac[0]), "v"(ac[1]));
+        if (ft > 0) {
 #pragma unroll
           for (int u = 0; u < RMAX; ++u)
-            if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(Scur, rb(ft) + u, tb);
-          {  // this tile's share of the DMA pieces (all of them go out in the first half of the tiles: time to land)
-            constexpr int PPT = (NZ8 + NZT + NFT / 2 - 1) / (NFT / 2);
-#pragma unroll
-            for (int u = 0; u < PPT; ++u)
-              if (ft * PPT + u < NZ8 + NZT) dma_piece(pl, ft * PPT + u);
-          }
-          // the loads above serve the NEXT tile: they must be issued before this tile's MFMAs, not after them (left to
-          // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency)
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int term = 0; term < NTERM; ++term) {
-            G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[0]),
-                                                            __builtin_bit_cast(bf16x8, Bw[0][term]), G[ft], 0, 0, 0);
-            G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[1]),
-                                                            __builtin_bit_cast(bf16x8, Bw[1][term]), G[ft], 0, 0, 0);
-          }
-#pragma unroll
-          for (int u = 0; u < GPT; ++u) {
-            // The Gram tile lives in VECTOR registers (inline asm: "v" operands).  Left to the compiler it goes to the
-            // accumulator file, which G^T fills completely at d = 512: round 3's build moved one G^T tile out to vector
-            // registers and back around this tile every chunk (32 v_accvgpr moves + 16 zeroing writes + a 12-cycle
-            // hazard stall) and read the finished Gram tile back through 16 more.  The first k-step takes C = 0.
-            // (No hazard bookkeeping is lost: the next reader of Snext is an iteration away.)
-            if (ft == 0 && u == 0)
-              asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
-            else
-              asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
-          }
-          if (ft > 0) {
-#pragma unroll
-            for (int u = 0; u < RMAX; ++u)
-              if (rb(ft - 1) + u < rb(ft)) look_use(ent[u], rb(ft - 1) + u, Bn);
-          }
-#pragma unroll
-          for (int u = 0; u < RMAX; ++u) ent[u] = enew[u];
-          ac[0] = an[0]; ac[1] = an[1];
-#pragma unroll
-          for (int u = 0; u < GPT; ++u) zc[u] = zn[u];
-          // wanted order inside the tile: an MFMA, two vector instructions of the lookups, an MFMA, ... (an MFMA keeps the
-          // SIMD's issue port for 8 of its 32 cycles: a few VALU instructions per MFMA are free, a block of them is not)
-#pragma unroll
-          for (int i = 0; i < 2 * NTERM + GPT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);  // pin the tile order: unpinned, the scheduler hoists every tile's loads (spills)
+            if (rb(ft - 1) + u < rb(ft)) asm volatile("" ::"v"(ent[u]));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // the Gram k-steps go FIRST in the tile: the tile's four gradient MFMAs then separate them from the next vector
+        // instruction that could read the Gram tile (inline asm: the compiler keeps no hazard book for it; the tile is
+        // read a whole iteration later anyway).  The Gram tile lives in VECTOR registers ("v" operands): left to the
+        // compiler it goes to the accumulator file, which G^T fills completely at d = 512 -- round 3's build moved one
+        // G^T tile out to vector registers and back around this tile every chunk.  The first k-step takes C = 0.
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) {
+          if (ft == 0 && u == 0)
+            asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
+          else
+            asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ft + 1 < NFT) {
+          an[0] = *reinterpret_cast<const i32x4*>(ad.a0 + (ft + 1) * 2048);
+          an[1] = *reinterpret_cast<const i32x4*>(ad.a1 + (ft + 1) * 2048);
+#pragma unroll
+          for (int u = 0; u < GPT; ++u) zn[u] = zread(ad, (ft + 1) * GPT + u);
+        } else {
+          // the NEXT iteration's first tile (its stages were published by this iteration's barrier or earlier): every read
+          // of this iteration's stages has been issued, so the addresses move on in place (stage + 1, or back by two)
+          const int dzt = stg == 2 ? -2 * L::ZT_BYTES : L::ZT_BYTES;  // transposed copy: stage k % 3 -> (k + 1) % 3
+          const int dz8 = stg == 0 ? -2 * L::Z8_BYTES : L::Z8_BYTES;  // int8 rows: stage (k + 2) % 3 -> k % 3
+          ad.a0 += dzt; ad.a1 += dzt;
+#pragma unroll
+          for (int m = 0; m < NZB; ++m) ad.z[m] += dz8;
+          an[0] = *reinterpret_cast<const i32x4*>(ad.a0);
+          an[1] = *reinterpret_cast<const i32x4*>(ad.a1);
+#pragma unroll
+          for (int u = 0; u < GPT; ++u) zn[u] = zread(ad, u);
+        }
+        i32x2 enew[RMAX];
 #pragma unroll
         for (int u = 0; u < RMAX; ++u)
-          if (rb(NFT - 1) + u < 16) look_use(ent[u], rb(NFT - 1) + u, Bn);
+          if (rb(ft) + u < rb(ft + 1)) enew[u] = look_issue(Scur, rb(ft) + u, tb);
+        {  // this tile's share of the DMA pieces (all of them go out in the first half of the tiles)
+          constexpr int PPT = (NZ8 + NZT + NFT / 2 - 1) / (NFT / 2);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+          for (int u = 0; u < PPT; ++u) {
+            const int i = ft * PPT + u;
+            if (i < NZ8)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc8, (lds_void*)(uintptr_t)(cur.z8dst + i * 1024), 16, z8off[i], cur.z8so, 0, 0);
+            else if (i < NZ8 + NZT)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrct, (lds_void*)(uintptr_t)(cur.ztdst + (i - NZ8) * 1024), 16, ztoff0, cur.ztso + (i - NZ8) * 1024, 0, 0);
+          }
+        }
+        // the loads above serve the NEXT tile: they must be issued before this tile's MFMAs, not after them (left to
+        // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int term = 0; term < NTERM; ++term) Bw[s2][term] = Bn[s2][term];
-        flush_lsum(m);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      };
-      // two chunks per trip, so that the two Gram tiles swap roles without register copies; an odd T runs one dummy chunk
-      for (int k = 0; k < T; k += 2) {
-        iteration(k, std::integral_constant<int, 0>{}, Sa, Sb);
-        iteration(k + 1, std::integral_constant<int, 1>{}, Sb, Sa);
+        for (int term = 0; term < NTERM; ++term) {
+          G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[0]),
+                                                          __builtin_bit_cast(bf16x8, Bw[0][term]), G[ft], 0, 0, 0);
+          G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[1]),
+                                                          __builtin_bit_cast(bf16x8, Bw[1][term]), G[ft], 0, 0, 0);
+        }
+        if (ft > 0) {
+#pragma unroll
+          for (int u = 0; u < RMAX; ++u)
+            if (rb(ft - 1) + u < rb(ft)) look_use(ent[u], rb(ft - 1) + u, Bn);
+        }
+        if (ft == 0) flush_lsum(cur.prev_cols_x);  // the sums of the previous iteration's lookups (complete since its last tile)
+        if (ft == NFT / 2) {  // the next iteration's bookkeeping, between this tile's MFMAs
+          cy = carry_for(k + 1, stg_n);
+        }
+#pragma unroll
+        for (int u = 0; u < RMAX; ++u) ent[u] = enew[u];
+        ac[0] = an[0]; ac[1] = an[1];
+#pragma unroll
+        for (int u = 0; u < GPT; ++u) zc[u] = zn[u];
+        // wanted order inside the tile: an MFMA, a few vector instructions of the lookups, an MFMA, ...
+#pragma unroll
+        for (int i = 0; i < 2 * NTERM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // pin the tile order: unpinned, the scheduler hoists every tile's loads (spills)
       }
-    } else {
-      // loss only (y-row blocks, or no gradient asked for): Gram + lookups per chunk
-      for (int k = 0; k + 1 < T; ++k) {
-        const int64_t t = t0 + k;
-        if (k + 2 < T) issue_z8(t + 2, k & 1);
-        const ChunkMeta m = chunk_meta((int)t + 1, true);
-        i32x16 S = gram((k + 1) & 1);
-        if (m.fix) fixup(S, m);
-        const unsigned char* tb = table_base(m);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb), r, Bw);
-        flush_lsum(m);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int term = 0; term < NTERM; ++term) Bw[s2][term] = Bn[s2][term];
+      stg = stg_n;
+    };
+    // two chunks per trip, so that the two Gram tiles (and the two address sets) swap roles without register copies; an
+    // odd T runs one dummy chunk
+    for (int k = 0; k < T; k += 2) {
+      iteration(k, std::integral_constant<int, 0>{}, Sa, Sb);
+      iteration(k + 1, std::integral_constant<int, 1>{}, Sb, Sa);
+    }
+    flush_lsum(cy.prev_cols_x);  // the last iteration's lookups belong to a dummy chunk (all masked: zeros)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (T > 0) {
+    // ============================================================== loss only (y-row blocks, or no gradient asked for)
+    issue_z8((int)t0, 0);
+    if (T > 1) issue_z8((int)t0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // also publishes the pair table
+    for (int k = 0; k < T; ++k) {
+      const int t = (int)t0 + k;
+      if (k + 2 < T) issue_z8(t + 2, (k + 2) % 3);
+      const ChunkMeta m = chunk_meta(t, true);
+      i32x16 S = gram(k % 3);
+      if (m.fix) fixup(S, m);
+      const unsigned char* tb = table_base(m.cols_x);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) look_use(look_issue(S, r, tb), r, Bw);
+      flush_lsum(m.cols_x);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
   } else {
     __syncthreads();
   }
+  double l_xx = 0.0, l_xy = 0.0, l_yy = 0.0;
   if (rows_x) { l_xx = l_cx; l_xy = l_cy; } else { l_yy = l_cy; }
 
   // ---- loss partial sums
@@ -1704,9 +1750,8 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 
   // ---- grad[i][f] = x[i][f] * rowsum_i - G^T[f][i]; a lane holds features 32 ft + 8 q + 4 hh + (0..3) of its row in
   // accumulator registers 4 q .. 4 q + 3: one 16-byte store each.  x is +-1: its sign comes from the int8 copy.
-  rowsum_d += (double)rowsum;
   rowsum_d += __shfl_xor(rowsum_d, 32, 64);
-  rowsum = (float)rowsum_d;
+  const float rowsum = (float)rowsum_d;
   if (vi) {
     float* out = a.grad_part + (size_t)sp * a.nx * D + gi * D + f0;
     const int8_t* xs = a.zi8 + gi * D + f0;
