@@ -84,7 +84,7 @@ def _profile(kind, config, lib_hash):
     """A committed profiles/ JSON of this round, or None when it was measured on a different build of the kernels:
     every file carries `kernels_hash` = dvg_source_hash() of the library it was measured on (tools/make_profiles.sh),
     and a number from another build would survive a kernel regression unchanged."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{kind}_{config}.json")
         if os.path.exists(path):
             d = json.load(open(path))
@@ -305,33 +305,54 @@ def layerwise_run(args):
         return {"error": repr(exc)}
 
 
-def sampler_roofline(per_kernel, cfg, plan, prof_steps):
-    """SURVEY.md 8d for the block-Gibbs draw: spin updates/s, the fraction of the VALU / LDS issue bound that the op
-    count of one update implies, and the algorithmic HBM bytes per draw against its duration (the chain state lives in
-    LDS for all sweeps of a draw, so HBM traffic is the tables in and the state / samples out, once per draw).
+def sampler_roofline(per_kernel, cfg, plan, prof_steps, config, lib_hash):
+    """SURVEY.md 8d for the block-Gibbs draw: spin updates/s, the bound that actually binds it, and the algorithmic HBM
+    bytes per draw against its duration (the chain state lives in LDS for all sweeps of a draw, so HBM traffic is the
+    tables in and the state / samples out, once per draw).
 
-    Op count per spin update (gibbs.hip): deg neighbour terms of 3 LDS reads (index u16, coupling f32,
-    state i8) and 2 VALU ops (select sign, add), plus one LDS state write, a quarter of a Philox4x32-10 call
-    (~100 VALU ops per call, shared by 4 sweeps), the bit-specified exp (~26 VALU ops) and ~10 VALU ops of
-    scale / clamp / compare / select.  A CU issues 128 VALU lane-ops per clock (4 SIMD-32) and serves 32 lanes of
-    4-byte-or-narrower LDS reads per clock (ds_read_b32 class: 2 cycles per wave-instruction)."""
+    The bound is instruction ISSUE (rounds 1-3 printed an LDS-operation model here and DESIGN.md admitted that it was not
+    what binds the kernel): one wave per SIMD issues in program order, at best one vector / LDS / scalar instruction per
+    4 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost": one wave's stream on one SIMD), two cycles of the
+    SIMD-32 per wave64 VALU instruction where waves share a SIMD.  The instruction counts are MEASURED: rocprofv3 PMC pass of
+    the draw alone (SQ_INSTS_VALU / SALU / LDS / SMEM, SQ_WAVES; tools/make_profiles.sh -> profiles/rNN_pmc_gibbs_insts_*.json,
+    hash-stamped like the other PMC files: a count from another build of the kernel is not used).  floor = max(wave-
+    instructions per wave x 4, VALU wave-instructions per SIMD x 2) cycles at 2.4 GHz; `issue_bound_frac` = floor / the
+    in-situ draw time.  What is left of 1 is latency the kernel does not hide (colour classes are dependent phases); the
+    floor itself only moves by issuing fewer instructions per spin update."""
     g = per_kernel.get("gibbs_sweeps")
     if not g or not g["work"]:
         return None
     deg = 2.0 * plan.n_edges / plan.n
-    lds_ops, valu_ops = 3.0 * deg + 1.0, 2.0 * deg + 25.0 + 26.0 + 10.0
-    cyc_lds, cyc_valu = lds_ops / 32.0, valu_ops / 128.0
-    bound = N_CUS * CLOCK_GHZ * 1e9 / max(cyc_lds, cyc_valu)
     rate = g["work"] / (g["total_ms"] * 1e-3)
     n, ne, C = plan.n, plan.n_edges, cfg["C"]
     hbm = (n + ne) * 4 + 2 * ne * 4 + 2 * ne * 2 + C * n * 2 + C * n * 4  # h, J, edge ids, CSR indices; state r+w; f32 samples
     per_draw_s = g["total_ms"] * 1e-3 / g["launches"]
-    return {"kernel": "gibbs_fast_kernel / gibbs_kernel", "spin_updates_per_s": rate, "avg_draw_us": per_draw_s * 1e6,
-            "draws_per_step": g["launches"] / prof_steps, "spin_updates_per_draw": g["work"] / g["launches"],
-            "bound": "lds" if cyc_lds >= cyc_valu else "valu", "bound_spin_updates_per_s": bound,
-            "valu_lds_bound_frac": rate / bound, "mean_degree": deg,
-            "ops_per_update": {"lds": lds_ops, "valu": valu_ops},
-            "hbm_bytes": hbm, "hbm_GBps": hbm / per_draw_s / 1e9, "hbm_frac_of_peak": hbm / per_draw_s / 1e9 / PEAK_HBM_GBS}
+    out = {"kernel": "gibbs_fast_kernel / gibbs_kernel", "spin_updates_per_s": rate, "avg_draw_us": per_draw_s * 1e6,
+           "draws_per_step": g["launches"] / prof_steps, "spin_updates_per_draw": g["work"] / g["launches"],
+           "bound": "instruction issue", "mean_degree": deg,
+           "hbm_bytes": hbm, "hbm_GBps": hbm / per_draw_s / 1e9, "hbm_frac_of_peak": hbm / per_draw_s / 1e9 / PEAK_HBM_GBS}
+    d, src = _profile("pmc_gibbs_insts", config, lib_hash)
+    out["issue_bound_source"] = src
+    rec = None
+    if d and (d.get("n"), d.get("chains"), d.get("sweeps")) == (n, C, cfg["sweeps"]):
+        recs = [r for k, r in d.get("kernels", {}).items() if "gibbs" in k]
+        rec = max(recs, key=lambda r: r["launches"]) if recs else None
+    if rec:
+        ins = rec["insts_per_launch"]
+        total = sum(ins.get(k, 0.0) for k in ("valu", "salu", "lds", "smem"))
+        per_wave = total / rec["waves"]
+        simds = min(1024.0, 4.0 * rec["cus_used"])
+        floor_cycles = max(per_wave * 4.0, ins.get("valu", 0.0) / simds * 2.0)
+        floor_s = floor_cycles / (CLOCK_GHZ * 1e9)
+        out.update({"issue_bound_draw_us": floor_s * 1e6, "issue_bound_frac": floor_s / per_draw_s,
+                    "issue_bound_spin_updates_per_s": g["work"] / g["launches"] / floor_s,
+                    "insts_per_wave_per_sweep": rec["insts_per_wave_per_sweep"],
+                    "insts_per_spin_update": {"valu": rec["valu_per_spin_update"], "lds": rec["lds_per_spin_update"]},
+                    "waves": rec["waves"], "waves_per_simd": rec["waves_per_simd"], "cus_used": rec["cus_used"],
+                    "draw_us_alone_under_pmc": rec["avg_us_alone_under_pmc"]})
+    else:
+        out.update({"issue_bound_draw_us": None, "issue_bound_frac": None})
+    return out
 
 
 def main():
@@ -528,7 +549,7 @@ def main():
                                     "ms_per_step": tt / prof_steps, "gflop_per_step": tw / prof_steps / 1e9}
         if "mmd_pm1" in cands and dom != "mmd_pm1":
             roofline["mmd_pair"] = entry("mmd_pm1")
-        roofline["sampler"] = sampler_roofline(per_kernel, cfg, model.sampler.plan, prof_steps)
+        roofline["sampler"] = sampler_roofline(per_kernel, cfg, model.sampler.plan, prof_steps, args.config, lib_hash)
         roofline["all_gemm_kernels"] = {k: {"tflops": v["work"] / (v["total_ms"] * 1e-3) / 1e12,
                                             "ms_per_step": v["total_ms"] / prof_steps,
                                             "avg_launch_us": v["total_ms"] * 1e3 / v["launches"]} for k, v in cands.items()}

@@ -481,6 +481,7 @@ class ModelWrapper:
             reconstructed_images = self._dvae.decoder(spins_cut)
             mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
             if not defer:
+                self._defer_measure(main, side)
                 main.wait_stream(side)
             # torch.autograd.grad hands the decoder's spin gradient back as the tensor the backward kernel wrote; .backward()
             # would route it through AccumulateGrad of the leaf, which CLONES it (67 MB at c3: an 86 us copy on the critical
@@ -527,13 +528,52 @@ class ModelWrapper:
         self._reduce_and_step(self._dvae_optimizer)
         return mse_loss, dvae_loss, _mmd_loss, spins
 
+    # Decision: join the MMD stream BEHIND the decoder's backward instead of in front of it?  It pays exactly when the
+    # side chain (draw -> MMD) is still running when the main stream reaches the join -- then a join in front of the
+    # backward stalls the main stream for the remainder, while the decoder's backward needs only the MSE gradient -- and
+    # costs a mid-backward dependency (~45 us at c2's size) when it is not.  Which of the two holds depends on the whole
+    # shape (sweeps and chains of the draw, n, B, R: tools/defer_crossover.py, profiles/r04_defer_mmd_join_crossover.txt:
+    # behind / first = 1.05 at c2, 0.85 at n = 512 with B = 128, 0.83 at the c5 slice, 1.00 at c3), so it is MEASURED
+    # instead of guessed from a work count (round 3 switched on (nx + ny) d >= 4e6, tuned on c3): the first eager steps
+    # of a shape join in front and time, with two HIP events, how long after the main stream reached the join the side
+    # stream finished; from then on the join is deferred iff that lag exceeds DEFER_LAG_MS.  The order of the join does
+    # not change any number (tests/test_gpu_step.py::test_deferred_mmd_join_is_bit_identical).
+    DEFER_LAG_MS = 0.05
+    DEFER_SAMPLES = 2
+
     def _defer_mmd_join(self, flat, samples) -> bool:
-        """Join the MMD stream behind the decoder's backward (instead of in front of it) when the pair kernel's work,
-        ~ (nx + ny) * d per spin row, outweighs the decoder forward's.  ``defer_mmd_join`` = True / False forces it."""
+        """``defer_mmd_join`` = True / False forces it; otherwise the measured decision for this shape, False while the
+        measurement is still running."""
         forced = getattr(self, "defer_mmd_join", None)
         if forced is not None:
             return bool(forced)
-        return (flat.shape[0] + samples.shape[0]) * flat.shape[1] >= 4_000_000
+        key = (tuple(flat.shape), tuple(samples.shape), int(getattr(self.sampler, "sweeps", 0)))
+        state = self.__dict__.setdefault("_defer_state", {})
+        rec = state.get(key)
+        if rec is None:
+            rec = state[key] = {"decision": None, "events": [], "lags": []}
+        if rec["decision"] is None and len(rec["events"]) >= self.DEFER_SAMPLES:
+            for ev_main, ev_side in rec["events"]:
+                ev_side.synchronize()  # (warm-up steps only: one host wait per shape)
+                rec["lags"].append(ev_main.elapsed_time(ev_side))  # > 0: the side stream finished that much LATER
+            rec["events"] = []
+            lags = sorted(rec["lags"])
+            rec["decision"] = bool(lags[len(lags) // 2] > self.DEFER_LAG_MS)
+        self._defer_rec = rec
+        return bool(rec["decision"])
+
+    def _defer_measure(self, main, side) -> None:
+        """Called at the join-in-front point of a step that is still measuring: marks "main stream reached the join" and
+        "side stream done" (never inside a stream capture)."""
+        rec = getattr(self, "_defer_rec", None)
+        if rec is None or rec["decision"] is not None or getattr(self, "defer_mmd_join", None) is not None:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        ev_main, ev_side = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_main.record(main)
+        ev_side.record(side)
+        rec["events"].append((ev_main, ev_side))
 
     # ------------------------------------------------------------------ hipGraph replay of the autoencoder half
     def _graph_eligible(self, opt_step, epoch, images) -> bool:

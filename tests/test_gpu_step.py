@@ -500,6 +500,37 @@ def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
         assert dev_ <= 1e-5, (name, dev_)
 
 
+@pytest.mark.parametrize("n,B,C,sweeps,qpu,want", [(128, 256, 256, 50, "Advantage_system4", False),       # c2: the MMD ends inside the decoder forward
+                                                   (1024, 256, 2048, 50, "Advantage2_system1", True)])    # c5 slice: the draw alone outlasts it
+def test_mmd_join_position_is_measured_per_shape(tmp_path, golden_dir, n, B, C, sweeps, qpu, want):
+    """``_defer_mmd_join`` has no work-count threshold any more (round 3: a constant tuned on c3): the first two eager
+    steps of a shape time how long after the main stream reached the join the side stream (draw -> MMD) finished, and the
+    join moves behind the decoder's backward iff that lag is positive.  The two shapes sit on either side of the
+    crossover with a wide margin (tools/defer_crossover.py: deferring costs 5 % at c2 and saves 17 % at the c5 slice);
+    the decision is reached before the step is captured and a forced value still overrides it."""
+    import yaml
+
+    cfg = yaml.safe_load(open(os.path.join(golden_dir, "step_params.yaml")))
+    cfg.update(BATCH_SIZE=B, N_REPLICAS=8, NUM_READS=C, GIBBS_SWEEPS=sweeps)
+    with open(tmp_path / "params.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    m = ModelWrapper(qpu, n_latents=n, training_parameter_file=str(tmp_path / "params.yaml"))
+    g = torch.Generator().manual_seed(0)
+    batches = [((torch.rand(B, 1, 32, 32, generator=g) < 0.13).float().cuda(), None) for _ in range(8)]
+    m.set_dataloader(batches)
+    m.train_init(1)
+    m.sync_losses, m.use_graph = False, True
+    for k in range(6):
+        m.step(batches[k], epoch=0)
+    torch.cuda.synchronize()
+    (rec,) = m._defer_state.values()
+    assert rec["decision"] is want, rec["lags"]
+    assert len(rec["lags"]) == m.DEFER_SAMPLES and (min(rec["lags"]) > m.DEFER_LAG_MS) is want
+    assert m._graph is not None and not m._graph_failed  # decided during the eager steps, captured with the decision
+    m.defer_mmd_join = not want
+    assert m._defer_mmd_join(torch.empty(B * 8, n), torch.empty(C, n)) is (not want)
+
+
 def test_deferred_decoder_join_pins_its_buffers_and_failures_close_the_fork(golden_dir, monkeypatch):
     """with the decoder's weight-gradient join deferred, the library's side stream still reads the
     decoder workspace / upstream gradient / spins after ``dvg_decoder_bwd_ex`` returns, and torch's allocator knows nothing

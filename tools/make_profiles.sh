@@ -5,7 +5,7 @@
 # Every JSON written by the aggregators carries kernels_hash = dvg_source_hash() of the library measured; bench.py drops
 # profiles whose hash differs from the library it runs.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
@@ -27,6 +27,13 @@ for C in c3 c2; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w_$C -- python3 $ROOT/bench.py --config $C --eager --no-cpu-baseline $ST > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_m_$C -- python3 $ROOT/bench.py --config $C --eager --no-cpu-baseline $ST > /dev/null 2>&1
 done
+# 2b. instruction counts of the sampler's draw alone (the issue bound of roofline.sampler): c3, c5 slice, c2
+for SPEC in "c3 512 256 200 zephyr" "c5 1024 2048 50 zephyr" "c2 128 256 50 pegasus"; do
+  set -- $SPEC
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_g_$1 -- python3 $ROOT/tools/gibbs_bench.py $2 $3 $4 default $5 > /dev/null 2>&1
+  (cd $ROOT/profiles && python aggregate_insts.py $(ls $OUT/pmc_g_$1/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_gibbs_insts_$1.json $2 $3 $4)
+done
+set -- $R
 cd $ROOT
 for C in c3 c2; do
   python profiles/aggregate_mfma.py $(ls $OUT/pmc_m_$C/*/*counter_collection.csv | head -1) $OUT/${R}_pmc_mfma_busy_$C.json
@@ -54,5 +61,5 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 DVG_FORCE_DIST=1 python -m torch.distributed.run --
 cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $ROOT/bench.py --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
 python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c3_step.txt; rm -rf $OUT/tr
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
-rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_*
+rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/pmc_g_*
 ls -la $OUT
