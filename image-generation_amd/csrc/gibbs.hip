@@ -130,7 +130,6 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 //   * the neighbour loop issues its LDS reads eight at a time (indices and couplings, then the eight states) and only
 //     the adds stay sequential -- the rolled loop paid two dependent LDS latencies per neighbour.
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
-constexpr int GIBBS_MAXS_BIG = 24;   // 8-wave instantiation for the 1024-spin graphs (20 slots at 64 lanes per chain)
 //   * (round 3) WPC = 2: TWO waves per chain (LPC = 64): a colour class of up to 128 spins is one pass of 128 lanes
 //     instead of two passes of 64, which halves the dependent slot-steps of a sweep.  With few chains (c3: 256) the draw is
 //     one instruction stream per chain on a quarter of the chip's SIMDs, issue-bound at one wave per SIMD (~4000
@@ -196,65 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   }
 
   const int passes = a.passes, n_slots = a.n_colours * passes;
-  if constexpr (MAXS > GIBBS_MAXS) {
-    // many-slot form: one packed register per slot (spin | CSR start << 16; the CSR end and the field offset are
-    // re-read from LDS per update) beside the four Philox words -- 5 MAXS registers instead of 8 MAXS
-    uint32_t spq[MAXS];
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-      spq[k] = 0xffffffffu;
-      if (k < n_slots) {
-        const int col = k / passes, pass = k - col * passes;
-        const int p = s_cls[col] + pass * LPC + l;
-        if (p < s_cls[col + 1]) {
-          const uint32_t i = s_order[p];
-          spq[k] = i | ((uint32_t)s_adjptr[i] << 16);
-        }
-      }
-    }
-    u32x4 rr[MAXS];
-    for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
-      const uint32_t tq = t >> 2, tw = t & 3u;
-      if (t == sweep0 || tw == 0u) {
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k)
-          if (spq[k] != 0xffffffffu) rr[k] = philox4x32_10(spq[k] & 0xffffu, cid, tq, STREAM_GIBBS, a.k0, a.k1);
-      }
-#pragma unroll
-      for (int k = 0; k < MAXS; ++k) {
-        if (k < n_slots) {
-          if (spq[k] != 0xffffffffu) {
-            const int i = (int)(spq[k] & 0xffffu);
-            float f = s_hs[i];
-            const int qe = s_adjptr[i + 1];
-            for (int q = (int)(spq[k] >> 16); q < qe; q += 8) {
-              int idx[8];
-              float w[8];
-              int8_t sv[8];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                const int qq = q + u < qe ? q + u : qe - 1;
-                idx[u] = s_adjidx[qq];
-                w[u] = s_adjJ[qq];
-              }
-#pragma unroll
-              for (int u = 0; u < 8; ++u) sv[u] = st[idx[u]];
-#pragma unroll
-              for (int u = 0; u < 8; ++u)
-                if (q + u < qe) f = __fadd_rn(f, sv[u] > 0 ? w[u] : -w[u]);
-            }
-            const float z = clampf(__fmul_rn(a.two_beta, f), -87.0f, 87.0f);
-            const float tt = spec_exp(z);
-            const float u01 = u32_to_unit(pick(rr[k], tw));
-            const float b = __fmul_rn(u01, __fadd_rn(1.0f, tt));
-            st[i] = (b < 1.0f) ? 1 : -1;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-  } else {
+  {
   // this lane's spin in each (colour, pass) slot (-1: none), with its CSR range and clamped field offset
   int sp[MAXS], q0[MAXS], q1[MAXS];
   float hs[MAXS];
@@ -416,13 +357,9 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
     if (wv <= 2) return launch_gibbs<64, 2>(a, s, fast, mc);
     if (wv <= 4) return launch_gibbs<64, 4>(a, s, fast, mc);
     if (wv <= 8) return launch_gibbs<64, 8>(a, s, fast, mc);
-    // The register-resident schedule with 24 slots needs the 256-register budget of an 8-wave workgroup.  Opt-in
-    // (option gibbs_bigfast = 1): alone it is the faster draw (2048 chains x 1024 spins x 50 sweeps: 1.49 ms against 2.20),
-    // but 8-wave workgroups put a ~110 KB LDS footprint on EVERY CU and starve the encoder's convolutions that run
-    // beside the draw in a training step (c5 step 5.0 ms against 4.0 with the 16-wave rolled form on half the CUs).
-    const bool big_fast = opt(OPT_GIBBS_BIGFAST) != 0;
-    if (fast && big_fast && !waves_env && g->n_colours * ((mc + 63) / 64) <= GIBBS_MAXS_BIG)
-      return launch_gibbs<64, 8, GIBBS_MAXS_BIG>(a, s, true, mc);
+    // (An 8-wave register-resident form of the fast schedule for these graphs -- 24 slots, `gibbs_bigfast` -- existed in
+    // rounds 2-3: the faster draw alone, 1.49 against 2.20 ms at the c5 slice, but its ~110 KB LDS footprint on EVERY CU
+    // starved the convolutions beside it: c5 step 5.0 against 4.0 ms.  Retired in round 4.)
     return launch_gibbs<64, 16>(a, s, fast, mc);
   }
 #define DVG_GIBBS_DISPATCH(LPC)                                              \

@@ -31,7 +31,6 @@ const OptDef kDefs[OPT_COUNT] = {
     {"mmd_blocks", 256, "MMD: target workgroup count of the pair kernels' column split"},
     {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule (bit-identical; A/B reference)"},
     {"gibbs_waves", 0, "sampler: waves per workgroup (0 = chosen by graph size)"},
-    {"gibbs_bigfast", 0, "sampler: 1 = 8-wave unrolled form for graphs above 72 KB of tables (faster alone, slower in a step)"},
     {"gibbs_waves_per_chain", 1, "sampler: 2 = two waves per chain where colour classes hold 65..128 spins and chains are few (the faster draw ALONE: generation; neutral inside a training step), 1 = one (default)"},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
     {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form: -1 evaluation-mode forward calls of 256 workgroups or more (default: 1.5x faster alone, neutral to slower inside a training step), 0 never, 1 every launch the shape allows, 2 / 3 forward / data-gradient launches only"},

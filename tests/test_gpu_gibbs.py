@@ -47,21 +47,6 @@ def test_gibbs_bit_exact(fam, n, C, sweeps):
         assert mism == 0, f"{mism} spin mismatches at call {call}"
 
 
-def test_gibbs_many_slot_fast_form_bit_exact():
-    """Option gibbs_bigfast = 1 selects the register-resident schedule for the 1024-spin graphs (24 slots, 8-wave
-    workgroups); the bit-exactness cases re-run under it in a child (tests/conftest.py applies DVG_TEST_OPTIONS through
-    dvg_set_option)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, DVG_TEST_OPTIONS="gibbs_bigfast=1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_gibbs.py"), "-q", "-m", "gpu",
-                        "-k", "test_gibbs_bit_exact and 1024"], env=env, cwd=root, capture_output=True, text=True,
-                       timeout=900)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_sample_ising_dict_path_and_sampleset():
     plan, nodes = _plan("pegasus", 64)
     rng = np.random.default_rng(1)
