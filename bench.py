@@ -420,7 +420,7 @@ def main():
         _lib.set_option(name, int(value))
     _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
-    is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel")  # noqa: E731
+    is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel", "conv_wino_kernel", "conv_wino_wgrad_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm) or nm == "gibbs_sweeps") if not args.breakdown else (1 << len(names)) - 1
     # The autoencoder half of every step is replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); on every 10th step the GRBM quasi-NLL update runs eagerly behind it.  --eager disables the graph.

@@ -97,6 +97,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_int,
          c_uint32, c_uint64, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p],
     ),
+    "dvg_gibbs_launch_info": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dvg_grbm_energy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dvg_grbm_suffstats_workspace_bytes": (c_size_t, [c_void_p]),
     "dvg_grbm_suffstats": (

@@ -130,6 +130,9 @@ struct ConvArgs {
   // only: the padding taps of the image border ((3H-2)^2 of 9 H^2 (pixel, tap) pairs are real: 69 % at 4x4, 84 % at 8x8)
   // are never staged or multiplied.  Same outputs, same number of BatchNorm partial rows.
   int posmajor = 0;
+  // Winograd launches (launch_conv_wino): CUs the persistent grid is sized for, 0 = all 256 (encoder.cpp: a training
+  // call's forward launches leave the sampler's CUs out, its data gradients share the chip with the weight-gradient chain)
+  int wino_cus = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (set through the ABI only: dvg_set_conv_precision; the library reads no environment variable)
 bool conv_precision_bf16();
@@ -148,6 +151,12 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind = 0);  // kind: 
 int conv_wino_stats_blocks(int64_t M, int Cout);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
+// Winograd form of a stride-1 3x3 layer's WEIGHT gradient (conv_wino_wgrad.hip): slabs [nslabs][16][Cin][Cout] (at most
+// conv_wino_wgrad_slab_floats), reduced and transformed back (G^T dU G) into the checkpoint layout `map` by the same call
+bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);
+size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
+int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
+                           const WeightMap& map, float* grad_w, hipStream_t s);
 int conv_stats_blocks(int64_t M, int Cout);
 // fold = 1 launches: M source pixels; usable when conv_fold_ok (whole row blocks per class)
 bool conv_fold_ok(int64_t Msrc);

@@ -40,6 +40,7 @@ struct WinoArgs {
   const float* bias;  // [Cout] or null
   float* out;         // [4 tiles][Cout]
   float* stats;       // [nblk][Cout][2] per tile block (sum, sum of squares) of the output, or null
+  int cus = 0;        // CUs the persistent grid is sized for (0 = 256)
   int Cin, Cout, L;   // L = log2 of the image side
   int nblk;           // tile blocks (of 32 WM quads)
 };
@@ -358,17 +359,23 @@ static bool wino_shape_ok(int64_t M, int Cin, int Cout, int L) {
 }
 
 // kind: 0 forward launch of a training call, 1 data-gradient launch, 2 forward launch of an evaluation call.
-// option enc_wino: -1 (default) evaluation-mode forward launches of 256 workgroups or more -- inside a training step the
-// form measured neutral to slower (its workgroups need whole CUs: the sampler, the weight-gradient GEMMs and the elementwise
-// kernels that the direct form shares CUs with wait for it) --, 0 never, 1 every launch the shape allows,
-// 2 / 3 like 1 for the forward / the data-gradient launches only (A/B measurements)
+// option enc_wino: -1 (default) every launch of 256 workgroups' worth of tile blocks or more (small launches keep the
+// direct form's finer tiles), 0 never, 1 every launch the shape allows, 2 / 3 like 1 for the forward / the data-gradient
+// launches only (A/B measurements).  Rounds 3 ran the form by default in evaluation-mode forward calls only: inside a
+// training step its whole-CU workgroups (512 registers per lane, 145 KB of LDS) measured neutral to slower.  The cause
+// was the GRID, not the form: 256 persistent workgroups beside the sampler's 64 resident workgroups leave 64 of them
+// waiting for a CU for a whole round.  Sized to the CUs the launch can actually get (ConvArgs.wino_cus; options
+// enc_wino_cus / enc_wino_cus_d) the form pays inside the step too: c3 10.54 -> 10.16 ms (round 4).
 bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   const int64_t o = opt(OPT_ENC_WINO);
   if (o == 0 || (o == 2 && kind == 1) || (o == 3 && kind != 1) || !wino_shape_ok(M, Cin, Cout, L)) return false;
   if (o >= 1) return true;
   const int cfg = wino_cfg(Cout);
   const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
-  return kind == 2 && blocks >= 256;            // small launches: the direct form's finer tiles
+  // evaluation-mode forward calls: from 256 workgroups' worth up (round 3).  Training calls: float32 operand mode only
+  // (the form is float32 arithmetic: in the f32x3 / bf16-input modes the direct kernel on the bf16 MFMA is the faster
+  // one) and from 1024 up -- c3's launches; a c2 step with its one eligible launch (256) measured 1.6 % slower
+  return kind == 2 ? blocks >= 256 : (blocks >= 1024 && conv_precision_mode() == 0);
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
@@ -387,9 +394,19 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int ny = a.Cout / C::CB;
-  int gx = 256 / ny;  // one workgroup per CU: persistent over its tile blocks
+  // one workgroup per CU, persistent over its tile blocks -- of the CUs this launch may count on (ConvArgs.wino_cus:
+  // a workgroup needs a WHOLE CU, so whatever runs beside the launch in a training step keeps its CUs and the grid is
+  // sized to the rest; workgroups that find no free CU start a whole round late: a 200-workgroup grid beside the
+  // sampler's 64 workgroups took the c3 step from 10.5 to 11.1 ms, a 192-workgroup grid to 10.3)
+  int cus = a.cus > 0 ? a.cus : 256;
+  if (cus < ny) cus = ny;
+  if (cus > 256) cus = 256;
+  int gx = cus / ny;
   if (gx < 1) gx = 1;
   if (gx > a.nblk) gx = a.nblk;
+  // every workgroup walks ceil(nblk / gx) tile blocks: the SMALLEST grid with that round count (72 workgroups over 256
+  // tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs beside the launch)
+  gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
   DVG_LAUNCH_WORK(K_IGEMM_WINO, flops, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, a);
   return DVG_OK;
 }
@@ -400,10 +417,12 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
               "conv_wino: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
   WinoArgs w;
   w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
-  w.Cin = a.Cin; w.Cout = a.Cout; w.L = a.L;
+  w.Cin = a.Cin; w.Cout = a.Cout; w.L = a.L; w.cus = a.wino_cus;
   const int cfg = wino_cfg(a.Cout);
   w.nblk = (int)(a.M / 4 / wino_tblk(cfg));
-  const double flops = 2.0 * (double)a.M * a.Cin * a.Cout * 9;  // algorithmic (direct-form) FLOPs of the layer
+  // EXECUTED matrix FLOPs: 16 transform-domain GEMMs over the M / 4 quads (4/9 of the direct form's 2 M Cin Cout 9;
+  // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
+  const double flops = 2.0 * (double)(a.M / 4) * 16.0 * a.Cin * a.Cout;
   if (cfg == 0) return launch_wino_cfg<2, 2, 8>(w, flops, s);
   return launch_wino_cfg<4, 1, 4>(w, flops, s);
 }

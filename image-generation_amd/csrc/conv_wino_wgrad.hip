@@ -1,0 +1,332 @@
+// Winograd F(2x2, 3x3) form of the WEIGHT gradient of the encoder's stride-1 3x3 layers
+// (/root/reference/src/encoder.py:28-36: what autograd computes for nn.Conv2d(3x3, padding 1) behind those lines).
+//
+// The forward form (conv_wino.hip) computes  Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 2x2 output quad; its adjoint in the
+// weights is again sixteen independent GEMMs, now with the QUADS as the reduction dimension:
+//     V[p][t][ci] = (B^T d_t B)[p]         the transformed 4x4 input patch of quad t   (p = 4 xi + nu: 16 positions)
+//     Z[p][t][co] = (A dY_t A^T)[p]        the transformed 2x2 output-gradient quad
+//     dU[p][ci][co] = sum_t V[p][t][ci] Z[p][t][co]                      <- the MFMA work: 16 x 2 T Cin Cout FLOPs
+//     dg = G^T dU G                        (3x3 per channel pair; the slab-reduce pass, wino_wgrad_reduce_kernel)
+// i.e. 8 M Cin Cout FLOPs where the direct form (conv_wgrad.hip) multiplies 18 M Cin Cout, padding taps included (31 % of
+// them at 4x4 images).  One workgroup = 4 waves, one per SIMD with the whole register file: a wave owns a 32 x 32 channel
+// tile of all 16 positions (256 accumulator registers).  The reduction runs over chunks of NQ quads whose transformed
+// operands sit in LDS as [quad][channel][16 floats] (64-byte entries, 16-byte slots XOR-swizzled by bits 2-3 of the
+// channel: conflict-free ds_read_b128 / ds_write_b128); each thread transforms one (quad, 4 channels) item per chunk --
+// 16 (input) or 4 (gradient) buffer_load_dwordx4 straight from global memory, a padding tap being an out-of-range
+// offset that loads zeros -- and writes it into the other stage while the matrix pipe works on this one.
+// K order: a thread keeps ONE quad position (its 16 patch offsets are constants of the kernel) and walks the images, so
+// the split over workgroups is (position group) x (image range); slabs are reduced in fixed order (no float atomics).
+#include <type_traits>
+
+#include "conv.h"
+#include "conv_tile.h"
+
+namespace dvg {
+
+struct WinoWgradArgs {
+  const float* in;   // [M][Cin]   layer input, Morton pixel order (quad t = rows 4t .. 4t+3)
+  const float* dy;   // [M][Cout]  gradient of the layer's output
+  float* slabs;      // [nsplit][16][Cin][Cout]
+  int64_t M;
+  int Cin, Cout, L;
+  int isplit;        // image-range splits (grid.z = position groups x isplit [x K groups inside the block])
+};
+
+template <int WA, int WB>
+struct WinoWgradCfg {
+  static constexpr int WK = 4 / (WA * WB);          // K groups inside the block (waves beyond the WA x WB channel tile)
+  static constexpr int CIB = 32 * WA, COB = 32 * WB;
+  static constexpr int QC = WK == 1 ? 8 : 4;         // quads per K group and chunk
+  static constexpr int NQ = QC * WK;                 // quads per chunk of the whole block
+  static constexpr int V_B = NQ * CIB * 64, Z_B = NQ * COB * 64, STAGE = V_B + Z_B;
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int NV = NQ * CIB / 4, NZ = NQ * COB / 4;  // (quad, 4-channel) items per chunk
+  static_assert(WA * WB * WK == 4 && NV + NZ <= 256 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+};
+
+template <int WA, int WB>
+__global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a) {
+  using C = WinoWgradCfg<WA, WB>;
+  constexpr int WK = C::WK, CIB = C::CIB, COB = C::COB, QC = C::QC, NQ = C::NQ, NV = C::NV, NZ = C::NZ;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  extern __shared__ __align__(16) unsigned char wwg_smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte*)wwg_smem;
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave / (WA * WB), wa = (wave / WB) % WA, wb = wave % WB;
+  const int tiles_b = a.Cout / COB;
+  const int a0 = ((int)blockIdx.x / tiles_b) * CIB, b0 = ((int)blockIdx.x % tiles_b) * COB;
+  const int H = 1 << a.L, HW = H * H, QI = HW / 4;             // quads per image
+  const int PGN = QI >= NQ ? QI / NQ : 1, IPC = QI >= NQ ? 1 : NQ / QI;  // position groups; images per chunk
+  const int n_img = (int)(a.M >> (2 * a.L));
+  const int pg = (int)blockIdx.z % PGN, isp = (int)blockIdx.z / PGN;
+  const int ichunks = (n_img + IPC - 1) / IPC;                            // chunks over the images of one position group
+  const int per = (ichunks + a.isplit - 1) / a.isplit;
+  const int c_beg = isp * per, c_end = c_beg + per < ichunks ? c_beg + per : ichunks;
+  const int nchunks = c_end > c_beg ? c_end - c_beg : 0;
+
+  // ---- this thread's transform item: (quad ql of the chunk, channels 4 c4 .. 4 c4 + 3) of the input (tid < NV) or of dY
+  // (roles change at wave boundaries -- NV and NZ are multiples of 64 -- so they are SCALAR conditions: plain branches, no
+  // exec masking, and the buffer descriptor of a wave's loads is wave-uniform)
+  static_assert(NV % 64 == 0 && NZ % 64 == 0, "transform roles per wave");
+  const bool is_v = wave < NV / 64, is_z = !is_v && wave < (NV + NZ) / 64;
+  const int item = is_v ? tid : tid - NV;
+  const int ql = is_v ? item / (CIB / 4) : (is_z ? item / (COB / 4) : 0);
+  const int c4 = is_v ? item % (CIB / 4) : (is_z ? item % (COB / 4) : 0);
+  const int qpos = QI >= NQ ? pg * NQ + ql : ql % QI;           // quad position inside its image (Morton index of (ty, tx))
+  const int isub = QI >= NQ ? 0 : ql / QI;                       // image of the chunk this quad belongs to
+  constexpr uint32_t PAD = 0xFFFF0000u;
+  uint32_t voff[16];  // V item: byte offsets of the 4x4 patch (padding: out of range -> zeros); Z item: the quad's 4 rows
+  {
+    const int ty = (int)morton_y((uint32_t)qpos), tx = (int)morton_x((uint32_t)qpos);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (is_v) {
+        const int y = 2 * ty - 1 + (e >> 2), x = 2 * tx - 1 + (e & 3);
+        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
+        voff[e] = ok ? (uint32_t)((isub * HW + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 4 * c4) * 4u : PAD;
+      } else {
+        voff[e] = (e < 4 && is_z) ? (uint32_t)((isub * HW + 4 * qpos + e) * a.Cout + b0 + 4 * c4) * 4u : PAD;
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)0xFFFF0000u, 0x00020000);
+  // where the item's four 64-byte entries go (stage 0): entry (ql, channel), slot s at (s ^ ((channel >> 2) & 3)) << 4
+  const int chan0 = 4 * c4;
+  const uint32_t wst = lds0 + (is_v ? 0u : (uint32_t)C::V_B) + (uint32_t)((ql * (is_v ? CIB : COB) + chan0) * 64);
+  const int wsw = (chan0 >> 2) & 3;  // (the same for the item's four channels: they share bits 2-3)
+  // MFMA operand addresses (stage 0): k-step s reads quads kg QC + 2 s + hh
+  const int rowA = wa * 32 + c, colB = wb * 32 + c;
+  uint32_t aaddr[4], baddr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aaddr[i] = lds0 + (uint32_t)(((kg * QC + hh) * CIB + rowA) * 64 + ((i ^ ((rowA >> 2) & 3)) << 4));
+    baddr[i] = lds0 + (uint32_t)C::V_B + (uint32_t)(((kg * QC + hh) * COB + colB) * 64 + ((i ^ ((colB >> 2) & 3)) << 4));
+  }
+
+  f32x4 raw[16];  // the item's raw rows (V: 16 patch pixels; Z: the quad's 4 pixels in raw[0..3])
+  auto issue_loads = [&](int ch) {  // chunk ch of this block: images (c_beg + ch) IPC ...
+    const int img = (c_beg + ch) * IPC;
+    const int soff_x = __builtin_amdgcn_readfirstlane(img * HW * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
+    // (images past the end -- a ragged last chunk of IPC > 1 -- must read zeros: their offsets are pushed out of range)
+    const bool live = img + isub < n_img;
+    if (is_v) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(live ? voff[e] : PAD), soff_x, 0));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)(live ? voff[e] : PAD), soff_y, 0));
+    }
+  };
+  auto store_entry = [&](int st, int k, const float (&v)[16]) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
+    }
+  };
+  auto transform = [&](int st) {  // raw -> the item's 4 entries in stage st
+    if (is_v) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float d[16], t[16], v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = raw[e][k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // B^T d
+          t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
+          t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
+          t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
+          t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {  // (.) B
+          v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
+          v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
+          v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
+          v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
+        }
+        store_entry(st, k, v);
+      }
+    } else if (is_z) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]: dY = [a b; c d] (rows 4t .. 4t+3 of the quad in Morton order)
+        const float qa = raw[0][k], qb = raw[1][k], qc = raw[2][k], qd = raw[3][k];
+        const float p0 = qa, q0 = qb, p1 = qa + qc, q1 = qb + qd, p2 = qa - qc, q2 = qb - qd, p3 = -qc, q3 = -qd;
+        float v[16];
+        v[0] = p0; v[1] = p0 + q0; v[2] = p0 - q0; v[3] = -q0;
+        v[4] = p1; v[5] = p1 + q1; v[6] = p1 - q1; v[7] = -q1;
+        v[8] = p2; v[9] = p2 + q2; v[10] = p2 - q2; v[11] = -q2;
+        v[12] = p3; v[13] = p3 + q3; v[14] = p3 - q3; v[15] = -q3;
+        store_entry(st, k, v);
+      }
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+
+  if (nchunks > 0) {
+    issue_loads(0);
+    transform(0);  // (the compiler waits for the loads at their first use)
+    if (nchunks > 1) issue_loads(1);
+    __syncthreads();
+    auto chunk = [&](int ch, auto stc) {
+      constexpr int st = decltype(stc)::value;
+      // MFMAs of chunk ch out of stage st: QC / 2 k-steps x 4 operand groups x 4 positions
+      f32x4 ca, cb, na, nb;
+      auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 4 ks + i: positions 4 i .. 4 i + 3 of k-step ks
+        x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[g & 3] + st * C::STAGE + (g >> 2) * 2 * CIB * 64));
+        y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 3] + st * C::STAGE + (g >> 2) * 2 * COB * 64));
+      };
+      load_grp(0, ca, cb);
+#pragma unroll
+      for (int g = 0; g < 2 * QC; ++g) {
+        if (g + 1 < 2 * QC) load_grp(g + 1, na, nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
+        ca = na; cb = nb;
+      }
+      // the next chunk's operands: transform what was loaded while the MFMAs above were issued, then fetch the one after
+      if (ch + 1 < nchunks) transform(st ^ 1);
+      if (ch + 2 < nchunks) issue_loads(ch + 2);
+      __syncthreads();
+    };
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      chunk(ch, std::integral_constant<int, 0>{});
+      if (ch + 1 < nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
+  }
+
+  // ---- raw slab of this (tile, split, K group): [16][Cin][Cout]
+  const size_t slab = ((size_t)blockIdx.z * WK + kg) * 16 * (size_t)a.Cin * a.Cout;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    float* dst = a.slabs + slab + ((size_t)p * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[p][r];
+  }
+}
+
+// dg = G^T (sum of the slabs' dU) G per (ci, co), written in the checkpoint layout; 8 lanes cooperate on one channel pair
+// (strided over the slabs, fixed-shape shuffle tree: deterministic).  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, WeightMap map,
+                                                                float* __restrict__ grad_w) {
+  const int64_t pairs = (int64_t)map.Ca * map.Cb, total = 16 * pairs;
+  const int sub = threadIdx.x & 7;
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < pairs; e += ((int64_t)gridDim.x * 256) >> 3) {
+    float u[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      float s = 0.f;
+      for (int k = sub; k < nslabs; k += 8) s += slabs[(size_t)k * total + (size_t)p * pairs + e];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      u[p] = s;
+    }
+    if (sub == 0) {
+      float t[3][4];  // G^T dU: rows r = 0..2 over xi
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        t[0][nu] = u[0 * 4 + nu] + 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]);
+        t[1][nu] = 0.5f * (u[1 * 4 + nu] - u[2 * 4 + nu]);
+        t[2][nu] = 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
+      }
+      const int b = (int)(e % map.Cb), av = (int)(e / map.Cb);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+        const float g1 = 0.5f * (t[r][1] - t[r][2]);
+        const float g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        grad_w[torch_weight_offset(map, 3 * r + 0, av, b)] = g0;
+        grad_w[torch_weight_offset(map, 3 * r + 1, av, b)] = g1;
+        grad_w[torch_weight_offset(map, 3 * r + 2, av, b)] = g2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host
+static bool wino_wgrad_shape_ok(int64_t M, int Cin, int Cout, int L) {
+  if (L < 1 || L > 5 || M <= 0 || (M & (((int64_t)1 << (2 * L)) - 1))) return false;  // whole images
+  if (Cout % 64 || !(Cin % 64 == 0 || Cin == 32)) return false;
+  if (M * (int64_t)(Cin > Cout ? Cin : Cout) * 4 >= 2147483647LL) return false;          // (32-bit buffer offsets)
+  return true;
+}
+
+struct WinoWgradGeom { int tiles, pgn, isplit, wk, nslabs; };
+static WinoWgradGeom wino_wgrad_geom(int64_t M, int Cin, int Cout, int L, int cus) {
+  WinoWgradGeom g;
+  const bool narrow = Cin % 64 != 0;  // Cin = 32: 32 x 64 tile, two K groups inside the block
+  const int cib = narrow ? 32 : 64, nq = 8;
+  g.wk = narrow ? 2 : 1;
+  g.tiles = (Cin / cib) * (Cout / 64);
+  const int qi = 1 << (2 * L - 2);
+  g.pgn = qi >= nq ? qi / nq : 1;
+  const int ipc = qi >= nq ? 1 : nq / qi;
+  const int n_img = (int)(M >> (2 * L));
+  const int ichunks = (n_img + ipc - 1) / ipc;
+  // one workgroup per CU of the budget; every workgroup at least 8 chunks deep
+  int want = cus / (g.tiles * g.pgn);
+  if (want < 1) want = 1;
+  if (want > ichunks / 8) want = ichunks / 8 > 0 ? ichunks / 8 : 1;
+  g.isplit = want;
+  g.nslabs = g.pgn * g.isplit * g.wk;
+  return g;
+}
+
+// kind of launch the policy is asked about: the weight gradient of a training call (option enc_wino_wgrad: -1 = with the
+// other training launches, i.e. float32 operand mode and >= 1024 workgroups' worth of tile blocks; 0 never; 1 whenever
+// the shape allows)
+bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
+  const int64_t o = opt(OPT_ENC_WINO_WGRAD);
+  if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
+  if (o >= 1) return true;
+  return conv_wino_ok(M, Cin, Cout, L, 0);
+}
+
+size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
+  const WinoWgradGeom g = wino_wgrad_geom(M, Cin, Cout, L, 256);  // (the largest split any CU budget gives)
+  return (size_t)g.nslabs * 16 * Cin * Cout;
+}
+
+int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
+                           const WeightMap& map, float* grad_w, hipStream_t s) {
+  DVG_REQUIRE(wino_wgrad_shape_ok(M, Cin, Cout, L), "conv_wino_wgrad: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)",
+              (long long)M, Cin, Cout, L);
+  int cus = (int)opt(OPT_ENC_WINO_CUS_W);
+  if (cus < 1) cus = 1;
+  if (cus > 256) cus = 256;
+  const WinoWgradGeom g = wino_wgrad_geom(M, Cin, Cout, L, cus);
+  WinoWgradArgs a;
+  a.in = in; a.dy = dy; a.slabs = slabs; a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.isplit = g.isplit;
+  const double flops = 2.0 * (double)(M / 4) * 16.0 * Cin * Cout;  // executed (4/9 of the direct form's)
+  const dim3 grid((unsigned)g.tiles, 1, (unsigned)(g.pgn * g.isplit));
+  if (g.wk == 1) {
+    using C = WinoWgradCfg<2, 2>;
+    auto kern = conv_wino_wgrad_kernel<2, 2>;
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  } else {
+    using C = WinoWgradCfg<1, 2>;
+    auto kern = conv_wino_wgrad_kernel<1, 2>;
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  }
+  const int64_t pairs = (int64_t)Cin * Cout;
+  int64_t blocks = (pairs * 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)slabs, g.nslabs, map, grad_w);
+  return DVG_OK;
+}
+
+}  // namespace dvg

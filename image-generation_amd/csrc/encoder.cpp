@@ -20,6 +20,7 @@ struct EncPlan {
   // offsets in floats
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
   bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
+  bool wino_w[4];             // ... its weight gradient too (conv_wino_wgrad.hip)
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, splitk;
   int ksplit[4];
   size_t total_floats;
@@ -53,6 +54,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
       p.wino_f[l] = p.wino_f[l] && ((mask >> (l - 1)) & 1);
       p.wino_d[l] = p.wino_d[l] && ((mask >> (2 + l)) & 1);
     }
+    p.wino_w[l] = l > 0 && training && conv_wino_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
     p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
@@ -67,6 +69,10 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
+      if (p.wino_w[l]) {
+        const size_t sw = conv_wino_wgrad_slab_floats(p.M[l], ch[l], C, p.L[l]);
+        if (sw > max_slab) max_slab = sw;
+      }
       const size_t sk_f = conv_splitk_floats(p.M[l], ch[l], C, 9, 0), sk_d = conv_splitk_floats(p.M[l], C, ch[l], 9, 0);
       if (sk_f > max_split) max_split = sk_f;
       if (sk_d > max_split) max_split = sk_d;
@@ -176,6 +182,7 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
       a.splitk_ws = W + pl.splitk;
+      a.wino_cus = training ? (int)opt(OPT_ENC_WINO_CUS) : 0;  // (a training call's forward runs beside the step's sampler draw)
       if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
       else DVG_TRY(launch_conv_igemm(a, s));
     }
@@ -260,6 +267,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
+    a.wino_cus = (int)opt(OPT_ENC_WINO_CUS_D);  // (the layer's weight-gradient chain runs beside it on the side stream)
     if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
     else DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
@@ -272,8 +280,13 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     WgradArgs wa;
     wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
-    DVG_TRY(launch_conv_wgrad(wa, s2));
-    DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    if (pl.wino_w[l]) {
+      DVG_TRY(launch_conv_wino_wgrad(W + pl.Xp[l - 1], dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONV_FWD, Cin, C, 9},
+                                     g->conv_w[l], s2));
+    } else {
+      DVG_TRY(launch_conv_wgrad(wa, s2));
+      DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
+    }
   }
   DVG_TRY(launch_colsum_batch(sums, s2));
   DVG_TRY(stream_order_after(s, s2));  // join

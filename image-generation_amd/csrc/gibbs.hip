@@ -277,6 +277,10 @@ static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_bl
   return b;
 }
 
+// dvg_gibbs_launch_info: the dispatch below runs with a probe set and reports its launch geometry instead of launching
+struct GibbsProbe { int workgroups; int threads; size_t lds; };
+static thread_local GibbsProbe* g_gibbs_probe = nullptr;
+
 // two waves per chain (fast kernel only): 4-wave workgroups of two chains
 static int launch_gibbs_wpc2(GibbsArgs a, hipStream_t s, int max_class) {
   constexpr int WAVES = 4, CPB = 2;
@@ -286,6 +290,7 @@ static int launch_gibbs_wpc2(GibbsArgs a, hipStream_t s, int max_class) {
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)ceil_div(a.n_chains, CPB);
+  if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
   return DVG_OK;
 }
@@ -300,10 +305,11 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
     set_error("gibbs: graph (n=%d, 2|E|=%d) needs %zu B of LDS > 160 KiB", a.n, a.n_adj, lds);
     return DVG_E_UNSUPPORTED;
   }
+  const int grid = (int)ceil_div(a.n_chains, CPB);
+  if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
   auto kern = fast ? gibbs_fast_kernel<LPC, WAVES, MAXS> : gibbs_kernel<LPC, WAVES>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)ceil_div(a.n_chains, CPB);
   // work = spin updates of the draw (bench.py's sampler roofline)
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
   return DVG_OK;
@@ -312,6 +318,8 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
 }  // namespace dvg
 
 using namespace dvg;
+
+static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipStream_t s);
 
 extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const float* quadratic,
                                 float prefactor, float h_lo, float h_hi, float j_lo, float j_hi,
@@ -332,7 +340,28 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   a.chain_id0 = chain_id0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
   a.sweep0 = sweep0; a.n_sweeps = n_sweeps; a.init = init;
   a.sweep0_dev = dyn ? &dyn->sweep0 : nullptr;
-  hipStream_t s = (hipStream_t)stream;
+  return gibbs_dispatch(g, a, n_chains, (hipStream_t)stream);
+}
+
+// The launch geometry dvg_gibbs_sample would use for `n_chains` chains on this graph (nothing is launched): workgroups,
+// threads per workgroup, LDS bytes per workgroup.  The host side sizes what runs BESIDE the draw with it (the encoder
+// forward's Winograd launches take whole CUs: ModelWrapper leaves the draw's CUs out of their persistent grid).
+extern "C" int dvg_gibbs_launch_info(const dvg_graph_t* g, int n_chains, int* workgroups, int* threads, size_t* lds_bytes) {
+  DVG_REQUIRE(g && n_chains > 0, "gibbs_launch_info: null graph / no chains");
+  GibbsArgs a{};
+  a.n = g->n; a.n_adj = g->n_adj; a.n_colours = g->n_colours; a.n_chains = n_chains;
+  GibbsProbe pr{0, 0, 0};
+  g_gibbs_probe = &pr;
+  const int rc = gibbs_dispatch(g, a, n_chains, nullptr);
+  g_gibbs_probe = nullptr;
+  DVG_TRY(rc);
+  if (workgroups) *workgroups = pr.workgroups;
+  if (threads) *threads = pr.threads;
+  if (lds_bytes) *lds_bytes = pr.lds;
+  return DVG_OK;
+}
+
+static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipStream_t s) {
   // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
   const int mc = g->max_class;
   const bool big = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 4) > 72 * 1024;

@@ -124,6 +124,16 @@ class GibbsSampler:
         self._state = None
         self.sweep_count = 0
 
+    def launch_info(self, num_reads: int) -> dict:
+        """Launch geometry of one draw of ``num_reads`` chains (``dvg_gibbs_launch_info``: nothing is launched):
+        ``workgroups``, ``threads`` per workgroup, ``lds_bytes`` per workgroup."""
+        import ctypes
+
+        wg, th, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+        _lib.check(_lib.lib().dvg_gibbs_launch_info(self.graph.ptr, int(num_reads), ctypes.byref(wg), ctypes.byref(th),
+                                                    ctypes.byref(lds)), "dvg_gibbs_launch_info")
+        return {"workgroups": wg.value, "threads": th.value, "lds_bytes": lds.value}
+
     def sample_native(self, linear: torch.Tensor, quadratic: torch.Tensor, prefactor: float,
                       linear_range=None, quadratic_range=None, num_reads: int = 256) -> torch.Tensor:
         """Device tensors in, (num_reads, n) float32 +-1 device tensor out; no host sync."""

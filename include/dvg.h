@@ -97,6 +97,11 @@ int dvg_gibbs_sample(const dvg_graph_t *g, const float *linear, const float *qua
                      int8_t *state, int n_chains, uint32_t chain_id0, uint64_t seed,
                      uint32_t sweep0, int n_sweeps, int init, float *samples_out,
                      const dvg_step_state_t *dyn, dvg_stream_t stream);
+/* The launch geometry dvg_gibbs_sample uses for n_chains chains on this graph (nothing is launched; any out pointer may
+ * be NULL): workgroups, threads per workgroup, LDS bytes per workgroup.  For callers that size what runs BESIDE the draw
+ * (ModelWrapper: option enc_wino_cus = the CUs the draw leaves; the reference has no counterpart -- its draw is a QPU
+ * call, /root/reference/src/model_wrapper.py:309-316). */
+int dvg_gibbs_launch_info(const dvg_graph_t *g, int n_chains, int *workgroups, int *threads, size_t *lds_bytes);
 
 /* ------------------------------------------------------------------ GRBM
  * Energy  E(x) = x.h + sum_e J_e x_i x_j  per row: the plugin's
