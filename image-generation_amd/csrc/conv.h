@@ -153,7 +153,8 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
 // Winograd form of a stride-1 3x3 layer's WEIGHT gradient (conv_wino_wgrad.hip): slabs [nslabs][16][Cin][Cout] (at most
 // conv_wino_wgrad_slab_floats), reduced and transformed back (G^T dU G) into the checkpoint layout `map` by the same call
-bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);
+bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);      // policy (options) + shape
+bool conv_wino_wgrad_shape(int64_t M, int Cin, int Cout, int L);   // shape only
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
 int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
                            const WeightMap& map, float* grad_w, hipStream_t s);

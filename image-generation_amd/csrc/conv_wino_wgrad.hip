@@ -108,16 +108,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   }
 
   f32x4 raw[16];  // the item's raw rows (V: 16 patch pixels; Z: the quad's 4 pixels in raw[0..3])
-  auto issue_loads = [&](int ch) {  // chunk ch of this block: images (c_beg + ch) IPC ...
+  auto issue_loads = [&](int ch, auto role_c) {  // chunk ch of this block: images (c_beg + ch) IPC ...
+    constexpr int ROLE = decltype(role_c)::value;  // 0: input item, 1: gradient item, 2: none
     const int img = (c_beg + ch) * IPC;
     const int soff_x = __builtin_amdgcn_readfirstlane(img * HW * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
     // (images past the end -- a ragged last chunk of IPC > 1 -- must read zeros: their offsets are pushed out of range)
-    const bool live = img + isub < n_img;
-    if (is_v) {
+    const bool live = ch < nchunks && img + isub < n_img;  // (chunk nchunks: the dummy that makes the count even)
+    if constexpr (ROLE == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(live ? voff[e] : PAD), soff_x, 0));
-    } else {
+    } else if constexpr (ROLE == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)(live ? voff[e] : PAD), soff_y, 0));
@@ -130,8 +131,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
       *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
     }
   };
-  auto transform = [&](int st) {  // raw -> the item's 4 entries in stage st
-    if (is_v) {
+  auto transform = [&](int st, auto role_c) {  // raw -> the item's 4 entries in stage st
+    constexpr int ROLE = decltype(role_c)::value;
+    if constexpr (ROLE == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float d[16], t[16], v[16];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
         }
         store_entry(st, k, v);
       }
-    } else if (is_z) {
+    } else if constexpr (ROLE == 1) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         // A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]: dY = [a b; c d] (rows 4t .. 4t+3 of the quad in Morton order)
@@ -173,10 +175,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
 #pragma unroll
   for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
 
-  if (nchunks > 0) {
-    issue_loads(0);
-    transform(0);  // (the compiler waits for the loads at their first use)
-    if (nchunks > 1) issue_loads(1);
+  // The chunk loop, instantiated per transform role (a wave-uniform choice made ONCE): inside, a chunk is one basic
+  // block -- MFMAs, operand reads and the next chunk's transform -- which the group pattern can interleave.  (With the
+  // role as a branch inside the chunk the transform sat in blocks of its own BEHIND the MFMAs: 2 QC x 4 MFMAs, then
+  // ~300 vector instructions with the matrix pipe idle -- one wave per SIMD, nobody else fills it: layer 3 at c3 464 us
+  // against 219 of matrix time.)
+  auto run = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    if (nchunks <= 0) return;
+    issue_loads(0, role_c);
+    transform(0, role_c);  // (the compiler waits for the loads at their first use)
+    issue_loads(1, role_c);
     __syncthreads();
     auto chunk = [&](int ch, auto stc) {
       constexpr int st = decltype(stc)::value;
@@ -187,24 +196,57 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
         y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 3] + st * C::STAGE + (g >> 2) * 2 * COB * 64));
       };
       load_grp(0, ca, cb);
+      na = ca; nb = cb;
+      __builtin_amdgcn_sched_barrier(0);
+      // first half of the chunk's MFMAs || the transform of the next chunk's raw rows (loaded in the middle of the
+      // PREVIOUS chunk, so they have landed) -> the other stage
 #pragma unroll
-      for (int g = 0; g < 2 * QC; ++g) {
-        if (g + 1 < 2 * QC) load_grp(g + 1, na, nb);
+      for (int g = 0; g < QC; ++g) {
+        load_grp(g + 1, na, nb);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
         ca = na; cb = nb;
       }
-      // the next chunk's operands: transform what was loaded while the MFMAs above were issued, then fetch the one after
-      if (ch + 1 < nchunks) transform(st ^ 1);
-      if (ch + 2 < nchunks) issue_loads(ch + 2);
+      transform(st ^ 1, role_c);
+      constexpr int NM = 4 * QC;                                          // MFMAs of a half
+      constexpr int NVI = ROLE == 0 ? 4 * 64 : (ROLE == 1 ? 4 * 28 : 0);  // vector instructions of the transform (about)
+      constexpr int VPM = (NVI + NM - 1) / NM;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // the next group's operand reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        if (ROLE != 2 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores: 16 per chunk
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the raw rows of chunk ch + 2: issued HERE, half a chunk of MFMAs ahead of the barrier behind which their
+      // transform starts
+      issue_loads(ch + 2, role_c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = QC; g < 2 * QC; ++g) {
+        if (g + 1 < 2 * QC) load_grp(g + 1, na, nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
+        ca = na; cb = nb;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
     };
+    // chunks in pairs, unconditionally (a conditional second chunk is a merge of two versions of all 256 accumulators,
+    // which the compiler implements by copying them): an odd count runs one dummy chunk of zeros
     for (int ch = 0; ch < nchunks; ch += 2) {
       chunk(ch, std::integral_constant<int, 0>{});
-      if (ch + 1 < nchunks) chunk(ch + 1, std::integral_constant<int, 1>{});
+      chunk(ch + 1, std::integral_constant<int, 1>{});
     }
-  }
+  };
+  if (is_v) run(std::integral_constant<int, 0>{});
+  else if (is_z) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 2>{});
 
   // ---- raw slab of this (tile, split, K group): [16][Cin][Cout]
   const size_t slab = ((size_t)blockIdx.z * WK + kg) * 16 * (size_t)a.Cin * a.Cout;
@@ -263,6 +305,8 @@ static bool wino_wgrad_shape_ok(int64_t M, int Cin, int Cout, int L) {
   return true;
 }
 
+bool conv_wino_wgrad_shape(int64_t M, int Cin, int Cout, int L) { return wino_wgrad_shape_ok(M, Cin, Cout, L); }
+
 struct WinoWgradGeom { int tiles, pgn, isplit, wk, nslabs; };
 static WinoWgradGeom wino_wgrad_geom(int64_t M, int Cin, int Cout, int L, int cus) {
   WinoWgradGeom g;
@@ -291,7 +335,9 @@ bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   const int64_t o = opt(OPT_ENC_WINO_WGRAD);
   if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
   if (o >= 1) return true;
-  return conv_wino_ok(M, Cin, Cout, L, 0);
+  // (Cin = 32 -- the 32 x 64 tile with two K groups, a quarter of the block idle in the transforms -- runs at 0.86x the
+  // direct kernel alone: the first 3x3 layer keeps the direct form)
+  return Cin % 64 == 0 && conv_wino_ok(M, Cin, Cout, L, 0);
 }
 
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {

@@ -52,3 +52,13 @@ extern "C" int dvg_dev_conv_wgrad(const float* in, const float* dy, float* slabs
   DVG_TRY(launch_conv_wgrad(wa, s));
   return launch_wgrad_reduce(slabs, wa.ksplit, WeightMap{mode, Cin, Cout, ntaps}, grad_w, s);
 }
+
+extern "C" size_t dvg_dev_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
+  return conv_wino_wgrad_shape(M, Cin, Cout, L) ? conv_wino_wgrad_slab_floats(M, Cin, Cout, L) : 0;
+}
+
+extern "C" int dvg_dev_conv_wino_wgrad(const float* in, const float* dy, float* slabs, float* grad_w, int mode, int64_t M,
+                                       int Cin, int Cout, int L, dvg_stream_t stream) {
+  DVG_REQUIRE(in && dy && slabs && grad_w, "dev_conv_wino_wgrad: null argument");
+  return launch_conv_wino_wgrad(in, dy, M, Cin, Cout, L, slabs, WeightMap{mode, Cin, Cout, 9}, grad_w, (hipStream_t)stream);
+}

@@ -39,8 +39,8 @@ const OptDef kDefs[OPT_COUNT] = {
     {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)"},
     {"enc_wino_cus", 256, "Winograd FORWARD launches of a training call: CUs the persistent grid is sized for -- a workgroup needs a whole CU, and the step's sampler draw, enqueued first, keeps its own (ModelWrapper sets 256 - the draw's workgroups, dvg_gibbs_launch_info)"},
     {"enc_wino_cus_d", 128, "the same for the data-gradient launches, which share the chip with the weight-gradient chain on the side stream (measured at c3: 128 -> 10.16 ms, 192 -> 10.23, 256 -> 10.6)"},
-    {"enc_wino_wgrad", 0, "encoder 3x3 WEIGHT gradients in the Winograd form (conv_wino_wgrad.hip): -1 with the other training launches (default), 0 never, 1 whenever the shape allows"},
-    {"enc_wino_cus_w", 128, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them)"},
+    {"enc_wino_wgrad", -1, "encoder 3x3 WEIGHT gradients in the Winograd form (conv_wino_wgrad.hip): -1 with the other training launches (default), 0 never, 1 whenever the shape allows"},
+    {"enc_wino_cus_w", 160, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;

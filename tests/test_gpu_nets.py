@@ -134,7 +134,8 @@ def test_encoder_winograd_form_matches_direct_form():
     gl = torch.from_numpy(np.random.default_rng(333).standard_normal((B, n)).astype(np.float32)).cuda()
     out = {}
     for mode in (0, -1, 1):
-        with _lib.option_scope(enc_wino=mode):
+        # (enc_wino = 1 also switches the weight gradients to their Winograd form, conv_wino_wgrad.hip)
+        with _lib.option_scope(enc_wino=mode, enc_wino_wgrad=1 if mode == 1 else -1):
             enc = _load(Encoder(n), params).eval()
             ev = enc(x).detach().cpu()
             enc = _load(Encoder(n), params).train()
