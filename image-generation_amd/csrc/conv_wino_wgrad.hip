@@ -14,6 +14,11 @@
 // channel: conflict-free ds_read_b128 / ds_write_b128); each thread transforms one (quad, 4 channels) item per chunk --
 // 16 (input) or 4 (gradient) buffer_load_dwordx4 straight from global memory, a padding tap being an out-of-range
 // offset that loads zeros -- and writes it into the other stage while the matrix pipe works on this one.
+// UPS = true: the decoder's Upsample(x2) + ConvTranspose2d 3x3 layers (/root/reference/src/decoder.py:34-46).  The layer is
+// a 3x3 convolution of the nearest-upsampled map, so the 4x4 input patch of the output quad of source pixel (i, j) is
+// d[u][v] = s[i + r(u)][j + r(v)], r = (-1, 0, 0, +1): along each axis B^T maps (x-, x0, x0, x+) to (x- - x0, 2 x0, 0,
+// x0 - x+) -- transform position 2 VANISHES in both directions, 9 of the 16 position GEMMs remain (xi, nu in {0, 1, 3}).
+// Nine MFMAs per k-step instead of the folded form's sixteen (class, tap) pairs, from a 3x3 SOURCE patch.
 // K order: a thread keeps ONE quad position (its 16 patch offsets are constants of the kernel) and walks the images, so
 // the split over workgroups is (position group) x (image range); slabs are reduced in fixed order (no float atomics).
 #include <type_traits>
@@ -24,7 +29,7 @@
 namespace dvg {
 
 struct WinoWgradArgs {
-  const float* in;   // [M][Cin]   layer input, Morton pixel order (quad t = rows 4t .. 4t+3)
+  const float* in;   // [M][Cin]   layer input, Morton pixel order (quad t = rows 4t .. 4t+3); UPS: the SOURCE map [M / 4][Cin]
   const float* dy;   // [M][Cout]  gradient of the layer's output
   float* slabs;      // [nsplit][16][Cin][Cout]
   int64_t M;
@@ -44,9 +49,10 @@ struct WinoWgradCfg {
   static_assert(WA * WB * WK == 4 && NV + NZ <= 256 && LDS_BYTES <= 160 * 1024, "unsupported tile");
 };
 
-template <int WA, int WB>
+template <int WA, int WB, bool UPS = false>
 __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a) {
   using C = WinoWgradCfg<WA, WB>;
+  constexpr int NE = UPS ? 9 : 16;  // raw rows of an input item: the 3x3 source patch, or the 4x4 patch
   constexpr int WK = C::WK, CIB = C::CIB, COB = C::COB, QC = C::QC, NQ = C::NQ, NV = C::NV, NZ = C::NZ;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
@@ -83,7 +89,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
     const int ty = (int)morton_y((uint32_t)qpos), tx = (int)morton_x((uint32_t)qpos);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      if (is_v) {
+      if (is_v && UPS) {  // source pixel (ty, tx) of the quad: 3x3 patch on the SOURCE grid (side H / 2)
+        const int y = ty - 1 + e / 3, x = tx - 1 + e % 3, Hs = H / 2;
+        const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
+        voff[e] = ok ? (uint32_t)((isub * (HW / 4) + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 4 * c4) * 4u : PAD;
+      } else if (is_v) {
         const int y = 2 * ty - 1 + (e >> 2), x = 2 * tx - 1 + (e & 3);
         const bool ok = y >= 0 && y < H && x >= 0 && x < H;
         voff[e] = ok ? (uint32_t)((isub * HW + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 4 * c4) * 4u : PAD;
@@ -111,12 +121,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   auto issue_loads = [&](int ch, auto role_c) {  // chunk ch of this block: images (c_beg + ch) IPC ...
     constexpr int ROLE = decltype(role_c)::value;  // 0: input item, 1: gradient item, 2: none
     const int img = (c_beg + ch) * IPC;
-    const int soff_x = __builtin_amdgcn_readfirstlane(img * HW * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
+    const int soff_x = __builtin_amdgcn_readfirstlane(img * (UPS ? HW / 4 : HW) * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
     // (images past the end -- a ragged last chunk of IPC > 1 -- must read zeros: their offsets are pushed out of range)
     const bool live = ch < nchunks && img + isub < n_img;  // (chunk nchunks: the dummy that makes the count even)
     if constexpr (ROLE == 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
+      for (int e = 0; e < NE; ++e)
         raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(live ? voff[e] : PAD), soff_x, 0));
     } else if constexpr (ROLE == 1) {
 #pragma unroll
@@ -127,13 +137,38 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   auto store_entry = [&](int st, int k, const float (&v)[16]) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
+      if (UPS && x == 2) continue;  // (positions 8..11 vanish: never read)
       const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
       *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
     }
   };
   auto transform = [&](int st, auto role_c) {  // raw -> the item's 4 entries in stage st
     constexpr int ROLE = decltype(role_c)::value;
-    if constexpr (ROLE == 0) {
+    if constexpr (ROLE == 0 && UPS) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // V = T s T^T, T = [1 -1 0; 0 2 0; 0 1 -1] at transform positions (0, 1, 3) x (0, 1, 3)
+        float sp[9], t[9], v[16];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sp[e] = raw[e][k];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {  // T s (columns q)
+          t[0 * 3 + q] = sp[0 * 3 + q] - sp[1 * 3 + q];
+          t[1 * 3 + q] = sp[1 * 3 + q] + sp[1 * 3 + q];
+          t[2 * 3 + q] = sp[1 * 3 + q] - sp[2 * 3 + q];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {  // (.) T^T: row x -> transform row (0, 1, 3)[x]
+          const int xr = x == 2 ? 3 : x;
+          v[xr * 4 + 0] = t[x * 3 + 0] - t[x * 3 + 1];
+          v[xr * 4 + 1] = t[x * 3 + 1] + t[x * 3 + 1];
+          v[xr * 4 + 2] = 0.f;
+          v[xr * 4 + 3] = t[x * 3 + 1] - t[x * 3 + 2];
+        }
+        v[8] = v[9] = v[10] = v[11] = 0.f;
+        store_entry(st, k, v);
+      }
+    } else if constexpr (ROLE == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float d[16], t[16], v[16];
@@ -205,19 +240,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
         load_grp(g + 1, na, nb);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
+          if (!UPS || ((g & 3) != 2 && m != 2))
+            acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
         ca = na; cb = nb;
       }
       transform(st ^ 1, role_c);
-      constexpr int NM = 4 * QC;                                          // MFMAs of a half
+      constexpr int NM = UPS ? QC / 4 * 9 : 4 * QC;                       // MFMAs of a half
       constexpr int NVI = ROLE == 0 ? 4 * 64 : (ROLE == 1 ? 4 * 28 : 0);  // vector instructions of the transform (about)
       constexpr int VPM = (NVI + NM - 1) / NM;
 #pragma unroll
       for (int i = 0; i < NM; ++i) {
-        if (i % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);            // the next group's operand reads
+        if (i % (UPS ? 3 : 4) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next group's operand reads
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-        if (ROLE != 2 && i % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores: 16 per chunk
+        if (ROLE != 2 && (UPS || i % 2 == 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores: 16 (12) per chunk
       }
       __builtin_amdgcn_sched_barrier(0);
       // the raw rows of chunk ch + 2: issued HERE, half a chunk of MFMAs ahead of the barrier behind which their
@@ -229,10 +265,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
         if (g + 1 < 2 * QC) load_grp(g + 1, na, nb);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
+          if (!UPS || ((g & 3) != 2 && m != 2))
+            acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
         ca = na; cb = nb;
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (!UPS) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        else if ((g & 3) != 2) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -252,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   const size_t slab = ((size_t)blockIdx.z * WK + kg) * 16 * (size_t)a.Cin * a.Cout;
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
+    if (UPS && ((p >> 2) == 2 || (p & 3) == 2)) continue;  // (vanishing positions: the reduce pass skips them too)
     float* dst = a.slabs + slab + ((size_t)p * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[p][r];
@@ -261,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
 // dg = G^T (sum of the slabs' dU) G per (ci, co), written in the checkpoint layout; 8 lanes cooperate on one channel pair
 // (strided over the slabs, fixed-shape shuffle tree: deterministic).  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, WeightMap map,
-                                                                float* __restrict__ grad_w) {
+                                                                float* __restrict__ grad_w, int ups) {
   const int64_t pairs = (int64_t)map.Ca * map.Cb, total = 16 * pairs;
   const int sub = threadIdx.x & 7;
   for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < pairs; e += ((int64_t)gridDim.x * 256) >> 3) {
@@ -269,7 +308,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       float s = 0.f;
-      for (int k = sub; k < nslabs; k += 8) s += slabs[(size_t)k * total + (size_t)p * pairs + e];
+      if (!(ups && ((p >> 2) == 2 || (p & 3) == 2)))  // (upsampled layers: positions with xi = 2 or nu = 2 are identically zero)
+        for (int k = sub; k < nslabs; k += 8) s += slabs[(size_t)k * total + (size_t)p * pairs + e];
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       s += __shfl_xor(s, 4, 64);
@@ -298,22 +338,23 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host
+// channel tiles: 64 x 64 (one K group), or 32 x 64 / 64 x 32 with two K groups inside the block
 static bool wino_wgrad_shape_ok(int64_t M, int Cin, int Cout, int L) {
   if (L < 1 || L > 5 || M <= 0 || (M & (((int64_t)1 << (2 * L)) - 1))) return false;  // whole images
-  if (Cout % 64 || !(Cin % 64 == 0 || Cin == 32)) return false;
+  const bool t22 = Cin % 64 == 0 && Cout % 64 == 0, t12 = Cin == 32 && Cout % 64 == 0, t21 = Cin % 64 == 0 && Cout == 32;
+  if (!(t22 || t12 || t21)) return false;
   if (M * (int64_t)(Cin > Cout ? Cin : Cout) * 4 >= 2147483647LL) return false;          // (32-bit buffer offsets)
   return true;
 }
-
 bool conv_wino_wgrad_shape(int64_t M, int Cin, int Cout, int L) { return wino_wgrad_shape_ok(M, Cin, Cout, L); }
 
 struct WinoWgradGeom { int tiles, pgn, isplit, wk, nslabs; };
 static WinoWgradGeom wino_wgrad_geom(int64_t M, int Cin, int Cout, int L, int cus) {
   WinoWgradGeom g;
-  const bool narrow = Cin % 64 != 0;  // Cin = 32: 32 x 64 tile, two K groups inside the block
-  const int cib = narrow ? 32 : 64, nq = 8;
-  g.wk = narrow ? 2 : 1;
-  g.tiles = (Cin / cib) * (Cout / 64);
+  const bool full = Cin % 64 == 0 && Cout % 64 == 0;
+  const int cib = Cin % 64 == 0 ? 64 : 32, cob = Cout % 64 == 0 ? 64 : 32, nq = 8;
+  g.wk = full ? 1 : 2;
+  g.tiles = (Cin / cib) * (Cout / cob);
   const int qi = 1 << (2 * L - 2);
   g.pgn = qi >= nq ? qi / nq : 1;
   const int ipc = qi >= nq ? 1 : nq / qi;
@@ -337,7 +378,7 @@ bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   if (o >= 1) return true;
   // (Cin = 32 -- the 32 x 64 tile with two K groups, a quarter of the block idle in the transforms -- runs at 0.86x the
   // direct kernel alone: the first 3x3 layer keeps the direct form)
-  return Cin % 64 == 0 && conv_wino_ok(M, Cin, Cout, L, 0);
+  return Cin % 64 == 0 && Cout % 64 == 0 && conv_wino_ok(M, Cin, Cout, L, 0);
 }
 
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
@@ -345,33 +386,42 @@ size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
   return (size_t)g.nslabs * 16 * Cin * Cout;
 }
 
+template <int WA, int WB, bool UPS>
+static int launch_wino_wgrad_cfg(const WinoWgradArgs& a, double flops, dim3 grid, hipStream_t s) {
+  using C = WinoWgradCfg<WA, WB>;
+  auto kern = conv_wino_wgrad_kernel<WA, WB, UPS>;
+  DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  return DVG_OK;
+}
+
+// ups = 1: `in` is the SOURCE map of an Upsample(x2) + 3x3 layer ([M / 4][Cin]); M, L describe the layer's OUTPUT grid
 int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
-                           const WeightMap& map, float* grad_w, hipStream_t s) {
+                           const WeightMap& map, float* grad_w, hipStream_t s, int ups, int cus) {
   DVG_REQUIRE(wino_wgrad_shape_ok(M, Cin, Cout, L), "conv_wino_wgrad: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)",
               (long long)M, Cin, Cout, L);
-  int cus = (int)opt(OPT_ENC_WINO_CUS_W);
+  if (cus <= 0) cus = (int)opt(OPT_ENC_WINO_CUS_W);
   if (cus < 1) cus = 1;
   if (cus > 256) cus = 256;
   const WinoWgradGeom g = wino_wgrad_geom(M, Cin, Cout, L, cus);
   WinoWgradArgs a;
   a.in = in; a.dy = dy; a.slabs = slabs; a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.isplit = g.isplit;
-  const double flops = 2.0 * (double)(M / 4) * 16.0 * Cin * Cout;  // executed (4/9 of the direct form's)
+  const double flops = 2.0 * (double)(M / 4) * (ups ? 9.0 : 16.0) * Cin * Cout;  // executed position GEMMs
   const dim3 grid((unsigned)g.tiles, 1, (unsigned)(g.pgn * g.isplit));
-  if (g.wk == 1) {
-    using C = WinoWgradCfg<2, 2>;
-    auto kern = conv_wino_wgrad_kernel<2, 2>;
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  const int cfg = (Cin % 64 == 0 ? 2 : 0) + (Cout % 64 == 0 ? 1 : 0);  // 3: 64x64, 1: 32x64, 2: 64x32
+  int rc;
+  if (ups) {
+    rc = cfg == 3 ? launch_wino_wgrad_cfg<2, 2, true>(a, flops, grid, s)
+       : cfg == 1 ? launch_wino_wgrad_cfg<1, 2, true>(a, flops, grid, s) : launch_wino_wgrad_cfg<2, 1, true>(a, flops, grid, s);
   } else {
-    using C = WinoWgradCfg<1, 2>;
-    auto kern = conv_wino_wgrad_kernel<1, 2>;
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+    rc = cfg == 3 ? launch_wino_wgrad_cfg<2, 2, false>(a, flops, grid, s)
+       : cfg == 1 ? launch_wino_wgrad_cfg<1, 2, false>(a, flops, grid, s) : launch_wino_wgrad_cfg<2, 1, false>(a, flops, grid, s);
   }
+  DVG_TRY(rc);
   const int64_t pairs = (int64_t)Cin * Cout;
   int64_t blocks = (pairs * 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)slabs, g.nslabs, map, grad_w);
+  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)slabs, g.nslabs, map, grad_w, ups);
   return DVG_OK;
 }
 

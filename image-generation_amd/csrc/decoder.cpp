@@ -23,6 +23,7 @@ struct DecPlan {
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partL, partW, partF, splitk;
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
+  bool wino_w[4];  // layer's weight gradient runs in the Winograd form (conv_wino_wgrad.hip, 9 of 16 positions)
   bool d22;      // layer 0 (3x3 on 2x2 images) runs as the dense per-image map (conv.h: WM_CONVT_D22_FWD)
   // Large batches: Linear(n, 4n) and layer 0 have nothing but a reshape between them, so the pair is ONE linear map per
   // image, spins (n) -> the 4 x 128 pre-BatchNorm values, with the composed weight Wc = Wlin . Weff (a 2 n x 4n x 512
@@ -77,6 +78,8 @@ DecPlan dec_plan(int64_t N, int n) {
     p.M[l] = N * ((int64_t)4 << (2 * l));
     const int C = ch[l + 1];
     p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
+    p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 && conv_precision_mode() == 0 &&
+                  conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO_WGRAD) > 0 || N >= 8192);
     p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]
     if (l == 0 && p.d22) p.nblk[l] = 4 * conv_stats_blocks(N, 4 * C);
@@ -94,6 +97,10 @@ DecPlan dec_plan(int64_t N, int n) {
                         : p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * (p.fold[l] || d22 ? 16 : 9) * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
+      if (p.wino_w[l]) {
+        const size_t sw = conv_wino_wgrad_slab_floats(p.M[l], ch[l], C, p.L[l]);
+        if (sw > max_slab) max_slab = sw;
+      }
       const size_t sk_f = d22 ? conv_splitk_floats(N, 4 * ch[l], 4 * C, 1, 0)
                               : p.fold[l] ? conv_splitk_floats(p.M[l], ch[l], C, 4, 0) : conv_splitk_floats(p.M[l], ch[l], C, 9, 0);
       const size_t sk_d = d22 ? conv_splitk_floats(N, 4 * C, 4 * ch[l], 1, 0)
@@ -417,6 +424,9 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       wa.M = N; wa.Cin = 4 * Cin; wa.Cout = 4 * C; wa.L = 0; wa.ntaps = 1; wa.ups = 0;
       DVG_TRY(launch_conv_wgrad(wa, s2));
       DVG_TRY(launch_wgrad_d22_reduce(W + pl.slabs, pl.ksplit[l], Cin, C, g->conv_w[l], s2));
+    } else if (pl.wino_w[l]) {
+      DVG_TRY(launch_conv_wino_wgrad(xin, dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONVT_FWD, Cin, C, 9},
+                                     g->conv_w[l], s2, 1, (int)opt(OPT_DEC_WINO_CUS_W)));
     } else if (pl.fold[l]) {
       wa.M = pl.M[l] / 4; wa.L = pl.L[l] - 1; wa.ntaps = 16; wa.ups = 0; wa.fold = 1;
       DVG_TRY(launch_conv_wgrad(wa, s2));

@@ -21,7 +21,7 @@ _SIGS = {
                            [ctypes.c_void_p]),
     "dvg_dev_encoder_layout": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "dvg_dev_wino_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "dvg_dev_conv_wino_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 3 +
+    "dvg_dev_conv_wino_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 4 +
                                 [ctypes.c_void_p]),
 }
 _bound = False
@@ -105,7 +105,7 @@ def conv_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ntaps=9, ups=0):
     return gw
 
 
-def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L):
+def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ups=0):
     """The 3x3 weight gradient in the Winograd form (csrc/conv_wino_wgrad.hip), or None when the shape does not qualify."""
     Lb = lib()
     dev = x_m.device
@@ -115,7 +115,7 @@ def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L):
     slabs = torch.empty(nf, device=dev)
     gw = torch.empty(w_shape, device=dev)
     _lib.check(Lb.dvg_dev_conv_wino_wgrad(x_m.data_ptr(), dy.data_ptr(), slabs.data_ptr(), gw.data_ptr(), mode, M, Cin, Cout, L,
-                                          _lib.stream_ptr(dev)))
+                                          int(ups), _lib.stream_ptr(dev)))
     return gw
 
 

@@ -28,11 +28,11 @@ int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
 size_t dvg_dev_wgrad_slab_floats(int64_t M, int Cin, int Cout, int ntaps);
 int dvg_dev_conv_wgrad(const float *in, const float *dy, float *slabs, float *grad_w, int mode, int64_t M, int Cin,
                        int Cout, int L, int ntaps, int ups, dvg_stream_t stream);
-/* The same weight gradient in the Winograd F(2x2,3x3) form (conv_wino_wgrad.hip; 3x3, no upsample): slabs of
+/* The same weight gradient in the Winograd F(2x2,3x3) form (conv_wino_wgrad.hip; ups = 1: `in` is the source map of an Upsample(x2) + 3x3 layer): slabs of
  * dvg_dev_wino_wgrad_slab_floats() floats (0 = the shape does not qualify). */
 size_t dvg_dev_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
 int dvg_dev_conv_wino_wgrad(const float *in, const float *dy, float *slabs, float *grad_w, int mode, int64_t M, int Cin,
-                            int Cout, int L, dvg_stream_t stream);
+                            int Cout, int L, int ups, dvg_stream_t stream);
 /* Where the encoder's workspace (dvg_encoder_workspace_bytes) keeps what a forward call saved, as FLOAT offsets:
  * out[0..3] = pre-BatchNorm convolution outputs Y[l] ([B * HW_l][C_l], Morton NHWC), out[4..7] = pooled stage outputs
  * Xp[l], out[8..11] = batch means, out[12..15] = batch inverse standard deviations.  Diagnostics only.  (Y[0] is only
