@@ -133,6 +133,9 @@ struct ConvArgs {
   // Winograd launches (launch_conv_wino): CUs the persistent grid is sized for, 0 = all 256 (encoder.cpp: a training
   // call's forward launches leave the sampler's CUs out, its data gradients share the chip with the weight-gradient chain)
   int wino_cus = 0;
+  // Winograd launches of the decoder's Upsample(x2) + 3x3 layers: 1 = forward (`in` is the source map, M / L of the output
+  // grid: 9 of 16 transform positions), 2 = data gradient (`out` = the source map's gradient, one row per output quad)
+  int wino_um = 0;
 };
 // process-wide precision of the forward / data-gradient GEMMs (set through the ABI only: dvg_set_conv_precision; the library reads no environment variable)
 bool conv_precision_bf16();
@@ -147,6 +150,7 @@ bool conv_precision_matches_forward(const void* ws);   // backward calls: same m
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 // Winograd F(2x2,3x3) form of a stride-1 3x3 layer (conv_wino.hip): same ConvArgs, `wp` = the transformed pack of
 // launch_wino_weight_pack ([Cin][Cout][16] floats), stats rows = conv_wino_stats_blocks
+bool conv_wino_shape(int64_t M, int Cin, int Cout, int L);  // shape only
 bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind = 0);  // kind: 0 training forward, 1 data gradient, 2 evaluation forward
 int conv_wino_stats_blocks(int64_t M, int Cout);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);

@@ -41,25 +41,37 @@ struct WinoArgs {
   float* out;         // [4 tiles][Cout]
   float* stats;       // [nblk][Cout][2] per tile block (sum, sum of squares) of the output, or null
   int cus = 0;        // CUs the persistent grid is sized for (0 = 256)
+  // (UM = 1: `in` is the SOURCE map [tiles][Cin] of an Upsample(x2) + 3x3 layer; UM = 2: its data gradient, `out` the source
+  // map's gradient [tiles][Cout] -- template argument of the kernel, see the header comment)
   int Cin, Cout, L;   // L = log2 of the image side
   int nblk;           // tile blocks (of 32 WM quads)
 };
 
-template <int WM, int WN, int KC>
+template <int WM, int WN, int KC, int UM = 0>
 struct WinoCfg {
   static constexpr int TBLK = 32 * WM, CB = 32 * WN, KS = KC / 2;
-  static constexpr int RAW_PIX = TBLK * 4 * KC * 4;          // bytes of raw pixels per stage
-  static constexpr int RAW_B = 64 + RAW_PIX;                 // + the zero entry padding taps read
+  static constexpr int PPQ = UM == 1 ? 1 : 4;                // raw pixels per quad (UM = 1: one source pixel)
+  static constexpr int RAW_PIX = TBLK * PPQ * KC * 4;        // bytes of raw pixels per stage
+  static constexpr int RAW_DMA = RAW_PIX < 4096 ? 4096 : RAW_PIX;  // (a DMA round is 256 lanes x 16 bytes: spare lanes fetch zeros)
+  static constexpr int RAW_B = 64 + RAW_DMA;                 // + the zero entry padding taps read
   static constexpr int V_B = KC * TBLK * 64, U_B = KC * CB * 64;
   static constexpr int OFF_RAW = 0, OFF_V = OFF_RAW + 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B;
   static constexpr int LDS_BYTES = OFF_RED + WM * CB * 2 * 4;
   static constexpr int NI = TBLK * KC / 256;                 // patches a thread transforms per chunk
-  static constexpr int RR = RAW_PIX / 4096, UR = U_B / 4096; // 4 KiB DMA rounds (256 lanes x 16 bytes) per chunk
+  static constexpr int RR = RAW_DMA / 4096, UR = U_B / 4096; // 4 KiB DMA rounds (256 lanes x 16 bytes) per chunk
 };
 
-template <int WM, int WN, int KC>
+// UM = 1 / 2: the decoder's Upsample(x2) + ConvTranspose2d 3x3 layers (/root/reference/src/decoder.py:34-46), forward and
+// data gradient.  The layer is a 3x3 convolution of the nearest-upsampled map, so the 4x4 input patch of the output quad of
+// source pixel (i, j) is d[u][v] = s[i + r(u)][j + r(v)], r = (-1, 0, 0, +1), and B^T maps (x-, x0, x0, x+) to
+// (x- - x0, 2 x0, 0, x0 - x+): transform position 2 vanishes in both directions, NINE of the sixteen position GEMMs remain
+// (the folded direct form multiplies sixteen (class, tap) pairs per source pixel).  The adjoint has the same shape: the
+// gradient of the source map is the 2x2 sum of the fine-grid data gradient, 1^T A^T M A 1 with A 1 = (1, 2, 0, -1)^T --
+// again only positions with xi, nu in {0, 1, 3} count, so only those are transformed and multiplied.
+template <int WM, int WN, int KC, int UM = 0>
 __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char* wsm) {
-  using C = WinoCfg<WM, WN, KC>;
+  using C = WinoCfg<WM, WN, KC, UM>;
+  constexpr int NP = UM == 1 ? 9 : 16;  // raw pixels of a patch
   constexpr int TBLK = C::TBLK, CB = C::CB, KS = C::KS, NI = C::NI;
   static_assert(WM * WN == 4 && KC % 2 == 0 && C::RR >= 1 && C::UR >= 1 && NI >= 1, "unsupported shape");
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
@@ -78,7 +90,18 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   constexpr int KG = 256 / TBLK;  // channel groups: the thread's NI patches are channels kb, kb + KG, ...
   const int tl = tid % TBLK, k0 = ((tid / TBLK) + tl / (64 / KC)) % KG;
   int poff[16];
-  {
+  if constexpr (UM == 1) {
+    // 3x3 patch of SOURCE pixels around the source pixel of quad tl (source image side H / 2; source pixel index = quad index)
+    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4), Hs = H / 2;
+    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int y = ty - 1 + e / 3, x = tx - 1 + e % 3;
+      const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
+      const int pos = img * (HW / 4) + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
+      poff[e] = ok ? 64 + (pos * KC + k0) * 4 : 0;
+    }
+  } else {
     const int img = (tl * 4) / HW, tq = tl - img * (HW / 4);  // quad index inside its image = Morton index of (ty, tx)
     const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
 #pragma unroll
@@ -109,16 +132,17 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
 
   // ---- DMA of one chunk's images
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cin * 4), 0x00020000);
+      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * TBLK * C::PPQ * a.Cin * 4), 0x00020000);
   int rvoff[C::RR];
 #pragma unroll
   for (int q = 0; q < C::RR; ++q) {
     const int byte = (q * 256 + tid) * 16, pos = byte / (KC * 4);
-    rvoff[q] = (4 * (pos % TBLK) + pos / TBLK) * a.Cin * 4 + byte % (KC * 4);
+    if constexpr (UM == 1) rvoff[q] = byte < C::RAW_PIX ? pos * a.Cin * 4 + byte % (KC * 4) : (int)0x7FFF0000;  // (spare lanes: out of range -> zeros)
+    else rvoff[q] = (4 * (pos % TBLK) + pos / TBLK) * a.Cin * 4 + byte % (KC * 4);
   }
   const int nch = a.Cin / KC;
   auto issue_raw = [&](int blk, int ch, int st) {
-    const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK * 4 * a.Cin + ch * KC) * 4);
+    const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK * C::PPQ * a.Cin + ch * KC) * 4);
 #pragma unroll
     for (int q = 0; q < C::RR; ++q) {
       const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + st * C::RAW_B + 64 + q * 4096 + wave * 1024));
@@ -140,11 +164,26 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   // ---- input transform of the thread's NI patches: raw stage `rs` -> transformed stage `vs`
   auto load_patch = [&](int rs, int j, float (&d)[16]) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
+    for (int e = 0; e < NP; ++e)
       d[e] = *reinterpret_cast<lds_cf32*>((uintptr_t)(lds0 + C::OFF_RAW + rs * C::RAW_B + j * (256 / TBLK) * 4 + (uint32_t)poff[e]));
   };
   auto store_patch = [&](int vs, int j, const float (&d)[16]) {
     float t[16], v[16];
+    if constexpr (UM == 1) {  // V = T s T^T, T = [1 -1 0; 0 2 0; 0 1 -1] -> transform positions (0, 1, 3) x (0, 1, 3)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        t[0 * 3 + q] = d[0 * 3 + q] - d[1 * 3 + q];
+        t[1 * 3 + q] = d[1 * 3 + q] + d[1 * 3 + q];
+        t[2 * 3 + q] = d[1 * 3 + q] - d[2 * 3 + q];
+      }
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const f32x4 o = {t[x * 3 + 0] - t[x * 3 + 1], t[x * 3 + 1] + t[x * 3 + 1], 0.f, t[x * 3 + 1] - t[x * 3 + 2]};
+        const int xr = x == 2 ? 3 : x;
+        *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + j * (256 / TBLK) * TBLK * 64 + (uint32_t)((xr ^ swt) << 4))) = o;
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // B^T d
       t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
@@ -189,19 +228,37 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cout * 4), 0x00020000);
-  const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;
+      a.out, 0, (int)((int64_t)a.nblk * TBLK * (UM == 2 ? 1 : 4) * a.Cout * 4), 0x00020000);
+  const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;   // quad row 4 hh of the lane's first quad: 4 pixels per quad
+  const int ovoff1 = (4 * hh * a.Cout + n0 + wn * 32 + c) * 4;   // (UM = 2: one row per quad)
+  (void)ovoff1;
   auto epilogue = [&](int blk) {
-    float s1 = 0.f, s2 = 0.f;
     const int col = n0 + wn * 32 + c;
     const float bias = a.bias ? a.bias[col] : 0.f;
+    if constexpr (UM == 2) {
+      // gradient of the source pixel = sum of its quad's four fine-grid gradients = sum_xi,nu w_xi w_nu M[xi][nu],
+      // w = A 1 = (1, 2, 0, -1): one output row per quad
+      const f32x16 r0 = (acc[0] + (acc[1] + acc[1])) - acc[3];
+      const f32x16 r1 = (acc[4] + (acc[5] + acc[5])) - acc[7];
+      const f32x16 r3 = (acc[12] + (acc[13] + acc[13])) - acc[15];
+      const f32x16 y = (r0 + (r1 + r1)) - r3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rq = (r & 3) + 8 * (r >> 2);
+        const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK + wm * 32 + rq) * a.Cout * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[r] + bias), rsrc_out, ovoff1, soff, 0);
+      }
+      return;
+    }
+    float s1 = 0.f, s2 = 0.f;
     // A^T M A on whole accumulator tiles (the transform is elementwise in the 16 rows a lane holds): element-by-element
     // access would make the compiler copy every 16-register accumulator tuple out of the AGPRs at once
     f32x16 y[4];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
-      const f32x16 t0 = (acc[0 + nu] + acc[4 + nu]) + acc[8 + nu];
-      const f32x16 t1 = (acc[4 + nu] - acc[8 + nu]) - acc[12 + nu];
+      if (UM == 1 && nu == 2) continue;  // (upsampled input: positions with xi = 2 or nu = 2 are identically zero)
+      const f32x16 t0 = UM == 1 ? acc[0 + nu] + acc[4 + nu] : (acc[0 + nu] + acc[4 + nu]) + acc[8 + nu];
+      const f32x16 t1 = UM == 1 ? acc[4 + nu] - acc[12 + nu] : (acc[4 + nu] - acc[8 + nu]) - acc[12 + nu];
       if (nu == 0) { y[0] = t0; y[2] = t1; }
       if (nu == 1) { y[0] = y[0] + t0; y[1] = t0; y[2] = y[2] + t1; y[3] = t1; }
       if (nu == 2) { y[0] = y[0] + t0; y[1] = y[1] - t0; y[2] = y[2] + t1; y[3] = y[3] - t1; }
@@ -257,24 +314,58 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
     load_grp(0, ca, cb);
     float d[16], t[16];
     __builtin_amdgcn_sched_barrier(0);
+    constexpr bool SK = UM != 0;  // upsampled forms: operand group 2 and position 2 of every group are never multiplied
 #pragma unroll
     for (int g = 0; g < 4 * KS; ++g) {
       const int ks = g >> 2, i = g & 3;
-      if (g + 1 < 4 * KS) load_grp(g + 1, na, nb);
+      if (SK && i == 2) continue;
+      {
+        const int gn = SK && ((g + 1) & 3) == 2 ? g + 2 : g + 1;  // the next group that has MFMAs
+        if (gn < 4 * KS) load_grp(gn, na, nb);
+      }
       if (ks < NI && i == 0) load_patch(st ^ 1, ks, d);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        if (ks < NI && i == 1) {  // B^T d, column m
-          t[0 * 4 + m] = d[0 * 4 + m] - d[2 * 4 + m];
-          t[1 * 4 + m] = d[1 * 4 + m] + d[2 * 4 + m];
-          t[2 * 4 + m] = d[2 * 4 + m] - d[1 * 4 + m];
-          t[3 * 4 + m] = d[1 * 4 + m] - d[3 * 4 + m];
-        }
-        if (ks < NI && i == 2) {  // (.) B, row m, and its store
-          const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], t[m * 4 + 2] - t[m * 4 + 1],
-                           t[m * 4 + 1] - t[m * 4 + 3]};
-          *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
+        if (SK && m == 2) continue;
+        const int mm = SK && m == 3 ? 2 : m;  // piece index 0..2 of the transform when a position is skipped
+        if constexpr (UM == 1) {
+          if (ks < NI && i == 1) {  // T s, column mm
+            t[0 * 3 + mm] = d[0 * 3 + mm] - d[1 * 3 + mm];
+            t[1 * 3 + mm] = d[1 * 3 + mm] + d[1 * 3 + mm];
+            t[2 * 3 + mm] = d[1 * 3 + mm] - d[2 * 3 + mm];
+          }
+          if (ks < NI && i == 3) {  // (.) T^T, row mm -> transform row (0, 1, 3)[mm], and its store
+            const f32x4 o = {t[mm * 3 + 0] - t[mm * 3 + 1], t[mm * 3 + 1] + t[mm * 3 + 1], 0.f, t[mm * 3 + 1] - t[mm * 3 + 2]};
+            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
+          }
+        } else if constexpr (UM == 2) {
+          if (ks < NI && i == 1) {  // B^T d: rows 0, 1, 3 only; columns m = 0, 1, 3 here and column 2 (an input of every row) with m = 0
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              const int q = cc == 0 ? m : 2;
+              if (cc == 1 && m != 0) continue;
+              t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
+              t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
+              t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
+            }
+          }
+          if (ks < NI && i == 3) {  // (.) B, row m in {0, 1, 3}, and its store
+            const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], 0.f, t[m * 4 + 1] - t[m * 4 + 3]};
+            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
+          }
+        } else {
+          if (ks < NI && i == 1) {  // B^T d, column m
+            t[0 * 4 + m] = d[0 * 4 + m] - d[2 * 4 + m];
+            t[1 * 4 + m] = d[1 * 4 + m] + d[2 * 4 + m];
+            t[2 * 4 + m] = d[2 * 4 + m] - d[1 * 4 + m];
+            t[3 * 4 + m] = d[1 * 4 + m] - d[3 * 4 + m];
+          }
+          if (ks < NI && i == 2) {  // (.) B, row m, and its store
+            const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], t[m * 4 + 2] - t[m * 4 + 1],
+                             t[m * 4 + 1] - t[m * 4 + 3]};
+            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[4 * i + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * i + m], 0, 0, 0);
@@ -302,10 +393,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   }
 }
 
-template <int WM, int WN, int KC>
+template <int WM, int WN, int KC, int UM = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
   extern __shared__ __align__(16) unsigned char wino_smem[];
-  conv_wino_body<WM, WN, KC>(a, wino_smem);
+  conv_wino_body<WM, WN, KC, UM>(a, wino_smem);
 }
 
 // U = G g G^T of every (reduction channel a, output channel b) pair, in the layout the kernel's DMA copies verbatim
@@ -358,6 +449,8 @@ static bool wino_shape_ok(int64_t M, int Cin, int Cout, int L) {
   return true;
 }
 
+bool conv_wino_shape(int64_t M, int Cin, int Cout, int L) { return wino_shape_ok(M, Cin, Cout, L); }
+
 // kind: 0 forward launch of a training call, 1 data-gradient launch, 2 forward launch of an evaluation call.
 // option enc_wino: -1 (default) every launch of 256 workgroups' worth of tile blocks or more (small launches keep the
 // direct form's finer tiles), 0 never, 1 every launch the shape allows, 2 / 3 like 1 for the forward / the data-gradient
@@ -380,10 +473,10 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
 
-template <int WM, int WN, int KC>
+template <int WM, int WN, int KC, int UM = 0>
 static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
-  using C = WinoCfg<WM, WN, KC>;
-  auto kern = conv_wino_kernel<WM, WN, KC>;
+  using C = WinoCfg<WM, WN, KC, UM>;
+  auto kern = conv_wino_kernel<WM, WN, KC, UM>;
   // the raised dynamic-LDS limit is a per-DEVICE function attribute: once per device (bit per ordinal), not per process
   static std::atomic<uint64_t> attr_set{0};
   int dev = 0;
@@ -413,7 +506,9 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
 
 // a.wp must be the transformed pack of launch_wino_weight_pack; a.M, Cin, Cout, L, bias, out, stats as for launch_conv_igemm
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
-  DVG_REQUIRE(wino_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold,
+  // wino_um = 1: Upsample(x2) + 3x3 forward (a.in = the SOURCE map, a.M / a.L of the output grid); 2: its data gradient
+  // (a.in = the fine-grid gradient, a.out = the source map's gradient, one row per quad)
+  DVG_REQUIRE(wino_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.wino_um >= 0 && a.wino_um <= 2,
               "conv_wino: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
   WinoArgs w;
   w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
@@ -422,7 +517,9 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   w.nblk = (int)(a.M / 4 / wino_tblk(cfg));
   // EXECUTED matrix FLOPs: 16 transform-domain GEMMs over the M / 4 quads (4/9 of the direct form's 2 M Cin Cout 9;
   // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
-  const double flops = 2.0 * (double)(a.M / 4) * 16.0 * a.Cin * a.Cout;
+  const double flops = 2.0 * (double)(a.M / 4) * (a.wino_um ? 9.0 : 16.0) * a.Cin * a.Cout;
+  if (a.wino_um == 1) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino_cfg<4, 1, 4, 1>(w, flops, s);
+  if (a.wino_um == 2) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 2>(w, flops, s) : launch_wino_cfg<4, 1, 4, 2>(w, flops, s);
   if (cfg == 0) return launch_wino_cfg<2, 2, 8>(w, flops, s);
   return launch_wino_cfg<4, 1, 4>(w, flops, s);
 }

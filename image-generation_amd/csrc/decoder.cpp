@@ -24,6 +24,7 @@ struct DecPlan {
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   bool wino_w[4];  // layer's weight gradient runs in the Winograd form (conv_wino_wgrad.hip, 9 of 16 positions)
+  bool wino_f[4], wino_d[4];  // ... its forward / data-gradient GEMM (conv_wino.hip, wino_um = 1 / 2)
   bool d22;      // layer 0 (3x3 on 2x2 images) runs as the dense per-image map (conv.h: WM_CONVT_D22_FWD)
   // Large batches: Linear(n, 4n) and layer 0 have nothing but a reshape between them, so the pair is ONE linear map per
   // image, spins (n) -> the 4 x 128 pre-BatchNorm values, with the composed weight Wc = Wlin . Weff (a 2 n x 4n x 512
@@ -80,7 +81,18 @@ DecPlan dec_plan(int64_t N, int n) {
     p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
     p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 && conv_precision_mode() == 0 &&
                   conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO_WGRAD) > 0 || N >= 8192);
-    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
+    {
+      // option dec_wino: -1 (default) the FORWARD launches from 8192 decoder rows up; 1 forward and data gradient
+      // whenever the shape allows, 2 / 3 forward / data gradient only, 0 never.  (The data gradient in this form measured
+      // neutral to slower inside the c3 step: it is a whole-CU kernel beside the whole-CU Winograd weight gradients,
+      // where the folded direct kernel shares CUs -- 9.74 ms with the forward alone, 9.80 with both at any split of the
+      // CUs between them.)
+      const int64_t o = opt(OPT_DEC_WINO);
+      const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() == 0 && (o > 0 || N >= 8192);
+      p.wino_f[l] = on && o != 3 && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
+      p.wino_d[l] = on && (o == 1 || o == 3) && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
+    }
+    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]
     if (l == 0 && p.d22) p.nblk[l] = 4 * conv_stats_blocks(N, 4 * C);
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
@@ -156,7 +168,8 @@ DecPlan dec_plan(int64_t N, int n) {
 // what of the plan the backward relies on the forward having done (which buffers hold what, in which pack format)
 uint32_t plan_signature(const DecPlan& pl) {
   return (uint32_t)pl.d22 | (uint32_t)pl.lc0 << 1 | (uint32_t)pl.fold[1] << 2 | (uint32_t)pl.fold[2] << 3 |
-         (uint32_t)conv_launch_mode(pl.N, 128) << 4 | (uint32_t)pl.tail << 12;
+         (uint32_t)conv_launch_mode(pl.N, 128) << 4 | (uint32_t)pl.tail << 12 | (uint32_t)pl.wino_f[1] << 13 |
+         (uint32_t)pl.wino_f[2] << 14 | (uint32_t)pl.wino_d[1] << 15 | (uint32_t)pl.wino_d[2] << 16;
 }
 
 int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws, size_t ws_bytes, const DecPlan& pl) {
@@ -214,6 +227,11 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l]};
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
+    // Winograd launches (conv_wino.hip, wino_um = 1 / 2) read the transformed pack U = G g G^T instead
+    for (int l = 1; l < 3; ++l) {
+      if (pl.wino_f[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, W + pl.wp[l], s));
+      if (pl.wino_d[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, W + pl.wpd[l], s));
+    }
   }
   if (pl.lc0) {
     // composed weight, both orientations (K-major operands of the forward and of the data-gradient GEMM), and bias:
@@ -265,7 +283,12 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
         a.in = spins; a.wp = W + pl.WcT; a.bias = W + pl.bc; a.bias_mod = 0; a.Cin = n;
       }
       a.splitk_ws = W + pl.splitk;
-      DVG_TRY(launch_conv_igemm(a, s));
+      if (pl.wino_f[l]) {  // Winograd on the upsampled map: 9 of 16 transform positions (conv_wino.hip, UM = 1)
+        a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.fold = 0; a.wino_um = 1; a.wino_cus = (int)opt(OPT_DEC_WINO_CUS);
+        DVG_TRY(launch_conv_wino(a, s));
+      } else {
+        DVG_TRY(launch_conv_igemm(a, s));
+      }
     } else if (pl.tail) {  // layer 2's activation happens while layer 3 stages its input (Xs[2] is never written)
       const DecActIn in{W + pl.Y[2], W + pl.mean[2], W + pl.invstd[2], p->bn_g[2], p->bn_b[2], training ? W + pl.mask[2] : nullptr};
       DVG_TRY(launch_dec_conv3_fwd_act(in, N, p->conv_w[3], p->conv_b[3], W + pl.Y[3], W + pl.stats[3], s));
@@ -413,7 +436,12 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     const bool d22 = l == 0 && pl.d22;
     if (d22) { a.M = N; a.Cin = 4 * C; a.Cout = 4 * Cin; a.L = 0; a.ntaps = 1; a.poolsum = 0; }
     a.splitk_ws = W + pl.splitk;
-    DVG_TRY(launch_conv_igemm(a, s));
+    if (pl.wino_d[l]) {  // fine-grid Winograd data gradient with the 2x2 sum folded into its output transform (UM = 2)
+      a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.poolsum = 0; a.fold = 0; a.wino_um = 2; a.wino_cus = (int)opt(OPT_DEC_WINO_CUS_D);
+      DVG_TRY(launch_conv_wino(a, s));
+    } else {
+      DVG_TRY(launch_conv_igemm(a, s));
+    }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
     DVG_REQUIRE(sums.add(W + pl.partB[l], (l == 2 && pl.tail) ? dec_tail_blocks(N) : EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0),
                 "decoder_bwd: column-sum batch full");

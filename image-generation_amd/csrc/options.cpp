@@ -43,6 +43,9 @@ const OptDef kDefs[OPT_COUNT] = {
     {"enc_wino_cus_w", 160, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them)"},
     {"dec_wino_wgrad", -1, "decoder Upsample(x2) + 3x3 layers: weight gradient in the Winograd form (9 of 16 transform positions; conv_wino_wgrad.hip): -1 from 8192 decoder rows up, 0 never, 1 whenever the shape allows"},
     {"dec_wino_cus_w", 256, "CUs those launches are sized for"},
+    {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions; conv_wino.hip): -1 the forward launches from 8192 decoder rows up (default), 0 never, 1 forward and data gradient whenever the shape allows, 2 / 3 forward / data gradient only"},
+    {"dec_wino_cus", 256, "CUs the decoder's Winograd forward launches are sized for"},
+    {"dec_wino_cus_d", 256, "... its data-gradient launches"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;

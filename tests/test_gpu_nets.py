@@ -258,6 +258,21 @@ def test_encoder_maxpool_exact_ties_route_to_first_element():
 
 @pytest.mark.parametrize("n,B,R", [(128, 8, 8), (64, 3, 1), (256, 5, 2), (192, 6, 2), (320, 4, 4), (448, 3, 2)])  # last three: UI sizes
 def test_decoder_matches_oracle_full_gradients(n, B, R):
+    _decoder_vs_oracle(n, B, R)
+
+
+@pytest.mark.parametrize("n,B,R", [(128, 8, 8), (256, 16, 2), (64, 32, 4)])
+def test_decoder_winograd_forms_match_oracle_full_gradients(n, B, R):
+    """The Upsample(x2) + ConvTranspose2d 3x3 layers in the Winograd form -- forward, data gradient and weight gradient
+    with 9 of the 16 transform positions (csrc/conv_wino.hip UM = 1 / 2, conv_wino_wgrad.hip UPS): the same float64
+    oracle comparison as the direct forms, same bars (options dec_wino / dec_wino_wgrad = 1 force the forms at these
+    sizes; by default they serve decoder batches of 8192 rows or more)."""
+    from image_generation_amd import _lib
+    with _lib.option_scope(dec_wino=1, dec_wino_wgrad=1):
+        _decoder_vs_oracle(n, B, R)
+
+
+def _decoder_vs_oracle(n, B, R):
     params = gen.make_params(n, "decoder", 21 + n)
     dec = _load(Decoder(n), params).train()
     p = _oracle_params(params)
