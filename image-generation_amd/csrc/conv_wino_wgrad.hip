@@ -297,42 +297,54 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   }
 }
 
-// dg = G^T (sum of the slabs' dU) G per (ci, co), written in the checkpoint layout; 8 lanes cooperate on one channel pair
-// (strided over the slabs, fixed-shape shuffle tree: deterministic).  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, WeightMap map,
-                                                                float* __restrict__ grad_w, int ups) {
-  const int64_t pairs = (int64_t)map.Ca * map.Cb, total = 16 * pairs;
+// Slab reduction in two passes.  (1) every (position, ci, co) element summed over the slabs by 8 lanes (strided over the
+// slabs, fixed-shape shuffle tree: deterministic), IN PLACE into slab 0 -- 16 Cin Cout work items: a one-pass form with one
+// item per channel pair had 64 workgroups for the decoder's 64 -> 32 layer, whose 512 slabs it then read for 405 us
+// in-situ, with the next layer's weight gradient waiting for the slab buffer behind it.  (2) dg = G^T dU G per channel
+// pair from slab 0, written in the checkpoint layout.  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+__global__ __launch_bounds__(256) void wino_wgrad_slabsum_kernel(float* __restrict__ slabs, int nslabs, int64_t pairs, int ups) {
+  const int64_t total = 16 * pairs;
   const int sub = threadIdx.x & 7;
-  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < pairs; e += ((int64_t)gridDim.x * 256) >> 3) {
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += ((int64_t)gridDim.x * 256) >> 3) {
+    const int p = (int)(e / pairs);
+    if (ups && ((p >> 2) == 2 || (p & 3) == 2)) continue;  // (upsampled layers: identically zero, never written)
+    float s = 0.f;
+    for (int k0 = sub; k0 < nslabs; k0 += 64) {  // eight loads in flight, summed in the same order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = k0 + 8 * u < nslabs ? slabs[(size_t)(k0 + 8 * u) * total + e] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (k0 + 8 * u < nslabs) s += v[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) slabs[e] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ du, WeightMap map, float* __restrict__ grad_w, int ups) {
+  const int64_t pairs = (int64_t)map.Ca * map.Cb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < pairs; e += (int64_t)gridDim.x * 256) {
     float u[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      float s = 0.f;
-      if (!(ups && ((p >> 2) == 2 || (p & 3) == 2)))  // (upsampled layers: positions with xi = 2 or nu = 2 are identically zero)
-        for (int k = sub; k < nslabs; k += 8) s += slabs[(size_t)k * total + (size_t)p * pairs + e];
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      u[p] = s;
+    for (int p = 0; p < 16; ++p) u[p] = (ups && ((p >> 2) == 2 || (p & 3) == 2)) ? 0.f : du[(size_t)p * pairs + e];
+    float t[3][4];  // G^T dU: rows r = 0..2 over xi
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      t[0][nu] = u[0 * 4 + nu] + 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]);
+      t[1][nu] = 0.5f * (u[1 * 4 + nu] - u[2 * 4 + nu]);
+      t[2][nu] = 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
     }
-    if (sub == 0) {
-      float t[3][4];  // G^T dU: rows r = 0..2 over xi
+    const int b = (int)(e % map.Cb), av = (int)(e / map.Cb);
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        t[0][nu] = u[0 * 4 + nu] + 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]);
-        t[1][nu] = 0.5f * (u[1 * 4 + nu] - u[2 * 4 + nu]);
-        t[2][nu] = 0.5f * (u[1 * 4 + nu] + u[2 * 4 + nu]) + u[3 * 4 + nu];
-      }
-      const int b = (int)(e % map.Cb), av = (int)(e / map.Cb);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-        const float g1 = 0.5f * (t[r][1] - t[r][2]);
-        const float g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
-        grad_w[torch_weight_offset(map, 3 * r + 0, av, b)] = g0;
-        grad_w[torch_weight_offset(map, 3 * r + 1, av, b)] = g1;
-        grad_w[torch_weight_offset(map, 3 * r + 2, av, b)] = g2;
-      }
+    for (int r = 0; r < 3; ++r) {
+      const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      const float g1 = 0.5f * (t[r][1] - t[r][2]);
+      const float g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+      grad_w[torch_weight_offset(map, 3 * r + 0, av, b)] = g0;
+      grad_w[torch_weight_offset(map, 3 * r + 1, av, b)] = g1;
+      grad_w[torch_weight_offset(map, 3 * r + 2, av, b)] = g2;
     }
   }
 }
@@ -376,9 +388,7 @@ bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   const int64_t o = opt(OPT_ENC_WINO_WGRAD);
   if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
   if (o >= 1) return true;
-  // (Cin = 32 -- the 32 x 64 tile with two K groups, a quarter of the block idle in the transforms -- runs at 0.86x the
-  // direct kernel alone: the first 3x3 layer keeps the direct form)
-  return Cin % 64 == 0 && Cout % 64 == 0 && conv_wino_ok(M, Cin, Cout, L, 0);
+  return conv_wino_ok(M, Cin, Cout, L, 0);
 }
 
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
@@ -419,9 +429,10 @@ int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin,
   }
   DVG_TRY(rc);
   const int64_t pairs = (int64_t)Cin * Cout;
-  int64_t blocks = (pairs * 8 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)slabs, g.nslabs, map, grad_w, ups);
+  int64_t blocks = (16 * pairs * 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_slabsum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, g.nslabs, pairs, ups);
+  DVG_LAUNCH(K_WGRAD_REDUCE, wino_wgrad_reduce_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, (const float*)slabs, map, grad_w, ups);
   return DVG_OK;
 }
 

@@ -21,8 +21,15 @@
  *     (3) one library-owned side stream + event ring per device, created under
  *     a mutex by the first *_workspace_bytes query or backward call on that
  *     device and used for the fork/join inside dvg_encoder_bwd /
- *     dvg_decoder_bwd.  Nothing else persists between calls; entry points are
- *     re-entrant per (stream, workspace).  HIP is initialised lazily by the
+ *     dvg_decoder_bwd, (4) the kernel-form options (dvg_set_option: named
+ *     integers, relaxed atomics, read per call).  RULE: options are ONE
+ *     configuration per process -- two models in one process cannot run under
+ *     different options concurrently (the plan-shaping ones are recorded per
+ *     workspace by a forward call, and a backward call under another plan fails
+ *     with DVG_E_INVALID instead of reading what its forward never wrote; the
+ *     grid-sizing ones -- enc_wino_cus and friends -- only move performance).
+ *     Nothing else persists between calls; entry points are re-entrant per
+ *     (stream, workspace).  HIP is initialised lazily by the
  *     first call in each process (the Dash app runs training in a spawned
  *     worker: /root/reference/app.py:37-43).
  */
