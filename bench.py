@@ -368,6 +368,9 @@ def main():
     ap.add_argument("--breakdown", default="", help="write the per-kernel HIP-event breakdown (JSON) to this path")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="a kernel-form option of the library (dvg_set_option), e.g. dec_lc0=0; may be repeated")
+    ap.add_argument("--batch", type=int, default=0, help="(with --child) override the configuration's batch size")
+    ap.add_argument("--wrapper", action="append", default=[], metavar="ATTR=VALUE",
+                    help="set a ModelWrapper attribute before the run (A/B measurements; not for the reported line)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="operands of the forward / data-gradient convolution GEMMs: f32 (the 1e-5 loss parity; the bench "
                          "line) or bf16 inputs with f32 accumulate (BASELINE.json configs[1] names bf16; reported beside it)")
@@ -382,6 +385,10 @@ def main():
         _cpu_leg(args.cpu_leg, args.threads, args.leg_warm, args.leg_steps, args.leg_seconds, args.leg_natural)
         return
     cfg = CONFIGS[args.config]
+    if args.batch > 0:  # size studies only (tools/): the reported line is always the named configuration
+        if not args.child:
+            raise SystemExit("--batch is for --child measurement runs")
+        cfg = CONFIGS[args.config] = dict(cfg, B=args.batch, desc=cfg["desc"] + f" [B overridden: {args.batch}]")
 
     from image_generation_amd import _lib
     from image_generation_amd.data import synthetic_images
@@ -426,6 +433,11 @@ def main():
     # launches); on every 10th step the GRBM quasi-NLL update runs eagerly behind it.  --eager disables the graph.
     # (several GPUs: two graphs per step with the eager RCCL all-reduce of the flat gradient buffer between them)
     model.use_graph = not args.eager
+    for kv in args.wrapper:  # A/B runs: ModelWrapper attributes (prepare_decoder=0, defer_mmd_join=1, ...)
+        name, _, value = kv.partition("=")
+        if not hasattr(model, name):
+            raise SystemExit(f"--wrapper: ModelWrapper has no attribute {name!r}")
+        setattr(model, name, {"none": None}.get(value.lower(), int(value) if value.lstrip("-").isdigit() else value))
     step_idx = 0
 
     def run(k):

@@ -135,6 +135,15 @@ SIGNATURES = {
         [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_int, POINTER(c_void_p), c_uint64, c_uint64, c_void_p,
          c_void_p, c_size_t, c_void_p, c_void_p],
     ),
+    "dvg_decoder_prepare": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_int64, c_int, c_uint64, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p],
+    ),
+    "dvg_decoder_fwd_ex": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_int, POINTER(c_void_p), c_uint64, c_uint64, c_void_p,
+         c_void_p, c_size_t, c_void_p, c_int, c_void_p],
+    ),
     "dvg_decoder_bwd": (
         c_int,
         [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_void_p, POINTER(DecoderGrads), c_void_p, c_void_p,

@@ -97,6 +97,10 @@ bool side_enabled();
 void side_stream_warm();  // create the current device's side stream + event ring now (outside any capture)
 hipStream_t side_stream(hipStream_t fallback);
 int stream_order_after(hipStream_t waiter, hipStream_t producer);
+// Weight-only prologues (streams.cpp): the per-workspace mark between dvg_decoder_prepare and the forward call that
+// consumes it.
+int prep_arm(const void* ws, uint64_t sig, hipStream_t producer);
+int prep_join(const void* ws, uint64_t sig, hipStream_t waiter, bool* armed, bool* matched);
 // The same in two halves: mark a point of `producer` now, make `waiter` wait for exactly that point later.
 int stream_mark(hipStream_t producer, hipEvent_t* mark);
 int stream_wait_mark(hipStream_t waiter, hipEvent_t mark);

@@ -195,18 +195,12 @@ extern "C" size_t dvg_decoder_workspace_bytes(int64_t N, int n_latents) {
   return dec_plan(N, n_latents).total_floats * sizeof(float);
 }
 
-extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
-                               const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
-                               size_t ws_bytes, const dvg_step_state_t* dyn, dvg_stream_t stream) {
-  const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
-  DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
-  conv_precision_note_forward(ws);
-  plan_note_forward(ws, plan_signature(pl));
-  DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
-  hipStream_t s = (hipStream_t)stream;
-  float* W = (float*)ws;
-
-  // Linear(n, 4n) -> X0 (N, 2x2 Morton, n)
+namespace {
+// Everything of a forward call that depends on the parameters (and the dropout stream) alone: the weight packs, the
+// composed Linear o ConvTranspose weights and bias, the Dropout2d keep-masks.  dvg_decoder_fwd runs it at its head;
+// dvg_decoder_prepare runs it ahead of time, beside whatever produces the spins.
+int dec_prologue(const dvg_decoder_params_t* p, int n, int64_t N, int training, const float* const dropout_keep[4],
+                 uint64_t seed, uint64_t offset, float* W, const DecPlan& pl, const dvg_step_state_t* dyn, hipStream_t s) {
   {  // all weight packs of the network (forward AND data-gradient layouts) in one launch
     PackJob jobs[8];
     jobs[0] = PackJob{p->lin_w, W + pl.wp_lin, WeightMap{WM_LIN_FWD, n, 4 * n, 1}, 0, N};
@@ -246,12 +240,6 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
     a.in = W + pl.wpd_lin; a.wp = W + pl.wp[0]; a.out = W + pl.Wc; a.M = n; a.Cin = 4 * n; a.Cout = 4 * C;
     DVG_TRY(launch_conv_igemm(a, s));
     DVG_TRY(launch_lc0_bias(p->lin_b, W + pl.wp[0], p->conv_b[0], n, C, W + pl.bc, s));
-  } else {
-    ConvArgs a;
-    a.in = spins; a.wp = W + pl.wp_lin; a.bias = p->lin_b; a.bias_perm = n; a.out = W + pl.X0; a.stats = nullptr;  // bias'[p*n + c] = b[c*4 + p]
-    a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
-    a.splitk_ws = W + pl.splitk;
-    DVG_TRY(launch_conv_igemm(a, s));
   }
   if (training) {  // Dropout2d keep-masks of all four stages: copied in (parity runs) or drawn on device, one launch
     bool given = dropout_keep != nullptr;
@@ -266,6 +254,61 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
       float* masks[4] = {W + pl.mask[0], W + pl.mask[1], W + pl.mask[2], W + pl.mask[3]};
       DVG_TRY(launch_dropout_masks(N, &pl.ch[1], masks, seed, offset, dyn ? &dyn->dropout_offset : nullptr, s));
     }
+  }
+  return DVG_OK;
+}
+
+uint64_t prologue_signature(const dvg_decoder_params_t* p, int n, int64_t N, int training, uint64_t seed, uint64_t offset,
+                            const dvg_step_state_t* dyn, const DecPlan& pl) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+  mix((uint64_t)n); mix((uint64_t)N); mix((uint64_t)training); mix(seed); mix(dyn ? ~0ull : offset); mix((uint64_t)(uintptr_t)dyn);
+  mix(plan_signature(pl)); mix((uint64_t)conv_precision_mode()); mix((uint64_t)(uintptr_t)p->lin_w); mix((uint64_t)(uintptr_t)p->conv_w[0]);
+  return h;
+}
+}  // namespace
+
+// The weight-only part of the NEXT dvg_decoder_fwd_ex(prepared = 1) on this workspace, enqueued on `stream` now: a
+// stream of the caller's that is forked off its main stream where the step starts, so that the packs, weight-space
+// products and mask draws (~190 us at B R = 32768) run beside the encoder instead of between the spins and the
+// decoder's first GEMM; the forward call joins them (an event recorded here, waited for there).  The parameters must not
+// change between the two calls; device-drawn dropout masks only (injected masks: call dvg_decoder_fwd, which copies them).
+extern "C" int dvg_decoder_prepare(const dvg_decoder_params_t* p, int n, int64_t N, int training, uint64_t seed,
+                                   uint64_t offset, void* ws, size_t ws_bytes, const dvg_step_state_t* dyn,
+                                   dvg_stream_t stream) {
+  const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  hipStream_t s = (hipStream_t)stream;
+  DVG_TRY(dec_prologue(p, n, N, training, nullptr, seed, offset, (float*)ws, pl, dyn, s));
+  return prep_arm(ws, prologue_signature(p, n, N, training, seed, offset, dyn, pl), s);
+}
+
+extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
+                                  const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
+                                  size_t ws_bytes, const dvg_step_state_t* dyn, int prepared, dvg_stream_t stream) {
+  const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
+  DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
+  conv_precision_note_forward(ws);
+  plan_note_forward(ws, plan_signature(pl));
+  DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
+  hipStream_t s = (hipStream_t)stream;
+  float* W = (float*)ws;
+  {
+    // a prologue in flight on this workspace is joined whatever it was prepared for (it writes what this call reads
+    // or rewrites); it is USED only when the caller says so and it was prepared for exactly this call
+    bool armed = false, matched = false;
+    DVG_TRY(prep_join(ws, prologue_signature(p, n, N, training, seed, offset, dyn, pl), s, &armed, &matched));
+    DVG_REQUIRE(!prepared || (armed && matched && dropout_keep == nullptr),
+                "decoder_fwd: prepared = 1 without a matching dvg_decoder_prepare on this workspace (same parameters, N, "
+                "training flag, dropout seed / offset, kernel-form options; device-drawn masks)");
+    if (!prepared) DVG_TRY(dec_prologue(p, n, N, training, dropout_keep, seed, offset, W, pl, dyn, s));
+  }
+  if (!pl.lc0) {  // Linear(n, 4n) -> X0 (N, 2x2 Morton, n)
+    ConvArgs a;
+    a.in = spins; a.wp = W + pl.wp_lin; a.bias = p->lin_b; a.bias_perm = n; a.out = W + pl.X0; a.stats = nullptr;  // bias'[p*n + c] = b[c*4 + p]
+    a.M = N; a.Cin = n; a.Cout = 4 * n; a.L = 0; a.ntaps = 1; a.ups = 0; a.poolsum = 0;
+    a.splitk_ws = W + pl.splitk;
+    DVG_TRY(launch_conv_igemm(a, s));
   }
   const float* x = W + pl.X0;
   for (int l = 0; l < 4; ++l) {
@@ -305,6 +348,12 @@ extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float
   }
   DVG_TRY(launch_dec_final_fwd(x, N, p->conv_w[4], p->conv_b[4], out, s));
   return DVG_OK;
+}
+
+extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
+                               const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
+                               size_t ws_bytes, const dvg_step_state_t* dyn, dvg_stream_t stream) {
+  return dvg_decoder_fwd_ex(p, n, spins, N, training, dropout_keep, seed, offset, out, ws, ws_bytes, dyn, 0, stream);
 }
 
 extern "C" int dvg_decoder_bwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,

@@ -40,7 +40,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"enc_wino_cus", 256, "Winograd FORWARD launches of a training call: CUs the persistent grid is sized for -- a workgroup needs a whole CU, and the step's sampler draw, enqueued first, keeps its own (ModelWrapper sets 256 - the draw's workgroups, dvg_gibbs_launch_info)"},
     {"enc_wino_cus_d", 128, "the same for the data-gradient launches, which share the chip with the weight-gradient chain on the side stream (measured at c3: 128 -> 10.16 ms, 192 -> 10.23, 256 -> 10.6)"},
     {"enc_wino_wgrad", -1, "encoder 3x3 WEIGHT gradients in the Winograd form (conv_wino_wgrad.hip): -1 with the other training launches (default), 0 never, 1 whenever the shape allows"},
-    {"enc_wino_cus_w", 128, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them)"},
+    {"enc_wino_cus_w", 128, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them; measured at c3 with enc_wino_cus_d: (128, 128) 9.40 ms, (160, 96) 9.64, (192, 64) 10.09, (192, 128) 9.41, (256, 128) 9.45; a budget of its own for layer 1's launch, the last of the step: neutral)"},
     {"dec_wino_wgrad", -1, "decoder Upsample(x2) + 3x3 layers: weight gradient in the Winograd form (9 of 16 transform positions; conv_wino_wgrad.hip): -1 from 8192 decoder rows up, 0 never, 1 whenever the shape allows"},
     {"dec_wino_cus_w", 256, "CUs those launches are sized for"},
     {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions; conv_wino.hip): -1 the forward launches from 8192 decoder rows up (default), 0 never, 1 forward and data gradient whenever the shape allows, 2 / 3 forward / data gradient only"},

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
@@ -56,6 +57,44 @@ hipStream_t side_stream(hipStream_t fallback) {
   if (!side_enabled()) return fallback;
   SideCtx* c = ctx();
   return c ? c->side : fallback;
+}
+
+// Per-workspace mark of a prologue in flight (dvg_decoder_prepare -> dvg_decoder_fwd_ex): its own event (the ring above is
+// reused after kEvents marks, and a whole encoder pass lies between the two calls) and the signature of what was prepared.
+namespace {
+struct PrepMark { hipEvent_t ev = nullptr; uint64_t sig = 0; bool armed = false; };
+std::mutex g_prep_mu;
+std::unordered_map<const void*, PrepMark> g_prep;
+}
+
+int prep_arm(const void* ws, uint64_t sig, hipStream_t producer) {
+  std::lock_guard<std::mutex> lock(g_prep_mu);
+  if (g_prep.size() > 256 && g_prep.find(ws) == g_prep.end()) {  // bounded: drop the marks nobody is waiting for
+    for (auto it = g_prep.begin(); it != g_prep.end();) {
+      if (!it->second.armed) { if (it->second.ev) (void)hipEventDestroy(it->second.ev); it = g_prep.erase(it); }
+      else ++it;
+    }
+  }
+  PrepMark& m = g_prep[ws];
+  if (!m.ev) DVG_CHECK_HIP(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+  DVG_CHECK_HIP(hipEventRecord(m.ev, producer));
+  m.sig = sig;
+  m.armed = true;
+  return DVG_OK;
+}
+
+// If a prologue is in flight for `ws`: `waiter` waits for it and the mark is consumed.  *armed / *matched report whether
+// there was one and whether it was prepared for `sig`.
+int prep_join(const void* ws, uint64_t sig, hipStream_t waiter, bool* armed, bool* matched) {
+  std::lock_guard<std::mutex> lock(g_prep_mu);
+  *armed = *matched = false;
+  auto it = g_prep.find(ws);
+  if (it == g_prep.end() || !it->second.armed) return DVG_OK;
+  *armed = true;
+  *matched = it->second.sig == sig;
+  it->second.armed = false;
+  DVG_CHECK_HIP(hipStreamWaitEvent(waiter, it->second.ev, 0));
+  return DVG_OK;
 }
 
 int stream_mark(hipStream_t producer, hipEvent_t* mark) {

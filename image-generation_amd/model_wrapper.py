@@ -87,6 +87,10 @@ class ModelWrapper:
         # use_graph: replay the autoencoder half of the step from a captured hipGraph (needs sync_losses = False);
         # ~120 kernel launches become one graph launch.  Off by default; bench.py turns it on.
         self.use_graph = False
+        # prepare_decoder: enqueue the decoder's weight-only prologue at the start of the step, beside the encoder
+        # (None: from PREPARE_DECODER_ROWS decoder rows up; True / False force it)
+        self.prepare_decoder = None
+        self._prep_stream = None
         # Replayed steps write their losses into the graph's static output tensors.  keep_step_losses = True (default)
         # appends a COPY per step to self.losses (two tiny device copies, ~0.5 % of a c2 step), as the reference's lists
         # hold one value per step; False appends nothing (throughput runs: self.last still holds the latest values).
@@ -468,6 +472,8 @@ class ModelWrapper:
             # The MMD needs only the spins and the draw, so it follows the draw on the side stream and runs under
             # the decoder forward and the MSE; the streams join before the two losses are added.
             main, side = torch.cuda.current_stream(self._device), self._side_stream
+            # (enqueued BEHIND the draw: a replayed graph submits its nodes in capture order, and the draw is the long pole)
+            self._prepare_decoder(images, main)
             latents = self._dvae.encoder(images)
             # The default (Gumbel) latent_to_discrete runs outside autograd: its backward is fed the SUM of the two spin
             # gradients (through the decoder and from the MMD) by ONE kernel -- dvg_gumbel_bwd2 -- instead of an add pass
@@ -697,6 +703,24 @@ class ModelWrapper:
             self.losses["dvae_losses"].append(dvae.clone())
         self.last.update(mse=mse, mmd=mmd)
         return mse, spins
+
+    # Below this many decoder rows (B * R) the prologue is left at the head of the decoder's forward: the extra fork / join
+    # of the captured step costs 40-70 us (measured at B R = 2048 ... 16384), more than the 20-60 us the prologue takes
+    # there; at 32768 rows it takes 190 us (the composed Linear o ConvTranspose weights) and the step gains 0.10-0.15 ms.
+    PREPARE_DECODER_ROWS = 32768
+
+    def _prepare_decoder(self, images, main) -> None:
+        """The decoder's weight-only prologue (packs, composed weights, dropout masks: ``Decoder.prepare``) on a stream
+        forked off the main stream where the step starts: it runs beside the encoder instead of between the spins and
+        the decoder's first GEMM, and the decoder's forward joins it.  ``prepare_decoder`` = True / False forces it."""
+        N = int(images.shape[0]) * self.N_REPLICAS
+        want = self.prepare_decoder if self.prepare_decoder is not None else N >= self.PREPARE_DECODER_ROWS
+        if not want or self._device.type != "cuda":
+            return
+        if self._prep_stream is None:
+            self._prep_stream = torch.cuda.Stream(device=self._device)
+        self._prep_stream.wait_stream(main)  # (the previous step's Adam has landed)
+        self._dvae.decoder.prepare(N, self._prep_stream)
 
     def _draw_overlapped(self):
         if self._device.type != "cuda":

@@ -170,8 +170,12 @@ class _DecoderFn(torch.autograd.Function):
         N = B * R
         st = module._native_struct(params)
         out = torch.empty((B, R, 1, 32, 32), dtype=torch.float32, device=x.device)
-        ws = _ws(L.dvg_decoder_workspace_bytes(N, n), x.device)
         training = bool(module.training)
+        # a prologue enqueued ahead of time (Decoder.prepare) is used when it was made for exactly this call
+        prep, module._prepared = module._prepared, None
+        prepared = (prep is not None and masks is None and prep["key"] == (N, n, training, int(seed), int(offset), x.device)
+                    and all(a.data_ptr() == b.data_ptr() for a, b in zip(prep["params"], params)))
+        ws = prep["ws"] if prepared else _ws(L.dvg_decoder_workspace_bytes(N, n), x.device)
         mask_arr = (ctypes.c_void_p * 4)()
         keep = []
         if training and masks is not None:
@@ -182,9 +186,13 @@ class _DecoderFn(torch.autograd.Function):
                 keep.append(m)
                 mask_arr[l] = m.data_ptr()
         with torch.cuda.device(x.device):
-            check(L.dvg_decoder_fwd(ctypes.byref(st), n, x.data_ptr(), N, int(training),
-                                    mask_arr if keep else None, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
-                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.DYN, stream_ptr(x.device)), "dvg_decoder_fwd")
+            if prep is not None and not prepared:
+                # made for another call (shape, mode or parameters changed in between): wait it out and do without
+                torch.cuda.current_stream(x.device).wait_stream(prep["stream"])
+            check(L.dvg_decoder_fwd_ex(ctypes.byref(st), n, x.data_ptr(), N, int(training),
+                                       mask_arr if keep else None, int(seed) & (2**64 - 1), int(offset) & (2**64 - 1),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.DYN, int(prepared),
+                                       stream_ptr(x.device)), "dvg_decoder_fwd_ex")
         ctx.module, ctx.training, ctx.shape = module, training, (B, R, n)
         ctx.need_input_grad = spins.requires_grad
         ctx.save_for_backward(x, ws, *params)
@@ -251,6 +259,7 @@ class Decoder(torch.nn.Module):
         self._dropout_calls = 0
         self._defer_join = False     # see _DecoderFn.backward; set and cleared by ModelWrapper around its own step
         self._deferred_keep = None   # tensors the library's side stream may still touch until the deferred join
+        self._prepared = None        # see prepare(): the prologue of the next forward, already enqueued
 
     def inject_dropout_masks(self, masks: Optional[List[torch.Tensor]]):
         """Use these keep-masks for the next training forward instead of the device RNG."""
@@ -277,6 +286,29 @@ class Decoder(torch.nn.Module):
             st.bn_nbt[l] = bn.num_batches_tracked.data_ptr()
         st.conv_w[4], st.conv_b[4] = params[18].data_ptr(), params[19].data_ptr()
         return st
+
+    def prepare(self, N: int, stream: "torch.cuda.Stream") -> None:
+        """Enqueues, on ``stream``, the part of the next ``forward`` over ``N = B * R`` latent rows that needs the
+        parameters and the dropout stream only (weight packs, composed weights, keep-masks: ``dvg_decoder_prepare``).
+        ``stream`` must already be ordered behind the last parameter update and behind whatever used the memory before
+        (``stream.wait_stream(main)`` where the step starts); the forward call joins it.  Without a matching forward the
+        preparation is dropped."""
+        if self._injected_masks is not None:
+            return
+        params = self._trainable()
+        dev = params[0].device
+        if dev.type != "cuda":
+            return
+        L = lib()
+        n, training = self.n_latents, bool(self.training)
+        st = self._native_struct(params)
+        ws = _ws(L.dvg_decoder_workspace_bytes(N, n), dev)  # (from the CURRENT stream's pool: that is where it lives on)
+        seed, offset = int(self.dropout_seed), int(self._dropout_calls)
+        with torch.cuda.device(dev):
+            check(L.dvg_decoder_prepare(ctypes.byref(st), n, N, int(training), seed & (2**64 - 1), offset & (2**64 - 1),
+                                        ws.data_ptr(), ws.numel(), _lib.DYN, stream.cuda_stream), "dvg_decoder_prepare")
+        self._prepared = {"key": (N, n, training, seed, offset, dev), "params": tuple(params), "ws": ws, "st": st,
+                          "stream": stream}
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         masks, self._injected_masks = self._injected_masks, None

@@ -245,6 +245,21 @@ int dvg_decoder_fwd(const dvg_decoder_params_t *p, int n_latents, const float *s
                     int training, const float *const dropout_keep[4], uint64_t seed,
                     uint64_t offset, float *out, void *ws, size_t ws_bytes, const dvg_step_state_t *dyn,
                     dvg_stream_t stream);
+/* The part of a forward call that depends on the parameters and the dropout stream alone (weight packs, the composed
+ * Linear o ConvTranspose weights, the Dropout2d keep-masks), enqueued on `stream` ahead of time: a training step hands
+ * in a stream forked off its main stream where the step starts, so that these launches (~190 us at B R = 32768) run
+ * beside the encoder instead of between the spins and the decoder's first GEMM.  The next
+ * dvg_decoder_fwd_ex(..., prepared = 1, ...) on the same workspace waits for them (an event recorded here) and skips
+ * its own prologue; it fails unless it is called with the same parameters, N, training flag, seed / offset / dyn and
+ * kernel-form options, which must not change in between.  A forward call with prepared = 0 (dvg_decoder_fwd) joins a
+ * prologue in flight on its workspace and then ignores it.  Device-drawn dropout masks only. */
+int dvg_decoder_prepare(const dvg_decoder_params_t *p, int n_latents, int64_t N, int training, uint64_t seed,
+                        uint64_t offset, void *ws, size_t ws_bytes, const dvg_step_state_t *dyn,
+                        dvg_stream_t stream);
+int dvg_decoder_fwd_ex(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                       int training, const float *const dropout_keep[4], uint64_t seed, uint64_t offset,
+                       float *out, void *ws, size_t ws_bytes, const dvg_step_state_t *dyn, int prepared,
+                       dvg_stream_t stream);
 int dvg_decoder_bwd(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
                     const float *grad_out, const dvg_decoder_grads_t *grads,
                     float *grad_spins /* (N,n) or NULL */, void *ws, size_t ws_bytes,

@@ -139,6 +139,81 @@ def test_deferred_mmd_join_is_bit_identical(golden_dir):
             assert torch.equal(sd_ref[k], sd[k]), (k, use_graph)
 
 
+def test_prepared_decoder_prologue_is_bit_identical(golden_dir):
+    """The decoder's weight-only prologue enqueued where the step starts (ModelWrapper.prepare_decoder, the form steps of
+    >= 32768 decoder rows take; dvg_decoder_prepare + dvg_decoder_fwd_ex(prepared = 1)) changes the schedule, not the
+    arithmetic: same dropout masks, same losses and same weights as the call that runs its own prologue, eager and
+    replayed -- with the dense first layer composed into the Linear layer (dec_lc0 = 1: the weight-space products are
+    part of the prologue) and without."""
+    from image_generation_amd import _lib
+
+    def run(prepare, use_graph):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=64, training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        imgs = torch.from_numpy(gen.make_images(B * 6, seed=5)).reshape(6, B, 1, 32, 32).cuda()
+        m.set_dataloader([(imgs[k], None) for k in range(6)])
+        m.train_init(1)
+        m.sync_losses = False
+        m.use_graph = use_graph
+        m.prepare_decoder = prepare
+        out = []
+        for k in range(6):
+            m.step((imgs[k], None), epoch=0)
+            out.append((float(m.last["mse"]), float(m.last["mmd"])))
+            assert m._dvae.decoder._prepared is None  # (consumed by the step's forward)
+        torch.cuda.synchronize()
+        return out, {k: v.clone() for k, v in m._dvae.state_dict().items()}
+
+    for lc0 in (-1, 1):
+        _lib.set_option("dec_lc0", lc0)
+        try:
+            ref, sd_ref = run(False, False)
+            for use_graph in (False, True):
+                got, sd = run(True, use_graph)
+                assert got == ref, (lc0, use_graph)
+                for k in sd_ref:
+                    assert torch.equal(sd_ref[k], sd[k]), (k, lc0, use_graph)
+        finally:
+            _lib.check(_lib.lib().dvg_reset_options())
+
+
+def test_decoder_prepare_is_checked_against_the_forward_call():
+    """dvg_decoder_fwd_ex(prepared = 1) fails loudly without a matching dvg_decoder_prepare; a preparation made for another
+    shape is dropped by the module (the forward runs its own prologue) and the result is the unprepared one."""
+    import ctypes
+    from image_generation_amd import _lib
+    from image_generation_amd.modules import Decoder
+
+    torch.manual_seed(1)
+    dec = Decoder(64).cuda().train()
+    x = torch.randn(32, 8, 64, device="cuda").sign()
+    side = torch.cuda.Stream()
+
+    def fwd(prepare_rows):
+        dec._dropout_calls = 0
+        if prepare_rows:
+            side.wait_stream(torch.cuda.current_stream())
+            dec.prepare(prepare_rows, side)
+        out = dec(x)
+        torch.cuda.synchronize()
+        return out.detach().clone()
+
+    plain = fwd(0)
+    assert torch.equal(fwd(256), plain)   # prepared for this call
+    assert torch.equal(fwd(128), plain)   # prepared for another N: dropped
+    assert dec._prepared is None
+    # straight at the C ABI: prepared = 1 on a workspace nobody prepared
+    L = _lib.lib()
+    params = dec._trainable()
+    st = dec._native_struct(params)
+    ws = torch.empty(L.dvg_decoder_workspace_bytes(256, 64), dtype=torch.uint8, device="cuda")
+    out = torch.empty(256 * 1024, device="cuda")
+    rc = L.dvg_decoder_fwd_ex(ctypes.byref(st), 64, x.data_ptr(), 256, 1, None, 0, 0, out.data_ptr(), ws.data_ptr(),
+                              ws.numel(), None, 1, _lib.stream_ptr(x.device))
+    assert rc != 0 and b"prepared = 1 without a matching dvg_decoder_prepare" in L.dvg_last_error()
+
+
 def test_bf16_conv_precision_trains_and_tracks_f32(tmp_path, golden_dir):
     """CONV_PRECISION: bf16 in the YAML switches the library's forward / data-gradient GEMMs to bf16 inputs (f32
     accumulate).  Same batches, same noise streams: the losses follow the float32 run at bf16's precision (percent level,
