@@ -91,6 +91,35 @@ __host__ __device__ __forceinline__ float packed_weight(const float* w, const We
   return acc;
 }
 
+// One (a, b) entry of the Winograd weight pack U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] (conv_wino.hip):
+// u[e][16] with e = a Cb + b, the four 16-byte slots (one per row of U) XOR-swizzled by (b >> 2) & 3.
+__device__ __forceinline__ void wino_pack_entry(const float* __restrict__ w, const WeightMap& map, uint32_t e,
+                                                float* __restrict__ u) {
+  typedef float pack_f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t av = e / (uint32_t)map.Cb, b = e - av * (uint32_t)map.Cb;
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = packed_weight(w, map, t, (int)av, (int)b);
+  float tg[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    tg[0][s] = g[s];
+    tg[1][s] = 0.5f * ((g[s] + g[3 + s]) + g[6 + s]);
+    tg[2][s] = 0.5f * ((g[s] - g[3 + s]) + g[6 + s]);
+    tg[3][s] = g[6 + s];
+  }
+  const int sw = (int)(b >> 2) & 3;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    pack_f32x4 o;
+    o[0] = tg[x][0];
+    o[1] = 0.5f * ((tg[x][0] + tg[x][1]) + tg[x][2]);
+    o[2] = 0.5f * ((tg[x][0] - tg[x][1]) + tg[x][2]);
+    o[3] = tg[x][2];
+    *reinterpret_cast<pack_f32x4*>(u + (size_t)e * 16 + ((x ^ sw) << 2)) = o;
+  }
+}
+
 // Implicit-GEMM 3x3 (or 1-tap) convolution:  out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] Wp[tap][ci][co] (+ bias)
 struct ConvArgs {
   const float* in;    // [(images * HW_in), Cin]; HW_in = HW/4 when `ups` (nearest-upsampled on the fly)
@@ -210,11 +239,12 @@ int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStrea
 // bf16t: the operand form of the launch the pack feeds (conv_launch_mode): 0 -> [tap][a][b], 3 / 4 / 5 -> K-major [tap][b][a]
 // rows: GEMM rows of the launch this pack feeds (launch_conv_igemm's M over all classes): together with map.Cb it
 // decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
-struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; };
+// wino = 1: the job writes the Winograd pack [Ca][Cb][16] of a 9-tap map instead (wino_pack_entry)
+struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; int wino = 0; };
 // operand form of one forward / data-gradient launch (ConvArgs.bf16): the process-wide mode mapped onto the kernels
 int conv_launch_mode(int64_t gemm_rows, int Cout);
 bool conv_pack_is_f32_kmajor(int launch_mode);  // the pack such a launch reads is the float32 K-major one
-constexpr int MAX_PACK_JOBS = 8;
+constexpr int MAX_PACK_JOBS = 12;
 int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s);
 
 }  // namespace dvg

@@ -851,16 +851,20 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const float* __restric
 
 struct PackJobs { PackJob job[MAX_PACK_JOBS]; };
 
+// (32-bit index arithmetic: a pack has < 2^31 entries, and the 64-bit divisions of the one-job kernel above were most of
+// this launch's time at small sizes -- it sits at the head of every forward call; one entry per thread up to 2048 x 256)
 __global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
   const PackJob& j = jobs.job[blockIdx.y];
   const WeightMap map = j.map;
-  const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int b = (int)(e % map.Cb);
-    const int a = (int)((e / map.Cb) % map.Ca);
-    const int tap = (int)(e / ((int64_t)map.Cb * map.Ca));
-    const float v = packed_weight(j.w, map, tap, a, b);
-    pack_store(j.wp, total, ((int64_t)tap * map.Cb + b) * map.Ca + a, e, v, j.bf16t);
+  const uint32_t Ca = (uint32_t)map.Ca, Cb = (uint32_t)map.Cb, total = (uint32_t)map.ntaps * Ca * Cb;
+  if (j.wino) {
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < Ca * Cb; e += gridDim.x * 256u) wino_pack_entry(j.w, map, e, j.wp);
+    return;
+  }
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    const uint32_t q = e / Cb, b = e - q * Cb, tap = q / Ca, a = q - tap * Ca;
+    const float v = packed_weight(j.w, map, (int)tap, (int)a, (int)b);
+    pack_store(j.wp, total, (int64_t)((tap * Cb + b) * Ca + a), e, v, j.bf16t);
   }
 }
 
@@ -875,8 +879,9 @@ int launch_weight_pack_multi(const PackJob* jobs, int njobs, hipStream_t s) {
     const int64_t t = (int64_t)jobs[k].map.ntaps * jobs[k].map.Ca * jobs[k].map.Cb;
     if (t > biggest) biggest = t;
   }
-  int64_t gx = ceil_div(biggest, 256 * 4);
-  if (gx > 256) gx = 256;
+  if (biggest >= (int64_t)1 << 31) { set_error("weight_pack_multi: a pack of %lld entries", (long long)biggest); return DVG_E_INVALID; }
+  int64_t gx = ceil_div(biggest, 256);
+  if (gx > 2048) gx = 2048;
   if (gx < 1) gx = 1;
   DVG_LAUNCH(K_WEIGHT_PACK, weight_pack_multi_kernel, dim3((unsigned)gx, (unsigned)njobs), dim3(256), 0, s, pj);
   return DVG_OK;

@@ -401,31 +401,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
 
 // U = G g G^T of every (reduction channel a, output channel b) pair, in the layout the kernel's DMA copies verbatim
 __global__ __launch_bounds__(256) void wino_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u) {
-  const int64_t total = (int64_t)map.Ca * map.Cb;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int b = (int)(e % map.Cb), av = (int)(e / map.Cb);
-    float g[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t] = packed_weight(w, map, t, av, b);
-    float tg[4][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      tg[0][s] = g[s];
-      tg[1][s] = 0.5f * ((g[s] + g[3 + s]) + g[6 + s]);
-      tg[2][s] = 0.5f * ((g[s] - g[3 + s]) + g[6 + s]);
-      tg[3][s] = g[6 + s];
-    }
-    const int sw = (b >> 2) & 3;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      f32x4 o;
-      o[0] = tg[x][0];
-      o[1] = 0.5f * ((tg[x][0] + tg[x][1]) + tg[x][2]);
-      o[2] = 0.5f * ((tg[x][0] - tg[x][1]) + tg[x][2]);
-      o[3] = tg[x][2];
-      *reinterpret_cast<f32x4*>(u + e * 16 + ((x ^ sw) << 2)) = o;
-    }
-  }
+  const uint32_t total = (uint32_t)map.Ca * (uint32_t)map.Cb;
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) wino_pack_entry(w, map, e, u);
 }
 
 int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s) {

@@ -220,12 +220,12 @@ int dec_prologue(const dvg_decoder_params_t* p, int n, int64_t N, int training, 
       jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l]};
       jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l]};
     }
-    DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
     // Winograd launches (conv_wino.hip, wino_um = 1 / 2) read the transformed pack U = G g G^T instead
     for (int l = 1; l < 3; ++l) {
-      if (pl.wino_f[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, W + pl.wp[l], s));
-      if (pl.wino_d[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, W + pl.wpd[l], s));
+      if (pl.wino_f[l]) jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l], 1};
+      if (pl.wino_d[l]) jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l], 1};
     }
+    DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
   }
   if (pl.lc0) {
     // composed weight, both orientations (K-major operands of the forward and of the data-gradient GEMM), and bias:

@@ -150,12 +150,10 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
     int nj = 0;
     for (int l = 1; l < 4; ++l) {
       const WeightMap mf{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}, md{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9};
-      if (pl.wino_f[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], mf, W + pl.wp[l], s));
-      else jobs[nj++] = PackJob{p->conv_w[l], W + pl.wp[l], mf, 0, pl.M[l]};
-      if (pl.wino_d[l]) DVG_TRY(launch_wino_weight_pack(p->conv_w[l], md, W + pl.wpd[l], s));
-      else jobs[nj++] = PackJob{p->conv_w[l], W + pl.wpd[l], md, 0, pl.M[l]};
+      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wp[l], mf, 0, pl.M[l], pl.wino_f[l] ? 1 : 0};  // (Winograd launches read U = G g G^T)
+      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wpd[l], md, 0, pl.M[l], pl.wino_d[l] ? 1 : 0};
     }
-    if (nj > 0) DVG_TRY(launch_weight_pack_multi(jobs, nj, s));
+    DVG_TRY(launch_weight_pack_multi(jobs, nj, s));
   }
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];

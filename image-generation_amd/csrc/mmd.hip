@@ -1593,7 +1593,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     i32x2 ent[RMAX];
 
     auto iteration = [&](int k, auto parity, i32x16& Scur, i32x16& Snext) {
-      constexpr int P = decltype(parity)::value;
+      (void)parity;  // (the two instantiations differ in which accumulator set is current: Scur / Snext)
       // ---- top: the one barrier (behind the wait for this wave's pieces of the previous iteration), the rare fixup
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
