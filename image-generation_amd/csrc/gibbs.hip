@@ -17,9 +17,10 @@
 namespace dvg {
 
 struct GibbsArgs {
-  const int32_t *order, *class_ptr, *adj_ptr, *adj_idx, *adj_eid;
+  const int32_t *order, *class_ptr, *adj_idx, *adj_eid;
+  const int32_t *adj_row, *adj_src4;  // padded-row image (graph.h)
   const float *linear, *quadratic;
-  int n, n_adj, n_colours;
+  int n, n_batches, max_batches, n_colours;
   float prefactor, h_lo, h_hi, j_lo, j_hi, two_beta;
   int8_t* state;
   float* samples_out;
@@ -32,41 +33,137 @@ struct GibbsArgs {
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
-// LPC = lanes per chain (16, 32 or 64); WAVES waves per workgroup.
+// ---------------------------------------------------------------- the LDS image and the neighbour sum (round 4)
+// The local field of a spin is  f = h_i + sum over its CSR row, IN ROW ORDER, of (s_j > 0 ? +J : -J)  in float32, each add
+// rounded (oracle/gibbs.py, "DVG block-Gibbs v1").  Rounds 1-3 spent ~12 VALU and 3.4 LDS instructions per neighbour on it
+// (index clamping, three address computations, compare / select / add); this form spends 3 and 1.5, for the same bits:
+//   * the state of a chain is kept as float16 +-1 in LDS, and the add is ONE v_fma_mix_f32:  fma(s, J, f) = rn(s J + f)
+//     with s J = +-J exact, i.e. exactly rn(f +- J) -- the same single rounding as the add it replaces;
+//   * rows are padded to whole batches of 4 entries (J = 0, any valid state: rn(f +- 0) = f; only the LAST partial sum
+//     can see a pad, and a -0 turned +0 there is the same exp(0)), so a batch is one ds_read_b128 of couplings and one
+//     ds_read_b64 of four 16-bit state offsets at immediate offsets from one address -- no per-neighbour index math;
+//   * every lane walks the same NB batches per round (NB = 5: 20 neighbours, the degree of the Zephyr graphs); a lane
+//     whose row is shorter reads the image's all-zero batch instead (one compare / select per BATCH), so the loads of a
+//     round are one straight line: 2 NB reads, then 4 NB state reads, then 4 NB dependent fmas.
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t gu32x2 __attribute__((ext_vector_type(2)));
+constexpr int GIBBS_NB = 5;
+
+struct GibbsLds {
+  float* hs;         // [n]  clamped prefactor * h
+  float* w;          // [4 (n_batches + 1)]  clamped prefactor * J per padded entry; the last batch is the zero batch
+  uint32_t* row;     // [n]  (first batch << 8) | batches
+  int32_t* cls;      // [n_colours + 1]
+  uint16_t* off;     // [4 (n_batches + 1)]  byte offset of the neighbour's state inside a chain's state row
+  uint16_t* order;   // [n]
+  _Float16* state;   // [chains][n_pad]
+};
+__host__ __device__ __forceinline__ size_t gibbs_lds_layout(int n, int n_batches, int n_colours, size_t off[7]) {
+  size_t b = 0;
+  off[0] = b; b += sizeof(float) * (size_t)((n + 3) & ~3);
+  off[1] = b; b += sizeof(float) * 4 * (size_t)(n_batches + 1);
+  off[2] = b; b += sizeof(uint32_t) * (size_t)n;
+  off[3] = b; b += sizeof(int32_t) * (size_t)(n_colours + 1);
+  b = (b + 7) & ~(size_t)7;
+  off[4] = b; b += sizeof(uint16_t) * 4 * (size_t)(n_batches + 1);
+  off[5] = b; b += sizeof(uint16_t) * (size_t)((n + 1) & ~1);
+  off[6] = b;
+  return b;
+}
+__device__ __forceinline__ GibbsLds gibbs_carve(unsigned char* smem, int n, int n_batches, int n_colours) {
+  size_t o[7];
+  gibbs_lds_layout(n, n_batches, n_colours, o);
+  GibbsLds L;
+  L.hs = reinterpret_cast<float*>(smem + o[0]);
+  L.w = reinterpret_cast<float*>(smem + o[1]);
+  L.row = reinterpret_cast<uint32_t*>(smem + o[2]);
+  L.cls = reinterpret_cast<int32_t*>(smem + o[3]);
+  L.off = reinterpret_cast<uint16_t*>(smem + o[4]);
+  L.order = reinterpret_cast<uint16_t*>(smem + o[5]);
+  L.state = reinterpret_cast<_Float16*>(smem + o[6]);
+  return L;
+}
+
+// stage the graph (coalesced reads of h, J and the padded-row image), all threads of the workgroup; ends with a barrier
+template <int NT>
+__device__ __forceinline__ void gibbs_stage(const GibbsArgs& a, const GibbsLds& L, int tid) {
+  const int n = a.n;
+  for (int i = tid; i < n; i += NT) {
+    L.hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
+    L.order[i] = (uint16_t)a.order[i];
+    L.row[i] = (uint32_t)a.adj_row[i];
+  }
+  const int n_ent = 4 * a.n_batches;
+  for (int q = tid; q < n_ent + 4; q += NT) {
+    const int src = q < n_ent ? a.adj_src4[q] : -1;
+    L.w[q] = src >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[src]]), a.j_lo, a.j_hi) : 0.0f;
+    L.off[q] = src >= 0 ? (uint16_t)(2 * a.adj_idx[src]) : (uint16_t)0;
+  }
+  for (int i = tid; i <= a.n_colours; i += NT) L.cls[i] = a.class_ptr[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ float gibbs_signed_add(_Float16 s, float w, float f) {
+  // rn(s w + f), s = +-1: v_fma_mix_f32 with a float16 first operand
+  return __builtin_fmaf((float)s, w, f);
+}
+
+// f + (the row's signed couplings, in row order); max_batches is uniform (the graph's longest row)
+__device__ __forceinline__ float gibbs_field(float f, uint32_t rowinfo, const GibbsLds& L, const _Float16* st,
+                                             int zero_batch, int max_batches) {
+  const int first = (int)(rowinfo >> 8), nb = (int)(rowinfo & 255u);
+  const unsigned char* stb = reinterpret_cast<const unsigned char*>(st);
+  for (int b0 = 0; b0 < max_batches; b0 += GIBBS_NB) {
+    gf32x4 w[GIBBS_NB];
+    gu32x2 o[GIBBS_NB];
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {
+      const int bi = b0 + j < nb ? first + b0 + j : zero_batch;
+      w[j] = *reinterpret_cast<const gf32x4*>(L.w + 4 * bi);
+      o[j] = *reinterpret_cast<const gu32x2*>(L.off + 4 * bi);
+    }
+    _Float16 h[GIBBS_NB][4];
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {
+      h[j][0] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] & 0xffffu));
+      h[j][1] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] >> 16));
+      h[j][2] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] & 0xffffu));
+      h[j][3] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] >> 16));
+    }
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {
+      f = gibbs_signed_add(h[j][0], w[j][0], f);
+      f = gibbs_signed_add(h[j][1], w[j][1], f);
+      f = gibbs_signed_add(h[j][2], w[j][2], f);
+      f = gibbs_signed_add(h[j][3], w[j][3], f);
+    }
+  }
+  return f;
+}
+
+__device__ __forceinline__ _Float16 gibbs_decide(float f, float two_beta, uint32_t word) {
+  const float z = clampf(__fmul_rn(two_beta, f), -87.0f, 87.0f);
+  const float tt = spec_exp(z);
+  const float b = __fmul_rn(u32_to_unit(word), __fadd_rn(1.0f, tt));
+  return (b < 1.0f) ? (_Float16)1.0f : (_Float16)-1.0f;
+}
+
+// LPC = lanes per chain (16, 32 or 64); WAVES waves per workgroup.  The rolled schedule: any graph; Philox per update.
 template <int LPC, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int n = a.n, n_adj = a.n_adj;
-  // LDS carve-up (all 4-byte aligned first, then 2-byte, then bytes)
-  float* s_hs = reinterpret_cast<float*>(smem);                    // [n]
-  float* s_adjJ = s_hs + n;                                        // [n_adj]
-  int32_t* s_cls = reinterpret_cast<int32_t*>(s_adjJ + n_adj);     // [n_colours + 1]
-  uint16_t* s_adjptr = reinterpret_cast<uint16_t*>(s_cls + a.n_colours + 1);  // [n + 1] (+pad)
-  uint16_t* s_order = s_adjptr + ((n + 2) & ~1);                   // [n] (+pad)
-  uint16_t* s_adjidx = s_order + ((n + 1) & ~1);                   // [n_adj] (+pad)
-  int8_t* s_state = reinterpret_cast<int8_t*>(s_adjidx + ((n_adj + 1) & ~1));
+  const int n = a.n;
+  const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
   const int n_pad = (n + 15) & ~15;
-
   const int tid = threadIdx.x;
-  constexpr int NT = WAVES * 64;
-  for (int i = tid; i < n; i += NT) {
-    s_hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
-    s_order[i] = (uint16_t)a.order[i];
-  }
-  for (int i = tid; i <= n; i += NT) s_adjptr[i] = (uint16_t)a.adj_ptr[i];
-  for (int q = tid; q < n_adj; q += NT) {
-    s_adjJ[q] = clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[q]]), a.j_lo, a.j_hi);
-    s_adjidx[q] = (uint16_t)a.adj_idx[q];
-  }
-  for (int i = tid; i <= a.n_colours; i += NT) s_cls[i] = a.class_ptr[i];
-  __syncthreads();
+  gibbs_stage<WAVES * 64>(a, L, tid);
 
   constexpr int CPW = 64 / LPC;  // chains per wave
   const int wave = tid >> 6, lane = tid & 63;
   const int sub = lane / LPC, l = lane % LPC;
   const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
   const bool valid = chain < a.n_chains;
-  int8_t* st = s_state + (size_t)(wave * CPW + sub) * n_pad;
+  _Float16* st = L.state + (size_t)(wave * CPW + sub) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
   // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
@@ -76,11 +173,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
     if (a.init) {
       for (int i = l; i < n; i += LPC) {
         u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
-        st[i] = (r.x >> 31) ? 1 : -1;
+        st[i] = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
       }
     } else {
       const int8_t* src = a.state + (size_t)chain * n;
-      for (int i = l; i < n; i += LPC) st[i] = src[i];
+      for (int i = l; i < n; i += LPC) st[i] = (_Float16)(float)src[i];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -90,21 +187,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
     for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
       const uint32_t tq = t >> 2, tw = t & 3u;
       for (int k = 0; k < a.n_colours; ++k) {
-        const int lo = s_cls[k], hi = s_cls[k + 1];
+        const int lo = L.cls[k], hi = L.cls[k + 1];
         for (int p = lo + l; p < hi; p += LPC) {
-          const int i = s_order[p];
-          float f = s_hs[i];
-          const int q1 = s_adjptr[i + 1];
-          for (int q = s_adjptr[i]; q < q1; ++q) {
-            const float w = s_adjJ[q];
-            f = __fadd_rn(f, st[s_adjidx[q]] > 0 ? w : -w);
-          }
-          float z = clampf(__fmul_rn(a.two_beta, f), -87.0f, 87.0f);
-          const float tt = spec_exp(z);
+          const int i = L.order[p];
+          const float f = gibbs_field(L.hs[i], L.row[i], L, st, a.n_batches, a.max_batches);
           const u32x4 r = philox4x32_10((uint32_t)i, cid, tq, STREAM_GIBBS, a.k0, a.k1);
-          const float u = u32_to_unit(pick(r, tw));
-          const float b = __fmul_rn(u, __fadd_rn(1.0f, tt));
-          st[i] = (b < 1.0f) ? 1 : -1;
+          st[i] = gibbs_decide(f, a.two_beta, pick(r, tw));
         }
         // the next class reads what this one wrote (same wave): order LDS traffic
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -113,9 +201,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
     }
     int8_t* dst = a.state + (size_t)chain * n;
     for (int i = l; i < n; i += LPC) {
-      const int8_t v = st[i];
-      dst[i] = v;
-      if (a.samples_out) a.samples_out[(size_t)chain * n + i] = (float)v;
+      const float v = (float)st[i];
+      dst[i] = (int8_t)v;
+      if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
     }
   }
 }
@@ -123,45 +211,25 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 // Fast path for graphs with at most GIBBS_MAXS (colour class, pass) slots per lane, a pass being LPC spins of a class
 // -- every graph the shipped solvers produce up to 512 spins.  Same arithmetic, same order, same random stream as
 // gibbs_kernel (bit-exact); what changes is the schedule:
-//   * a lane owns the same spin of every slot in every sweep, so its CSR range, local field offset and spin index
+//   * a lane owns the same spin of every slot in every sweep, so its row descriptor, local field offset and spin index
 //     are read from LDS once, before the sweep loop, and live in registers;
 //   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends,
-//     instead of being recomputed every sweep;
-//   * the neighbour loop issues its LDS reads eight at a time (indices and couplings, then the eight states) and only
-//     the adds stay sequential -- the rolled loop paid two dependent LDS latencies per neighbour.
+//     instead of being recomputed every sweep.
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
 //   * (round 3) WPC = 2: TWO waves per chain (LPC = 64): a colour class of up to 128 spins is one pass of 128 lanes
 //     instead of two passes of 64, which halves the dependent slot-steps of a sweep.  With few chains (c3: 256) the draw is
-//     one instruction stream per chain on a quarter of the chip's SIMDs, issue-bound at one wave per SIMD (~4000
-//     instructions per sweep); it runs beside the encoder forward and the MMD cannot start before it ends.  The two waves
-//     of a chain meet at a workgroup barrier per colour class (every wave of the workgroup runs the same classes).
+//     one instruction stream per chain on a quarter of the chip's SIMDs, issue-bound at one wave per SIMD; it runs beside
+//     the encoder forward and the MMD cannot start before it ends.  The two waves of a chain meet at a workgroup barrier
+//     per colour class (every wave of the workgroup runs the same classes).
 template <int LPC, int WAVES, int MAXS = GIBBS_MAXS, int WPC = 1>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   static_assert(WPC == 1 || (LPC == 64 && WAVES % WPC == 0 && MAXS <= GIBBS_MAXS), "two waves per chain: 64-lane chains only");
   extern __shared__ __align__(16) unsigned char smem[];
-  const int n = a.n, n_adj = a.n_adj;
-  float* s_hs = reinterpret_cast<float*>(smem);
-  float* s_adjJ = s_hs + n;
-  int32_t* s_cls = reinterpret_cast<int32_t*>(s_adjJ + n_adj);
-  uint16_t* s_adjptr = reinterpret_cast<uint16_t*>(s_cls + a.n_colours + 1);
-  uint16_t* s_order = s_adjptr + ((n + 2) & ~1);
-  uint16_t* s_adjidx = s_order + ((n + 1) & ~1);
-  int8_t* s_state = reinterpret_cast<int8_t*>(s_adjidx + ((n_adj + 1) & ~1));
+  const int n = a.n;
+  const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
   const int n_pad = (n + 15) & ~15;
-
   const int tid = threadIdx.x;
-  constexpr int NT = WAVES * 64;
-  for (int i = tid; i < n; i += NT) {
-    s_hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
-    s_order[i] = (uint16_t)a.order[i];
-  }
-  for (int i = tid; i <= n; i += NT) s_adjptr[i] = (uint16_t)a.adj_ptr[i];
-  for (int q = tid; q < n_adj; q += NT) {
-    s_adjJ[q] = clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[q]]), a.j_lo, a.j_hi);
-    s_adjidx[q] = (uint16_t)a.adj_idx[q];
-  }
-  for (int i = tid; i <= a.n_colours; i += NT) s_cls[i] = a.class_ptr[i];
-  __syncthreads();
+  gibbs_stage<WAVES * 64>(a, L, tid);
 
   constexpr int CPW = 64 / LPC;
   constexpr int LPCE = LPC * WPC;  // lanes that work on one chain
@@ -169,7 +237,7 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   const int sub = lane / LPC, l = WPC == 1 ? lane % LPC : lane + 64 * (wave % WPC);
   const int chain = WPC == 1 ? (blockIdx.x * WAVES + wave) * CPW + sub : blockIdx.x * (WAVES / WPC) + wave / WPC;
   const bool valid = chain < a.n_chains;
-  int8_t* st = s_state + (size_t)(WPC == 1 ? wave * CPW + sub : wave / WPC) * n_pad;
+  _Float16* st = L.state + (size_t)(WPC == 1 ? wave * CPW + sub : wave / WPC) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
   // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
@@ -179,11 +247,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
     if (a.init) {
       for (int i = l; i < n; i += LPCE) {
         u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
-        st[i] = (r.x >> 31) ? 1 : -1;
+        st[i] = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
       }
     } else {
       const int8_t* src = a.state + (size_t)chain * n;
-      for (int i = l; i < n; i += LPCE) st[i] = src[i];
+      for (int i = l; i < n; i += LPCE) st[i] = (_Float16)(float)src[i];
     }
   }
   if constexpr (WPC > 1) {
@@ -196,18 +264,19 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
 
   const int passes = a.passes, n_slots = a.n_colours * passes;
   {
-  // this lane's spin in each (colour, pass) slot (-1: none), with its CSR range and clamped field offset
-  int sp[MAXS], q0[MAXS], q1[MAXS];
+  // this lane's spin in each (colour, pass) slot (-1: none), with its row descriptor and clamped field offset
+  int sp[MAXS];
+  uint32_t row[MAXS];
   float hs[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) {
-    sp[k] = -1; q0[k] = 0; q1[k] = 0; hs[k] = 0.f;
+    sp[k] = -1; row[k] = 0; hs[k] = 0.f;
     if (k < n_slots) {
       const int col = k / passes, pass = k - col * passes;
-      const int p = s_cls[col] + pass * LPCE + l;
-      if (valid && p < s_cls[col + 1]) {
-        const int i = s_order[p];
-        sp[k] = i; q0[k] = s_adjptr[i]; q1[k] = s_adjptr[i + 1]; hs[k] = s_hs[i];
+      const int p = L.cls[col] + pass * LPCE + l;
+      if (valid && p < L.cls[col + 1]) {
+        const int i = L.order[p];
+        sp[k] = i; row[k] = L.row[i]; hs[k] = L.hs[i];
       }
     }
   }
@@ -223,29 +292,8 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
     for (int k = 0; k < MAXS; ++k) {
       if (k < n_slots) {
         if (sp[k] >= 0) {
-          float f = hs[k];
-          const int qe = q1[k];
-          for (int q = q0[k]; q < qe; q += 8) {
-            int idx[8];
-            float w[8];
-            int8_t sv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int qq = q + u < qe ? q + u : qe - 1;  // clamped: the batch is one straight line of LDS reads
-              idx[u] = s_adjidx[qq];
-              w[u] = s_adjJ[qq];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sv[u] = st[idx[u]];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (q + u < qe) f = __fadd_rn(f, sv[u] > 0 ? w[u] : -w[u]);
-          }
-          const float z = clampf(__fmul_rn(a.two_beta, f), -87.0f, 87.0f);
-          const float tt = spec_exp(z);
-          const float u01 = u32_to_unit(pick(rr[k], tw));
-          const float b = __fmul_rn(u01, __fadd_rn(1.0f, tt));
-          st[sp[k]] = (b < 1.0f) ? 1 : -1;
+          const float f = gibbs_field(hs[k], row[k], L, st, a.n_batches, a.max_batches);
+          st[sp[k]] = gibbs_decide(f, a.two_beta, pick(rr[k], tw));
         }
         // the next class reads what this one wrote (same wave, or the chain's two waves): order LDS traffic.  (Passes of
         // one class are independent of each other, so a fence between them is harmless.)
@@ -262,19 +310,15 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   if (!valid) return;
   int8_t* dst = a.state + (size_t)chain * n;
   for (int i = l; i < n; i += LPCE) {
-    const int8_t v = st[i];
-    dst[i] = v;
-    if (a.samples_out) a.samples_out[(size_t)chain * n + i] = (float)v;
+    const float v = (float)st[i];
+    dst[i] = (int8_t)v;
+    if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
   }
 }
 
-static size_t gibbs_lds_bytes(int n, int n_adj, int n_colours, int chains_per_block) {
-  size_t b = 0;
-  b += sizeof(float) * (size_t)(n + n_adj);
-  b += sizeof(int32_t) * (size_t)(n_colours + 1);
-  b += sizeof(uint16_t) * (size_t)(((n + 2) & ~1) + ((n + 1) & ~1) + ((n_adj + 1) & ~1));
-  b += (size_t)chains_per_block * ((n + 15) & ~15);
-  return b;
+static size_t gibbs_lds_bytes(int n, int n_batches, int n_colours, int chains_per_block) {
+  size_t o[7];
+  return gibbs_lds_layout(n, n_batches, n_colours, o) + sizeof(_Float16) * (size_t)chains_per_block * ((n + 15) & ~15);
 }
 
 // dvg_gibbs_launch_info: the dispatch below runs with a probe set and reports its launch geometry instead of launching
@@ -285,7 +329,7 @@ static thread_local GibbsProbe* g_gibbs_probe = nullptr;
 static int launch_gibbs_wpc2(GibbsArgs a, hipStream_t s, int max_class) {
   constexpr int WAVES = 4, CPB = 2;
   a.passes = (max_class + 127) / 128;
-  const size_t lds = gibbs_lds_bytes(a.n, a.n_adj, a.n_colours, CPB);
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CPB);
   auto kern = gibbs_fast_kernel<64, WAVES, GIBBS_MAXS, 2>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -300,9 +344,9 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
   a.passes = (max_class + LPC - 1) / LPC;
   fast = fast && a.n_colours * a.passes <= MAXS;
   constexpr int CPB = WAVES * (64 / LPC);
-  const size_t lds = gibbs_lds_bytes(a.n, a.n_adj, a.n_colours, CPB);
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CPB);
   if (lds > 160 * 1024) {
-    set_error("gibbs: graph (n=%d, 2|E|=%d) needs %zu B of LDS > 160 KiB", a.n, a.n_adj, lds);
+    set_error("gibbs: graph (n=%d, %d neighbour batches) needs %zu B of LDS > 160 KiB", a.n, a.n_batches, lds);
     return DVG_E_UNSUPPORTED;
   }
   const int grid = (int)ceil_div(a.n_chains, CPB);
@@ -328,12 +372,12 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
                                 float* samples_out, const dvg_step_state_t* dyn, dvg_stream_t stream) {
   DVG_REQUIRE(g && linear && quadratic && state, "gibbs: null argument");
   DVG_REQUIRE(n_chains > 0 && n_sweeps >= 0, "gibbs: n_chains=%d n_sweeps=%d", n_chains, n_sweeps);
-  DVG_REQUIRE(g->n <= 65535 && g->n_adj <= 65535, "gibbs: graph too large (n=%d, 2|E|=%d)", g->n, g->n_adj);
+  DVG_REQUIRE(g->n <= 32767, "gibbs: graph too large (n=%d: 16-bit state offsets)", g->n);
   GibbsArgs a;
-  a.order = g->order; a.class_ptr = g->class_ptr; a.adj_ptr = g->adj_ptr;
-  a.adj_idx = g->adj_idx; a.adj_eid = g->adj_eid;
+  a.order = g->order; a.class_ptr = g->class_ptr;
+  a.adj_idx = g->adj_idx; a.adj_eid = g->adj_eid; a.adj_row = g->adj_row; a.adj_src4 = g->adj_src4;
   a.linear = linear; a.quadratic = quadratic;
-  a.n = g->n; a.n_adj = g->n_adj; a.n_colours = g->n_colours;
+  a.n = g->n; a.n_batches = g->n_batches; a.max_batches = g->max_batches; a.n_colours = g->n_colours;
   a.prefactor = prefactor; a.h_lo = h_lo; a.h_hi = h_hi; a.j_lo = j_lo; a.j_hi = j_hi;
   a.two_beta = 2.0f * beta;
   a.state = state; a.samples_out = samples_out; a.n_chains = n_chains;
@@ -349,7 +393,7 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
 extern "C" int dvg_gibbs_launch_info(const dvg_graph_t* g, int n_chains, int* workgroups, int* threads, size_t* lds_bytes) {
   DVG_REQUIRE(g && n_chains > 0, "gibbs_launch_info: null graph / no chains");
   GibbsArgs a{};
-  a.n = g->n; a.n_adj = g->n_adj; a.n_colours = g->n_colours; a.n_chains = n_chains;
+  a.n = g->n; a.n_batches = g->n_batches; a.max_batches = g->max_batches; a.n_colours = g->n_colours; a.n_chains = n_chains;
   GibbsProbe pr{0, 0, 0};
   g_gibbs_probe = &pr;
   const int rc = gibbs_dispatch(g, a, n_chains, nullptr);
@@ -364,7 +408,7 @@ extern "C" int dvg_gibbs_launch_info(const dvg_graph_t* g, int n_chains, int* wo
 static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipStream_t s) {
   // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
   const int mc = g->max_class;
-  const bool big = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 4) > 72 * 1024;
+  const bool big = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024;
   // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
   const bool force_generic = opt(OPT_GIBBS_GENERIC) != 0;
   const bool fast = !force_generic;
@@ -376,7 +420,7 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger
   // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
   // encoder's convolutions that run beside the draw (c3: 19.15 ms with four waves, 19.4 with two, 19.7 with one).
-  const bool small = gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
+  const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
   const int waves = waves_env ? waves_env : (small ? 1 : 4);
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
@@ -403,7 +447,7 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // beside the encoder forward on twice the workgroups and the STEP does not move (c3 11.74 vs 11.76 ms, the encoder's
   // GEMMs 433 -> 450-500 us each in-situ), so the default stays one wave per chain.
   if (fast && !waves_env && mc > 64 && mc <= 128 && g->n_colours <= GIBBS_MAXS && n_chains <= 1024 &&
-      gibbs_lds_bytes(g->n, g->n_adj, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) == 2)
+      gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) == 2)
     return launch_gibbs_wpc2(a, s, mc);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
   if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }

@@ -61,8 +61,29 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
     int d = adj_ptr[i + 1] - adj_ptr[i];
     if (d > g->max_degree) g->max_degree = d;
   }
+  // padded-row image for the sampler (gibbs.hip): row i occupies batches [first, first + ceil(deg / 4))
+  int32_t* row = new (std::nothrow) int32_t[n];
+  int32_t* src4 = new (std::nothrow) int32_t[(size_t)4 * (n + (size_t)n_edges / 2 + 1)];  // sum of ceil(d/4) <= n + |adj|/4
+  if (!row || !src4) { delete[] row; delete[] src4; delete g; DVG_REQUIRE(false, "graph_create: out of host memory"); }
+  int nb = 0;
+  for (int i = 0; i < n; ++i) {
+    const int d = adj_ptr[i + 1] - adj_ptr[i], b = (d + 3) / 4;
+    row[i] = (int32_t)(((uint32_t)nb << 8) | (uint32_t)(b > 255 ? 255 : b));
+    for (int k = 0; k < 4 * b; ++k) src4[4 * (size_t)nb + k] = k < d ? adj_ptr[i] + k : -1;
+    if (b > g->max_batches) g->max_batches = b;
+    nb += b;
+  }
+  g->n_batches = nb;
   hipGetDevice(&g->device);
-  int rc;
+  int rc = (g->max_batches > 255 || nb >= (1 << 24)) ? DVG_E_UNSUPPORTED : DVG_OK;
+  if (rc == DVG_OK) rc = upload(&g->adj_row, row, n);
+  if (rc == DVG_OK) rc = upload(&g->adj_src4, src4, (size_t)4 * nb);
+  delete[] row; delete[] src4;
+  if (rc != DVG_OK) {
+    if (rc == DVG_E_UNSUPPORTED) set_error("graph_create: a spin with more than 1020 neighbours");
+    dvg_graph_destroy(g);
+    return rc;
+  }
   if ((rc = upload(&g->edge_i, edge_i, n_edges)) || (rc = upload(&g->edge_j, edge_j, n_edges)) ||
       (rc = upload(&g->order, order, n)) || (rc = upload(&g->class_ptr, class_ptr, n_colours + 1)) ||
       (rc = upload(&g->adj_ptr, adj_ptr, n + 1)) || (rc = upload(&g->adj_idx, adj_idx, 2 * n_edges)) ||
@@ -77,7 +98,7 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
 extern "C" int dvg_graph_destroy(dvg_graph_t* g) {
   if (!g) return DVG_OK;
   hipFree(g->edge_i); hipFree(g->edge_j); hipFree(g->order); hipFree(g->class_ptr);
-  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid);
+  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid); hipFree(g->adj_row); hipFree(g->adj_src4);
   delete g;
   return DVG_OK;
 }

@@ -11,5 +11,9 @@ struct dvg_graph {
   int32_t *class_ptr;            // [n_colours + 1]
   int32_t *adj_ptr;              // [n + 1]
   int32_t *adj_idx, *adj_eid;    // [2 n_edges]
+  // The sampler's LDS image of the neighbour lists (gibbs.hip): every CSR row padded to whole batches of 4 entries.
+  int n_batches, max_batches;    // batches over all rows; the longest row's batches
+  int32_t *adj_row;              // [n]  (first batch of the row << 8) | its batches
+  int32_t *adj_src4;             // [4 n_batches]  CSR position of the entry, -1 for padding
   int32_t h_class_ptr[65];       // host copy (n_colours <= 64)
 };
