@@ -491,11 +491,14 @@ def main():
 
     per_kernel = {}
     for i, nm in enumerate(names):
-        ms, cnt, work = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        ms, cnt, work, share = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         L.dvg_prof_query(i, ctypes.byref(ms), ctypes.byref(cnt))
         L.dvg_prof_query_work(i, ctypes.byref(work))
+        L.dvg_prof_query_share(i, ctypes.byref(share))
         if cnt.value:
-            per_kernel[nm] = {"total_ms": ms.value, "launches": cnt.value, "work": work.value}
+            # share_ms: duration x the share of the chip's CUs the launch's grid was sized for (1 except for the
+            # CU-budgeted Winograd grids, which are handed 128-224 CUs because another kernel holds the rest)
+            per_kernel[nm] = {"total_ms": ms.value, "launches": cnt.value, "work": work.value, "share_ms": share.value}
     if dp.rank == 0:
         # dominant kernel = the GEMM kernel (one template instantiation = one rocprof kernel name) with the
         # largest total time; achieved = its executed FLOPs (2*rows*Cin*Cout*taps per launch -- the folded-upsample
@@ -527,6 +530,11 @@ def main():
             e = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak_of(k), "unit": "TFLOP/s",
                  "frac": ach / peak_of(k), "avg_launch_us": v["total_ms"] * 1e3 / v["launches"], "launches": v["launches"],
                  "gflop_per_launch": v["work"] / v["launches"] / 1e9, "ms_per_step": v["total_ms"] / prof_steps}
+            if v.get("share_ms", 0.0) > 0.0 and v["share_ms"] < 0.999 * v["total_ms"]:
+                # a persistent whole-CU grid sized to a CU budget (conv_wino*.hip): `frac` above prices it against the WHOLE
+                # chip's peak although the launch was given part of it; this is the same work against the CUs it was given
+                e["cu_share"] = v["share_ms"] / v["total_ms"]
+                e["frac_of_cu_budget"] = v["work"] / (v["share_ms"] * 1e-3) / 1e12 / peak_of(k)
             if "algorithmic_work" in v:
                 e["unit"] = "TFLOP/s (bf16 products executed: 6 per algorithmic float32 multiply-add)"
                 e["algorithmic_f32_tflops"] = v["algorithmic_work"] / (v["total_ms"] * 1e-3) / 1e12
@@ -566,6 +574,10 @@ def main():
                                                              "executed_over_reference": tw / prof_steps / 1e9 / ref_gflop},
                                     "frac": tw / (tt * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
                                     "ms_per_step": tt / prof_steps, "gflop_per_step": tw / prof_steps / 1e9}
+            ts = sum(v.get("share_ms", v["total_ms"]) for v in conv.values())
+            if 0.0 < ts < 0.999 * tt:  # (see frac_of_cu_budget above: the Winograd launches are sized to part of the chip)
+                roofline["conv_all"]["frac_of_cu_budget"] = tw / (ts * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS)
+                roofline["conv_all"]["cu_share"] = ts / tt
         if "mmd_pm1" in cands and dom != "mmd_pm1":
             roofline["mmd_pair"] = entry("mmd_pm1")
         roofline["sampler"] = sampler_roofline(per_kernel, cfg, model.sampler.plan, prof_steps, args.config, lib_hash)

@@ -177,6 +177,7 @@ SIGNATURES = {
     "dvg_prof_kernel_name": (c_char_p, [c_int]),
     "dvg_prof_query": (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
     "dvg_prof_query_work": (c_int, [c_int, POINTER(c_double)]),
+    "dvg_prof_query_share": (c_int, [c_int, POINTER(c_double)]),
 }
 
 

@@ -108,15 +108,18 @@ int stream_wait_mark(hipStream_t waiter, hipEvent_t mark);
 // Profiler hooks (prof.cpp).  begin/end record a hipEvent pair on `s` when enabled.
 bool prof_on(int id);
 void prof_begin(int id, hipStream_t s);
-void prof_end(int id, hipStream_t s, double work);
+void prof_end(int id, hipStream_t s, double work, float share);
 
-// `work`: algorithmic work of the launch (FLOPs for the GEMM kernels), summed per kernel id
+// `work`: algorithmic work of the launch (FLOPs for the GEMM kernels), summed per kernel id.  `share`: the fraction of the
+// chip's CUs the launch's grid was SIZED for (persistent whole-CU grids that are given a CU budget because another
+// kernel holds the rest: conv_wino*.hip); the profiler sums duration x share beside the plain duration
+// (dvg_prof_query_share), so a kernel that is handed half the chip is also priced against half the chip's peak.
 struct ProfScope {
-  int id; hipStream_t s; bool on; double work;
-  ProfScope(int id_, hipStream_t s_, double work_ = 0.0) : id(id_), s(s_), on(prof_on(id_)), work(work_) {
+  int id; hipStream_t s; bool on; double work; float share;
+  ProfScope(int id_, hipStream_t s_, double work_ = 0.0, float share_ = 1.0f) : id(id_), s(s_), on(prof_on(id_)), work(work_), share(share_) {
     if (on) prof_begin(id, s);
   }
-  ~ProfScope() { if (on) prof_end(id, s, work); }
+  ~ProfScope() { if (on) prof_end(id, s, work, share); }
 };
 
 // Launch helper: kernel<<<grid, block, shmem, stream>>>(args...) wrapped in a profiler scope,
@@ -124,9 +127,12 @@ struct ProfScope {
 #define DVG_LAUNCH(id, kernel, grid, block, shmem, stream, ...) \
   DVG_LAUNCH_WORK(id, 0.0, kernel, grid, block, shmem, stream, __VA_ARGS__)
 
-#define DVG_LAUNCH_WORK(id, work, kernel, grid, block, shmem, stream, ...)              \
+#define DVG_LAUNCH_WORK(id, work, kernel, grid, block, shmem, stream, ...) \
+  DVG_LAUNCH_WORK_SHARE(id, work, 1.0f, kernel, grid, block, shmem, stream, __VA_ARGS__)
+
+#define DVG_LAUNCH_WORK_SHARE(id, work, share, kernel, grid, block, shmem, stream, ...) \
   do {                                                                                  \
-    dvg::ProfScope _ps((id), (stream), (work));                                         \
+    dvg::ProfScope _ps((id), (stream), (work), (share));                                \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                \
     hipError_t _le = hipGetLastError();                                                 \
     if (_le != hipSuccess) {                                                            \

@@ -477,7 +477,8 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   // every workgroup walks ceil(nblk / gx) tile blocks: the SMALLEST grid with that round count (72 workgroups over 256
   // tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs beside the launch)
   gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
-  DVG_LAUNCH_WORK(K_IGEMM_WINO, flops, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, a);
+  // (one workgroup per CU: the grid IS the number of CUs the launch occupies)
+  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, a);
   return DVG_OK;
 }
 

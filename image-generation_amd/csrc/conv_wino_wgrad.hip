@@ -401,7 +401,8 @@ static int launch_wino_wgrad_cfg(const WinoWgradArgs& a, double flops, dim3 grid
   using C = WinoWgradCfg<WA, WB>;
   auto kern = conv_wino_wgrad_kernel<WA, WB, UPS>;
   DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-  DVG_LAUNCH_WORK(K_WGRAD_WINO, flops, kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  const unsigned wgs = grid.x * grid.y * grid.z;  // (one workgroup per CU)
+  DVG_LAUNCH_WORK_SHARE(K_WGRAD_WINO, flops, (float)(wgs > 256u ? 256u : wgs) / 256.0f, kern, grid, dim3(256), C::LDS_BYTES, s, a);
   return DVG_OK;
 }
 

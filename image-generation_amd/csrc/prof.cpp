@@ -26,7 +26,7 @@ static const char* kNames[K_COUNT] = {
     "dec_bn_act_bwd_apply", "dec_conv3_fwd", "dec_conv3_bwd", "dec_final_fwd", "dec_final_bwd",
     "mse", "adam", "misc", "conv_igemm_weight_space", "conv_wino_kernel", "conv_wino_wgrad_kernel"};
 
-struct EvPair { hipEvent_t a, b; };
+struct EvPair { hipEvent_t a, b; float share = 1.0f; };
 static uint64_t g_mask = 0;
 static std::mutex g_mu;
 static std::vector<EvPair> g_pairs[K_COUNT];
@@ -34,6 +34,7 @@ static std::vector<EvPair> g_free;
 static double g_ms[K_COUNT];
 static int64_t g_n[K_COUNT];
 static double g_work[K_COUNT];
+static double g_ms_share[K_COUNT];  // sum of duration x the share of the chip's CUs the launch's grid was sized for
 static thread_local EvPair g_open[K_COUNT];
 
 bool prof_on(int id) { return (g_mask >> id) & 1ull; }
@@ -47,9 +48,10 @@ void prof_begin(int id, hipStream_t s) {
   g_open[id] = p;
 }
 
-void prof_end(int id, hipStream_t s, double work) {
+void prof_end(int id, hipStream_t s, double work, float share) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_work[id] += work;
+  g_open[id].share = share;
   hipEventRecord(g_open[id].b, s);
   g_pairs[id].push_back(g_open[id]);
 }
@@ -58,7 +60,7 @@ static void drain(int id) {
   for (auto& p : g_pairs[id]) {
     hipEventSynchronize(p.b);
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[id] += ms; g_n[id] += 1; }
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[id] += ms; g_ms_share[id] += (double)ms * p.share; g_n[id] += 1; }
     g_free.push_back(p);
   }
   g_pairs[id].clear();
@@ -80,7 +82,7 @@ const char* dvg_last_error(void) { return g_err; }
 int dvg_prof_enable(uint64_t kernel_mask) { g_mask = kernel_mask; return DVG_OK; }
 int dvg_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_n[i] = 0; g_work[i] = 0; }
+  for (int i = 0; i < K_COUNT; ++i) { drain(i); g_ms[i] = 0; g_ms_share[i] = 0; g_n[i] = 0; g_work[i] = 0; }
   return DVG_OK;
 }
 int dvg_prof_num_kernels(void) { return K_COUNT; }
@@ -91,6 +93,13 @@ int dvg_prof_query(int id, double* total_ms, int64_t* launches) {
   drain(id);
   if (total_ms) *total_ms = g_ms[id];
   if (launches) *launches = g_n[id];
+  return DVG_OK;
+}
+int dvg_prof_query_share(int id, double* share_ms) {
+  if (id < 0 || id >= K_COUNT || !share_ms) { set_error("bad kernel id %d", id); return DVG_E_INVALID; }
+  std::lock_guard<std::mutex> lk(g_mu);
+  drain(id);
+  *share_ms = g_ms_share[id];
   return DVG_OK;
 }
 int dvg_prof_query_work(int id, double* work) {

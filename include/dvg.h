@@ -351,6 +351,9 @@ const char *dvg_prof_kernel_name(int id);
 int dvg_prof_query(int id, double *total_ms, int64_t *launches);
 /* algorithmic work (FLOPs for the GEMM-shaped kernels, 0 otherwise) summed over the timed launches */
 int dvg_prof_query_work(int id, double *work);
+/* sum over the kernel's launches of duration x the share of the chip's CUs the launch's grid was sized for (1 for every
+ * kernel but the CU-budgeted persistent Winograd grids): the time base of roofline fractions "of the CUs it was given" */
+int dvg_prof_query_share(int id, double *share_ms);
 
 #ifdef __cplusplus
 }

@@ -61,5 +61,10 @@ HSA_ENABLE_IPC_MODE_LEGACY=0 DVG_FORCE_DIST=1 python -m torch.distributed.run --
 cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $ROOT/bench.py --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
 python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c3_step.txt; rm -rf $OUT/tr
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
+python tools/wino_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_alone_c3.txt
+python tools/wino_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_wgrad_alone_c3.txt
+# kernel timeline of one c2 step (eager: under rocprofv3 the captured graph's gaps are the profiler's)
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr2 -- python3 $ROOT/bench.py --config c2 --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
+python tools/trace_step.py $(ls $OUT/tr2/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c2_step.txt; rm -rf $OUT/tr2
 rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/pmc_g_*
 ls -la $OUT
