@@ -1,6 +1,7 @@
 // Shared plumbing for libdvg.so: error reporting, launch + optional event profiling.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -86,7 +87,7 @@ enum KernelId : int {
 enum Opt : int {
   OPT_IGEMM_DMA = 0, OPT_IGEMM_POSMAJOR, OPT_IGEMM_THR128, OPT_IGEMM_THR64, OPT_IGEMM_THR32, OPT_IGEMM_NO32, OPT_WGRAD_DMA,
   OPT_DEC_FOLD, OPT_DEC_D22, OPT_DEC_LC0, OPT_MMD_W128, OPT_MMD_D256, OPT_MMD_BLOCKS, OPT_GIBBS_GENERIC, OPT_GIBBS_WAVES,
-  OPT_GIBBS_WAVES_PER_CHAIN, OPT_SIDE_STREAM, OPT_ENC_WINO, OPT_ENC_WINO_MASK, OPT_ENC_L0_FUSED, OPT_DEC_TAIL_FUSED, OPT_ENC_WINO_CUS, OPT_ENC_WINO_CUS_D, OPT_ENC_WINO_WGRAD, OPT_ENC_WINO_CUS_W, OPT_DEC_WINO_WGRAD, OPT_DEC_WINO_CUS_W, OPT_DEC_WINO, OPT_DEC_WINO_CUS, OPT_DEC_WINO_CUS_D, OPT_COUNT
+  OPT_GIBBS_WAVES_PER_CHAIN, OPT_SIDE_STREAM, OPT_ENC_WINO, OPT_ENC_WINO_MASK, OPT_ENC_L0_FUSED, OPT_DEC_TAIL_FUSED, OPT_ENC_WINO_CUS, OPT_ENC_WINO_CUS_D, OPT_ENC_WINO_WGRAD, OPT_ENC_WINO_CUS_W, OPT_DEC_WINO_WGRAD, OPT_DEC_WINO_CUS_W, OPT_DEC_WINO, OPT_DEC_WINO_CUS, OPT_DEC_WINO_CUS_D, OPT_WINO_MIN_BLOCKS, OPT_COUNT
 };
 int64_t opt(Opt id);
 
@@ -141,6 +142,19 @@ struct ProfScope {
       return DVG_E_HIP;                                                                 \
     }                                                                                   \
   } while (0)
+
+// The raised dynamic-LDS limit of a kernel (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE attribute: set it
+// once per device and call site (`done`: a static bit set per device ordinal), not once per process.
+static inline int raise_dynamic_lds(std::atomic<uint64_t>& done, const void* kern, int bytes) {
+  int dev = 0;
+  DVG_CHECK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    DVG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return DVG_OK;
+}
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -664,12 +664,9 @@ static int launch_igemm_cfg(int id, double flops, dim3 grid, const ConvArgs& a, 
   // (LDS-DMA form: the neighbour table is sized by the launch's tap count; the other forms always carry 16 per row)
   const size_t lds = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM >= 3 ? sizeof(int) * (size_t)BM * (a.ntaps > 9 ? 16 : 9) : 0);
   auto kern = conv_igemm_kernel<BM, BN, WM, WN, WK, PM>;
-  static bool attr_set = false;  // one instantiation = one static
+  static std::atomic<uint64_t> attr_done{0};  // one instantiation = one static
   constexpr size_t lds_max = conv_igemm_lds_bytes<BM, BN, WM, WN, WK, PM>() + (PM >= 3 ? sizeof(int) * (size_t)BM * 16 : 0);
-  if (lds_max > 64 * 1024 && !attr_set) {
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    attr_set = true;
-  }
+  if (lds_max > 64 * 1024) DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, (int)lds_max));
   DVG_LAUNCH_WORK(id, flops, kern, grid, dim3(WM * WN * WK * 64), lds, s, a);
   return DVG_OK;
 }

@@ -739,11 +739,8 @@ template <int WA, int WB, int WT, bool FOLD = false>
 static int launch_wgrad9_dma(int id, double flops, dim3 grid, const WgradArgs& a, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(128 * 32 * WA * 4 + (FOLD ? 128 : 32) * 32 * WB * 4);
   auto kern = conv_wgrad9_dma_kernel<WA, WB, WT, FOLD>;
-  static bool attr_set = false;  // one instantiation = one static
-  if (lds > 64 * 1024 && !attr_set) {
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // one instantiation = one static
+  if (lds > 64 * 1024) DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, (int)lds));
   DVG_LAUNCH_WORK(id, flops, kern, grid, dim3(WA * WB * WT * 64), lds, s, a);
   return DVG_OK;
 }
@@ -788,11 +785,8 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
   }
   if (a.ntaps == 1 && wgrad1_dma_ok(a.M, a.Cin, a.Cout)) {
     auto kern = conv_wgrad1_dma_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-      DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, 65536));
     DVG_LAUNCH_WORK(K_WGRAD_2x2, flops, kern, dim3((unsigned)((a.Cin / 128) * (a.Cout / 128)), (unsigned)a.ksplit), dim3(256), 65536, s, a);
     return DVG_OK;
   }

@@ -444,8 +444,10 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
   // evaluation-mode forward calls: from 256 workgroups' worth up (round 3).  Training calls: float32 operand mode only
   // (the form is float32 arithmetic: in the f32x3 / bf16-input modes the direct kernel on the bf16 MFMA is the faster
-  // one) and from 1024 up -- c3's launches; a c2 step with its one eligible launch (256) measured 1.6 % slower
-  return kind == 2 ? blocks >= 256 : (blocks >= 1024 && conv_precision_mode() == 0);
+  // one) and from option wino_min_blocks (512) up -- all of c3's launches, the larger ones of mid-size batches; a c2 step
+  // with its one 256-block launch switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the
+  // persistent grid 128 CUs there)
+  return kind == 2 ? blocks >= 256 : (blocks >= opt(OPT_WINO_MIN_BLOCKS) && conv_precision_mode() == 0);
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
@@ -455,14 +457,8 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   using C = WinoCfg<WM, WN, KC, UM>;
   auto kern = conv_wino_kernel<WM, WN, KC, UM>;
   // the raised dynamic-LDS limit is a per-DEVICE function attribute: once per device (bit per ordinal), not per process
-  static std::atomic<uint64_t> attr_set{0};
-  int dev = 0;
-  DVG_CHECK_HIP(hipGetDevice(&dev));
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set.fetch_or(bit, std::memory_order_release);
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
   const int ny = a.Cout / C::CB;
   // one workgroup per CU, persistent over its tile blocks -- of the CUs this launch may count on (ConvArgs.wino_cus:
   // a workgroup needs a WHOLE CU, so whatever runs beside the launch in a training step keeps its CUs and the grid is

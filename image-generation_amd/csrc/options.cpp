@@ -46,6 +46,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions; conv_wino.hip): -1 the forward launches from 8192 decoder rows up (default), 0 never, 1 forward and data gradient whenever the shape allows, 2 / 3 forward / data gradient only"},
     {"dec_wino_cus", 256, "CUs the decoder's Winograd forward launches are sized for"},
     {"dec_wino_cus_d", 256, "... its data-gradient launches"},
+    {"wino_min_blocks", 512, "encoder Winograd launches of a training call (enc_wino = -1): from this many workgroups' worth of tiles up (measured, n = 512 model: 1024 / 512 / 256 -> B = 512: 2.16 / 2.13 / 2.06 ms, B = 1024: 3.03 / 2.82 / 2.82, B = 2048: 4.67 / 4.60 / 4.53; c2: 0.920 / 0.924 / 0.953 -- 512 is the lowest value that costs c2 nothing)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;
