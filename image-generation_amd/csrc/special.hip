@@ -415,20 +415,32 @@ int launch_enc_proj_fwd(const float* P, int64_t B, int n, const float* w, const 
 __global__ __launch_bounds__(256) void enc_proj_bwd_kernel(const float* __restrict__ P, int64_t B, int n,
                                                            const float* __restrict__ w, const float* __restrict__ dl,
                                                            float* __restrict__ dP, float* __restrict__ part) {
+  // four latent units per thread (n % 32 == 0): five 16-byte loads and four 16-byte stores in flight per item instead of
+  // five 4-byte loads -- the one-float form ran at 0.6 TB/s on the head of the encoder's backward chain (c3: 137 us for
+  // 75 MB); the partial sums keep their two-stage fixed order (per thread, then per block)
   __shared__ float red[5 * 256];
-  const int64_t total = B * n;
+  const int n4 = n >> 2;
+  const int64_t total = B * n4;
   const float wv[4] = {w[0], w[1], w[2], w[3]};
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % n);
-    const int64_t base = (e / n) * 4 * n + c;
-    const float g = dl[e];
+    const int c4 = (int)(e % n4);
+    const int64_t b = e / n4;
+    const float4 g = *reinterpret_cast<const float4*>(dl + b * n + 4 * c4);
+    const float* p = P + b * 4 * n + 4 * c4;
+    float* dp = dP + b * 4 * n + 4 * c4;
+    float4 pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] = *reinterpret_cast<const float4*>(p + (size_t)k * n);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      acc[k] = fmaf(g, P[base + (size_t)k * n], acc[k]);
-      dP[base + (size_t)k * n] = g * wv[k];
+      acc[k] = fmaf(g.x, pv[k].x, acc[k]);
+      acc[k] = fmaf(g.y, pv[k].y, acc[k]);
+      acc[k] = fmaf(g.z, pv[k].z, acc[k]);
+      acc[k] = fmaf(g.w, pv[k].w, acc[k]);
+      *reinterpret_cast<float4*>(dp + (size_t)k * n) = make_float4(g.x * wv[k], g.y * wv[k], g.z * wv[k], g.w * wv[k]);
     }
-    acc[4] += g;
+    acc[4] += g.x; acc[4] += g.y; acc[4] += g.z; acc[4] += g.w;
   }
 #pragma unroll
   for (int k = 0; k < 5; ++k) red[k * 256 + threadIdx.x] = acc[k];
