@@ -442,12 +442,14 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   if (o >= 1) return true;
   const int cfg = wino_cfg(Cout);
   const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
-  // evaluation-mode forward calls: from 256 workgroups' worth up (round 3).  Training calls: float32 operand mode only
-  // (the form is float32 arithmetic: in the f32x3 / bf16-input modes the direct kernel on the bf16 MFMA is the faster
-  // one) and from option wino_min_blocks (512) up -- all of c3's launches, the larger ones of mid-size batches; a c2 step
-  // with its one 256-block launch switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the
-  // persistent grid 128 CUs there)
-  return kind == 2 ? blocks >= 256 : (blocks >= opt(OPT_WINO_MIN_BLOCKS) && conv_precision_mode() == 0);
+  // evaluation-mode forward calls: from 256 workgroups' worth up (round 3).  Training calls: the float32 and f32x3 operand
+  // modes (the form is strict float32 arithmetic on 4/9 of the multiplications: faster than the split direct kernel
+  // too; in the bf16-input mode the direct kernel on the bf16 MFMA is the faster one) and from option wino_min_blocks
+  // (512) up -- all of c3's launches, the larger ones of mid-size batches; a c2 step with its one 256-block launch
+  // switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the persistent grid 128 CUs there)
+  // (kind 3: a weight gradient -- float32 in every operand mode; forward / data gradient: not in the bf16-input mode)
+  if (kind == 3) return blocks >= opt(OPT_WINO_MIN_BLOCKS);
+  return kind == 2 ? blocks >= 256 : (blocks >= opt(OPT_WINO_MIN_BLOCKS) && conv_precision_mode() != 1);
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }

@@ -388,7 +388,7 @@ bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   const int64_t o = opt(OPT_ENC_WINO_WGRAD);
   if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
   if (o >= 1) return true;
-  return conv_wino_ok(M, Cin, Cout, L, 0);
+  return conv_wino_ok(M, Cin, Cout, L, 3);
 }
 
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {

@@ -79,7 +79,8 @@ DecPlan dec_plan(int64_t N, int n) {
     p.M[l] = N * ((int64_t)4 << (2 * l));
     const int C = ch[l + 1];
     p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
-    p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 && conv_precision_mode() == 0 &&
+    // (weight gradients are float32 in every operand mode, so this form serves all three)
+    p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 &&
                   conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO_WGRAD) > 0 || N >= 8192);
     {
       // option dec_wino: -1 (default) the FORWARD launches from 8192 decoder rows up; 1 forward and data gradient
@@ -88,7 +89,10 @@ DecPlan dec_plan(int64_t N, int n) {
       // where the folded direct kernel shares CUs -- 9.74 ms with the forward alone, 9.80 with both at any split of the
       // CUs between them.)
       const int64_t o = opt(OPT_DEC_WINO);
-      const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() == 0 && (o > 0 || N >= 8192);
+      // (strict float32 arithmetic: also the faster form in the f32x3 mode -- 4/9 of the multiplications at f32 rate
+      // against 6/16 of the matrix time plus the split arithmetic -- and at least as exact; the bf16-input mode keeps
+      // the direct kernel on the bf16 MFMA)
+      const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() != 1 && (o > 0 || N >= 8192);
       p.wino_f[l] = on && o != 3 && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
       p.wino_d[l] = on && (o == 1 || o == 3) && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
     }

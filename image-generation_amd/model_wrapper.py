@@ -466,6 +466,7 @@ class ModelWrapper:
         # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
         # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
         # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
+        self._hold_device_while_measuring()
         samples = self._draw_overlapped() if self.overlap_sampler else None
         self._dvae.decoder._defer_join = True  # (this step always runs the encoder's backward behind the decoder's)
         if samples is not None and self.overlap_mmd:
@@ -583,10 +584,23 @@ class ModelWrapper:
                 ev_side.synchronize()
                 rec["lags"].append(ev_main.elapsed_time(ev_side))  # > 0: the side stream finished that much LATER
             rec["events"] = []
-            lags = sorted(rec["lags"])
-            rec["decision"] = bool(lags[len(lags) // 2] > self.DEFER_LAG_MS)
+            # (the LARGEST of the samples: a sample taken while the host was the slower side reads ~0)
+            rec["decision"] = bool(max(rec["lags"]) > self.DEFER_LAG_MS)
         self._defer_rec = rec
         return bool(rec["decision"])
+
+    def _hold_device_while_measuring(self) -> None:
+        """The lag behind ``_defer_mmd_join`` must be the DEVICE's: an eager step whose launches the host issues more
+        slowly than the GPU runs them (the first steps of a process: module loads, allocator growth) finds both streams
+        idle at the join and measures ~0 whatever the shape.  So a step that is going to measure starts with a spin kernel
+        on the main stream, in front of the fork of the side stream: the host enqueues the whole step behind it and the
+        two chains then run at the device's pace.  A few milliseconds, twice per shape."""
+        if (self._device is None or self._device.type != "cuda" or not (self.overlap_sampler and self.overlap_mmd)
+                or getattr(self, "defer_mmd_join", None) is not None or torch.cuda.is_current_stream_capturing()):
+            return
+        rec = getattr(self, "_defer_rec", None)
+        if rec is None or rec["decision"] is None:
+            torch.cuda._sleep(2_000_000)  # (~20 ms: the counter behind it runs at 100 MHz)
 
     def _defer_measure(self, main, side) -> None:
         """Called at the join-in-front point of a step that is still measuring: marks "main stream reached the join" and
