@@ -227,11 +227,15 @@ __global__ __launch_bounds__(256) void mmd_prep_kernel(const float* __restrict__
   const float* p = row < nx ? x + row * d : y + (row - nx) * d;
   float acc = 0.f;
   bool bad = false;
-  for (int k = lane; k < d; k += 64) {
-    const float v = p[k];
-    acc = fmaf(v, v, acc);
-    bad |= !(v == 1.0f || v == -1.0f);
-    zi8[row * d + k] = v > 0.f ? (int8_t)1 : (int8_t)-1;
+  // four entries per lane and trip (d % 32 == 0): one 16-byte load, one 4-byte store of the int8 copy -- the one-float
+  // form stored single bytes and ran at 1.1 TB/s (c3: 77 us at the head of the MMD chain)
+  uint32_t* z4 = reinterpret_cast<uint32_t*>(zi8 + row * d);
+  for (int k = lane; k < d / 4; k += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 4 * k);
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    bad |= !(v.x == 1.0f || v.x == -1.0f) | !(v.y == 1.0f || v.y == -1.0f) | !(v.z == 1.0f || v.z == -1.0f) | !(v.w == 1.0f || v.w == -1.0f);
+    z4[k] = (v.x > 0.f ? 0x01u : 0xffu) | (v.y > 0.f ? 0x0100u : 0xff00u) | (v.z > 0.f ? 0x010000u : 0xff0000u) |
+            (v.w > 0.f ? 0x01000000u : 0xff000000u);
   }
   if (__any(bad) && lane == 0) atomicOr(not_pm1, 1);
 #pragma unroll
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* _
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= a.d) return;
   const bool is_x = jb < a.ztb_y;
-  const float* src = is_x ? a.x : a.y;
+  const int8_t* z8 = is_x ? a.zi8 : a.zi8 + a.nx * (int64_t)a.d;
   const int64_t cnt = is_x ? a.nx : a.ny;
   const int64_t row0 = (is_x ? jb : jb - a.ztb_y) * 32;
   uint32_t packed[16];
@@ -842,7 +846,8 @@ __global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* _
     for (int half = 0; half < 2; ++half) {
       const int k = 2 * q + half, s = k >> 4, hh = (k >> 3) & 1, e = k & 7;
       const int64_t row = row0 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
-      const uint32_t b = row < cnt ? (__float_as_uint(src[row * a.d + f]) >> 16) : 0u;
+      // (+-1 rows -- the kernel has returned otherwise: bf16(+-1) from the sign of the int8 copy, a quarter of the bytes)
+      const uint32_t b = row < cnt ? (z8[row * a.d + f] > 0 ? 0x3f80u : 0xbf80u) : 0u;
       v |= b << (16 * half);
     }
     packed[q] = v;

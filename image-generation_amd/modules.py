@@ -216,7 +216,10 @@ class _DecoderFn(torch.autograd.Function):
         gs.conv_w[4], gs.conv_b[4] = grads[18].data_ptr(), grads[19].data_ptr()
         go = grad_out.contiguous().float()
         gx = torch.empty_like(x) if ctx.need_input_grad else None
-        defer = bool(getattr(module, "_defer_join", False))
+        # (deferral only when the gradients land in the optimizer's buffer: handed back as fresh tensors, autograd's
+        # AccumulateGrad may CLONE them on the caller's stream -- it does when anything else holds a reference, and
+        # _deferred_keep below does -- i.e. read them before the library's side stream has written them)
+        defer = bool(getattr(module, "_defer_join", False)) and direct
         with torch.cuda.device(x.device):
             # defer_join (set by ModelWrapper around its own step, where the encoder's backward always follows on the same
             # stream): the tail of the weight-gradient chain overlaps the head of the encoder's data-gradient chain
