@@ -41,6 +41,8 @@ struct WinoArgs {
   float* out;         // [4 tiles][Cout]
   float* stats;       // [nblk][Cout][2] per tile block (sum, sum of squares) of the output, or null
   int cus = 0;        // CUs the persistent grid is sized for (0 = 256)
+  int* dyn = nullptr; // [32] zeroed tile counters (dyn[y]: tile blocks handed out beyond the first round; dyn[16 + y]:
+                      // workgroups done): tile blocks are then dealt dynamically (see the kernel), else round-robin
   // (UM = 1: `in` is the SOURCE map [tiles][Cin] of an Upsample(x2) + 3x3 layer; UM = 2: its data gradient, `out` the source
   // map's gradient [tiles][Cout] -- template argument of the kernel, see the header comment)
   int Cin, Cout, L;   // L = log2 of the image side
@@ -56,7 +58,8 @@ struct WinoCfg {
   static constexpr int RAW_B = 64 + RAW_DMA;                 // + the zero entry padding taps read
   static constexpr int V_B = KC * TBLK * 64, U_B = KC * CB * 64;
   static constexpr int OFF_RAW = 0, OFF_V = OFF_RAW + 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B;
-  static constexpr int LDS_BYTES = OFF_RED + WM * CB * 2 * 4;
+  static constexpr int OFF_NEXT = OFF_RED + WM * CB * 2 * 4;  // the next tile block of a dynamically scheduled grid
+  static constexpr int LDS_BYTES = OFF_NEXT + 16;
   static constexpr int NI = TBLK * KC / 256;                 // patches a thread transforms per chunk
   static constexpr int RR = RAW_DMA / 4096, UR = U_B / 4096; // 4 KiB DMA rounds (256 lanes x 16 bytes) per chunk
 };
@@ -207,14 +210,40 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
 
   f32x16 acc[16];
 
-  // ---- the workgroup's sequence of chunks: tile blocks blockIdx.x, + gridDim.x, ... x (Cin / KC) chunks each
-  const int nmine = ((int)a.nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int VT = nmine * nch;
-  auto blk_of = [&](int v) { return (int)blockIdx.x + (v / nch) * (int)gridDim.x; };
-  if (VT <= 0) return;
-  issue_raw(blk_of(0), 0, 0);
+  // ---- the workgroup's sequence of tile blocks x (Cin / KC) chunks each.  Static: blocks blockIdx.x, + gridDim.x, ...
+  // Dynamic (a.dyn): every block is the next one not yet handed out (an atomic counter per grid row, fetched a whole tile
+  // block ahead by one lane and passed on through LDS): a workgroup that gets its CU late -- the launch shares the chip
+  // with a kernel that still holds it -- simply takes fewer blocks, or none, where the static deal makes the whole
+  // launch wait for that workgroup's full share.  Outputs and BatchNorm partials are per tile block, so who computes
+  // a block changes no bit.
+  const bool dynq = a.dyn != nullptr;
+  volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
+  auto finish = [&]() {  // the last workgroup of the grid row to finish leaves the counters zeroed for the next launch
+    if (dynq && tid == 0 && atomicAdd(a.dyn + 16 + blockIdx.y, 1) == (int)gridDim.x - 1) {
+      atomicExch(a.dyn + blockIdx.y, 0);
+      atomicExch(a.dyn + 16 + blockIdx.y, 0);
+    }
+  };
+  // (dynamic: the first block too -- a workgroup that is dispatched after the work is done must find nothing to do -- and
+  // always TWO blocks ahead: the id of the block after next is asked for when a block starts and handed round at its end,
+  // so nobody ever waits for the atomic and the chunk loop below is the static form's, instruction for instruction)
+  int blk_cur = (int)blockIdx.x, blk_nxt = blk_cur + (int)gridDim.x;
+  if (dynq) {
+    if (tid == 0) { nslot[0] = atomicAdd(a.dyn + blockIdx.y, 1); nslot[1] = atomicAdd(a.dyn + blockIdx.y, 1); }
+    __syncthreads();
+    blk_cur = __builtin_amdgcn_readfirstlane(nslot[0]);
+    blk_nxt = __builtin_amdgcn_readfirstlane(nslot[1]);
+    __syncthreads();
+  }
+  bool has_next = blk_nxt < a.nblk;
+  if (blk_cur >= a.nblk) { finish(); return; }
+  // virtual chunk numbering (kept from the static form so that the chunk body is branch-free arithmetic): the current
+  // block's chunks are vbase .. vbase + nch - 1, the next block's follow, VT ends the sequence the prefetch may look into
+  int vbase = 0, VT = (has_next ? 2 : 1) * nch;
+  auto blk_of = [&](int v) { return blk_cur + ((v - vbase) / nch) * (blk_nxt - blk_cur); };
+  issue_raw(blk_cur, 0, 0);
   issue_u(0, 0);
-  if (VT > 1) issue_raw(blk_of(1), 1 % nch, 1);
+  issue_raw(blk_cur, 1 % nch, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -300,7 +329,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   // operands of group g + 1 are requested before the MFMAs of group g, and the next chunk's input transform rides in the
   // shadows of the MFMAs a few instructions at a time: patch j is read at the start of k-step j, its B^T d columns follow
   // beside the MFMAs of group 1, its (.) B rows and their stores beside those of group 2.
-  auto chunk = [&](int v, auto stc) {
+  auto chunk = [&](int v, auto stc) {  // virtual chunk v: chunk v - vbase of tile block blk_cur
     constexpr int st = decltype(stc)::value;
     // (branch-free: past the end of the sequence the last chunk is fetched and transformed again, into stages nobody reads)
     const int v1 = v + 1 < VT ? v + 1 : VT - 1, v2 = v + 2 < VT ? v + 2 : VT - 1;
@@ -380,8 +409,11 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
   // (nested on purpose: the accumulators are zeroed and consumed in straight-line code of the outer loop.  A flat chunk
   // loop with a conditional epilogue made every chunk end in a merge of "old" and "zeroed" accumulators, which the compiler
   // implements by moving all 256 of them through VGPRs; an even chunk count keeps the stage parity per tile block)
-  int v = 0;
-  for (int bi = 0; bi < nmine; ++bi) {
+  int v = 0, par = 1;
+  bool go = true;
+  while (go) {
+    int fetched = 0;
+    if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);  // (the block after next; in flight under this block)
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
     for (int ch = 0; ch < nch; ch += 2) {
@@ -389,8 +421,22 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char*
       chunk(v + 1, std::integral_constant<int, 1>{});
       v += 2;
     }
-    epilogue((int)blockIdx.x + bi * (int)gridDim.x);
+    epilogue(blk_cur);
+    go = has_next;
+    blk_cur = blk_nxt;
+    if (dynq) {  // (two slots in turn: ONE barrier per block hands the id round; a slot is rewritten two blocks later)
+      par ^= 1;
+      if (tid == 0) nslot[par] = fetched;
+      __syncthreads();
+      blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
+    } else {
+      blk_nxt = blk_cur + (int)gridDim.x;
+    }
+    has_next = blk_nxt < a.nblk;
+    vbase += nch;
+    VT = vbase + (has_next ? 2 : 1) * nch;
   }
+  finish();
 }
 
 template <int WM, int WN, int KC, int UM = 0>
@@ -472,11 +518,14 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   int gx = cus / ny;
   if (gx < 1) gx = 1;
   if (gx > a.nblk) gx = a.nblk;
-  // every workgroup walks ceil(nblk / gx) tile blocks: the SMALLEST grid with that round count (72 workgroups over 256
-  // tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs beside the launch)
-  gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
+  // dynamic deal of the tile blocks (option wino_dynamic) -- else every workgroup walks ceil(nblk / gx) tile blocks: the SMALLEST grid with that
+  // round count (72 workgroups over 256 tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs
+  // beside the launch)
+  WinoArgs ad = a;
+  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16) ? dyn_tile_counters() : nullptr;
+  if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
   // (one workgroup per CU: the grid IS the number of CUs the launch occupies)
-  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, a);
+  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, ad);
   return DVG_OK;
 }
 

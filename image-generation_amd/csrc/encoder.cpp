@@ -180,7 +180,10 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
       a.splitk_ws = W + pl.splitk;
-      a.wino_cus = training ? (int)opt(OPT_ENC_WINO_CUS) : 0;  // (a training call's forward runs beside the step's sampler draw)
+      // (a training call's forward runs beside the step's sampler draw, which holds its CUs: with the static deal of tile
+      // blocks the grid is sized to the rest; with the dynamic deal -- option wino_dynamic, the default -- it is sized to
+      // the chip and the workgroups that get their CU late, when the draw ends, take what is left)
+      a.wino_cus = (training && opt(OPT_WINO_DYNAMIC) == 0) ? (int)opt(OPT_ENC_WINO_CUS) : 0;
       if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
       else DVG_TRY(launch_conv_igemm(a, s));
     }

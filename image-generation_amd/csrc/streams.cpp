@@ -20,8 +20,11 @@ constexpr int kMaxDevices = 16;
 constexpr int kEvents = 64;
 // The library is entered from the caller's thread (forward) and from the autograd engine's worker thread (backward):
 // creation is serialised by a mutex and published through an acquire/release flag, the event-ring cursor is atomic.
+constexpr int kDynSets = 8, kDynInts = 32;
 struct SideCtx {
   hipStream_t side = nullptr;
+  int* dyn = nullptr;  // [kDynSets][kDynInts] zero-initialised tile counters of the dynamically scheduled persistent grids
+  std::atomic<unsigned> dyn_next{0};
   hipEvent_t ev[kEvents] = {};
   std::atomic<unsigned> next{0};
   std::atomic<bool> ready{false};
@@ -40,6 +43,10 @@ SideCtx* ctx() {
   if (!c.side && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) { c.side = nullptr; return nullptr; }
   for (int i = 0; i < kEvents; ++i)
     if (!c.ev[i] && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) != hipSuccess) { c.ev[i] = nullptr; return nullptr; }
+  if (!c.dyn) {
+    if (hipMalloc((void**)&c.dyn, sizeof(int) * kDynSets * kDynInts) != hipSuccess) { c.dyn = nullptr; return nullptr; }
+    if (hipMemset(c.dyn, 0, sizeof(int) * kDynSets * kDynInts) != hipSuccess) { (void)hipFree(c.dyn); c.dyn = nullptr; return nullptr; }
+  }
   c.ready.store(true, std::memory_order_release);
   return &c;
 }
@@ -49,7 +56,18 @@ bool side_enabled();
 
 // Creates the device's side stream and event ring now (never under a stream capture: the workspace-size queries and
 // dvg_graph_create call this, and they always precede the first captured step).
-void side_stream_warm() { if (side_enabled()) (void)ctx(); }
+void side_stream_warm() { (void)ctx(); }
+
+// A set of zeroed tile counters for ONE launch of a dynamically scheduled persistent grid (conv_wino.hip): the kernel
+// leaves the set zeroed again (its last workgroup resets it), sets are handed out round-robin so that launches in flight
+// on different streams do not share one.  nullptr before side_stream_warm() has run on this device (never under a capture).
+int* dyn_tile_counters() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  SideCtx& c = g_ctx[dev];
+  if (!c.ready.load(std::memory_order_acquire) || !c.dyn) return nullptr;
+  return c.dyn + (c.dyn_next.fetch_add(1, std::memory_order_relaxed) % kDynSets) * kDynInts;
+}
 
 bool side_enabled() { return opt(OPT_SIDE_STREAM) != 0; }
 
