@@ -20,7 +20,7 @@ constexpr int kMaxDevices = 16;
 constexpr int kEvents = 64;
 // The library is entered from the caller's thread (forward) and from the autograd engine's worker thread (backward):
 // creation is serialised by a mutex and published through an acquire/release flag, the event-ring cursor is atomic.
-constexpr int kDynSets = 8, kDynInts = 32;
+constexpr int kDynSets = 32, kDynInts = 32;
 struct SideCtx {
   hipStream_t side = nullptr;
   int* dyn = nullptr;  // [kDynSets][kDynInts] zero-initialised tile counters of the dynamically scheduled persistent grids
@@ -59,8 +59,8 @@ bool side_enabled();
 void side_stream_warm() { (void)ctx(); }
 
 // A set of zeroed tile counters for ONE launch of a dynamically scheduled persistent grid (conv_wino.hip): the kernel
-// leaves the set zeroed again (its last workgroup resets it), sets are handed out round-robin so that launches in flight
-// on different streams do not share one.  nullptr before side_stream_warm() has run on this device (never under a capture).
+// leaves the set zeroed again (its last workgroup resets it), sets are handed out round-robin (32 of them) so that launches in
+// flight on different streams do not share one.  nullptr before side_stream_warm() has run on this device (never under a capture).
 int* dyn_tile_counters() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;

@@ -599,8 +599,9 @@ class ModelWrapper:
                 or getattr(self, "defer_mmd_join", None) is not None or torch.cuda.is_current_stream_capturing()):
             return
         rec = getattr(self, "_defer_rec", None)
-        if rec is None or rec["decision"] is None:
-            torch.cuda._sleep(2_000_000)  # (~20 ms: the counter behind it runs at 100 MHz)
+        spin = getattr(torch.cuda, "_sleep", None)
+        if spin is not None and (rec is None or rec["decision"] is None):
+            spin(2_000_000)  # (~20 ms: the counter behind it runs at 100 MHz)
 
     def _defer_measure(self, main, side) -> None:
         """Called at the join-in-front point of a step that is still measuring: marks "main stream reached the join" and

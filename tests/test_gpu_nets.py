@@ -125,8 +125,8 @@ def test_decoder_tail_fused_equals_separate_passes():
 def test_encoder_winograd_form_matches_direct_form():
     """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip) against the direct implicit GEMM, on whole
     networks: evaluation-mode forward and training-mode forward + backward under the default (option enc_wino = -1:
-    evaluation launches of 256 workgroups' worth or more, training launches -- forward and data gradient -- of 1024 or
-    more: at this size the first 3x3 layer's two launches) and with every launch switched (enc_wino = 1)."""
+    evaluation launches of 256 workgroups' worth or more, training launches -- forward and data gradient -- of
+    `wino_min_blocks` = 512 or more: at this size the first two 3x3 layers' launches) and with every launch switched (enc_wino = 1)."""
     from image_generation_amd import _lib
     n, B = 128, 1024
     params = gen.make_params(n, "encoder", 111)
@@ -155,6 +155,30 @@ def test_encoder_winograd_form_matches_direct_form():
             # (5e-3: the bar of the full-size step test against float64 -- the first layers' gradients pass through three
             # BatchNorm backward passes, whose cancellations amplify any float32 rounding difference to ~1e-3)
             assert rel(out[mode][2][k], g) < 5e-3, (mode, k, rel(out[mode][2][k], g))
+
+
+def test_winograd_dynamic_tile_deal_is_bit_identical():
+    """Option wino_dynamic (default 1): the Winograd forward / data-gradient launches hand their tile blocks out through an
+    atomic counter instead of round-robin.  Which workgroup computes a block must not change a bit: outputs, BatchNorm
+    statistics (through the logits) and every gradient equal the static deal's exactly, with all launches switched
+    (enc_wino = 1), at a size where workgroups take several blocks each and at one where most get none."""
+    from image_generation_amd import _lib
+    for n, B in ((128, 1024), (64, 96)):
+        params = gen.make_params(n, "encoder", 111)
+        x = torch.from_numpy(gen.make_images(B, 222)).cuda()
+        gl = torch.from_numpy(np.random.default_rng(333).standard_normal((B, n)).astype(np.float32)).cuda()
+        out = {}
+        for dyn in (0, 1):
+            with _lib.option_scope(enc_wino=1, wino_dynamic=dyn):
+                for rep in range(2):  # (twice: the second run starts from the counters the first one left behind)
+                    enc = _load(Encoder(n), params).train()
+                    lg = enc(x)
+                    (lg * gl).sum().backward()
+                    torch.cuda.synchronize()
+                out[dyn] = (lg.detach().clone(), {k: v.grad.detach().clone() for k, v in enc.named_parameters()})
+        assert torch.equal(out[0][0], out[1][0]), (n, B)
+        for k, g in out[0][1].items():
+            assert torch.equal(g, out[1][1][k]), (n, B, k)
 
 
 def test_decoder_matches_reference_fixture(fx):
