@@ -6,39 +6,54 @@ namespace dvg {
 
 // ---------------------------------------------------------------- Gumbel-softmax, 2 classes
 // Plugin default latent_to_discrete (call site /root/reference/src/model_wrapper.py:184-188, :297).
+// one element of the Gumbel-softmax (2 classes): spin = argmax, dspin = d p0 / d logit * 2
+__device__ __forceinline__ void gumbel_element(float l, int64_t e, const float* __restrict__ gumbels, uint32_t k0, uint32_t k1,
+                                               uint32_t off_lo, uint32_t off_hi, float tau, float& spin, float& ds) {
+  float g0, g1;
+  if (gumbels) {
+    g0 = gumbels[2 * e];
+    g1 = gumbels[2 * e + 1];
+  } else {
+    const u32x4 r = philox4x32_10((uint32_t)e, off_lo, off_hi ^ (uint32_t)(e >> 32), STREAM_GUMBEL, k0, k1);
+    // u = (k + 1/2) 2^-23 with k the top 23 bits: every value is exact in float32 and strictly inside (0, 1), so the
+    // Gumbel noise is finite (|g| < 17).  A 24-bit k does NOT work: 16777215 + 0.5 rounds to 2^24, u = 1, g = +inf,
+    // and (inf - inf) in the softmax below poisons the whole encoder gradient -- a 2^-24 event per draw, i.e. a few
+    // per cent per training step at B R n = 2.6e5 (found by a soak run; regression test in tests/test_gpu_losses.py).
+    const float u0 = __fmul_rn(__uint2float_rn(r.x >> 9) + 0.5f, 1.1920928955078125e-07f);
+    const float u1 = __fmul_rn(__uint2float_rn(r.y >> 9) + 0.5f, 1.1920928955078125e-07f);
+    g0 = -logf(-logf(u0));
+    g1 = -logf(-logf(u1));
+  }
+  const float y0 = __fdiv_rn(__fadd_rn(l, g0), tau);
+  const float y1 = __fdiv_rn(g1, tau);
+  const float m = fmaxf(y0, y1);
+  const float e0 = expf(y0 - m), e1 = expf(y1 - m);
+  const float p0 = e0 / (e0 + e1);
+  spin = (y0 >= y1) ? 1.0f : -1.0f;  // argmax, ties -> class 0 (+1)
+  ds = 2.0f * p0 * (1.0f - p0) / tau;
+}
+
+// four consecutive latent units per thread (n % 4 == 0): one 16-byte load of the logits, two 16-byte stores
 __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, int64_t B, int n, int R,
                                                          float tau, const float* __restrict__ gumbels,
                                                          uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi,
                                                          const uint64_t* __restrict__ off_dev,
                                                          float* __restrict__ spins, float* __restrict__ dspin) {
   if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
-  const int64_t total = B * R * (int64_t)n;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e % n);
-    const int64_t b = e / ((int64_t)n * R);
-    const float l = logits[b * n + i];
-    float g0, g1;
-    if (gumbels) {
-      g0 = gumbels[2 * e];
-      g1 = gumbels[2 * e + 1];
-    } else {
-      const u32x4 r = philox4x32_10((uint32_t)e, off_lo, off_hi ^ (uint32_t)(e >> 32), STREAM_GUMBEL, k0, k1);
-      // u = (k + 1/2) 2^-23 with k the top 23 bits: every value is exact in float32 and strictly inside (0, 1), so the
-      // Gumbel noise is finite (|g| < 17).  A 24-bit k does NOT work: 16777215 + 0.5 rounds to 2^24, u = 1, g = +inf,
-      // and (inf - inf) in the softmax below poisons the whole encoder gradient -- a 2^-24 event per draw, i.e. a few
-      // per cent per training step at B R n = 2.6e5 (found by a soak run; regression test in tests/test_gpu_losses.py).
-      const float u0 = __fmul_rn(__uint2float_rn(r.x >> 9) + 0.5f, 1.1920928955078125e-07f);
-      const float u1 = __fmul_rn(__uint2float_rn(r.y >> 9) + 0.5f, 1.1920928955078125e-07f);
-      g0 = -logf(-logf(u0));
-      g1 = -logf(-logf(u1));
-    }
-    const float y0 = __fdiv_rn(__fadd_rn(l, g0), tau);
-    const float y1 = __fdiv_rn(g1, tau);
-    const float m = fmaxf(y0, y1);
-    const float e0 = expf(y0 - m), e1 = expf(y1 - m);
-    const float p0 = e0 / (e0 + e1);
-    spins[e] = (y0 >= y1) ? 1.0f : -1.0f;  // argmax, ties -> class 0 (+1)
-    dspin[e] = 2.0f * p0 * (1.0f - p0) / tau;
+  const int n4 = n >> 2;
+  const int64_t total4 = B * R * (int64_t)n4;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (int64_t)gridDim.x * 256) {
+    const int i4 = (int)(q % n4);
+    const int64_t b = q / ((int64_t)n4 * R);
+    const float4 l = *reinterpret_cast<const float4*>(logits + b * n + 4 * i4);
+    const int64_t e = 4 * q;
+    float4 sp, ds;
+    gumbel_element(l.x, e, gumbels, k0, k1, off_lo, off_hi, tau, sp.x, ds.x);
+    gumbel_element(l.y, e + 1, gumbels, k0, k1, off_lo, off_hi, tau, sp.y, ds.y);
+    gumbel_element(l.z, e + 2, gumbels, k0, k1, off_lo, off_hi, tau, sp.z, ds.z);
+    gumbel_element(l.w, e + 3, gumbels, k0, k1, off_lo, off_hi, tau, sp.w, ds.w);
+    *reinterpret_cast<float4*>(spins + e) = sp;
+    *reinterpret_cast<float4*>(dspin + e) = ds;
   }
 }
 
@@ -183,7 +198,9 @@ extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, floa
                               dvg_stream_t stream) {
   DVG_REQUIRE(logits && spins && dspin, "gumbel_fwd: null argument");
   DVG_REQUIRE(B > 0 && n > 0 && R > 0 && tau > 0.f, "gumbel_fwd: B=%lld n=%d R=%d tau=%g", (long long)B, n, R, tau);
-  DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_kernel, dim3(grid_for(B * R * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
+  DVG_REQUIRE(n % 4 == 0 && ((((uintptr_t)logits | (uintptr_t)spins | (uintptr_t)dspin) & 15) == 0),
+              "gumbel_fwd: n=%d must be a multiple of 4 and the tensors 16-byte aligned", n);
+  DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_kernel, dim3(grid_for(B * R * (int64_t)(n / 4))), dim3(256), 0, (hipStream_t)stream,
              logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
              (uint32_t)(offset >> 32), dyn ? &dyn->gumbel_offset : nullptr, spins, dspin);
   return DVG_OK;

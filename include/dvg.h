@@ -27,7 +27,14 @@
  *     different options concurrently (the plan-shaping ones are recorded per
  *     workspace by a forward call, and a backward call under another plan fails
  *     with DVG_E_INVALID instead of reading what its forward never wrote; the
- *     grid-sizing ones -- enc_wino_cus and friends -- only move performance).
+ *     grid-sizing ones -- enc_wino_cus and friends -- only move performance),
+ *     (5) host-side bookkeeping keyed by workspace pointer: the mode and plan a
+ *     forward call ran under (checked by its backward call) and the mark of a
+ *     dvg_decoder_prepare in flight (one event per workspace), (6) per device, a
+ *     pool of 32 sets of tile counters in device memory for the dynamically
+ *     scheduled Winograd grids (option wino_dynamic): a launch takes the next
+ *     set and leaves it zeroed; more than 32 such launches in flight at once
+ *     on one device are not supported.
  *     Nothing else persists between calls; entry points are re-entrant per
  *     (stream, workspace).  HIP is initialised lazily by the
  *     first call in each process (the Dash app runs training in a spawned
