@@ -88,3 +88,34 @@ def test_dataset_size_is_the_references_random_split_subset():
     torch.manual_seed(5)
     dl = data.get_dataloader(32, 10, dataset_size=100, seed=1, device="cpu")
     assert len(dl) == 10 and dl.images.shape == (100, 1, 32, 32)
+
+
+def test_schedule_decisions_of_the_wrapper_need_no_gpu():
+    """Round 4's host-side schedule decisions: the decoder's weight-only prologue is forked only from
+    ``PREPARE_DECODER_ROWS`` decoder rows up (a fork costs a captured step more than the prologue takes below that) unless
+    ``prepare_decoder`` forces it; on a CPU device both the preparation and the device-hold of the join measurement are
+    no-ops; the MMD-join decision takes the LARGEST measured lag (a host-bound sample reads ~0)."""
+    from image_generation_amd.modules import Decoder
+
+    m = ModelWrapper.__new__(ModelWrapper)
+    m.prepare_decoder, m._prep_stream, m._device, m.N_REPLICAS = None, None, torch.device("cpu"), 8
+    assert ModelWrapper.PREPARE_DECODER_ROWS == 32768
+    m._prepare_decoder(torch.zeros(4096, 1, 32, 32), None)   # 32768 rows, but no GPU: nothing happens
+    assert m._prep_stream is None
+    m.overlap_sampler = m.overlap_mmd = True
+    m.sampler = None
+    m._hold_device_while_measuring()                          # (returns before touching torch.cuda)
+    dec = Decoder(32)
+    dec.prepare(64, None)                                     # CPU parameters: a no-op, nothing pending
+    assert dec._prepared is None
+    # the decision rule itself
+    m.DEFER_SAMPLES, m.DEFER_LAG_MS = 2, 0.05
+    rec = {"decision": None, "events": [], "lags": [0.004, 0.9]}
+    m.__dict__["_defer_state"] = {((16, 32), (4, 32), 0): rec}
+
+    class _Ev:  # two already-synchronised "event pairs" whose lags are 0.004 and 0.9 ms
+        def __init__(self, v): self.v = v
+        def synchronize(self): pass
+        def elapsed_time(self, other): return other.v - self.v
+    rec["lags"], rec["events"] = [], [(_Ev(0.0), _Ev(0.004)), (_Ev(0.0), _Ev(0.9))]
+    assert m._defer_mmd_join(torch.empty(16, 32), torch.empty(4, 32)) is True and rec["lags"] == [0.004, 0.9]
