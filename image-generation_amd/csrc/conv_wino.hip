@@ -485,6 +485,9 @@ bool conv_wino_shape(int64_t M, int Cin, int Cout, int L) { return wino_shape_ok
 bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   const int64_t o = opt(OPT_ENC_WINO);
   if (o == 0 || (o == 2 && kind == 1) || (o == 3 && kind != 1) || !wino_shape_ok(M, Cin, Cout, L)) return false;
+  // (the bf16-input mode means bf16-rounded operands for every forward / data-gradient launch: the float32 Winograd form
+  // would silently compute those layers in float32, forced or not; weight gradients -- kind 3 -- are float32 in every mode)
+  if (kind != 3 && conv_precision_mode() == 1) return false;
   if (o >= 1) return true;
   const int cfg = wino_cfg(Cout);
   const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
@@ -495,7 +498,7 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   // switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the persistent grid 128 CUs there)
   // (kind 3: a weight gradient -- float32 in every operand mode; forward / data gradient: not in the bf16-input mode)
   if (kind == 3) return blocks >= opt(OPT_WINO_MIN_BLOCKS);
-  return kind == 2 ? blocks >= 256 : (blocks >= opt(OPT_WINO_MIN_BLOCKS) && conv_precision_mode() != 1);
+  return kind == 2 ? blocks >= 256 : blocks >= opt(OPT_WINO_MIN_BLOCKS);
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
