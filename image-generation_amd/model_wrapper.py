@@ -273,7 +273,9 @@ class ModelWrapper:
         launches are persistent grids of whole-CU workgroups (library option ``enc_wino_cus``), and a workgroup that finds
         no free CU starts a whole round late (c3: 200 of them beside the draw's 64 workgroups cost 0.6 ms, 192 gain 0.25).
         A draw of more than 128 workgroups (c5: one per 16 chains) leaves too little: those launches then take the whole
-        chip and queue behind the draw's first workgroups like any other kernel."""
+        chip and queue behind the draw's first workgroups like any other kernel.  (Read by the library only under option
+        ``wino_dynamic = 0``: with the dynamic deal of tile blocks, the default since round 4, the forward grids are
+        chip-sized and the workgroups that wait for the draw's CUs take what is left when they start.)"""
         if self._device is None or self._device.type != "cuda" or self.sampler is None or not hasattr(self.sampler, "launch_info"):
             return
         from . import _lib
