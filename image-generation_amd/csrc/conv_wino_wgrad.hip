@@ -382,8 +382,8 @@ static WinoWgradGeom wino_wgrad_geom(int64_t M, int Cin, int Cout, int L, int cu
 }
 
 // kind of launch the policy is asked about: the weight gradient of a training call (option enc_wino_wgrad: -1 = with the
-// other training launches, i.e. float32 operand mode and >= 1024 workgroups' worth of tile blocks; 0 never; 1 whenever
-// the shape allows)
+// other training launches, i.e. from option wino_min_blocks workgroups' worth of tile blocks up -- in every operand mode:
+// weight gradients are float32 in all of them; 0 never; 1 whenever the shape allows)
 bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   const int64_t o = opt(OPT_ENC_WINO_WGRAD);
   if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;

@@ -33,11 +33,11 @@ const OptDef kDefs[OPT_COUNT] = {
     {"gibbs_waves", 0, "sampler: waves per workgroup (0 = chosen by graph size)"},
     {"gibbs_waves_per_chain", 1, "sampler: 2 = two waves per chain where colour classes hold 65..128 spins and chains are few (the faster draw ALONE: generation; neutral inside a training step), 1 = one (default)"},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
-    {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form: -1 launches of 256 workgroups or more (default), 0 never, 1 every launch the shape allows, 2 / 3 forward / data-gradient launches only"},
+    {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form: -1 by size (default: evaluation-mode forward launches of 256 workgroups' worth of tiles or more, training launches of wino_min_blocks or more), 0 never, 1 every launch the shape allows, 2 / 3 forward / data-gradient launches only; never in the bf16-input mode"},
     {"enc_wino_mask", 0, "A/B: when non-zero, picks the Winograd form per launch instead of enc_wino: bit l-1 = forward of layer l (1..3), bit 2+l = its data gradient"},
     {"enc_l0_fused", 1, "encoder layer 0: 1 = its output is recomputed by every pass that needs it (BatchNorm statistics, BN/pool/LeakyReLU, both backward passes, the weight gradient) and never stored (default; 2 = the same with the backward in two passes), 0 = stored and re-read (rounds 1-2)"},
     {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)"},
-    {"enc_wino_cus", 256, "Winograd FORWARD launches of a training call: CUs the persistent grid is sized for -- a workgroup needs a whole CU, and the step's sampler draw, enqueued first, keeps its own (ModelWrapper sets 256 - the draw's workgroups, dvg_gibbs_launch_info)"},
+    {"enc_wino_cus", 256, "Winograd FORWARD launches of a training call: CUs the persistent grid is sized for -- a workgroup needs a whole CU, and the step's sampler draw, enqueued first, keeps its own (ModelWrapper sets 256 - the draw's workgroups, dvg_gibbs_launch_info); read only under wino_dynamic = 0"},
     {"enc_wino_cus_d", 128, "the same for the data-gradient launches, which share the chip with the weight-gradient chain on the side stream (measured at c3: 128 -> 10.16 ms, 192 -> 10.23, 256 -> 10.6)"},
     {"enc_wino_wgrad", -1, "encoder 3x3 WEIGHT gradients in the Winograd form (conv_wino_wgrad.hip): -1 with the other training launches (default), 0 never, 1 whenever the shape allows"},
     {"enc_wino_cus_w", 128, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them; measured at c3 with enc_wino_cus_d: (128, 128) 9.40 ms, (160, 96) 9.64, (192, 64) 10.09, (192, 128) 9.41, (256, 128) 9.45; a budget of its own for layer 1's launch, the last of the step: neutral)"},
