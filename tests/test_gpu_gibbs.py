@@ -47,6 +47,38 @@ def test_gibbs_bit_exact(fam, n, C, sweeps):
         assert mism == 0, f"{mism} spin mismatches at call {call}"
 
 
+@pytest.mark.parametrize("n,p_edge,C,sweeps", [(77, 0.35, 19, 6), (130, 0.22, 70, 4), (61, 0.03, 5, 3)])
+def test_gibbs_bit_exact_on_arbitrary_graphs(n, p_edge, C, sweeps):
+    """Graphs the shipped solvers do not produce: an odd spin count (the LDS image's alignment padding), degrees beyond
+    the 20 neighbours of one round of the neighbour sum (77 spins at p = 0.35: up to ~35 -> two rounds of 5 batches, last
+    batches partly padding), isolated spins (rows of zero batches: the all-zero batch only), dozens of colour classes
+    (the rolled schedule), and a sparse graph whose rows are single partly-padded batches -- both schedules against the C
+    oracle, bit for bit."""
+    rng = np.random.default_rng(n)
+    iu, ju = np.triu_indices(n, 1)
+    keep = rng.uniform(size=iu.size) < p_edge
+    keep &= (iu != 3) & (ju != 3)                      # spin 3 is isolated
+    ei, ej = iu[keep].astype(np.int64), ju[keep].astype(np.int64)
+    plan = graphs.build_plan(n, ei, ej)
+    deg = np.diff(plan.adj_ptr)
+    assert deg[3] == 0 and (p_edge < 0.1 or deg.max() > 20)
+    h = (0.5 * rng.uniform(-1, 1, n)).astype(np.float32)
+    J = (2.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)
+    hs, Js = gibbs.scaled_fields(h, J, 0.3, (-4, 4), (-1, 1))
+    ids = np.arange(C, dtype=np.uint32) + 7
+    lin = torch.from_numpy(h).cuda(); quad = torch.from_numpy(J).cuda()
+    for generic in (0, 1):
+        with _lib.option_scope(gibbs_generic=generic):
+            s = smp.GibbsSampler(plan, list(range(n)), beta=1.5, sweeps=sweeps, seed=SEED, persistent=True, chain_offset=7,
+                                 h_range=(-4, 4), j_range=(-1, 1))
+            want = cref.init_state(ids, n, SEED)
+            for call in range(2):
+                got = s.sample_native(lin, quad, 0.3, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
+                want = cref.gibbs_sweeps(want, ids, hs, Js, 1.5, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
+                                         plan.adj_eid, SEED, call * sweeps, sweeps)
+                assert int((got != want.astype(np.float32)).sum()) == 0, (generic, call)
+
+
 def test_sample_ising_dict_path_and_sampleset():
     plan, nodes = _plan("pegasus", 64)
     rng = np.random.default_rng(1)
