@@ -445,6 +445,367 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
   conv_wino_body<WM, WN, KC, UM>(a, wino_smem);
 }
 
+// ===================================================================================================================
+// The two-waves-per-SIMD form (round 5): EIGHT waves per workgroup, the 16 (9) transform positions of a 32 quad x 32
+// channel sub-tile split over a wave PAIR -- wave w and wave w + 4 land on the same SIMD, read the same transformed
+// operands and hold the transform rows xi in {0, 1} and {2, 3}: 8 accumulator tiles = 128 registers each, so the two fit
+// the register file side by side and one wave's operand waits, LDS-DMA issue and transform arithmetic fall under the
+// other's MFMAs (the one-wave form above left the matrix pipe idle for every exposed ds_read: PMC busy 0.21-0.37 in a
+// training step, round 4).  Same LDS images, same DMA, same chunk sequence, same outputs per tile block; what changes:
+// every thread transforms ONE patch per chunk (512 threads), and the output transform Y = A^T M A needs rows of M from
+// both waves of a pair, so each wave first applies the column half (C_xi = M[xi][.] A, lane-local as before), the pair
+// swaps ONE row of C through LDS (two rounds of 4 KB per wave in the transformed-input stage the block's last chunk has
+// just finished with), and each wave then owns one output row of the quad: wave set 0 the pixels 4 q, 4 q + 1, set 1 the
+// pixels 4 q + 2, 4 q + 3.  Behind the upsample (UM = 1: xi, nu in {0, 1, 3}) set 0 holds xi = 0, 1 (6 MFMAs per k-step)
+// and set 1 xi = 3 (3 MFMAs): unequal, but they share one matrix pipe.
+template <int WM, int WN, int KC, int UM = 0>
+struct Wino8Cfg {
+  static constexpr int TBLK = 32 * WM, CB = 32 * WN, KS = KC / 2;
+  static constexpr int PPQ = UM == 1 ? 1 : 4;                // raw pixels per quad (UM = 1: one source pixel)
+  static constexpr int RAW_PIX = TBLK * PPQ * KC * 4;        // bytes of raw pixels per stage
+  static constexpr int RAW_PIECES = RAW_PIX / 1024;          // 1 KiB DMA pieces (one wave instruction each)
+  static constexpr int RAW_B = 64 + RAW_PIX;                 // + the zero entry padding taps read
+  static constexpr int V_B = KC * TBLK * 64, U_B = KC * CB * 64;
+  static constexpr int U_PIECES = U_B / 1024;
+  static constexpr int OFF_RAW = 0, OFF_V = OFF_RAW + 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B;
+  static constexpr int OFF_NEXT = OFF_RED + 2 * WM * CB * 2 * 4;
+  static constexpr int LDS_BYTES = OFF_NEXT + 16;
+  static_assert(WM * WN == 4 && TBLK * KC == 512 && RAW_PIX % 1024 == 0 && U_PIECES % 8 == 0 && V_B >= 8 * 4096, "unsupported shape");
+};
+
+template <int WM, int WN, int KC, int UM>
+__device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char* wsm) {
+  using C = Wino8Cfg<WM, WN, KC, UM>;
+  static_assert(UM == 0 || UM == 1, "forward / data gradient of a plain 3x3 layer, or the forward behind an upsample");
+  constexpr int NP = UM == 1 ? 9 : 16;  // raw pixels of a patch
+  constexpr int TBLK = C::TBLK, CB = C::CB, KS = C::KS;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ps = wave >> 2, pw = wave & 3;  // position set (transform rows 2 ps, 2 ps + 1) and sub-tile of the pair
+  const int wm = pw / WN, wn = pw % WN;
+  const int n0 = blockIdx.y * CB;
+  const int H = 1 << a.L, HW = H * H;
+
+  // ---- the thread's patch: quad tl of the tile block, channel k0 of the chunk (rotated by the quad so that the 32 lanes
+  // of a read spread over the banks); a padding tap reads the stage's zero entry
+  const int tl = tid % TBLK, k0 = ((tid / TBLK) + tl / (64 / KC)) % KC;
+  int poff[16];
+  if constexpr (UM == 1) {
+    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4), Hs = H / 2;
+    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int y = ty - 1 + e / 3, x = tx - 1 + e % 3;
+      const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
+      const int pos = img * (HW / 4) + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
+      poff[e] = ok ? 64 + (pos * KC + k0) * 4 : 0;
+    }
+  } else {
+    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4);
+    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
+        const int px = img * HW + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
+        const int pos = (px & 3) * TBLK + (px >> 2);
+        poff[i * 4 + j] = ok ? 64 + (pos * KC + k0) * 4 : 0;
+      }
+  }
+  const uint32_t vst = lds0 + C::OFF_V + (uint32_t)((k0 * TBLK + tl) * 64);
+  const int swt = (tl >> 2) & 3;
+  // MFMA operands: entry (k, row), slot xi at (xi ^ ((row >> 2) & 3)) << 4; this wave reads xi = 2 ps and 2 ps + 1
+  const int rowA = wm * 32 + c, colB = wn * 32 + c;
+  uint32_t aaddr[2], baddr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aaddr[i] = lds0 + C::OFF_V + (uint32_t)((hh * TBLK + rowA) * 64 + (((2 * ps + i) ^ ((rowA >> 2) & 3)) << 4));
+    baddr[i] = lds0 + C::OFF_U + (uint32_t)((hh * CB + colB) * 64 + (((2 * ps + i) ^ ((colB >> 2) & 3)) << 4));
+  }
+  if (tid < 32) *reinterpret_cast<float*>(wsm + C::OFF_RAW + (tid >> 4) * C::RAW_B + (tid & 15) * 4) = 0.f;
+
+  // ---- DMA of one chunk's images: 1 KiB pieces, piece p by wave p % 8; scalar offsets carry the chunk
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * TBLK * C::PPQ * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.u), 0, (int)((int64_t)a.Cin * a.Cout * 64), 0x00020000);
+  constexpr int RPW = (C::RAW_PIECES + 7) / 8, UPW = C::U_PIECES / 8;  // pieces per wave
+  int rvoff[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int byte = ((wave + 8 * q) * 64 + lane) * 16, pos = byte / (KC * 4);
+    if constexpr (UM == 1) rvoff[q] = pos * a.Cin * 4 + byte % (KC * 4);
+    else rvoff[q] = (4 * (pos % TBLK) + pos / TBLK) * a.Cin * 4 + byte % (KC * 4);
+  }
+  int usoff[UPW];  // scalar part of a weight piece's source: row kk of the chunk, bytes `within` of that row's CB entries
+#pragma unroll
+  for (int q = 0; q < UPW; ++q) {
+    const int off = (wave + 8 * q) * 1024, kk = off / (CB * 64), within = off % (CB * 64);
+    usoff[q] = __builtin_amdgcn_readfirstlane((kk * a.Cout + n0) * 64 + within);
+  }
+  const int nch = a.Cin / KC;
+  auto issue_raw = [&](int blk, int ch, int st) {
+    const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK * C::PPQ * a.Cin + ch * KC) * 4);
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      if (wave + 8 * q < C::RAW_PIECES) {
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + st * C::RAW_B + 64 + (wave + 8 * q) * 1024));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
+      }
+    }
+  };
+  auto issue_u = [&](int ch, int st) {
+    const int sbase = __builtin_amdgcn_readfirstlane(ch * KC * a.Cout * 64);
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + (wave + 8 * q) * 1024));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_void_t*)(uintptr_t)dst, 16, lane * 16, sbase + usoff[q], 0, 0);
+    }
+  };
+
+  // ---- input transform of the thread's patch: raw stage `rs` -> transformed stage `vs`
+  auto load_patch = [&](int rs, float (&d)[16]) {
+#pragma unroll
+    for (int e = 0; e < NP; ++e)
+      d[e] = *reinterpret_cast<lds_cf32*>((uintptr_t)(lds0 + C::OFF_RAW + rs * C::RAW_B + (uint32_t)poff[e]));
+  };
+  // B^T d, column m (UM = 1: T s, column m of 3)
+  auto xform_col = [&](int m, const float (&d)[16], float (&t)[16]) {
+    if constexpr (UM == 1) {
+      t[0 * 3 + m] = d[0 * 3 + m] - d[1 * 3 + m];
+      t[1 * 3 + m] = d[1 * 3 + m] + d[1 * 3 + m];
+      t[2 * 3 + m] = d[1 * 3 + m] - d[2 * 3 + m];
+    } else {
+      t[0 * 4 + m] = d[0 * 4 + m] - d[2 * 4 + m];
+      t[1 * 4 + m] = d[1 * 4 + m] + d[2 * 4 + m];
+      t[2 * 4 + m] = d[2 * 4 + m] - d[1 * 4 + m];
+      t[3 * 4 + m] = d[1 * 4 + m] - d[3 * 4 + m];
+    }
+  };
+  // (.) B, row m, and its store (UM = 1: row m of 3 -> transform row (0, 1, 3)[m])
+  auto xform_row_store = [&](int vs, int m, const float (&t)[16]) {
+    if constexpr (UM == 1) {
+      const f32x4 o = {t[m * 3 + 0] - t[m * 3 + 1], t[m * 3 + 1] + t[m * 3 + 1], 0.f, t[m * 3 + 1] - t[m * 3 + 2]};
+      const int xr = m == 2 ? 3 : m;
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + (uint32_t)((xr ^ swt) << 4))) = o;
+    } else {
+      const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], t[m * 4 + 2] - t[m * 4 + 1], t[m * 4 + 1] - t[m * 4 + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + (uint32_t)((m ^ swt) << 4))) = o;
+    }
+  };
+  constexpr int NPIECE = UM == 1 ? 3 : 4;  // pieces of each transform half (columns, then rows)
+
+  f32x16 acc[8];  // acc[4 i + nu] = M[2 ps + i][nu] of the wave's 32 quads x 32 channels
+
+  const bool dynq = a.dyn != nullptr;
+  volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
+  auto finish = [&]() {
+    if (dynq && tid == 0 && atomicAdd(a.dyn + 16 + blockIdx.y, 1) == (int)gridDim.x - 1) {
+      atomicExch(a.dyn + blockIdx.y, 0);
+      atomicExch(a.dyn + 16 + blockIdx.y, 0);
+    }
+  };
+  int blk_cur = (int)blockIdx.x, blk_nxt = blk_cur + (int)gridDim.x;
+  if (dynq) {
+    if (tid == 0) { nslot[0] = atomicAdd(a.dyn + blockIdx.y, 1); nslot[1] = atomicAdd(a.dyn + blockIdx.y, 1); }
+    __syncthreads();
+    blk_cur = __builtin_amdgcn_readfirstlane(nslot[0]);
+    blk_nxt = __builtin_amdgcn_readfirstlane(nslot[1]);
+    __syncthreads();
+  }
+  bool has_next = blk_nxt < a.nblk;
+  if (blk_cur >= a.nblk) { finish(); return; }
+  int vbase = 0, VT = (has_next ? 2 : 1) * nch;
+  auto blk_of = [&](int v) { return blk_cur + ((v - vbase) / nch) * (blk_nxt - blk_cur); };
+  issue_raw(blk_cur, 0, 0);
+  issue_u(0, 0);
+  issue_raw(blk_cur, 1 % nch, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    float d[16], t[16];
+    load_patch(0, d);
+#pragma unroll
+    for (int m = 0; m < NPIECE; ++m) xform_col(m, d, t);
+#pragma unroll
+    for (int m = 0; m < NPIECE; ++m) xform_row_store(0, m, t);
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+      a.out, 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cout * 4), 0x00020000);
+  const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;  // quad row 4 hh of the lane's first quad: 4 pixels per quad
+  const uint32_t xaddr = lds0 + C::OFF_V + C::V_B + (uint32_t)(lane * 16);  // exchange slots: stage 1 of the transformed input
+
+  // the epilogue of wave set PSC (compile-time copy of ps)
+  auto epilogue = [&](int blk, auto psc) {
+    constexpr int PSC = decltype(psc)::value;
+    const int col = n0 + wn * 32 + c;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    // column half of the output transform on the wave's own rows: C_i[b] = sum_nu M[2 ps + i][nu] A[nu][b]
+    f32x16 c00 = {0}, c01 = {0}, c10, c11;  // c<i><b>
+    if constexpr (UM == 1) {
+      if constexpr (PSC == 0) { c00 = acc[0] + acc[1]; c01 = acc[1] - acc[3]; }
+      c10 = acc[4] + acc[5]; c11 = acc[5] - acc[7];
+    } else {
+      c00 = (acc[0] + acc[1]) + acc[2]; c01 = (acc[1] - acc[2]) - acc[3];
+      c10 = (acc[4] + acc[5]) + acc[6]; c11 = (acc[5] - acc[6]) - acc[7];
+    }
+    // the pair swaps one row: set 0 gives C_1 (its i = 1) and takes C_2; set 1 gives C_2 (its i = 0) and takes C_1.
+    // (UM = 1: C_2 = 0 -- set 1 gives nothing)
+    f32x16 y0, y1;  // the wave's output row a = PSC: pixels 2 a + 0, 2 a + 1 of every quad
+    const uint32_t mine = xaddr + (uint32_t)(wave * 4096), theirs = xaddr + (uint32_t)((wave ^ 4) * 4096);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x16& give = PSC == 0 ? (b == 0 ? c10 : c11) : (b == 0 ? c00 : c01);
+      if (!(UM == 1 && PSC == 1)) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 o = {give[4 * r4], give[4 * r4 + 1], give[4 * r4 + 2], give[4 * r4 + 3]};
+          *reinterpret_cast<lds_f32x4*>((uintptr_t)(mine + r4 * 1024)) = o;
+        }
+      }
+      __syncthreads();
+      f32x16 got;
+      if (!(UM == 1 && PSC == 0)) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 o = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(theirs + r4 * 1024));
+          got[4 * r4] = o[0]; got[4 * r4 + 1] = o[1]; got[4 * r4 + 2] = o[2]; got[4 * r4 + 3] = o[3];
+        }
+      }
+      f32x16 yb;
+      if constexpr (UM == 1) {
+        if constexpr (PSC == 0) yb = (b == 0 ? c00 : c01) + (b == 0 ? c10 : c11);  // Y[0][b] = C_0 + C_1
+        else yb = got - (b == 0 ? c10 : c11);                                      // Y[1][b] = C_1 - C_3
+      } else {
+        if constexpr (PSC == 0) yb = ((b == 0 ? c00 : c01) + (b == 0 ? c10 : c11)) + got;  // Y[0][b] = (C_0 + C_1) + C_2
+        else yb = (got - (b == 0 ? c00 : c01)) - (b == 0 ? c10 : c11);                      // Y[1][b] = (C_1 - C_2) - C_3
+      }
+      if (b == 0) y0 = yb; else y1 = yb;
+      __syncthreads();  // (the slots are rewritten by round 1 / by the next chunk's transform)
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rq = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float v = (q == 0 ? y0[r] : y1[r]) + bias;
+        const int soff = __builtin_amdgcn_readfirstlane(((blk * TBLK + wm * 32) * 4 + rq + 2 * PSC + q) * a.Cout * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_out, ovoff, soff, 0);
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+    }
+    if (a.stats) {
+      float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const int slot = ((PSC * WM + wm) * CB + wn * 32 + c) * 2;
+      if (hh == 0) { red[slot] = s1; red[slot + 1] = s2; }
+      __syncthreads();
+      if (tid < CB) {  // (waves 0 .. CB / 64 - 1: set 0)
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2 * WM; ++w) { t1 += red[(w * CB + tid) * 2]; t2 += red[(w * CB + tid) * 2 + 1]; }
+        float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
+        dst[0] = t1; dst[1] = t2;
+      }
+    }
+  };
+
+  // One chunk of wave set PSC: KS k-steps x 2 transform rows (groups) x 4 (3) MFMAs as one pinned stream -- the operands
+  // of the next group are requested before this group's MFMAs, the thread's patch of the NEXT chunk is read at the start
+  // and transformed beside the MFMAs of the second and third executed groups, a piece per MFMA.
+  auto chunk = [&](int v, auto stc, auto psc) {
+    constexpr int st = decltype(stc)::value;
+    constexpr int PSC = decltype(psc)::value;
+    const int v1 = v + 1 < VT ? v + 1 : VT - 1, v2 = v + 2 < VT ? v + 2 : VT - 1;
+    issue_u(v1 % nch, st ^ 1);
+    issue_raw(blk_of(v2), v2 % nch, st);
+    f32x4 ca, cb, na, nb;
+    auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 2 ks + i: transform row 2 ps + i of k-step ks
+      x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[g & 1] + st * C::V_B + (g >> 1) * 2 * TBLK * 64));
+      y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 1] + st * C::U_B + (g >> 1) * 2 * CB * 64));
+    };
+    // (UM = 1, set 1: transform row 2 is identically zero -- only the odd groups exist)
+    constexpr int G0 = (UM == 1 && PSC == 1) ? 1 : 0, GSTEP = (UM == 1 && PSC == 1) ? 2 : 1;
+    constexpr int NG = (2 * KS - G0 + GSTEP - 1) / GSTEP;  // executed groups of the chunk
+    constexpr int EC = NG >= 3 ? 1 : 0;                    // the group that carries the column half of the transform
+    static_assert(NG >= 2, "the transform needs two executed groups per chunk");
+    load_grp(G0, ca, cb);
+    float d[16], t[16];
+    load_patch(st ^ 1, d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = G0; g < 2 * KS; g += GSTEP) {
+      const int e = (g - G0) / GSTEP;  // ordinal of the group among the executed ones
+      if (g + GSTEP < 2 * KS) load_grp(g + GSTEP, na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      int piece = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (UM == 1 && m == 2) continue;
+        if (e == EC) xform_col(piece, d, t);
+        if (e == EC + 1) xform_row_store(st ^ 1, piece, t);
+        ++piece;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ca = na; cb = nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  auto run = [&](auto psc) {
+    constexpr int PSC = decltype(psc)::value;
+    int v = 0, par = 1;
+    bool go = true;
+    while (go) {
+      int fetched = 0;
+      if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
+      for (int ch = 0; ch < nch; ch += 2) {
+        chunk(v, std::integral_constant<int, 0>{}, psc);
+        chunk(v + 1, std::integral_constant<int, 1>{}, psc);
+        v += 2;
+      }
+      epilogue(blk_cur, psc);
+      go = has_next;
+      blk_cur = blk_nxt;
+      if (dynq) {
+        par ^= 1;
+        if (tid == 0) nslot[par] = fetched;
+        __syncthreads();
+        blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
+      } else {
+        blk_nxt = blk_cur + (int)gridDim.x;
+      }
+      has_next = blk_nxt < a.nblk;
+      vbase += nch;
+      VT = vbase + (has_next ? 2 : 1) * nch;
+    }
+  };
+  // (one instantiation per wave set: which rows of M a wave holds decides its MFMA pattern behind the upsample and its
+  // half of the epilogue; the sets meet at every workgroup barrier -- both paths execute the same number of them)
+  if (ps == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+  finish();
+}
+
+template <int WM, int WN, int KC, int UM = 0>
+__global__ __launch_bounds__(512) void conv_wino8_kernel(WinoArgs a) {
+  extern __shared__ __align__(16) unsigned char wino_smem[];
+  conv_wino8_body<WM, WN, KC, UM>(a, wino_smem);
+}
+
 // U = G g G^T of every (reduction channel a, output channel b) pair, in the layout the kernel's DMA copies verbatim
 __global__ __launch_bounds__(256) void wino_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u) {
   const uint32_t total = (uint32_t)map.Ca * (uint32_t)map.Cb;
@@ -532,6 +893,27 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   return DVG_OK;
 }
 
+// the eight-wave form of the same launch (option wino_waves = 8)
+template <int WM, int WN, int KC, int UM = 0>
+static int launch_wino8_cfg(const WinoArgs& a, double flops, hipStream_t s) {
+  using C = Wino8Cfg<WM, WN, KC, UM>;
+  auto kern = conv_wino8_kernel<WM, WN, KC, UM>;
+  static std::atomic<uint64_t> attr_done{0};
+  DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
+  const int ny = a.Cout / C::CB;
+  int cus = a.cus > 0 ? a.cus : 256;
+  if (cus < ny) cus = ny;
+  if (cus > 256) cus = 256;
+  int gx = cus / ny;
+  if (gx < 1) gx = 1;
+  if (gx > a.nblk) gx = a.nblk;
+  WinoArgs ad = a;
+  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16) ? dyn_tile_counters() : nullptr;
+  if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
+  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), C::LDS_BYTES, s, ad);
+  return DVG_OK;
+}
+
 // a.wp must be the transformed pack of launch_wino_weight_pack; a.M, Cin, Cout, L, bias, out, stats as for launch_conv_igemm
 int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   // wino_um = 1: Upsample(x2) + 3x3 forward (a.in = the SOURCE map, a.M / a.L of the output grid); 2: its data gradient
@@ -546,6 +928,10 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   // EXECUTED matrix FLOPs: 16 transform-domain GEMMs over the M / 4 quads (4/9 of the direct form's 2 M Cin Cout 9;
   // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
   const double flops = 2.0 * (double)(a.M / 4) * (a.wino_um ? 9.0 : 16.0) * a.Cin * a.Cout;
+  if (opt(OPT_WINO_WAVES) == 8 && a.wino_um != 2) {
+    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1>(w, flops, s);
+    return cfg == 0 ? launch_wino8_cfg<2, 2, 8>(w, flops, s) : launch_wino8_cfg<4, 1, 4>(w, flops, s);
+  }
   if (a.wino_um == 1) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino_cfg<4, 1, 4, 1>(w, flops, s);
   if (a.wino_um == 2) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 2>(w, flops, s) : launch_wino_cfg<4, 1, 4, 2>(w, flops, s);
   if (cfg == 0) return launch_wino_cfg<2, 2, 8>(w, flops, s);

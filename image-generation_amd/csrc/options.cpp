@@ -48,6 +48,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"dec_wino_cus_d", 256, "... its data-gradient launches"},
     {"wino_min_blocks", 512, "encoder Winograd launches of a training call (enc_wino = -1): from this many workgroups' worth of tiles up (measured, n = 512 model: 1024 / 512 / 256 -> B = 512: 2.16 / 2.13 / 2.06 ms, B = 1024: 3.03 / 2.82 / 2.82, B = 2048: 4.67 / 4.60 / 4.53; c2: 0.920 / 0.924 / 0.953 -- 512 is the lowest value that costs c2 nothing)"},
     {"wino_dynamic", 1, "Winograd forward / data-gradient launches deal their tile blocks dynamically (an atomic counter per grid row) instead of round-robin: a workgroup that gets its CU late takes fewer blocks (1 default, 0 = the static deal of rounds 3-4)"},
+    {"wino_waves", 8, "Winograd forward / data-gradient kernels: 8 = two waves per SIMD, the transform positions of a sub-tile split over a wave pair (round 5, default), 4 = one wave per SIMD with all 16 positions (rounds 3-4; A/B reference)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;
