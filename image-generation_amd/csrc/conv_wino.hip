@@ -473,7 +473,7 @@ struct Wino8Cfg {
   static_assert(WM * WN == 4 && TBLK * KC == 512 && RAW_PIX % 1024 == 0 && U_PIECES % 8 == 0 && V_B >= 8 * 4096, "unsupported shape");
 };
 
-template <int WM, int WN, int KC, int UM>
+template <int WM, int WN, int KC, int UM, int TAIL>
 __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char* wsm) {
   using C = Wino8Cfg<WM, WN, KC, UM>;
   static_assert(UM == 0 || UM == 1, "forward / data gradient of a plain 3x3 layer, or the forward behind an upsample");
@@ -557,13 +557,14 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       }
     }
   };
-  auto issue_u = [&](int ch, int st) {
+  auto issue_u_piece = [&](int ch, int st, int q) {
     const int sbase = __builtin_amdgcn_readfirstlane(ch * KC * a.Cout * 64);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + (wave + 8 * q) * 1024));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_void_t*)(uintptr_t)dst, 16, lane * 16, sbase + usoff[q], 0, 0);
+  };
+  auto issue_u = [&](int ch, int st) {
 #pragma unroll
-    for (int q = 0; q < UPW; ++q) {
-      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + (wave + 8 * q) * 1024));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_void_t*)(uintptr_t)dst, 16, lane * 16, sbase + usoff[q], 0, 0);
-    }
+    for (int q = 0; q < UPW; ++q) issue_u_piece(ch, st, q);
   };
 
   // ---- input transform of the thread's patch: raw stage `rs` -> transformed stage `vs`
@@ -618,8 +619,6 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   }
   bool has_next = blk_nxt < a.nblk;
   if (blk_cur >= a.nblk) { finish(); return; }
-  int vbase = 0, VT = (has_next ? 2 : 1) * nch;
-  auto blk_of = [&](int v) { return blk_cur + ((v - vbase) / nch) * (blk_nxt - blk_cur); };
   issue_raw(blk_cur, 0, 0);
   issue_u(0, 0);
   issue_raw(blk_cur, 1 % nch, 1);
@@ -721,12 +720,23 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   // One chunk of wave set PSC: KS k-steps x 2 transform rows (groups) x 4 (3) MFMAs as one pinned stream -- the operands
   // of the next group are requested before this group's MFMAs, the thread's patch of the NEXT chunk is read at the start
   // and transformed beside the MFMAs of the second and third executed groups, a piece per MFMA.
-  auto chunk = [&](int v, auto stc, auto psc) {
+  // TAIL = 1: the chunk's LAST group of MFMAs is issued BEHIND the chunk barrier -- its operands are in registers when
+  // the wave arrives there -- between the next chunk's first operand reads and its LDS-DMA pieces, so the matrix pipe
+  // has 4 (3) MFMAs to run while the barrier releases, the DMA instructions issue and the first ds_reads of the new
+  // chunk travel; the first chunk of a tile block has no such tail in front (FIRST), the last one flushes its own behind
+  // its barrier (LAST), in front of the epilogue.
+  f32x4 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+  auto chunk = [&](int cix, auto stc, auto psc, auto firstc, auto lastc) {  // chunk cix of tile block blk_cur
     constexpr int st = decltype(stc)::value;
     constexpr int PSC = decltype(psc)::value;
-    const int v1 = v + 1 < VT ? v + 1 : VT - 1, v2 = v + 2 < VT ? v + 2 : VT - 1;
-    issue_u(v1 % nch, st ^ 1);
-    issue_raw(blk_of(v2), v2 % nch, st);
+    constexpr bool FIRST = decltype(firstc)::value != 0, LAST = decltype(lastc)::value != 0;
+    // what the chunk prefetches: the weights of the next chunk (past the block's end: chunk 0 again), the raw pixels of
+    // the chunk after next (past the end: the next block's, or -- no next block -- this block's last chunk once more,
+    // into a stage nobody reads)
+    const int u_ch = cix + 1 < nch ? cix + 1 : 0;
+    const bool over = cix + 2 >= nch;
+    const int r_ch = !over ? cix + 2 : (has_next ? cix + 2 - nch : nch - 1);
+    const int r_blk = over && has_next ? blk_nxt : blk_cur;
     f32x4 ca, cb, na, nb;
     auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 2 ks + i: transform row 2 ps + i of k-step ks
       x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[g & 1] + st * C::V_B + (g >> 1) * 2 * TBLK * 64));
@@ -735,15 +745,37 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
     // (UM = 1, set 1: transform row 2 is identically zero -- only the odd groups exist)
     constexpr int G0 = (UM == 1 && PSC == 1) ? 1 : 0, GSTEP = (UM == 1 && PSC == 1) ? 2 : 1;
     constexpr int NG = (2 * KS - G0 + GSTEP - 1) / GSTEP;  // executed groups of the chunk
-    constexpr int EC = NG >= 3 ? 1 : 0;                    // the group that carries the column half of the transform
-    static_assert(NG >= 2, "the transform needs two executed groups per chunk");
-    load_grp(G0, ca, cb);
+    constexpr int NOWN = TAIL ? NG - 1 : NG;               // ... in front of the chunk barrier
+    constexpr int EC = NOWN >= 3 ? 1 : 0;                  // the group that carries the column half of the transform
+    static_assert(NOWN >= 2, "the transform needs two executed groups per chunk");
     float d[16], t[16];
-    load_patch(st ^ 1, d);
+    if constexpr (!TAIL) {
+      issue_u(u_ch, st ^ 1);
+      issue_raw(r_blk, r_ch, st);
+      load_grp(G0, ca, cb);
+      load_patch(st ^ 1, d);
+    } else {
+      load_grp(G0, ca, cb);
+      load_patch(st ^ 1, d);
+      __builtin_amdgcn_sched_barrier(0);
+      int q = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (UM == 1 && m == 2) continue;
+        if constexpr (!FIRST) acc[4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[m], tb[m], acc[4 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q < UPW) issue_u_piece(u_ch, st ^ 1, q);
+        ++q;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (; q < UPW; ++q) issue_u_piece(u_ch, st ^ 1, q);
+      issue_raw(r_blk, r_ch, st);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = G0; g < 2 * KS; g += GSTEP) {
-      const int e = (g - G0) / GSTEP;  // ordinal of the group among the executed ones
+    for (int e = 0; e < NOWN; ++e) {  // e: ordinal of the group among the executed ones
+      const int g = G0 + e * GSTEP;
       if (g + GSTEP < 2 * KS) load_grp(g + GSTEP, na, nb);
       __builtin_amdgcn_sched_barrier(0);
       int piece = 0;
@@ -759,23 +791,41 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       }
       ca = na; cb = nb;
     }
+    if constexpr (TAIL) { ta = ca; tb = cb; }  // (the last group is always an odd one: transform row 2 ps + 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (TAIL && LAST) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (UM == 1 && m == 2) continue;
+        acc[4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[m], tb[m], acc[4 + m], 0, 0, 0);
+      }
+    }
   };
 
   auto run = [&](auto psc) {
-    constexpr int PSC = decltype(psc)::value;
-    int v = 0, par = 1;
+    int par = 1;
     bool go = true;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     while (go) {
       int fetched = 0;
       if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);
 #pragma unroll
       for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
-      for (int ch = 0; ch < nch; ch += 2) {
-        chunk(v, std::integral_constant<int, 0>{}, psc);
-        chunk(v + 1, std::integral_constant<int, 1>{}, psc);
-        v += 2;
+      if constexpr (TAIL) {
+        // (first, middle pairs, last: the middle chunks run stage 1, stage 0 in turn -- an even chunk count)
+        chunk(0, I0{}, psc, I1{}, I0{});
+        for (int ch = 2; ch < nch; ch += 2) {
+          chunk(ch - 1, I1{}, psc, I0{}, I0{});
+          chunk(ch, I0{}, psc, I0{}, I0{});
+        }
+        chunk(nch - 1, I1{}, psc, I0{}, I1{});
+      } else {
+        for (int ch = 0; ch < nch; ch += 2) {
+          chunk(ch, I0{}, psc, I0{}, I0{});
+          chunk(ch + 1, I1{}, psc, I0{}, I0{});
+        }
       }
       epilogue(blk_cur, psc);
       go = has_next;
@@ -789,8 +839,6 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
         blk_nxt = blk_cur + (int)gridDim.x;
       }
       has_next = blk_nxt < a.nblk;
-      vbase += nch;
-      VT = vbase + (has_next ? 2 : 1) * nch;
     }
   };
   // (one instantiation per wave set: which rows of M a wave holds decides its MFMA pattern behind the upsample and its
@@ -800,10 +848,10 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   finish();
 }
 
-template <int WM, int WN, int KC, int UM = 0>
+template <int WM, int WN, int KC, int UM = 0, int TAIL = 1>
 __global__ __launch_bounds__(512) void conv_wino8_kernel(WinoArgs a) {
   extern __shared__ __align__(16) unsigned char wino_smem[];
-  conv_wino8_body<WM, WN, KC, UM>(a, wino_smem);
+  conv_wino8_body<WM, WN, KC, UM, TAIL>(a, wino_smem);
 }
 
 // U = G g G^T of every (reduction channel a, output channel b) pair, in the layout the kernel's DMA copies verbatim
@@ -894,10 +942,10 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
 }
 
 // the eight-wave form of the same launch (option wino_waves = 8)
-template <int WM, int WN, int KC, int UM = 0>
+template <int WM, int WN, int KC, int UM = 0, int TAIL = 1>
 static int launch_wino8_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   using C = Wino8Cfg<WM, WN, KC, UM>;
-  auto kern = conv_wino8_kernel<WM, WN, KC, UM>;
+  auto kern = conv_wino8_kernel<WM, WN, KC, UM, TAIL>;
   static std::atomic<uint64_t> attr_done{0};
   DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
   const int ny = a.Cout / C::CB;
@@ -929,8 +977,13 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
   const double flops = 2.0 * (double)(a.M / 4) * (a.wino_um ? 9.0 : 16.0) * a.Cin * a.Cout;
   if (opt(OPT_WINO_WAVES) == 8 && a.wino_um != 2) {
-    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1>(w, flops, s);
+    // (the 32-channel tile behind the upsample has two groups per chunk in wave set 1: no tail to hold back)
+    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
     return cfg == 0 ? launch_wino8_cfg<2, 2, 8>(w, flops, s) : launch_wino8_cfg<4, 1, 4>(w, flops, s);
+  }
+  if (opt(OPT_WINO_WAVES) == 9 && a.wino_um != 2) {  // A/B: the eight-wave form without the tail behind the barrier
+    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1, 0>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
+    return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 0, 0>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 0, 0>(w, flops, s);
   }
   if (a.wino_um == 1) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino_cfg<4, 1, 4, 1>(w, flops, s);
   if (a.wino_um == 2) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 2>(w, flops, s) : launch_wino_cfg<4, 1, 4, 2>(w, flops, s);

@@ -297,6 +297,277 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a
   }
 }
 
+// ===================================================================================================================
+// The two-waves-per-SIMD form (round 5): eight waves per workgroup, the 16 (9) transform positions of a 32 x 32 channel
+// sub-tile split over a wave PAIR (waves w and w + 4 share a SIMD): rows xi in {0, 1} and {2, 3} of dU, 8 accumulator tiles
+// = 128 registers each, so the pair fits the register file side by side and one wave's operand waits and transform
+// arithmetic fall under the other's MFMAs.  The positions are independent in the weight gradient: no exchange, each wave
+// stores its own eight slab planes.  Transform items are (quad, TWO channels) -- 16 (4) buffer_load_dwordx2 per thread
+// and chunk, 32 (8) registers in flight -- so that all eight waves carry a role (64 x 64 tile: waves 0-3 the input
+// transform, waves 4-7 the gradient transform: one of each per SIMD).
+template <int WA, int WB>
+struct WinoWgrad8Cfg {
+  static constexpr int WK = 4 / (WA * WB);          // K groups inside the block (wave pairs beyond the WA x WB channel tile)
+  static constexpr int CIB = 32 * WA, COB = 32 * WB;
+  static constexpr int QC = WK == 1 ? 8 : 4;         // quads per K group and chunk
+  static constexpr int NQ = QC * WK;                 // quads per chunk of the whole block
+  static constexpr int V_B = NQ * CIB * 64, Z_B = NQ * COB * 64, STAGE = V_B + Z_B;
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int NV = NQ * CIB / 2, NZ = NQ * COB / 2;  // (quad, 2-channel) items per chunk
+  static_assert(WA * WB * WK == 4 && NV + NZ <= 512 && NV % 64 == 0 && NZ % 64 == 0 && LDS_BYTES <= 160 * 1024, "unsupported tile");
+};
+
+template <int WA, int WB, bool UPS = false>
+__global__ __launch_bounds__(512) void conv_wino_wgrad8_kernel(WinoWgradArgs a) {
+  using C = WinoWgrad8Cfg<WA, WB>;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int NE = UPS ? 9 : 16;  // raw rows of an input item: the 3x3 source patch, or the 4x4 patch
+  constexpr int CIB = C::CIB, COB = C::COB, QC = C::QC, NQ = C::NQ, NV = C::NV, NZ = C::NZ;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  extern __shared__ __align__(16) unsigned char wwg_smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte*)wwg_smem;
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ps = wave >> 2, wr = wave & 3;  // position set (transform rows 2 ps, 2 ps + 1); place of the pair in the tile
+  const int kg = wr / (WA * WB), wa = (wr / WB) % WA, wb = wr % WB;
+  const int tiles_b = a.Cout / COB;
+  const int a0 = ((int)blockIdx.x / tiles_b) * CIB, b0 = ((int)blockIdx.x % tiles_b) * COB;
+  const int H = 1 << a.L, HW = H * H, QI = HW / 4;
+  const int PGN = QI >= NQ ? QI / NQ : 1, IPC = QI >= NQ ? 1 : NQ / QI;
+  const int n_img = (int)(a.M >> (2 * a.L));
+  const int pg = (int)blockIdx.z % PGN, isp = (int)blockIdx.z / PGN;
+  const int ichunks = (n_img + IPC - 1) / IPC;
+  const int per = (ichunks + a.isplit - 1) / a.isplit;
+  const int c_beg = isp * per, c_end = c_beg + per < ichunks ? c_beg + per : ichunks;
+  const int nchunks = c_end > c_beg ? c_end - c_beg : 0;
+
+  // ---- this thread's transform item: (quad ql of the chunk, channels 2 c2, 2 c2 + 1) of the input (tid < NV) or of dY
+  const bool is_v = wave < NV / 64, is_z = !is_v && wave < (NV + NZ) / 64;
+  const int item = is_v ? tid : tid - NV;
+  const int ql = is_v ? item / (CIB / 2) : (is_z ? item / (COB / 2) : 0);
+  const int c2 = is_v ? item % (CIB / 2) : (is_z ? item % (COB / 2) : 0);
+  const int qpos = QI >= NQ ? pg * NQ + ql : ql % QI;
+  const int isub = QI >= NQ ? 0 : ql / QI;
+  constexpr uint32_t PAD = 0xFFFF0000u;
+  uint32_t voff[16];
+  {
+    const int ty = (int)morton_y((uint32_t)qpos), tx = (int)morton_x((uint32_t)qpos);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (is_v && UPS) {
+        const int y = ty - 1 + e / 3, x = tx - 1 + e % 3, Hs = H / 2;
+        const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
+        voff[e] = ok ? (uint32_t)((isub * (HW / 4) + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 2 * c2) * 4u : PAD;
+      } else if (is_v) {
+        const int y = 2 * ty - 1 + (e >> 2), x = 2 * tx - 1 + (e & 3);
+        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
+        voff[e] = ok ? (uint32_t)((isub * HW + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 2 * c2) * 4u : PAD;
+      } else {
+        voff[e] = (e < 4 && is_z) ? (uint32_t)((isub * HW + 4 * qpos + e) * a.Cout + b0 + 2 * c2) * 4u : PAD;
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)0xFFFF0000u, 0x00020000);
+  const int chan0 = 2 * c2;
+  const uint32_t wst = lds0 + (is_v ? 0u : (uint32_t)C::V_B) + (uint32_t)((ql * (is_v ? CIB : COB) + chan0) * 64);
+  const int wsw = (chan0 >> 2) & 3;  // (the same for the item's two channels)
+  // MFMA operand addresses (stage 0): k-step s reads quads kg QC + 2 s + hh; this wave reads the slots of rows 2 ps, 2 ps + 1
+  const int rowA = wa * 32 + c, colB = wb * 32 + c;
+  uint32_t aaddr[2], baddr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aaddr[i] = lds0 + (uint32_t)(((kg * QC + hh) * CIB + rowA) * 64 + (((2 * ps + i) ^ ((rowA >> 2) & 3)) << 4));
+    baddr[i] = lds0 + (uint32_t)C::V_B + (uint32_t)(((kg * QC + hh) * COB + colB) * 64 + (((2 * ps + i) ^ ((colB >> 2) & 3)) << 4));
+  }
+
+  f32x2 raw[16];
+  auto issue_loads = [&](int ch, auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;  // 0: input item, 1: gradient item, 2: none
+    const int img = (c_beg + ch) * IPC;
+    const int soff_x = __builtin_amdgcn_readfirstlane(img * (UPS ? HW / 4 : HW) * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
+    const bool live = ch < nchunks && img + isub < n_img;
+    if constexpr (ROLE == 0) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        raw[e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (int)(live ? voff[e] : PAD), soff_x, 0));
+    } else if constexpr (ROLE == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        raw[e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_y, (int)(live ? voff[e] : PAD), soff_y, 0));
+    }
+  };
+  auto store_entry = [&](int st, int k, const float (&v)[16]) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      if (UPS && x == 2) continue;
+      const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
+    }
+  };
+  auto transform = [&](int st, auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    if constexpr (ROLE == 0 && UPS) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float sp[9], t[9], v[16];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sp[e] = raw[e][k];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          t[0 * 3 + q] = sp[0 * 3 + q] - sp[1 * 3 + q];
+          t[1 * 3 + q] = sp[1 * 3 + q] + sp[1 * 3 + q];
+          t[2 * 3 + q] = sp[1 * 3 + q] - sp[2 * 3 + q];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+          const int xr = x == 2 ? 3 : x;
+          v[xr * 4 + 0] = t[x * 3 + 0] - t[x * 3 + 1];
+          v[xr * 4 + 1] = t[x * 3 + 1] + t[x * 3 + 1];
+          v[xr * 4 + 2] = 0.f;
+          v[xr * 4 + 3] = t[x * 3 + 1] - t[x * 3 + 2];
+        }
+        v[8] = v[9] = v[10] = v[11] = 0.f;
+        store_entry(st, k, v);
+      }
+    } else if constexpr (ROLE == 0) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float d[16], t[16], v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = raw[e][k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
+          t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
+          t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
+          t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
+          v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
+          v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
+          v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
+        }
+        store_entry(st, k, v);
+      }
+    } else if constexpr (ROLE == 1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float qa = raw[0][k], qb = raw[1][k], qc = raw[2][k], qd = raw[3][k];
+        const float p0 = qa, q0 = qb, p1 = qa + qc, q1 = qb + qd, p2 = qa - qc, q2 = qb - qd, p3 = -qc, q3 = -qd;
+        float v[16];
+        v[0] = p0; v[1] = p0 + q0; v[2] = p0 - q0; v[3] = -q0;
+        v[4] = p1; v[5] = p1 + q1; v[6] = p1 - q1; v[7] = -q1;
+        v[8] = p2; v[9] = p2 + q2; v[10] = p2 - q2; v[11] = -q2;
+        v[12] = p3; v[13] = p3 + q3; v[14] = p3 - q3; v[15] = -q3;
+        store_entry(st, k, v);
+      }
+    }
+  };
+
+  f32x16 acc[8];  // acc[4 i + nu] = dU[2 ps + i][nu] of the wave's 32 x 32 channel pairs
+#pragma unroll
+  for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
+
+  // The chunk loop per (transform role, position set): both are wave-uniform choices made ONCE (see the one-wave form)
+  auto run = [&](auto role_c, auto psc) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr int PSC = decltype(psc)::value;  // -1: either set (plain layers: the sets differ in addresses only)
+    if (nchunks <= 0) return;
+    issue_loads(0, role_c);
+    transform(0, role_c);
+    issue_loads(1, role_c);
+    __syncthreads();
+    // groups of a chunk: g = 2 ks + i (k-step ks, transform row 2 ps + i); behind the upsample row 2 is identically zero:
+    // set 1 runs the odd groups only, and position nu = 2 is skipped everywhere
+    constexpr int G0 = (UPS && PSC == 1) ? 1 : 0, GSTEP = (UPS && PSC == 1) ? 2 : 1;
+    constexpr int NGRP = (QC - G0 + GSTEP - 1) / GSTEP, NH = NGRP / 2;  // executed groups of a chunk, of its first half
+    constexpr int MPG = UPS ? 3 : 4;                                     // MFMAs per group
+    auto chunk = [&](int ch, auto stc) {
+      constexpr int st = decltype(stc)::value;
+      f32x4 ca, cb, na, nb;
+      auto load_grp = [&](int g, f32x4& x, f32x4& y) {
+        x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[g & 1] + st * C::STAGE + (g >> 1) * 2 * CIB * 64));
+        y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 1] + st * C::STAGE + (g >> 1) * 2 * COB * 64));
+      };
+      load_grp(G0, ca, cb);
+      na = ca; nb = cb;
+      __builtin_amdgcn_sched_barrier(0);
+      // first half of the chunk's MFMAs || the transform of the next chunk's raw rows -> the other stage
+#pragma unroll
+      for (int e = 0; e < NH; ++e) {
+        const int g = G0 + e * GSTEP;
+        load_grp(g + GSTEP, na, nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (!UPS || m != 2)
+            acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
+        ca = na; cb = nb;
+      }
+      transform(st ^ 1, role_c);
+      constexpr int NM = NH * MPG;                                         // MFMAs of the first half
+      constexpr int NVI = ROLE == 0 ? 2 * 64 : (ROLE == 1 ? 2 * 28 : 0);  // vector instructions of the transform (about)
+      constexpr int NST = ROLE == 2 ? 0 : (UPS && ROLE == 0 ? 6 : 8);     // its LDS stores
+      constexpr int VPM = (NVI + NM - 1) / NM;
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (i % MPG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next group's operand reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores, spread evenly
+        if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      issue_loads(ch + 2, role_c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = NH; e < NGRP; ++e) {
+        const int g = G0 + e * GSTEP;
+        if (e + 1 < NGRP) load_grp(g + GSTEP, na, nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (!UPS || m != 2)
+            acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
+        ca = na; cb = nb;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    };
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      chunk(ch, std::integral_constant<int, 0>{});
+      chunk(ch + 1, std::integral_constant<int, 1>{});
+    }
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  using PX = std::integral_constant<int, -1>;
+  if constexpr (UPS) {
+    if (ps == 0) { if (is_v) run(R0{}, R0{}); else if (is_z) run(R1{}, R0{}); else run(R2{}, R0{}); }
+    else { if (is_v) run(R0{}, R1{}); else if (is_z) run(R1{}, R1{}); else run(R2{}, R1{}); }
+  } else {
+    if (is_v) run(R0{}, PX{}); else if (is_z) run(R1{}, PX{}); else run(R2{}, PX{});
+  }
+
+  // ---- raw slab of this (tile, split, K group): planes 8 ps .. 8 ps + 7 of [16][Cin][Cout]
+  const size_t slab = ((size_t)blockIdx.z * C::WK + kg) * 16 * (size_t)a.Cin * a.Cout;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (UPS && (j & 3) == 2) continue;               // (vanishing positions: the reduce pass skips them too)
+    const int p = 8 * ps + j;
+    if (UPS && (p >> 2) == 2) continue;              // (wave-uniform: set 1's first row)
+    float* dst = a.slabs + slab + ((size_t)p * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[j][r];
+  }
+}
+
 // Slab reduction in two passes.  (1) every (position, ci, co) element summed over the slabs by 8 lanes (strided over the
 // slabs, fixed-shape shuffle tree: deterministic), IN PLACE into slab 0 -- 16 Cin Cout work items: a one-pass form with one
 // item per channel pair had 64 workgroups for the decoder's 64 -> 32 layer, whose 512 slabs it then read for 405 us
@@ -397,7 +668,18 @@ size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
 }
 
 template <int WA, int WB, bool UPS>
+static int launch_wino_wgrad8_cfg(const WinoWgradArgs& a, double flops, dim3 grid, hipStream_t s) {
+  using C = WinoWgrad8Cfg<WA, WB>;
+  auto kern = conv_wino_wgrad8_kernel<WA, WB, UPS>;
+  DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+  const unsigned wgs = grid.x * grid.y * grid.z;  // (one workgroup per CU)
+  DVG_LAUNCH_WORK_SHARE(K_WGRAD_WINO, flops, (float)(wgs > 256u ? 256u : wgs) / 256.0f, kern, grid, dim3(512), C::LDS_BYTES, s, a);
+  return DVG_OK;
+}
+
+template <int WA, int WB, bool UPS>
 static int launch_wino_wgrad_cfg(const WinoWgradArgs& a, double flops, dim3 grid, hipStream_t s) {
+  if (opt(OPT_WINO_WAVES) >= 8) return launch_wino_wgrad8_cfg<WA, WB, UPS>(a, flops, grid, s);
   using C = WinoWgradCfg<WA, WB>;
   auto kern = conv_wino_wgrad_kernel<WA, WB, UPS>;
   DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));

@@ -33,7 +33,18 @@ for name, Cin, Cout, L in (("layer 1", 32, 64, 4), ("layer 2", 64, 128, 3), ("la
     gw_s = dev.conv_wino_wgrad(dev.nchw_to_morton(xn[:nb].float()), dev.nchw_to_morton(dyn[:nb].float()), 0, shape, nb << (2 * L), Cin, Cout, L)
     rel = lambda a: float((a.double() - ref).norm() / ref.norm())
     t_d = timeit(lambda: dev.conv_wgrad(x, dy, 0, shape, M, Cin, Cout, L))
-    t_w = timeit(lambda: dev.conv_wino_wgrad(x, dy, 0, shape, M, Cin, Cout, L))
     gf = 2.0 * M * Cin * Cout * 9 / 1e9
-    print(f"{name} M={M:8d} {Cin:4d}->{Cout:4d}  wino {t_w:8.1f} us ({gf / t_w * 1e3:6.1f} TFLOP/s of direct-form FLOPs)   direct {t_d:8.1f} us ({gf / t_d * 1e3:6.1f})"
+    ge = 2.0 * (M / 4) * 16 * Cin * Cout / 1e9  # executed GFLOP of the Winograd form
+    print(f"{name} M={M:8d} {Cin:4d}->{Cout:4d}  direct (grid sized for 256 CUs) {t_d:7.1f} us ({gf / t_d * 1e3:6.1f} TFLOP/s direct-form)"
           f"   wino vs direct {float((gw - gd).norm() / gd.norm()):.1e}   vs float64 (B={nb}): wino {rel(gw_s):.1e} direct {rel(gd_s):.1e}")
+    # the Winograd form at the CU budget the training step gives it (option enc_wino_cus_w: 128, beside the data gradient)
+    # and on the whole chip, both wave counts, interleaved rounds in one process (minimum of 2); slab reduce included
+    for cus in (128, 256):
+        ts = {}
+        for rnd in range(2):
+            for waves in (8, 4):
+                with _lib.option_scope(wino_waves=waves, enc_wino_cus_w=cus):
+                    t = timeit(lambda: dev.conv_wino_wgrad(x, dy, 0, shape, M, Cin, Cout, L))
+                ts[waves] = min(ts.get(waves, 1e30), t)
+        print(f"        wino, grid sized for {cus:3d} CUs:  8 waves {ts[8]:7.1f} us ({gf / ts[8] * 1e3:6.1f} TFLOP/s direct-form, {ge / ts[8] * 1e3 / 157.3:.2f} of the f32 peak executed)"
+              f"   4 waves {ts[4]:7.1f} us ({gf / ts[4] * 1e3:6.1f}, {ge / ts[4] * 1e3 / 157.3:.2f})")
