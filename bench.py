@@ -191,7 +191,10 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", config, "--threads", str(threads), "--leg-warm", str(warm),
                "--leg-steps", str(min_steps), "--leg-seconds", str(secs)] + (["--leg-natural"] if natural else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"threads"')][-1])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"threads"')]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"cpu leg ({threads} threads) failed with code {r.returncode}: {r.stderr[-400:]}")
+        return json.loads(lines[-1])
 
     thread_sweep = {}
     for t in points:
@@ -610,7 +613,10 @@ def main():
             "roofline": roofline,
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+            try:  # (a failed or timed-out child must not cost the line its GPU measurement)
+                out["cpu_baseline"] = cpu_baseline(args.config)
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": repr(exc)}
             out["loss_parity"] = loss_parity()
         if args.parity and args.gpus == 1:
             out["loss_parity"] = dict(loss_parity(), note="12 fixture steps in this arithmetic mode (every forward / data-gradient launch)")

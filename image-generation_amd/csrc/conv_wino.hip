@@ -47,6 +47,7 @@ struct WinoArgs {
   // map's gradient [tiles][Cout] -- template argument of the kernel, see the header comment)
   int Cin, Cout, L;   // L = log2 of the image side
   int nblk;           // tile blocks (of 32 WM quads)
+  int abl = 0;        // DIAGNOSTIC (temporary): parts of the epilogue switched off
 };
 
 template <int WM, int WN, int KC, int UM = 0>
@@ -622,8 +623,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   issue_raw(blk_cur, 0, 0);
   issue_u(0, 0);
   issue_raw(blk_cur, 1 % nch, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  __syncthreads();  // (the workgroup fence waits for the LDS-DMA pieces: see the chunk's end)
   {
     float d[16], t[16];
     load_patch(0, d);
@@ -637,13 +637,27 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cout * 4), 0x00020000);
   const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;  // quad row 4 hh of the lane's first quad: 4 pixels per quad
+  const float bias = a.bias ? a.bias[n0 + wn * 32 + c] : 0.f;   // (the lane's output channel is the same for every tile block)
   const uint32_t xaddr = lds0 + C::OFF_V + C::V_B + (uint32_t)(lane * 16);  // exchange slots: stage 1 of the transformed input
+
+  // outputs of the tile block just finished (pixels 2 ps, 2 ps + 1 of the wave's 32 quads x 32 channels), stored beside the
+  // next block's first MFMAs (or behind the last block): store idx = 2 r + q is accumulator row r of pixel 2 ps + q
+  f32x16 py0, py1;
+  int pblk = 0;
+  auto store_pending = [&](int idx) {
+    const int r = idx >> 1, q = idx & 1;
+    const int rq = 4 * ((r & 3) + 8 * (r >> 2));
+    // (the row index is kept opaque: distributed over the sum, its 32 constant parts x Cout would be hoisted out of the
+    // tile-block loop into 32 scalar registers, which then spill)
+    int row = __builtin_amdgcn_readfirstlane((pblk * TBLK + wm * 32) * 4 + 2 * ps);
+    asm volatile("" : "+s"(row));
+    const int soff = (row + rq + q) * a.Cout * 4;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q == 0 ? py0[r] : py1[r]), rsrc_out, ovoff, soff, 0);
+  };
 
   // the epilogue of wave set PSC (compile-time copy of ps)
   auto epilogue = [&](int blk, auto psc) {
     constexpr int PSC = decltype(psc)::value;
-    const int col = n0 + wn * 32 + c;
-    const float bias = a.bias ? a.bias[col] : 0.f;
     // column half of the output transform on the wave's own rows: C_i[b] = sum_nu M[2 ps + i][nu] A[nu][b]
     f32x16 c00 = {0}, c01 = {0}, c10, c11;  // c<i><b>
     if constexpr (UM == 1) {
@@ -660,6 +674,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const f32x16& give = PSC == 0 ? (b == 0 ? c10 : c11) : (b == 0 ? c00 : c01);
+      if (a.abl & 2) { if (b == 0) y0 = give + c00; else y1 = give + c01; continue; }
       if (!(UM == 1 && PSC == 1)) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -687,20 +702,19 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       if (b == 0) y0 = yb; else y1 = yb;
       __syncthreads();  // (the slots are rewritten by round 1 / by the next chunk's transform)
     }
+    // (+ bias; the stores wait: they are issued beside the MFMAs of the next tile block's first chunk -- store_pending --
+    // all workgroups reach their epilogues together, and 64 KB per workgroup stored at once is a burst the memory
+    // system serialises: 1.8 us of an 8-chunk block's 20 us, measured by switching the stores off)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rq = 4 * ((r & 3) + 8 * (r >> 2));
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float v = (q == 0 ? y0[r] : y1[r]) + bias;
-        const int soff = __builtin_amdgcn_readfirstlane(((blk * TBLK + wm * 32) * 4 + rq + 2 * PSC + q) * a.Cout * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_out, ovoff, soff, 0);
-        s1 += v;
-        s2 = fmaf(v, v, s2);
-      }
+      const float v0 = y0[r] + bias, v1 = y1[r] + bias;
+      py0[r] = v0; py1[r] = v1;
+      s1 += v0; s2 = fmaf(v0, v0, s2);
+      s1 += v1; s2 = fmaf(v1, v1, s2);
     }
-    if (a.stats) {
+    pblk = blk;
+    if (a.stats && !(a.abl & 4)) {
       float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -726,10 +740,10 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   // chunk travel; the first chunk of a tile block has no such tail in front (FIRST), the last one flushes its own behind
   // its barrier (LAST), in front of the epilogue.
   f32x4 ta = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
-  auto chunk = [&](int cix, auto stc, auto psc, auto firstc, auto lastc) {  // chunk cix of tile block blk_cur
+  auto chunk = [&](int cix, auto stc, auto psc, auto firstc, auto lastc, auto pendc) {  // chunk cix of tile block blk_cur
     constexpr int st = decltype(stc)::value;
     constexpr int PSC = decltype(psc)::value;
-    constexpr bool FIRST = decltype(firstc)::value != 0, LAST = decltype(lastc)::value != 0;
+    constexpr bool FIRST = decltype(firstc)::value != 0, LAST = decltype(lastc)::value != 0, PEND = decltype(pendc)::value != 0;
     // what the chunk prefetches: the weights of the next chunk (past the block's end: chunk 0 again), the raw pixels of
     // the chunk after next (past the end: the next block's, or -- no next block -- this block's last chunk once more,
     // into a stage nobody reads)
@@ -784,15 +798,33 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
         if (UM == 1 && m == 2) continue;
         if (e == EC) xform_col(piece, d, t);
         if (e == EC + 1) xform_row_store(st ^ 1, piece, t);
+        __builtin_amdgcn_sched_barrier(0);
+        // (the first chunk's first product into a tile starts from the constant 0: no pass that zeroes 128 registers)
+        if (TAIL && FIRST && e < 2 / GSTEP) acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], (f32x16){0}, 0, 0, 0);
+        else acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PEND) {
+          // the previous tile block's 32 output stores beside the MFMAs of the first two groups -- the ones that start
+          // from the constant 0: a store's register is free again before the accumulator tiles come alive, and the
+          // stores have the rest of the chunk to complete
+          constexpr int MPG = UM == 1 ? 3 : 4, NMS = 2 * MPG, SPM = (32 + NMS - 1) / NMS;
+          const int mi = e * MPG + piece;
+          if (mi < NMS) {
+#pragma unroll
+            for (int idx = mi * SPM; idx < (mi + 1) * SPM && idx < 32; ++idx) store_pending(idx);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         ++piece;
-        __builtin_amdgcn_sched_barrier(0);
-        acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
       }
       ca = na; cb = nb;
     }
     if constexpr (TAIL) { ta = ca; tb = cb; }  // (the last group is always an odd one: transform row 2 ps + 1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The chunk barrier.  hipcc counts the LDS-DMA pieces (buffer_load ... lds builtins) on vmcnt and the workgroup fence
+    // of __syncthreads() waits for exactly them: `s_waitcnt vmcnt(N)` with N = the vector-memory operations issued BEHIND
+    // the last piece -- the output stores of the previous tile block, which may stay in flight across the barrier.  (An
+    // inline-asm vmcnt(0) here, as in the one-wave form, drains those stores too and hides the wait from the compiler,
+    // which then repeats it in front of the next chunk's first ds_read.)
     __syncthreads();
     if constexpr (TAIL && LAST) {
 #pragma unroll
@@ -805,29 +837,35 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
 
   auto run = [&](auto psc) {
     int par = 1;
-    bool go = true;
+    bool go = true, pend = false;
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     while (go) {
       int fetched = 0;
       if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
       if constexpr (TAIL) {
         // (first, middle pairs, last: the middle chunks run stage 1, stage 0 in turn -- an even chunk count)
-        chunk(0, I0{}, psc, I1{}, I0{});
+        if (pend) chunk(0, I0{}, psc, I1{}, I0{}, I1{});
+        else chunk(0, I0{}, psc, I1{}, I0{}, I0{});
         for (int ch = 2; ch < nch; ch += 2) {
-          chunk(ch - 1, I1{}, psc, I0{}, I0{});
-          chunk(ch, I0{}, psc, I0{}, I0{});
+          chunk(ch - 1, I1{}, psc, I0{}, I0{}, I0{});
+          chunk(ch, I0{}, psc, I0{}, I0{}, I0{});
         }
-        chunk(nch - 1, I1{}, psc, I0{}, I1{});
+        chunk(nch - 1, I1{}, psc, I0{}, I1{}, I0{});
       } else {
+        if (pend) {
+#pragma unroll
+          for (int idx = 0; idx < 32; ++idx) store_pending(idx);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
         for (int ch = 0; ch < nch; ch += 2) {
-          chunk(ch, I0{}, psc, I0{}, I0{});
-          chunk(ch + 1, I1{}, psc, I0{}, I0{});
+          chunk(ch, I0{}, psc, I0{}, I0{}, I0{});
+          chunk(ch + 1, I1{}, psc, I0{}, I0{}, I0{});
         }
       }
       epilogue(blk_cur, psc);
+      pend = true;
       go = has_next;
       blk_cur = blk_nxt;
       if (dynq) {
@@ -840,6 +878,8 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       }
       has_next = blk_nxt < a.nblk;
     }
+#pragma unroll
+    for (int idx = 0; idx < 32; ++idx) store_pending(idx);  // (the last block's)
   };
   // (one instantiation per wave set: which rows of M a wave holds decides its MFMA pattern behind the upsample and its
   // half of the epilogue; the sets meet at every workgroup barrier -- both paths execute the same number of them)
@@ -934,7 +974,11 @@ static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   // round count (72 workgroups over 256 tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs
   // beside the launch)
   WinoArgs ad = a;
-  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16) ? dyn_tile_counters() : nullptr;
+  // (the dynamic deal hands every workgroup TWO blocks up front: a launch of fewer than about three rounds keeps the
+  // static deal, where the grid is shrunk to its round count -- an evaluation forward at the 256-block threshold would
+  // otherwise be done by half the grid in two rounds.  Dynamic launches of one device must be ordered on ONE stream:
+  // the counters are a per-device pool that the launch's last workgroup re-zeroes.)
+  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16 && a.nblk >= 3 * gx) ? dyn_tile_counters() : nullptr;
   if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
   // (one workgroup per CU: the grid IS the number of CUs the launch occupies)
   DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, ad);
@@ -956,7 +1000,12 @@ static int launch_wino8_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx > a.nblk) gx = a.nblk;
   WinoArgs ad = a;
-  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16) ? dyn_tile_counters() : nullptr;
+  ad.abl = (int)(opt(OPT_WINO_WAVES) >> 4);
+  // (the dynamic deal hands every workgroup TWO blocks up front: a launch of fewer than about three rounds keeps the
+  // static deal, where the grid is shrunk to its round count -- an evaluation forward at the 256-block threshold would
+  // otherwise be done by half the grid in two rounds.  Dynamic launches of one device must be ordered on ONE stream:
+  // the counters are a per-device pool that the launch's last workgroup re-zeroes.)
+  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16 && a.nblk >= 3 * gx) ? dyn_tile_counters() : nullptr;
   if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
   DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), C::LDS_BYTES, s, ad);
   return DVG_OK;
@@ -976,7 +1025,7 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   // EXECUTED matrix FLOPs: 16 transform-domain GEMMs over the M / 4 quads (4/9 of the direct form's 2 M Cin Cout 9;
   // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
   const double flops = 2.0 * (double)(a.M / 4) * (a.wino_um ? 9.0 : 16.0) * a.Cin * a.Cout;
-  if (opt(OPT_WINO_WAVES) == 8 && a.wino_um != 2) {
+  if ((opt(OPT_WINO_WAVES) & 15) == 8 && a.wino_um != 2) {
     // (the 32-channel tile behind the upsample has two groups per chunk in wave set 1: no tail to hold back)
     if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
     return cfg == 0 ? launch_wino8_cfg<2, 2, 8>(w, flops, s) : launch_wino8_cfg<4, 1, 4>(w, flops, s);

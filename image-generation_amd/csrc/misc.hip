@@ -57,6 +57,24 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict
   }
 }
 
+// one latent unit per thread: any n, any alignment (the same per-element arithmetic and Philox counters: same bits)
+__global__ __launch_bounds__(256) void gumbel_fwd_scalar_kernel(const float* __restrict__ logits, int64_t B, int n, int R,
+                                                                float tau, const float* __restrict__ gumbels,
+                                                                uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi,
+                                                                const uint64_t* __restrict__ off_dev,
+                                                                float* __restrict__ spins, float* __restrict__ dspin) {
+  if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
+  const int64_t total = B * R * (int64_t)n;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e % n);
+    const int64_t b = e / ((int64_t)n * R);
+    float sp, ds;
+    gumbel_element(logits[b * n + i], e, gumbels, k0, k1, off_lo, off_hi, tau, sp, ds);
+    spins[e] = sp;
+    dspin[e] = ds;
+  }
+}
+
 // gs2 (optional): a second gradient wrt the spins, added to the first on the way in (the training step has two: the
 // decoder's and the MMD's; summing them here saves the separate add pass over (B, R, n))
 __global__ __launch_bounds__(256) void gumbel_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ gs2,
@@ -198,8 +216,12 @@ extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, floa
                               dvg_stream_t stream) {
   DVG_REQUIRE(logits && spins && dspin, "gumbel_fwd: null argument");
   DVG_REQUIRE(B > 0 && n > 0 && R > 0 && tau > 0.f, "gumbel_fwd: B=%lld n=%d R=%d tau=%g", (long long)B, n, R, tau);
-  DVG_REQUIRE(n % 4 == 0 && ((((uintptr_t)logits | (uintptr_t)spins | (uintptr_t)dspin) & 15) == 0),
-              "gumbel_fwd: n=%d must be a multiple of 4 and the tensors 16-byte aligned", n);
+  if (n % 4 != 0 || ((((uintptr_t)logits | (uintptr_t)spins | (uintptr_t)dspin) & 15) != 0)) {  // (e.g. a slice view)
+    DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_scalar_kernel, dim3(grid_for(B * R * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
+               logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
+               (uint32_t)(offset >> 32), dyn ? &dyn->gumbel_offset : nullptr, spins, dspin);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_kernel, dim3(grid_for(B * R * (int64_t)(n / 4))), dim3(256), 0, (hipStream_t)stream,
              logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
              (uint32_t)(offset >> 32), dyn ? &dyn->gumbel_offset : nullptr, spins, dspin);

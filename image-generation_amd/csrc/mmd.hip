@@ -1890,7 +1890,9 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
     int64_t S2 = ceil_div(mmd_target_blocks(), p.rb128x);
     if (S2 > chunks / 16) S2 = chunks / 16;
     if (S2 < 1) S2 = 1;
-    const bool shape_ok = d % 128 == 0 && d <= 512;
+    // (the 128-row-block kernel addresses both chunk images through 32-bit buffer offsets: the int8 rows and the bf16
+    // transposed copy, 2 (nx + ny) d bytes, must stay below 2^31 -- larger problems keep the 32-row kernels' 64-bit pointers)
+    const bool shape_ok = d % 128 == 0 && d <= 512 && (int64_t)(nx + ny) * (int64_t)d * 2 < 2147483647LL;
     const int env = mmd_w128_env();
     p.w128 = shape_ok && (env == 1 || (env != 0 && S2 <= 4 && p.rb128x * S2 >= 128));
     if (env == 1 && shape_ok) { S2 = S2 > 16 ? 16 : S2; }

@@ -468,7 +468,7 @@ class ModelWrapper:
         # The sampler draw of this step needs nothing but the current GRBM parameters, so it is enqueued FIRST, on a
         # side HIP stream, and runs under the encoder/decoder forward (it occupies a few dozen CUs for hundreds of
         # microseconds).  Same draw, same position in the sampler's random stream as in the reference's order.
-        self._hold_device_while_measuring()
+        self._hold_device_while_measuring(int(images.shape[0]) * int(self.N_REPLICAS))
         samples = self._draw_overlapped() if self.overlap_sampler else None
         self._dvae.decoder._defer_join = True  # (this step always runs the encoder's backward behind the decoder's)
         if samples is not None and self.overlap_mmd:
@@ -580,6 +580,13 @@ class ModelWrapper:
         rec = state.get(key)
         if rec is None:
             rec = state[key] = {"decision": None, "events": [], "lags": []}
+        self._defer_rec = rec
+        self.__dict__.setdefault("_defer_by_rows", {})[int(flat.shape[0])] = rec
+        if self._device is not None and self._device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # never wait for an event inside a stream capture (it would fail the capture and force eager steps for the
+            # rest of the process): the graph bakes in whatever is decided so far -- _graph_eligible keeps an undecided
+            # shape eager until its measurement is in
+            return bool(rec["decision"])
         if rec["decision"] is None and len(rec["events"]) >= self.DEFER_SAMPLES:
             for ev_main, ev_side in rec["events"]:
                 ev_main.synchronize()  # (warm-up steps only: one host wait per shape)
@@ -588,19 +595,28 @@ class ModelWrapper:
             rec["events"] = []
             # (the LARGEST of the samples: a sample taken while the host was the slower side reads ~0)
             rec["decision"] = bool(max(rec["lags"]) > self.DEFER_LAG_MS)
-        self._defer_rec = rec
         return bool(rec["decision"])
 
-    def _hold_device_while_measuring(self) -> None:
+    def _defer_undecided(self) -> bool:
+        """True while the shape the last step ran on is still being measured (its graph must not be captured yet)."""
+        if getattr(self, "defer_mmd_join", None) is not None or not (self.overlap_sampler and self.overlap_mmd):
+            return False
+        rec = getattr(self, "_defer_rec", None)
+        return rec is not None and rec["decision"] is None
+
+    def _hold_device_while_measuring(self, rows: int) -> None:
         """The lag behind ``_defer_mmd_join`` must be the DEVICE's: an eager step whose launches the host issues more
         slowly than the GPU runs them (the first steps of a process: module loads, allocator growth) finds both streams
         idle at the join and measures ~0 whatever the shape.  So a step that is going to measure starts with a spin kernel
         on the main stream, in front of the fork of the side stream: the host enqueues the whole step behind it and the
-        two chains then run at the device's pace.  A few milliseconds, twice per shape."""
+        two chains then run at the device's pace.  ~20 ms on each of the DEFER_SAMPLES measuring steps of a shape and on the
+        step that reads the events (``rows`` = rows of the flattened spins of the step about to run: B x replicas)."""
         if (self._device is None or self._device.type != "cuda" or not (self.overlap_sampler and self.overlap_mmd)
                 or getattr(self, "defer_mmd_join", None) is not None or torch.cuda.is_current_stream_capturing()):
             return
-        rec = getattr(self, "_defer_rec", None)
+        # (keyed on the shape of the step that is about to run: the record of the PREVIOUS step's shape says nothing
+        # about a new one; a shape never seen before has no record yet and measures)
+        rec = self.__dict__.get("_defer_by_rows", {}).get(int(rows))
         spin = getattr(torch.cuda, "_sleep", None)
         if spin is not None and (rec is None or rec["decision"] is None):
             spin(2_000_000)  # (~20 ms: the counter behind it runs at 100 MHz)
@@ -624,7 +640,7 @@ class ModelWrapper:
         eagerly behind the replay, on the replay's static spins); noise-injected (parity) steps take the eager path.
         With several GPUs the step is two graphs with the (eager) all-reduce between them."""
         return (self.use_graph and self._device.type == "cuda" and self.noise_hook is None and not self._graph_failed
-                and self._eager_steps >= 3 and not self.sync_losses
+                and self._eager_steps >= 3 and not self.sync_losses and not self._defer_undecided()
                 and (self._static_images is None or images.shape == self._static_images.shape))
 
     def _host_counters(self):

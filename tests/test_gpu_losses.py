@@ -164,6 +164,25 @@ def test_gumbel_injected_noise_bit_exact_spins_and_grad():
     np.testing.assert_allclose(lg.grad.cpu().numpy(), lr.grad.numpy(), rtol=2e-4, atol=2e-6 * float(lr.grad.abs().max()))
 
 
+def test_gumbel_any_width_and_alignment_equals_the_vector_form():
+    """dvg_gumbel_fwd takes any n and any 4-byte-aligned pointers (a contiguous slice view): the one-unit-per-thread form
+    runs the same per-element arithmetic and Philox counters as the four-unit form, so on a shared shape the bits agree."""
+    torch.manual_seed(3)
+    B, R, n = 8, 4, 6  # n % 4 != 0
+    logits = torch.randn(B, n) * 2
+    g = -torch.empty(B, R, n, 2).exponential_().log()
+    want = plugin.gumbel_latent_to_discrete(logits, R, gumbels=g)
+    got = F.gumbel_latent_to_discrete(logits.cuda(), R, gumbels=g.cuda())
+    assert torch.equal(got.cpu(), torch.sign(want))
+    # a misaligned view of a 16-byte-aligned buffer, device RNG: equal to the aligned call element for element
+    B, R, n = 8, 4, 64
+    buf = torch.randn(B * n + 1, device="cuda")
+    view = buf[1:].view(B, n)
+    a = F.gumbel_latent_to_discrete(view, R, seed=77, offset=9)
+    b = F.gumbel_latent_to_discrete(view.clone(), R, seed=77, offset=9)
+    assert torch.equal(a, b)
+
+
 def test_gumbel_device_rng_statistics():
     B, R, n = 64, 8, 256
     logits = torch.linspace(-1, 1, n).repeat(B, 1).cuda()

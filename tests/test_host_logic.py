@@ -104,7 +104,7 @@ def test_schedule_decisions_of_the_wrapper_need_no_gpu():
     assert m._prep_stream is None
     m.overlap_sampler = m.overlap_mmd = True
     m.sampler = None
-    m._hold_device_while_measuring()                          # (returns before touching torch.cuda)
+    m._hold_device_while_measuring(4096 * 8)                  # (returns before touching torch.cuda)
     dec = Decoder(32)
     dec.prepare(64, None)                                     # CPU parameters: a no-op, nothing pending
     assert dec._prepared is None
@@ -118,4 +118,7 @@ def test_schedule_decisions_of_the_wrapper_need_no_gpu():
         def synchronize(self): pass
         def elapsed_time(self, other): return other.v - self.v
     rec["lags"], rec["events"] = [], [(_Ev(0.0), _Ev(0.004)), (_Ev(0.0), _Ev(0.9))]
+    m.__dict__["_defer_rec"] = rec
+    assert m._defer_undecided() is True                       # (a shape still being measured is not captured into a graph)
     assert m._defer_mmd_join(torch.empty(16, 32), torch.empty(4, 32)) is True and rec["lags"] == [0.004, 0.9]
+    assert m._defer_undecided() is False and m.__dict__["_defer_by_rows"][16] is rec
