@@ -276,16 +276,34 @@ def extra_config_run(args, config):
 
     cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "30", "--warmup", "5", "--child",
            "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+
+    def child(extra):
+        r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-        d = json.loads(lines[-1])
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"child run {extra} failed with code {r.returncode}: {r.stderr[-300:]}")
+        return json.loads(lines[-1])
+
+    try:
+        d = child([])
         rf = d["roofline"]
-        return {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                "dominant_kernel": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")},
-                "sampler": rf.get("sampler")}
+        out = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+               "dtype": d["dtype"],
+               "dominant_kernel": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")},
+               "sampler": rf.get("sampler")}
     except Exception as exc:  # the headline line must not depend on the extra runs
         return {"error": repr(exc)}
+    if config == "c2":
+        # BASELINE.json configs[1] names c2 "bf16"; SURVEY 8d: "bf16 GEMM inputs / f32 accumulate ... report both" -- the
+        # same workload in the two other operand modes, beside the float32 number above (never the bench `value`)
+        for key, prec in (("bf16_inputs", "bf16"), ("f32x3", "f32x3")):
+            try:
+                dd = child(["--precision", prec])
+                out[key] = {"value": dd["value"], "unit": dd["unit"], "ms_per_step": dd["ms_per_step"], "dtype": dd["dtype"],
+                            "dominant_kernel": {k: dd["roofline"].get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}}
+            except Exception as exc:
+                out[key] = {"error": repr(exc)}
+    return out
 
 
 def layerwise_run(args):
@@ -477,31 +495,44 @@ def main():
         raise SystemExit(f"bench: rank {dp.rank}: the timed steps produced non-finite numbers: {workload_losses}")
     per_rank = dp.gather_objects({"rank": dp.rank, "dist": dp.describe(), "mse": last_mse, "mmd": last_mmd})
     prof_steps = args.steps
-    if model.use_graph:
-        # hipGraph replays cannot carry per-kernel event records, so the per-kernel HIP-event timing behind
-        # `roofline` comes from an eager pass of the SAME steps right after the timed region (same kernels, same
-        # shapes, same stream; durations agree with the rocprofv3 summary in profiles/).
-        model.use_graph = False
-        prof_steps = max(10, min(args.steps, 30))
-        L.dvg_prof_reset()
-        L.dvg_prof_enable(mask)
-        run(prof_steps)
-        torch.cuda.synchronize()
-        L.dvg_prof_enable(0)
-        model.use_graph = True
-
     import ctypes
 
+    def query_kernels():
+        res = {}
+        for i, nm in enumerate(names):
+            ms, cnt, work, share = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            L.dvg_prof_query(i, ctypes.byref(ms), ctypes.byref(cnt))
+            L.dvg_prof_query_work(i, ctypes.byref(work))
+            L.dvg_prof_query_share(i, ctypes.byref(share))
+            if cnt.value:
+                # share_ms: duration x the share of the chip's CUs the launch's grid was sized for (1 except for the
+                # CU-budgeted Winograd grids, which are handed 128-224 CUs because another kernel holds the rest)
+                res[nm] = {"total_ms": ms.value, "launches": cnt.value, "work": work.value, "share_ms": share.value}
+        return res
+
+    passes = []
+    if model.use_graph:
+        # hipGraph replays cannot carry per-kernel event records, so the per-kernel HIP-event timing behind
+        # `roofline` comes from eager passes of the SAME steps right after the timed region (same kernels, same
+        # shapes, same streams).  THREE passes, the per-kernel MEDIAN is reported and the spread of the headline
+        # fraction beside it (`frac_passes`): how the host paces an eager step moves what runs beside what -- one pass
+        # gave 0.28 .. 0.34 for the same 9.04 ms step in round 4.
+        model.use_graph = False
+        prof_steps = max(10, min(args.steps, 20))
+        for _ in range(3):
+            L.dvg_prof_reset()
+            L.dvg_prof_enable(mask)
+            run(prof_steps)
+            torch.cuda.synchronize()
+            L.dvg_prof_enable(0)
+            passes.append(query_kernels())
+        model.use_graph = True
+    else:
+        passes.append(query_kernels())
     per_kernel = {}
-    for i, nm in enumerate(names):
-        ms, cnt, work, share = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-        L.dvg_prof_query(i, ctypes.byref(ms), ctypes.byref(cnt))
-        L.dvg_prof_query_work(i, ctypes.byref(work))
-        L.dvg_prof_query_share(i, ctypes.byref(share))
-        if cnt.value:
-            # share_ms: duration x the share of the chip's CUs the launch's grid was sized for (1 except for the
-            # CU-budgeted Winograd grids, which are handed 128-224 CUs because another kernel holds the rest)
-            per_kernel[nm] = {"total_ms": ms.value, "launches": cnt.value, "work": work.value, "share_ms": share.value}
+    for nm in passes[0]:
+        rows = sorted((p_[nm] for p_ in passes if nm in p_), key=lambda r_: r_["total_ms"])
+        per_kernel[nm] = dict(rows[len(rows) // 2], total_ms_passes=[r_["total_ms"] for r_ in rows])
     if dp.rank == 0:
         # dominant kernel = the GEMM kernel (one template instantiation = one rocprof kernel name) with the
         # largest total time; achieved = its executed FLOPs (2*rows*Cin*Cout*taps per launch -- the folded-upsample
@@ -533,6 +564,8 @@ def main():
             e = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": peak_of(k), "unit": "TFLOP/s",
                  "frac": ach / peak_of(k), "avg_launch_us": v["total_ms"] * 1e3 / v["launches"], "launches": v["launches"],
                  "gflop_per_launch": v["work"] / v["launches"] / 1e9, "ms_per_step": v["total_ms"] / prof_steps}
+            if len(v.get("total_ms_passes", ())) > 1:  # (slowest .. fastest pass; `frac` is the median pass)
+                e["frac_passes"] = [v["work"] / (t * 1e-3) / 1e12 / peak_of(k) for t in sorted(v["total_ms_passes"], reverse=True)]
             if v.get("share_ms", 0.0) > 0.0 and v["share_ms"] < 0.999 * v["total_ms"]:
                 # a persistent whole-CU grid sized to a CU budget (conv_wino*.hip): `frac` above prices it against the WHOLE
                 # chip's peak although the launch was given part of it; this is the same work against the CUs it was given
@@ -559,8 +592,8 @@ def main():
         dom = max(cands, key=lambda k: cands[k]["total_ms"])
         roofline = entry(dom)
         roofline["timing"] = ("HIP events over the timed region" if args.eager else
-                              f"HIP events over an eager pass of {prof_steps} steps right after the timed region "
-                              "(graph replays cannot carry per-kernel events); in-situ durations: the step runs the "
+                              f"HIP events over three eager passes of {prof_steps} steps right after the timed region, per-kernel "
+                              "median (graph replays cannot carry per-kernel events); in-situ durations: the step runs the "
                               "sampler / MMD / weight-gradient chains beside the critical chain on other streams")
         roofline["kernels_hash"] = lib_hash
         conv = {k: v for k, v in cands.items() if k.startswith("conv_")}

@@ -13,14 +13,16 @@
 //   M[xi][nu][quad][co] = sum_ci V U       16 independent GEMMs: the MFMA work
 //   Y[quad][2x2][co]    = A^T M A (+bias)  A^T = [1 1 1 0; 0 1 -1 -1]
 //
-// One workgroup = 4 waves, ONE per SIMD with the whole register file (16 accumulator tiles of 32 quads x 32 channels =
-// 256 AGPRs per wave).  Channels are walked in chunks of KC; per chunk three LDS images: the raw input pixels of the
-// block's images [pixel][KC] and the transformed weights [k][co][16] arrive by LDS-DMA, the transformed input
-// [k][quad][16] is written by the block itself (each thread transforms TBLK KC / 256 patches per chunk, under the
-// previous chunk's MFMAs).  Two stages of each, one barrier per chunk, and the chunk sequence runs on across the tile
-// blocks a workgroup owns (persistent grid), so the staging pipeline is filled once per workgroup, not once per tile.
-// A 64-byte entry (16 transform positions of one (k, row)) is read as four ds_read_b128 whose 16-byte slots are XOR-ed
-// with bits 2-3 of the row: conflict-free for the 16 lanes of a read pass.
+// One workgroup = 8 waves on one CU (145 KB of LDS), two per SIMD; a wave PAIR shares a sub-tile of 32 quads x 32
+// channels and splits its 16 transform positions (conv_wino8_body below).  Channels are walked in chunks of KC; per
+// chunk three LDS images: the raw input pixels of the block's images [pixel][KC] and the transformed weights
+// [k][co][16] arrive by LDS-DMA, the transformed input [k][quad][16] is written by the block itself (each thread
+// transforms one patch per chunk, under the previous chunk's MFMAs).  Two stages of each, one barrier per chunk, and
+// the chunk sequence runs on across the tile blocks a workgroup owns (persistent grid), so the staging pipeline is
+// filled once per workgroup, not once per tile.  A 64-byte entry (16 transform positions of one (k, row)) is read as
+// ds_read_b128 whose 16-byte slots are XOR-ed with bits 2-3 of the row: conflict-free for the 16 lanes of a read pass.
+// (Rounds 3-4 ran one wave per SIMD with all 16 positions -- 256 accumulator registers -- and left the matrix pipe idle
+// for every exposed wait: deleted in round 5, see DESIGN.md.)
 #include <atomic>
 
 #include "conv.h"
@@ -43,417 +45,23 @@ struct WinoArgs {
   int cus = 0;        // CUs the persistent grid is sized for (0 = 256)
   int* dyn = nullptr; // [32] zeroed tile counters (dyn[y]: tile blocks handed out beyond the first round; dyn[16 + y]:
                       // workgroups done): tile blocks are then dealt dynamically (see the kernel), else round-robin
-  // (UM = 1: `in` is the SOURCE map [tiles][Cin] of an Upsample(x2) + 3x3 layer; UM = 2: its data gradient, `out` the source
-  // map's gradient [tiles][Cout] -- template argument of the kernel, see the header comment)
+  // (UM = 1: `in` is the SOURCE map [tiles][Cin] of an Upsample(x2) + 3x3 layer -- template argument of the kernel)
   int Cin, Cout, L;   // L = log2 of the image side
   int nblk;           // tile blocks (of 32 WM quads)
-  int abl = 0;        // DIAGNOSTIC (temporary): parts of the epilogue switched off
 };
 
-template <int WM, int WN, int KC, int UM = 0>
-struct WinoCfg {
-  static constexpr int TBLK = 32 * WM, CB = 32 * WN, KS = KC / 2;
-  static constexpr int PPQ = UM == 1 ? 1 : 4;                // raw pixels per quad (UM = 1: one source pixel)
-  static constexpr int RAW_PIX = TBLK * PPQ * KC * 4;        // bytes of raw pixels per stage
-  static constexpr int RAW_DMA = RAW_PIX < 4096 ? 4096 : RAW_PIX;  // (a DMA round is 256 lanes x 16 bytes: spare lanes fetch zeros)
-  static constexpr int RAW_B = 64 + RAW_DMA;                 // + the zero entry padding taps read
-  static constexpr int V_B = KC * TBLK * 64, U_B = KC * CB * 64;
-  static constexpr int OFF_RAW = 0, OFF_V = OFF_RAW + 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B;
-  static constexpr int OFF_NEXT = OFF_RED + WM * CB * 2 * 4;  // the next tile block of a dynamically scheduled grid
-  static constexpr int LDS_BYTES = OFF_NEXT + 16;
-  static constexpr int NI = TBLK * KC / 256;                 // patches a thread transforms per chunk
-  static constexpr int RR = RAW_DMA / 4096, UR = U_B / 4096; // 4 KiB DMA rounds (256 lanes x 16 bytes) per chunk
-};
-
-// UM = 1 / 2: the decoder's Upsample(x2) + ConvTranspose2d 3x3 layers (/root/reference/src/decoder.py:34-46), forward and
-// data gradient.  The layer is a 3x3 convolution of the nearest-upsampled map, so the 4x4 input patch of the output quad of
-// source pixel (i, j) is d[u][v] = s[i + r(u)][j + r(v)], r = (-1, 0, 0, +1), and B^T maps (x-, x0, x0, x+) to
-// (x- - x0, 2 x0, 0, x0 - x+): transform position 2 vanishes in both directions, NINE of the sixteen position GEMMs remain
-// (the folded direct form multiplies sixteen (class, tap) pairs per source pixel).  The adjoint has the same shape: the
-// gradient of the source map is the 2x2 sum of the fine-grid data gradient, 1^T A^T M A 1 with A 1 = (1, 2, 0, -1)^T --
-// again only positions with xi, nu in {0, 1, 3} count, so only those are transformed and multiplied.
-template <int WM, int WN, int KC, int UM = 0>
-__device__ __forceinline__ void conv_wino_body(const WinoArgs& a, unsigned char* wsm) {
-  using C = WinoCfg<WM, WN, KC, UM>;
-  constexpr int NP = UM == 1 ? 9 : 16;  // raw pixels of a patch
-  constexpr int TBLK = C::TBLK, CB = C::CB, KS = C::KS, NI = C::NI;
-  static_assert(WM * WN == 4 && KC % 2 == 0 && C::RR >= 1 && C::UR >= 1 && NI >= 1, "unsupported shape");
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
-  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int n0 = blockIdx.y * CB;
-  const int H = 1 << a.L, HW = H * H;
-
-  // ---- per-thread constants of the input transform: LDS offsets (inside a raw stage) of the 4x4 patch of quad `tl`
-  // (the thread's NI patches are that quad at channels k0 + j * 256 / TBLK); a padding tap reads the stage's zero entry
-  // Raw stage layout: pixel px of the block sits at position (px & 3) TBLK + (px >> 2) (quad-position-major: the DMA's
-  // per-lane SOURCE picks the pixel), KC floats each; the 64 lanes of a wave read the same tap of 64 consecutive quads,
-  // and a lane's channel is rotated by its quad index, so that a read spreads over 32 banks (pixel-major order with one
-  // channel per wave put all 64 lanes on 2 banks: the kernel ran at a third of its MFMA time).
-  constexpr int KG = 256 / TBLK;  // channel groups: the thread's NI patches are channels kb, kb + KG, ...
-  const int tl = tid % TBLK, k0 = ((tid / TBLK) + tl / (64 / KC)) % KG;
-  int poff[16];
-  if constexpr (UM == 1) {
-    // 3x3 patch of SOURCE pixels around the source pixel of quad tl (source image side H / 2; source pixel index = quad index)
-    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4), Hs = H / 2;
-    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int y = ty - 1 + e / 3, x = tx - 1 + e % 3;
-      const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
-      const int pos = img * (HW / 4) + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
-      poff[e] = ok ? 64 + (pos * KC + k0) * 4 : 0;
-    }
-  } else {
-    const int img = (tl * 4) / HW, tq = tl - img * (HW / 4);  // quad index inside its image = Morton index of (ty, tx)
-    const int ty = (int)morton_y((uint32_t)tq), tx = (int)morton_x((uint32_t)tq);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
-        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
-        const int px = img * HW + (int)morton((uint32_t)(ok ? y : 0), (uint32_t)(ok ? x : 0));
-        const int pos = (px & 3) * TBLK + (px >> 2);
-        poff[i * 4 + j] = ok ? 64 + (pos * KC + k0) * 4 : 0;
-      }
-  }
-  // where the thread's transformed patches go / where the wave's MFMA operands come from (absolute LDS addresses, stage 0)
-  const uint32_t vst = lds0 + C::OFF_V + (uint32_t)((k0 * TBLK + tl) * 64);
-  const int swt = (tl >> 2) & 3;
-  const int rowA = wm * 32 + c, colB = wn * 32 + c;
-  uint32_t aaddr[2][4], baddr[2][4];
-#pragma unroll
-  for (int st = 0; st < 2; ++st)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      aaddr[st][i] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)((hh * TBLK + rowA) * 64 + ((i ^ ((rowA >> 2) & 3)) << 4));
-      baddr[st][i] = lds0 + C::OFF_U + st * C::U_B + (uint32_t)((hh * CB + colB) * 64 + ((i ^ ((colB >> 2) & 3)) << 4));
-    }
-  // the zero entries
-  if (tid < 32) *reinterpret_cast<float*>(wsm + C::OFF_RAW + (tid >> 4) * C::RAW_B + (tid & 15) * 4) = 0.f;
-
-  // ---- DMA of one chunk's images
-  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * TBLK * C::PPQ * a.Cin * 4), 0x00020000);
-  int rvoff[C::RR];
-#pragma unroll
-  for (int q = 0; q < C::RR; ++q) {
-    const int byte = (q * 256 + tid) * 16, pos = byte / (KC * 4);
-    if constexpr (UM == 1) rvoff[q] = byte < C::RAW_PIX ? pos * a.Cin * 4 + byte % (KC * 4) : (int)0x7FFF0000;  // (spare lanes: out of range -> zeros)
-    else rvoff[q] = (4 * (pos % TBLK) + pos / TBLK) * a.Cin * 4 + byte % (KC * 4);
-  }
-  const int nch = a.Cin / KC;
-  auto issue_raw = [&](int blk, int ch, int st) {
-    const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK * C::PPQ * a.Cin + ch * KC) * 4);
-#pragma unroll
-    for (int q = 0; q < C::RR; ++q) {
-      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + st * C::RAW_B + 64 + q * 4096 + wave * 1024));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
-    }
-  };
-  auto issue_u = [&](int ch, int st) {
-#pragma unroll
-    for (int q = 0; q < C::UR; ++q) {
-      const int off = q * 4096 + wave * 1024;               // position in the chunk image [KC][CB][64 bytes]
-      const int kk = off / (CB * 64), within = off % (CB * 64);
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.u) +
-                                 ((size_t)(ch * KC + kk) * a.Cout + n0) * 64 + within + lane * 16;
-      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + off));
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (lds_void_t*)(uintptr_t)dst, 16, 0, 0);
-    }
-  };
-
-  // ---- input transform of the thread's NI patches: raw stage `rs` -> transformed stage `vs`
-  auto load_patch = [&](int rs, int j, float (&d)[16]) {
-#pragma unroll
-    for (int e = 0; e < NP; ++e)
-      d[e] = *reinterpret_cast<lds_cf32*>((uintptr_t)(lds0 + C::OFF_RAW + rs * C::RAW_B + j * (256 / TBLK) * 4 + (uint32_t)poff[e]));
-  };
-  auto store_patch = [&](int vs, int j, const float (&d)[16]) {
-    float t[16], v[16];
-    if constexpr (UM == 1) {  // V = T s T^T, T = [1 -1 0; 0 2 0; 0 1 -1] -> transform positions (0, 1, 3) x (0, 1, 3)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        t[0 * 3 + q] = d[0 * 3 + q] - d[1 * 3 + q];
-        t[1 * 3 + q] = d[1 * 3 + q] + d[1 * 3 + q];
-        t[2 * 3 + q] = d[1 * 3 + q] - d[2 * 3 + q];
-      }
-#pragma unroll
-      for (int x = 0; x < 3; ++x) {
-        const f32x4 o = {t[x * 3 + 0] - t[x * 3 + 1], t[x * 3 + 1] + t[x * 3 + 1], 0.f, t[x * 3 + 1] - t[x * 3 + 2]};
-        const int xr = x == 2 ? 3 : x;
-        *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + j * (256 / TBLK) * TBLK * 64 + (uint32_t)((xr ^ swt) << 4))) = o;
-      }
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // B^T d
-      t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
-      t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
-      t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
-      t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {  // (.) B
-      v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
-      v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
-      v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
-      v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
-      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + j * (256 / TBLK) * TBLK * 64 + (uint32_t)((x ^ swt) << 4))) = o;
-    }
-  };
-
-  f32x16 acc[16];
-
-  // ---- the workgroup's sequence of tile blocks x (Cin / KC) chunks each.  Static: blocks blockIdx.x, + gridDim.x, ...
-  // Dynamic (a.dyn): every block is the next one not yet handed out (an atomic counter per grid row, fetched a whole tile
-  // block ahead by one lane and passed on through LDS): a workgroup that gets its CU late -- the launch shares the chip
-  // with a kernel that still holds it -- simply takes fewer blocks, or none, where the static deal makes the whole
-  // launch wait for that workgroup's full share.  Outputs and BatchNorm partials are per tile block, so who computes
-  // a block changes no bit.
-  const bool dynq = a.dyn != nullptr;
-  volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
-  auto finish = [&]() {  // the last workgroup of the grid row to finish leaves the counters zeroed for the next launch
-    if (dynq && tid == 0 && atomicAdd(a.dyn + 16 + blockIdx.y, 1) == (int)gridDim.x - 1) {
-      atomicExch(a.dyn + blockIdx.y, 0);
-      atomicExch(a.dyn + 16 + blockIdx.y, 0);
-    }
-  };
-  // (dynamic: the first block too -- a workgroup that is dispatched after the work is done must find nothing to do -- and
-  // always TWO blocks ahead: the id of the block after next is asked for when a block starts and handed round at its end,
-  // so nobody ever waits for the atomic and the chunk loop below is the static form's, instruction for instruction)
-  int blk_cur = (int)blockIdx.x, blk_nxt = blk_cur + (int)gridDim.x;
-  if (dynq) {
-    if (tid == 0) { nslot[0] = atomicAdd(a.dyn + blockIdx.y, 1); nslot[1] = atomicAdd(a.dyn + blockIdx.y, 1); }
-    __syncthreads();
-    blk_cur = __builtin_amdgcn_readfirstlane(nslot[0]);
-    blk_nxt = __builtin_amdgcn_readfirstlane(nslot[1]);
-    __syncthreads();
-  }
-  bool has_next = blk_nxt < a.nblk;
-  if (blk_cur >= a.nblk) { finish(); return; }
-  // virtual chunk numbering (kept from the static form so that the chunk body is branch-free arithmetic): the current
-  // block's chunks are vbase .. vbase + nch - 1, the next block's follow, VT ends the sequence the prefetch may look into
-  int vbase = 0, VT = (has_next ? 2 : 1) * nch;
-  auto blk_of = [&](int v) { return blk_cur + ((v - vbase) / nch) * (blk_nxt - blk_cur); };
-  issue_raw(blk_cur, 0, 0);
-  issue_u(0, 0);
-  issue_raw(blk_cur, 1 % nch, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      float d[16];
-      load_patch(0, j, d);
-      store_patch(0, j, d);
-    }
-  }
-  __syncthreads();
-
-  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (int)((int64_t)a.nblk * TBLK * (UM == 2 ? 1 : 4) * a.Cout * 4), 0x00020000);
-  const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;   // quad row 4 hh of the lane's first quad: 4 pixels per quad
-  const int ovoff1 = (4 * hh * a.Cout + n0 + wn * 32 + c) * 4;   // (UM = 2: one row per quad)
-  (void)ovoff1;
-  auto epilogue = [&](int blk) {
-    const int col = n0 + wn * 32 + c;
-    const float bias = a.bias ? a.bias[col] : 0.f;
-    if constexpr (UM == 2) {
-      // gradient of the source pixel = sum of its quad's four fine-grid gradients = sum_xi,nu w_xi w_nu M[xi][nu],
-      // w = A 1 = (1, 2, 0, -1): one output row per quad
-      const f32x16 r0 = (acc[0] + (acc[1] + acc[1])) - acc[3];
-      const f32x16 r1 = (acc[4] + (acc[5] + acc[5])) - acc[7];
-      const f32x16 r3 = (acc[12] + (acc[13] + acc[13])) - acc[15];
-      const f32x16 y = (r0 + (r1 + r1)) - r3;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rq = (r & 3) + 8 * (r >> 2);
-        const int soff = __builtin_amdgcn_readfirstlane((blk * TBLK + wm * 32 + rq) * a.Cout * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[r] + bias), rsrc_out, ovoff1, soff, 0);
-      }
-      return;
-    }
-    float s1 = 0.f, s2 = 0.f;
-    // A^T M A on whole accumulator tiles (the transform is elementwise in the 16 rows a lane holds): element-by-element
-    // access would make the compiler copy every 16-register accumulator tuple out of the AGPRs at once
-    f32x16 y[4];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      if (UM == 1 && nu == 2) continue;  // (upsampled input: positions with xi = 2 or nu = 2 are identically zero)
-      const f32x16 t0 = UM == 1 ? acc[0 + nu] + acc[4 + nu] : (acc[0 + nu] + acc[4 + nu]) + acc[8 + nu];
-      const f32x16 t1 = UM == 1 ? acc[4 + nu] - acc[12 + nu] : (acc[4 + nu] - acc[8 + nu]) - acc[12 + nu];
-      if (nu == 0) { y[0] = t0; y[2] = t1; }
-      if (nu == 1) { y[0] = y[0] + t0; y[1] = t0; y[2] = y[2] + t1; y[3] = t1; }
-      if (nu == 2) { y[0] = y[0] + t0; y[1] = y[1] - t0; y[2] = y[2] + t1; y[3] = y[3] - t1; }
-      if (nu == 3) { y[1] = y[1] - t0; y[3] = y[3] - t1; }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // quad gt = blk TBLK + 32 wm + crow(r, hh), rows 4 gt + q: one per-lane offset for the whole kernel, the rest scalar
-      const int rq = 4 * ((r & 3) + 8 * (r >> 2));
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = y[q][r] + bias;
-        const int soff = __builtin_amdgcn_readfirstlane(((blk * TBLK + wm * 32) * 4 + rq + q) * a.Cout * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_out, ovoff, soff, 0);
-        s1 += v;
-        s2 = fmaf(v, v, s2);
-      }
-    }
-    if (a.stats) {
-      float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (hh == 0) { red[(wm * CB + wn * 32 + c) * 2] = s1; red[(wm * CB + wn * 32 + c) * 2 + 1] = s2; }
-      __syncthreads();
-      if (tid < CB) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) { t1 += red[(w * CB + tid) * 2]; t2 += red[(w * CB + tid) * 2 + 1]; }
-        float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
-        dst[0] = t1; dst[1] = t2;
-      }
-    }
-  };
-
-  // One chunk = KS k-steps x 4 operand groups x 4 MFMAs, written as ONE pinned instruction stream (a fence after every
-  // piece): left to itself the compiler loads each group's operands right before its MFMAs and waits for them with the
-  // matrix pipe draining, and puts a whole patch transform (16 LDS reads, a wait, ~50 VALU) between two MFMAs.  Here the
-  // operands of group g + 1 are requested before the MFMAs of group g, and the next chunk's input transform rides in the
-  // shadows of the MFMAs a few instructions at a time: patch j is read at the start of k-step j, its B^T d columns follow
-  // beside the MFMAs of group 1, its (.) B rows and their stores beside those of group 2.
-  auto chunk = [&](int v, auto stc) {  // virtual chunk v: chunk v - vbase of tile block blk_cur
-    constexpr int st = decltype(stc)::value;
-    // (branch-free: past the end of the sequence the last chunk is fetched and transformed again, into stages nobody reads)
-    const int v1 = v + 1 < VT ? v + 1 : VT - 1, v2 = v + 2 < VT ? v + 2 : VT - 1;
-    issue_u(v1 % nch, st ^ 1);
-    issue_raw(blk_of(v2), v2 % nch, st);
-    f32x4 ca, cb, na, nb;
-    auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 4 ks + i: positions 4 i .. 4 i + 3 of k-step ks
-      x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st][g & 3] + (g >> 2) * 2 * TBLK * 64));
-      y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st][g & 3] + (g >> 2) * 2 * CB * 64));
-    };
-    load_grp(0, ca, cb);
-    float d[16], t[16];
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr bool SK = UM != 0;  // upsampled forms: operand group 2 and position 2 of every group are never multiplied
-#pragma unroll
-    for (int g = 0; g < 4 * KS; ++g) {
-      const int ks = g >> 2, i = g & 3;
-      if (SK && i == 2) continue;
-      {
-        const int gn = SK && ((g + 1) & 3) == 2 ? g + 2 : g + 1;  // the next group that has MFMAs
-        if (gn < 4 * KS) load_grp(gn, na, nb);
-      }
-      if (ks < NI && i == 0) load_patch(st ^ 1, ks, d);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        if (SK && m == 2) continue;
-        const int mm = SK && m == 3 ? 2 : m;  // piece index 0..2 of the transform when a position is skipped
-        if constexpr (UM == 1) {
-          if (ks < NI && i == 1) {  // T s, column mm
-            t[0 * 3 + mm] = d[0 * 3 + mm] - d[1 * 3 + mm];
-            t[1 * 3 + mm] = d[1 * 3 + mm] + d[1 * 3 + mm];
-            t[2 * 3 + mm] = d[1 * 3 + mm] - d[2 * 3 + mm];
-          }
-          if (ks < NI && i == 3) {  // (.) T^T, row mm -> transform row (0, 1, 3)[mm], and its store
-            const f32x4 o = {t[mm * 3 + 0] - t[mm * 3 + 1], t[mm * 3 + 1] + t[mm * 3 + 1], 0.f, t[mm * 3 + 1] - t[mm * 3 + 2]};
-            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
-          }
-        } else if constexpr (UM == 2) {
-          if (ks < NI && i == 1) {  // B^T d: rows 0, 1, 3 only; columns m = 0, 1, 3 here and column 2 (an input of every row) with m = 0
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-              const int q = cc == 0 ? m : 2;
-              if (cc == 1 && m != 0) continue;
-              t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
-              t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
-              t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
-            }
-          }
-          if (ks < NI && i == 3) {  // (.) B, row m in {0, 1, 3}, and its store
-            const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], 0.f, t[m * 4 + 1] - t[m * 4 + 3]};
-            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
-          }
-        } else {
-          if (ks < NI && i == 1) {  // B^T d, column m
-            t[0 * 4 + m] = d[0 * 4 + m] - d[2 * 4 + m];
-            t[1 * 4 + m] = d[1 * 4 + m] + d[2 * 4 + m];
-            t[2 * 4 + m] = d[2 * 4 + m] - d[1 * 4 + m];
-            t[3 * 4 + m] = d[1 * 4 + m] - d[3 * 4 + m];
-          }
-          if (ks < NI && i == 2) {  // (.) B, row m, and its store
-            const f32x4 o = {t[m * 4 + 0] - t[m * 4 + 2], t[m * 4 + 1] + t[m * 4 + 2], t[m * 4 + 2] - t[m * 4 + 1],
-                             t[m * 4 + 1] - t[m * 4 + 3]};
-            *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + (st ^ 1) * C::V_B + ks * (256 / TBLK) * TBLK * 64 + (uint32_t)((m ^ swt) << 4))) = o;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[4 * i + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * i + m], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      ca = na; cb = nb;
-    }
-    static_assert(NI <= KS, "one patch per k-step");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-  // (nested on purpose: the accumulators are zeroed and consumed in straight-line code of the outer loop.  A flat chunk
-  // loop with a conditional epilogue made every chunk end in a merge of "old" and "zeroed" accumulators, which the compiler
-  // implements by moving all 256 of them through VGPRs; an even chunk count keeps the stage parity per tile block)
-  int v = 0, par = 1;
-  bool go = true;
-  while (go) {
-    int fetched = 0;
-    if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);  // (the block after next; in flight under this block)
-#pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
-    for (int ch = 0; ch < nch; ch += 2) {
-      chunk(v, std::integral_constant<int, 0>{});
-      chunk(v + 1, std::integral_constant<int, 1>{});
-      v += 2;
-    }
-    epilogue(blk_cur);
-    go = has_next;
-    blk_cur = blk_nxt;
-    if (dynq) {  // (two slots in turn: ONE barrier per block hands the id round; a slot is rewritten two blocks later)
-      par ^= 1;
-      if (tid == 0) nslot[par] = fetched;
-      __syncthreads();
-      blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
-    } else {
-      blk_nxt = blk_cur + (int)gridDim.x;
-    }
-    has_next = blk_nxt < a.nblk;
-    vbase += nch;
-    VT = vbase + (has_next ? 2 : 1) * nch;
-  }
-  finish();
-}
-
-template <int WM, int WN, int KC, int UM = 0>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoArgs a) {
-  extern __shared__ __align__(16) unsigned char wino_smem[];
-  conv_wino_body<WM, WN, KC, UM>(a, wino_smem);
-}
-
-// ===================================================================================================================
-// The two-waves-per-SIMD form (round 5): EIGHT waves per workgroup, the 16 (9) transform positions of a 32 quad x 32
-// channel sub-tile split over a wave PAIR -- wave w and wave w + 4 land on the same SIMD, read the same transformed
-// operands and hold the transform rows xi in {0, 1} and {2, 3}: 8 accumulator tiles = 128 registers each, so the two fit
-// the register file side by side and one wave's operand waits, LDS-DMA issue and transform arithmetic fall under the
-// other's MFMAs (the one-wave form above left the matrix pipe idle for every exposed ds_read: PMC busy 0.21-0.37 in a
-// training step, round 4).  Same LDS images, same DMA, same chunk sequence, same outputs per tile block; what changes:
-// every thread transforms ONE patch per chunk (512 threads), and the output transform Y = A^T M A needs rows of M from
+// UM = 1: the decoder's Upsample(x2) + ConvTranspose2d 3x3 layers (/root/reference/src/decoder.py:34-46), forward.  The
+// layer is a 3x3 convolution of the nearest-upsampled map, so the 4x4 input patch of the output quad of source pixel
+// (i, j) is d[u][v] = s[i + r(u)][j + r(v)], r = (-1, 0, 0, +1), and B^T maps (x-, x0, x0, x+) to (x- - x0, 2 x0, 0,
+// x0 - x+): transform position 2 vanishes in both directions, NINE of the sixteen position GEMMs remain (the folded
+// direct form multiplies sixteen (class, tap) pairs per source pixel).
+//
+// Two waves per SIMD: EIGHT waves per workgroup, the 16 (9) transform positions of a 32 quad x 32 channel sub-tile
+// split over a wave PAIR -- wave w and wave w + 4 land on the same SIMD, read the same transformed operands and hold
+// the transform rows xi in {0, 1} and {2, 3}: 8 accumulator tiles = 128 registers each, so the two fit the register
+// file side by side and one wave's operand waits, LDS-DMA issue and transform arithmetic fall under the other's MFMAs
+// (the one-wave form of rounds 3-4 left the matrix pipe idle for every exposed ds_read: PMC busy 0.21-0.37 in a
+// training step).  Every thread transforms ONE patch per chunk (512 threads), and the output transform Y = A^T M A needs rows of M from
 // both waves of a pair, so each wave first applies the column half (C_xi = M[xi][.] A, lane-local as before), the pair
 // swaps ONE row of C through LDS (two rounds of 4 KB per wave in the transformed-input stage the block's last chunk has
 // just finished with), and each wave then owns one output row of the quad: wave set 0 the pixels 4 q, 4 q + 1, set 1 the
@@ -477,7 +85,8 @@ struct Wino8Cfg {
 template <int WM, int WN, int KC, int UM, int TAIL>
 __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char* wsm) {
   using C = Wino8Cfg<WM, WN, KC, UM>;
-  static_assert(UM == 0 || UM == 1, "forward / data gradient of a plain 3x3 layer, or the forward behind an upsample");
+  static_assert(UM >= 0 && UM <= 2, "plain 3x3 layer (forward / data gradient); forward / data gradient behind an upsample");
+  constexpr bool SK = UM != 0;  // upsampled forms: transform row / column 2 is never multiplied (9 of 16 positions)
   constexpr int NP = UM == 1 ? 9 : 16;  // raw pixels of a patch
   constexpr int TBLK = C::TBLK, CB = C::CB, KS = C::KS;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
@@ -576,7 +185,16 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   };
   // B^T d, column m (UM = 1: T s, column m of 3)
   auto xform_col = [&](int m, const float (&d)[16], float (&t)[16]) {
-    if constexpr (UM == 1) {
+    if constexpr (UM == 2) {  // rows 0, 1, 3 of B^T d; piece m is column (0, 1, 3)[m], piece 0 also column 2 (an input of every row)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc == 1 && m != 0) continue;
+        const int q = cc == 1 ? 2 : (m == 2 ? 3 : m);
+        t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
+        t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
+        t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
+      }
+    } else if constexpr (UM == 1) {
       t[0 * 3 + m] = d[0 * 3 + m] - d[1 * 3 + m];
       t[1 * 3 + m] = d[1 * 3 + m] + d[1 * 3 + m];
       t[2 * 3 + m] = d[1 * 3 + m] - d[2 * 3 + m];
@@ -589,7 +207,11 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   };
   // (.) B, row m, and its store (UM = 1: row m of 3 -> transform row (0, 1, 3)[m])
   auto xform_row_store = [&](int vs, int m, const float (&t)[16]) {
-    if constexpr (UM == 1) {
+    if constexpr (UM == 2) {  // (.) B on row xr = (0, 1, 3)[m]: columns 0, 1, 3
+      const int xr = m == 2 ? 3 : m;
+      const f32x4 o = {t[xr * 4 + 0] - t[xr * 4 + 2], t[xr * 4 + 1] + t[xr * 4 + 2], 0.f, t[xr * 4 + 1] - t[xr * 4 + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + (uint32_t)((xr ^ swt) << 4))) = o;
+    } else if constexpr (UM == 1) {
       const f32x4 o = {t[m * 3 + 0] - t[m * 3 + 1], t[m * 3 + 1] + t[m * 3 + 1], 0.f, t[m * 3 + 1] - t[m * 3 + 2]};
       const int xr = m == 2 ? 3 : m;
       *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + (uint32_t)((xr ^ swt) << 4))) = o;
@@ -598,7 +220,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst + vs * C::V_B + (uint32_t)((m ^ swt) << 4))) = o;
     }
   };
-  constexpr int NPIECE = UM == 1 ? 3 : 4;  // pieces of each transform half (columns, then rows)
+  constexpr int NPIECE = SK ? 3 : 4;  // pieces of each transform half (columns, then rows)
 
   f32x16 acc[8];  // acc[4 i + nu] = M[2 ps + i][nu] of the wave's 32 quads x 32 channels
 
@@ -635,8 +257,10 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (int)((int64_t)a.nblk * TBLK * 4 * a.Cout * 4), 0x00020000);
+      a.out, 0, (int)((int64_t)a.nblk * TBLK * (UM == 2 ? 1 : 4) * a.Cout * 4), 0x00020000);
   const int ovoff = (16 * hh * a.Cout + n0 + wn * 32 + c) * 4;  // quad row 4 hh of the lane's first quad: 4 pixels per quad
+  const int ovoff1 = (4 * hh * a.Cout + n0 + wn * 32 + c) * 4;  // (UM = 2: one row per quad)
+  (void)ovoff1;
   const float bias = a.bias ? a.bias[n0 + wn * 32 + c] : 0.f;   // (the lane's output channel is the same for every tile block)
   const uint32_t xaddr = lds0 + C::OFF_V + C::V_B + (uint32_t)(lane * 16);  // exchange slots: stage 1 of the transformed input
 
@@ -644,20 +268,57 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
   // next block's first MFMAs (or behind the last block): store idx = 2 r + q is accumulator row r of pixel 2 ps + q
   f32x16 py0, py1;
   int pblk = 0;
+  constexpr int NSTORE = UM == 2 ? 16 : 32;  // (UM = 2: ONE output row per quad, held by wave set 0)
   auto store_pending = [&](int idx) {
-    const int r = idx >> 1, q = idx & 1;
-    const int rq = 4 * ((r & 3) + 8 * (r >> 2));
-    // (the row index is kept opaque: distributed over the sum, its 32 constant parts x Cout would be hoisted out of the
+    // (the row index is kept opaque: distributed over the sum, its constant parts x Cout would be hoisted out of the
     // tile-block loop into 32 scalar registers, which then spill)
-    int row = __builtin_amdgcn_readfirstlane((pblk * TBLK + wm * 32) * 4 + 2 * ps);
-    asm volatile("" : "+s"(row));
-    const int soff = (row + rq + q) * a.Cout * 4;
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q == 0 ? py0[r] : py1[r]), rsrc_out, ovoff, soff, 0);
+    if constexpr (UM == 2) {  // (wave set 0 only: the callers know their set at compile time)
+      const int rq = (idx & 3) + 8 * (idx >> 2);
+      int row = __builtin_amdgcn_readfirstlane(pblk * TBLK + wm * 32);
+      asm volatile("" : "+s"(row));
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(py0[idx]), rsrc_out, ovoff1, (row + rq) * a.Cout * 4, 0);
+    } else {
+      const int r = idx >> 1, q = idx & 1;
+      const int rq = 4 * ((r & 3) + 8 * (r >> 2));
+      int row = __builtin_amdgcn_readfirstlane((pblk * TBLK + wm * 32) * 4 + 2 * ps);
+      asm volatile("" : "+s"(row));
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(q == 0 ? py0[r] : py1[r]), rsrc_out, ovoff, (row + rq + q) * a.Cout * 4, 0);
+    }
   };
 
   // the epilogue of wave set PSC (compile-time copy of ps)
   auto epilogue = [&](int blk, auto psc) {
     constexpr int PSC = decltype(psc)::value;
+    if constexpr (UM == 2) {
+      // data gradient behind the upsample: the gradient of the source pixel is the sum of its quad's four fine-grid
+      // gradients = sum_xi,nu w_xi w_nu M[xi][nu], w = A 1 = (1, 2, 0, -1).  Set 0 holds rows 0, 1, set 1 row 3: set 1
+      // gives its row sum r3, set 0 forms (r0 + 2 r1) - r3 and keeps the ONE output row per quad.
+      const f32x16 rr = (acc[4] + (acc[5] + acc[5])) - acc[7];  // row 2 ps + 1: xi = 1 (set 0) or 3 (set 1)
+      const uint32_t mine = xaddr + (uint32_t)(wave * 4096), theirs = xaddr + (uint32_t)((wave ^ 4) * 4096);
+      if constexpr (PSC == 1) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 o = {rr[4 * r4], rr[4 * r4 + 1], rr[4 * r4 + 2], rr[4 * r4 + 3]};
+          *reinterpret_cast<lds_f32x4*>((uintptr_t)(mine + r4 * 1024)) = o;
+        }
+      }
+      __syncthreads();
+      if constexpr (PSC == 0) {
+        const f32x16 r0 = (acc[0] + (acc[1] + acc[1])) - acc[3];
+        f32x16 got;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 o = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(theirs + r4 * 1024));
+          got[4 * r4] = o[0]; got[4 * r4 + 1] = o[1]; got[4 * r4 + 2] = o[2]; got[4 * r4 + 3] = o[3];
+        }
+        const f32x16 y = (r0 + (rr + rr)) - got;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) py0[r] = y[r] + bias;
+      }
+      pblk = blk;
+      __syncthreads();  // (the slots are rewritten by the next chunk's transform)
+      return;
+    }
     // column half of the output transform on the wave's own rows: C_i[b] = sum_nu M[2 ps + i][nu] A[nu][b]
     f32x16 c00 = {0}, c01 = {0}, c10, c11;  // c<i><b>
     if constexpr (UM == 1) {
@@ -674,7 +335,6 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const f32x16& give = PSC == 0 ? (b == 0 ? c10 : c11) : (b == 0 ? c00 : c01);
-      if (a.abl & 2) { if (b == 0) y0 = give + c00; else y1 = give + c01; continue; }
       if (!(UM == 1 && PSC == 1)) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -714,7 +374,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       s1 += v1; s2 = fmaf(v1, v1, s2);
     }
     pblk = blk;
-    if (a.stats && !(a.abl & 4)) {
+    if (a.stats) {
       float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -757,7 +417,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 1] + st * C::U_B + (g >> 1) * 2 * CB * 64));
     };
     // (UM = 1, set 1: transform row 2 is identically zero -- only the odd groups exist)
-    constexpr int G0 = (UM == 1 && PSC == 1) ? 1 : 0, GSTEP = (UM == 1 && PSC == 1) ? 2 : 1;
+    constexpr int G0 = (SK && PSC == 1) ? 1 : 0, GSTEP = (SK && PSC == 1) ? 2 : 1;
     constexpr int NG = (2 * KS - G0 + GSTEP - 1) / GSTEP;  // executed groups of the chunk
     constexpr int NOWN = TAIL ? NG - 1 : NG;               // ... in front of the chunk barrier
     constexpr int EC = NOWN >= 3 ? 1 : 0;                  // the group that carries the column half of the transform
@@ -775,7 +435,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       int q = 0;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        if (UM == 1 && m == 2) continue;
+        if (SK && m == 2) continue;
         if constexpr (!FIRST) acc[4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[m], tb[m], acc[4 + m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (q < UPW) issue_u_piece(u_ch, st ^ 1, q);
@@ -795,7 +455,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       int piece = 0;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        if (UM == 1 && m == 2) continue;
+        if (SK && m == 2) continue;
         if (e == EC) xform_col(piece, d, t);
         if (e == EC + 1) xform_row_store(st ^ 1, piece, t);
         __builtin_amdgcn_sched_barrier(0);
@@ -807,11 +467,11 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
           // the previous tile block's 32 output stores beside the MFMAs of the first two groups -- the ones that start
           // from the constant 0: a store's register is free again before the accumulator tiles come alive, and the
           // stores have the rest of the chunk to complete
-          constexpr int MPG = UM == 1 ? 3 : 4, NMS = 2 * MPG, SPM = (32 + NMS - 1) / NMS;
+          constexpr int MPG = SK ? 3 : 4, NMS = 2 * MPG, SPM = (NSTORE + NMS - 1) / NMS;
           const int mi = e * MPG + piece;
-          if (mi < NMS) {
+          if (mi < NMS && !(UM == 2 && PSC == 1)) {
 #pragma unroll
-            for (int idx = mi * SPM; idx < (mi + 1) * SPM && idx < 32; ++idx) store_pending(idx);
+            for (int idx = mi * SPM; idx < (mi + 1) * SPM && idx < NSTORE; ++idx) store_pending(idx);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -829,13 +489,14 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
     if constexpr (TAIL && LAST) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        if (UM == 1 && m == 2) continue;
+        if (SK && m == 2) continue;
         acc[4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[m], tb[m], acc[4 + m], 0, 0, 0);
       }
     }
   };
 
   auto run = [&](auto psc) {
+    constexpr int PSC = decltype(psc)::value;
     int par = 1;
     bool go = true, pend = false;
     using I0 = std::integral_constant<int, 0>;
@@ -853,9 +514,9 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
         }
         chunk(nch - 1, I1{}, psc, I0{}, I1{}, I0{});
       } else {
-        if (pend) {
+        if (pend && !(UM == 2 && PSC == 1)) {
 #pragma unroll
-          for (int idx = 0; idx < 32; ++idx) store_pending(idx);
+          for (int idx = 0; idx < NSTORE; ++idx) store_pending(idx);
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) acc[p] = (f32x16){0};
@@ -878,8 +539,10 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       }
       has_next = blk_nxt < a.nblk;
     }
+    if constexpr (!(UM == 2 && PSC == 1)) {
 #pragma unroll
-    for (int idx = 0; idx < 32; ++idx) store_pending(idx);  // (the last block's)
+      for (int idx = 0; idx < NSTORE; ++idx) store_pending(idx);  // (the last block's)
+    }
   };
   // (one instantiation per wave set: which rows of M a wave holds decides its MFMA pattern behind the upsample and its
   // half of the epilogue; the sets meet at every workgroup barrier -- both paths execute the same number of them)
@@ -952,40 +615,6 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }
 
-template <int WM, int WN, int KC, int UM = 0>
-static int launch_wino_cfg(const WinoArgs& a, double flops, hipStream_t s) {
-  using C = WinoCfg<WM, WN, KC, UM>;
-  auto kern = conv_wino_kernel<WM, WN, KC, UM>;
-  // the raised dynamic-LDS limit is a per-DEVICE function attribute: once per device (bit per ordinal), not per process
-  static std::atomic<uint64_t> attr_done{0};
-  DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
-  const int ny = a.Cout / C::CB;
-  // one workgroup per CU, persistent over its tile blocks -- of the CUs this launch may count on (ConvArgs.wino_cus:
-  // a workgroup needs a WHOLE CU, so whatever runs beside the launch in a training step keeps its CUs and the grid is
-  // sized to the rest; workgroups that find no free CU start a whole round late: a 200-workgroup grid beside the
-  // sampler's 64 workgroups took the c3 step from 10.5 to 11.1 ms, a 192-workgroup grid to 10.3)
-  int cus = a.cus > 0 ? a.cus : 256;
-  if (cus < ny) cus = ny;
-  if (cus > 256) cus = 256;
-  int gx = cus / ny;
-  if (gx < 1) gx = 1;
-  if (gx > a.nblk) gx = a.nblk;
-  // dynamic deal of the tile blocks (option wino_dynamic) -- else every workgroup walks ceil(nblk / gx) tile blocks: the SMALLEST grid with that
-  // round count (72 workgroups over 256 tile blocks take the 4 rounds that 64 take, and 8 more CUs from whatever runs
-  // beside the launch)
-  WinoArgs ad = a;
-  // (the dynamic deal hands every workgroup TWO blocks up front: a launch of fewer than about three rounds keeps the
-  // static deal, where the grid is shrunk to its round count -- an evaluation forward at the 256-block threshold would
-  // otherwise be done by half the grid in two rounds.  Dynamic launches of one device must be ordered on ONE stream:
-  // the counters are a per-device pool that the launch's last workgroup re-zeroes.)
-  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.Cin / KC >= 2 && ny <= 16 && a.nblk >= 3 * gx) ? dyn_tile_counters() : nullptr;
-  if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
-  // (one workgroup per CU: the grid IS the number of CUs the launch occupies)
-  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), C::LDS_BYTES, s, ad);
-  return DVG_OK;
-}
-
-// the eight-wave form of the same launch (option wino_waves = 8)
 template <int WM, int WN, int KC, int UM = 0, int TAIL = 1>
 static int launch_wino8_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   using C = Wino8Cfg<WM, WN, KC, UM>;
@@ -1000,7 +629,6 @@ static int launch_wino8_cfg(const WinoArgs& a, double flops, hipStream_t s) {
   if (gx < 1) gx = 1;
   if (gx > a.nblk) gx = a.nblk;
   WinoArgs ad = a;
-  ad.abl = (int)(opt(OPT_WINO_WAVES) >> 4);
   // (the dynamic deal hands every workgroup TWO blocks up front: a launch of fewer than about three rounds keeps the
   // static deal, where the grid is shrunk to its round count -- an evaluation forward at the 256-block threshold would
   // otherwise be done by half the grid in two rounds.  Dynamic launches of one device must be ordered on ONE stream:
@@ -1025,19 +653,10 @@ int launch_conv_wino(const ConvArgs& a, hipStream_t s) {
   // EXECUTED matrix FLOPs: 16 transform-domain GEMMs over the M / 4 quads (4/9 of the direct form's 2 M Cin Cout 9;
   // the roofline prices what the matrix pipe does -- a rate in direct-form FLOPs would pass the f32 MFMA peak)
   const double flops = 2.0 * (double)(a.M / 4) * (a.wino_um ? 9.0 : 16.0) * a.Cin * a.Cout;
-  if ((opt(OPT_WINO_WAVES) & 15) == 8 && a.wino_um != 2) {
-    // (the 32-channel tile behind the upsample has two groups per chunk in wave set 1: no tail to hold back)
-    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
-    return cfg == 0 ? launch_wino8_cfg<2, 2, 8>(w, flops, s) : launch_wino8_cfg<4, 1, 4>(w, flops, s);
-  }
-  if (opt(OPT_WINO_WAVES) == 9 && a.wino_um != 2) {  // A/B: the eight-wave form without the tail behind the barrier
-    if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1, 0>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
-    return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 0, 0>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 0, 0>(w, flops, s);
-  }
-  if (a.wino_um == 1) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino_cfg<4, 1, 4, 1>(w, flops, s);
-  if (a.wino_um == 2) return cfg == 0 ? launch_wino_cfg<2, 2, 8, 2>(w, flops, s) : launch_wino_cfg<4, 1, 4, 2>(w, flops, s);
-  if (cfg == 0) return launch_wino_cfg<2, 2, 8>(w, flops, s);
-  return launch_wino_cfg<4, 1, 4>(w, flops, s);
+  // (the 32-channel tile behind the upsample has two groups per chunk in wave set 1: no tail to hold back)
+  if (a.wino_um == 1) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 1>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 1, 0>(w, flops, s);
+  if (a.wino_um == 2) return cfg == 0 ? launch_wino8_cfg<2, 2, 8, 2>(w, flops, s) : launch_wino8_cfg<4, 1, 4, 2, 0>(w, flops, s);
+  return cfg == 0 ? launch_wino8_cfg<2, 2, 8>(w, flops, s) : launch_wino8_cfg<4, 1, 4>(w, flops, s);
 }
 
 }  // namespace dvg

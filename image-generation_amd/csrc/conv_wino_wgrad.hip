@@ -8,12 +8,12 @@
 //     dU[p][ci][co] = sum_t V[p][t][ci] Z[p][t][co]                      <- the MFMA work: 16 x 2 T Cin Cout FLOPs
 //     dg = G^T dU G                        (3x3 per channel pair; the slab-reduce pass, wino_wgrad_reduce_kernel)
 // i.e. 8 M Cin Cout FLOPs where the direct form (conv_wgrad.hip) multiplies 18 M Cin Cout, padding taps included (31 % of
-// them at 4x4 images).  One workgroup = 4 waves, one per SIMD with the whole register file: a wave owns a 32 x 32 channel
-// tile of all 16 positions (256 accumulator registers).  The reduction runs over chunks of NQ quads whose transformed
-// operands sit in LDS as [quad][channel][16 floats] (64-byte entries, 16-byte slots XOR-swizzled by bits 2-3 of the
-// channel: conflict-free ds_read_b128 / ds_write_b128); each thread transforms one (quad, 4 channels) item per chunk --
-// 16 (input) or 4 (gradient) buffer_load_dwordx4 straight from global memory, a padding tap being an out-of-range
-// offset that loads zeros -- and writes it into the other stage while the matrix pipe works on this one.
+// them at 4x4 images).  One workgroup = 8 waves, two per SIMD: a wave PAIR owns a 32 x 32 channel tile and splits its 16
+// positions (conv_wino_wgrad8_kernel below).  The reduction runs over chunks of NQ quads whose transformed operands sit
+// in LDS as [quad][channel][16 floats] (64-byte entries, 16-byte slots XOR-swizzled by bits 2-3 of the channel); each
+// thread transforms one (quad, 2 channels) item per chunk -- 16 (input) or 4 (gradient) buffer_load_dwordx2 straight
+// from global memory, a padding tap being an out-of-range offset that loads zeros -- and writes it into the other stage
+// while the matrix pipe works on this one.
 // UPS = true: the decoder's Upsample(x2) + ConvTranspose2d 3x3 layers (/root/reference/src/decoder.py:34-46).  The layer is
 // a 3x3 convolution of the nearest-upsampled map, so the 4x4 input patch of the output quad of source pixel (i, j) is
 // d[u][v] = s[i + r(u)][j + r(v)], r = (-1, 0, 0, +1): along each axis B^T maps (x-, x0, x0, x+) to (x- - x0, 2 x0, 0,
@@ -37,272 +37,11 @@ struct WinoWgradArgs {
   int isplit;        // image-range splits (grid.z = position groups x isplit [x K groups inside the block])
 };
 
-template <int WA, int WB>
-struct WinoWgradCfg {
-  static constexpr int WK = 4 / (WA * WB);          // K groups inside the block (waves beyond the WA x WB channel tile)
-  static constexpr int CIB = 32 * WA, COB = 32 * WB;
-  static constexpr int QC = WK == 1 ? 8 : 4;         // quads per K group and chunk
-  static constexpr int NQ = QC * WK;                 // quads per chunk of the whole block
-  static constexpr int V_B = NQ * CIB * 64, Z_B = NQ * COB * 64, STAGE = V_B + Z_B;
-  static constexpr int LDS_BYTES = 2 * STAGE;
-  static constexpr int NV = NQ * CIB / 4, NZ = NQ * COB / 4;  // (quad, 4-channel) items per chunk
-  static_assert(WA * WB * WK == 4 && NV + NZ <= 256 && LDS_BYTES <= 160 * 1024, "unsupported tile");
-};
-
-template <int WA, int WB, bool UPS = false>
-__global__ __launch_bounds__(256, 1) void conv_wino_wgrad_kernel(WinoWgradArgs a) {
-  using C = WinoWgradCfg<WA, WB>;
-  constexpr int NE = UPS ? 9 : 16;  // raw rows of an input item: the 3x3 source patch, or the 4x4 patch
-  constexpr int WK = C::WK, CIB = C::CIB, COB = C::COB, QC = C::QC, NQ = C::NQ, NV = C::NV, NZ = C::NZ;
-  typedef __attribute__((address_space(3))) unsigned char lds_byte;
-  typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
-  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-  extern __shared__ __align__(16) unsigned char wwg_smem[];
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte*)wwg_smem;
-  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, c = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave / (WA * WB), wa = (wave / WB) % WA, wb = wave % WB;
-  const int tiles_b = a.Cout / COB;
-  const int a0 = ((int)blockIdx.x / tiles_b) * CIB, b0 = ((int)blockIdx.x % tiles_b) * COB;
-  const int H = 1 << a.L, HW = H * H, QI = HW / 4;             // quads per image
-  const int PGN = QI >= NQ ? QI / NQ : 1, IPC = QI >= NQ ? 1 : NQ / QI;  // position groups; images per chunk
-  const int n_img = (int)(a.M >> (2 * a.L));
-  const int pg = (int)blockIdx.z % PGN, isp = (int)blockIdx.z / PGN;
-  const int ichunks = (n_img + IPC - 1) / IPC;                            // chunks over the images of one position group
-  const int per = (ichunks + a.isplit - 1) / a.isplit;
-  const int c_beg = isp * per, c_end = c_beg + per < ichunks ? c_beg + per : ichunks;
-  const int nchunks = c_end > c_beg ? c_end - c_beg : 0;
-
-  // ---- this thread's transform item: (quad ql of the chunk, channels 4 c4 .. 4 c4 + 3) of the input (tid < NV) or of dY
-  // (roles change at wave boundaries -- NV and NZ are multiples of 64 -- so they are SCALAR conditions: plain branches, no
-  // exec masking, and the buffer descriptor of a wave's loads is wave-uniform)
-  static_assert(NV % 64 == 0 && NZ % 64 == 0, "transform roles per wave");
-  const bool is_v = wave < NV / 64, is_z = !is_v && wave < (NV + NZ) / 64;
-  const int item = is_v ? tid : tid - NV;
-  const int ql = is_v ? item / (CIB / 4) : (is_z ? item / (COB / 4) : 0);
-  const int c4 = is_v ? item % (CIB / 4) : (is_z ? item % (COB / 4) : 0);
-  const int qpos = QI >= NQ ? pg * NQ + ql : ql % QI;           // quad position inside its image (Morton index of (ty, tx))
-  const int isub = QI >= NQ ? 0 : ql / QI;                       // image of the chunk this quad belongs to
-  constexpr uint32_t PAD = 0xFFFF0000u;
-  uint32_t voff[16];  // V item: byte offsets of the 4x4 patch (padding: out of range -> zeros); Z item: the quad's 4 rows
-  {
-    const int ty = (int)morton_y((uint32_t)qpos), tx = (int)morton_x((uint32_t)qpos);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (is_v && UPS) {  // source pixel (ty, tx) of the quad: 3x3 patch on the SOURCE grid (side H / 2)
-        const int y = ty - 1 + e / 3, x = tx - 1 + e % 3, Hs = H / 2;
-        const bool ok = e < 9 && y >= 0 && y < Hs && x >= 0 && x < Hs;
-        voff[e] = ok ? (uint32_t)((isub * (HW / 4) + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 4 * c4) * 4u : PAD;
-      } else if (is_v) {
-        const int y = 2 * ty - 1 + (e >> 2), x = 2 * tx - 1 + (e & 3);
-        const bool ok = y >= 0 && y < H && x >= 0 && x < H;
-        voff[e] = ok ? (uint32_t)((isub * HW + (int)morton((uint32_t)y, (uint32_t)x)) * a.Cin + a0 + 4 * c4) * 4u : PAD;
-      } else {
-        voff[e] = (e < 4 && is_z) ? (uint32_t)((isub * HW + 4 * qpos + e) * a.Cout + b0 + 4 * c4) * 4u : PAD;
-      }
-    }
-  }
-  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)0xFFFF0000u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)0xFFFF0000u, 0x00020000);
-  // where the item's four 64-byte entries go (stage 0): entry (ql, channel), slot s at (s ^ ((channel >> 2) & 3)) << 4
-  const int chan0 = 4 * c4;
-  const uint32_t wst = lds0 + (is_v ? 0u : (uint32_t)C::V_B) + (uint32_t)((ql * (is_v ? CIB : COB) + chan0) * 64);
-  const int wsw = (chan0 >> 2) & 3;  // (the same for the item's four channels: they share bits 2-3)
-  // MFMA operand addresses (stage 0): k-step s reads quads kg QC + 2 s + hh
-  const int rowA = wa * 32 + c, colB = wb * 32 + c;
-  uint32_t aaddr[4], baddr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    aaddr[i] = lds0 + (uint32_t)(((kg * QC + hh) * CIB + rowA) * 64 + ((i ^ ((rowA >> 2) & 3)) << 4));
-    baddr[i] = lds0 + (uint32_t)C::V_B + (uint32_t)(((kg * QC + hh) * COB + colB) * 64 + ((i ^ ((colB >> 2) & 3)) << 4));
-  }
-
-  f32x4 raw[16];  // the item's raw rows (V: 16 patch pixels; Z: the quad's 4 pixels in raw[0..3])
-  auto issue_loads = [&](int ch, auto role_c) {  // chunk ch of this block: images (c_beg + ch) IPC ...
-    constexpr int ROLE = decltype(role_c)::value;  // 0: input item, 1: gradient item, 2: none
-    const int img = (c_beg + ch) * IPC;
-    const int soff_x = __builtin_amdgcn_readfirstlane(img * (UPS ? HW / 4 : HW) * a.Cin * 4), soff_y = __builtin_amdgcn_readfirstlane(img * HW * a.Cout * 4);
-    // (images past the end -- a ragged last chunk of IPC > 1 -- must read zeros: their offsets are pushed out of range)
-    const bool live = ch < nchunks && img + isub < n_img;  // (chunk nchunks: the dummy that makes the count even)
-    if constexpr (ROLE == 0) {
-#pragma unroll
-      for (int e = 0; e < NE; ++e)
-        raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(live ? voff[e] : PAD), soff_x, 0));
-    } else if constexpr (ROLE == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        raw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)(live ? voff[e] : PAD), soff_y, 0));
-    }
-  };
-  auto store_entry = [&](int st, int k, const float (&v)[16]) {
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      if (UPS && x == 2) continue;  // (positions 8..11 vanish: never read)
-      const f32x4 o = {v[x * 4], v[x * 4 + 1], v[x * 4 + 2], v[x * 4 + 3]};
-      *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
-    }
-  };
-  auto transform = [&](int st, auto role_c) {  // raw -> the item's 4 entries in stage st
-    constexpr int ROLE = decltype(role_c)::value;
-    if constexpr (ROLE == 0 && UPS) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // V = T s T^T, T = [1 -1 0; 0 2 0; 0 1 -1] at transform positions (0, 1, 3) x (0, 1, 3)
-        float sp[9], t[9], v[16];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) sp[e] = raw[e][k];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {  // T s (columns q)
-          t[0 * 3 + q] = sp[0 * 3 + q] - sp[1 * 3 + q];
-          t[1 * 3 + q] = sp[1 * 3 + q] + sp[1 * 3 + q];
-          t[2 * 3 + q] = sp[1 * 3 + q] - sp[2 * 3 + q];
-        }
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {  // (.) T^T: row x -> transform row (0, 1, 3)[x]
-          const int xr = x == 2 ? 3 : x;
-          v[xr * 4 + 0] = t[x * 3 + 0] - t[x * 3 + 1];
-          v[xr * 4 + 1] = t[x * 3 + 1] + t[x * 3 + 1];
-          v[xr * 4 + 2] = 0.f;
-          v[xr * 4 + 3] = t[x * 3 + 1] - t[x * 3 + 2];
-        }
-        v[8] = v[9] = v[10] = v[11] = 0.f;
-        store_entry(st, k, v);
-      }
-    } else if constexpr (ROLE == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float d[16], t[16], v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) d[e] = raw[e][k];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {  // B^T d
-          t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
-          t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
-          t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
-          t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {  // (.) B
-          v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
-          v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
-          v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
-          v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
-        }
-        store_entry(st, k, v);
-      }
-    } else if constexpr (ROLE == 1) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]: dY = [a b; c d] (rows 4t .. 4t+3 of the quad in Morton order)
-        const float qa = raw[0][k], qb = raw[1][k], qc = raw[2][k], qd = raw[3][k];
-        const float p0 = qa, q0 = qb, p1 = qa + qc, q1 = qb + qd, p2 = qa - qc, q2 = qb - qd, p3 = -qc, q3 = -qd;
-        float v[16];
-        v[0] = p0; v[1] = p0 + q0; v[2] = p0 - q0; v[3] = -q0;
-        v[4] = p1; v[5] = p1 + q1; v[6] = p1 - q1; v[7] = -q1;
-        v[8] = p2; v[9] = p2 + q2; v[10] = p2 - q2; v[11] = -q2;
-        v[12] = p3; v[13] = p3 + q3; v[14] = p3 - q3; v[15] = -q3;
-        store_entry(st, k, v);
-      }
-    }
-  };
-
-  f32x16 acc[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
-
-  // The chunk loop, instantiated per transform role (a wave-uniform choice made ONCE): inside, a chunk is one basic
-  // block -- MFMAs, operand reads and the next chunk's transform -- which the group pattern can interleave.  (With the
-  // role as a branch inside the chunk the transform sat in blocks of its own BEHIND the MFMAs: 2 QC x 4 MFMAs, then
-  // ~300 vector instructions with the matrix pipe idle -- one wave per SIMD, nobody else fills it: layer 3 at c3 464 us
-  // against 219 of matrix time.)
-  auto run = [&](auto role_c) {
-    constexpr int ROLE = decltype(role_c)::value;
-    if (nchunks <= 0) return;
-    issue_loads(0, role_c);
-    transform(0, role_c);  // (the compiler waits for the loads at their first use)
-    issue_loads(1, role_c);
-    __syncthreads();
-    auto chunk = [&](int ch, auto stc) {
-      constexpr int st = decltype(stc)::value;
-      // MFMAs of chunk ch out of stage st: QC / 2 k-steps x 4 operand groups x 4 positions
-      f32x4 ca, cb, na, nb;
-      auto load_grp = [&](int g, f32x4& x, f32x4& y) {  // group g = 4 ks + i: positions 4 i .. 4 i + 3 of k-step ks
-        x = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[g & 3] + st * C::STAGE + (g >> 2) * 2 * CIB * 64));
-        y = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[g & 3] + st * C::STAGE + (g >> 2) * 2 * COB * 64));
-      };
-      load_grp(0, ca, cb);
-      na = ca; nb = cb;
-      __builtin_amdgcn_sched_barrier(0);
-      // first half of the chunk's MFMAs || the transform of the next chunk's raw rows (loaded in the middle of the
-      // PREVIOUS chunk, so they have landed) -> the other stage
-#pragma unroll
-      for (int g = 0; g < QC; ++g) {
-        load_grp(g + 1, na, nb);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (!UPS || ((g & 3) != 2 && m != 2))
-            acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
-        ca = na; cb = nb;
-      }
-      transform(st ^ 1, role_c);
-      constexpr int NM = UPS ? QC / 4 * 9 : 4 * QC;                       // MFMAs of a half
-      constexpr int NVI = ROLE == 0 ? 4 * 64 : (ROLE == 1 ? 4 * 28 : 0);  // vector instructions of the transform (about)
-      constexpr int VPM = (NVI + NM - 1) / NM;
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        if (i % (UPS ? 3 : 4) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next group's operand reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-        if (ROLE != 2 && (UPS || i % 2 == 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores: 16 (12) per chunk
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // the raw rows of chunk ch + 2: issued HERE, half a chunk of MFMAs ahead of the barrier behind which their
-      // transform starts
-      issue_loads(ch + 2, role_c);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = QC; g < 2 * QC; ++g) {
-        if (g + 1 < 2 * QC) load_grp(g + 1, na, nb);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (!UPS || ((g & 3) != 2 && m != 2))
-            acc[4 * (g & 3) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 3) + m], 0, 0, 0);
-        ca = na; cb = nb;
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (!UPS) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        else if ((g & 3) != 2) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-    };
-    // chunks in pairs, unconditionally (a conditional second chunk is a merge of two versions of all 256 accumulators,
-    // which the compiler implements by copying them): an odd count runs one dummy chunk of zeros
-    for (int ch = 0; ch < nchunks; ch += 2) {
-      chunk(ch, std::integral_constant<int, 0>{});
-      chunk(ch + 1, std::integral_constant<int, 1>{});
-    }
-  };
-  if (is_v) run(std::integral_constant<int, 0>{});
-  else if (is_z) run(std::integral_constant<int, 1>{});
-  else run(std::integral_constant<int, 2>{});
-
-  // ---- raw slab of this (tile, split, K group): [16][Cin][Cout]
-  const size_t slab = ((size_t)blockIdx.z * WK + kg) * 16 * (size_t)a.Cin * a.Cout;
-#pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    if (UPS && ((p >> 2) == 2 || (p & 3) == 2)) continue;  // (vanishing positions: the reduce pass skips them too)
-    float* dst = a.slabs + slab + ((size_t)p * a.Cin + a0 + wa * 32) * a.Cout + b0 + wb * 32 + c;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(size_t)crow16(r, hh) * a.Cout] = acc[p][r];
-  }
-}
-
-// ===================================================================================================================
-// The two-waves-per-SIMD form (round 5): eight waves per workgroup, the 16 (9) transform positions of a 32 x 32 channel
-// sub-tile split over a wave PAIR (waves w and w + 4 share a SIMD): rows xi in {0, 1} and {2, 3} of dU, 8 accumulator tiles
-// = 128 registers each, so the pair fits the register file side by side and one wave's operand waits and transform
-// arithmetic fall under the other's MFMAs.  The positions are independent in the weight gradient: no exchange, each wave
-// stores its own eight slab planes.  Transform items are (quad, TWO channels) -- 16 (4) buffer_load_dwordx2 per thread
+// Eight waves per workgroup, two per SIMD (round 5; rounds 3-4 ran four waves with all 16 positions = 256 accumulator
+// registers each): the 16 (9) transform positions of a 32 x 32 channel sub-tile are split over a wave PAIR (waves w and
+// w + 4 share a SIMD): rows xi in {0, 1} and {2, 3} of dU, 8 accumulator tiles = 128 registers each, so the pair fits the
+// register file side by side and one wave's operand waits and transform arithmetic fall under the other's MFMAs.  The
+// positions are independent in the weight gradient: no exchange, each wave stores its own eight slab planes.  Transform items are (quad, TWO channels) -- 16 (4) buffer_load_dwordx2 per thread
 // and chunk, 32 (8) registers in flight -- so that all eight waves carry a role (64 x 64 tile: waves 0-3 the input
 // transform, waves 4-7 the gradient transform: one of each per SIMD).
 template <int WA, int WB>
@@ -407,63 +146,70 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad8_kernel(WinoWgradArgs a) 
       *reinterpret_cast<lds_f32x4*>((uintptr_t)(wst + st * C::STAGE + k * 64 + (uint32_t)((x ^ wsw) << 4))) = o;
     }
   };
-  auto transform = [&](int st, auto role_c) {
+  // The transform in two phases, so that the raw registers are free EARLY: phase 1 consumes every raw value (the first
+  // matrix product: B^T d, T s, or the row combinations of the gradient quad) into tt, phase 2 forms the second product
+  // and stores the entries.  Between them the loads of the chunk after next are issued: a quarter into the chunk, where
+  // they have three quarters of a chunk and the barrier to land (issued behind the whole transform they had a quarter,
+  // and every chunk opened with the matrix pipe waiting for memory).
+  float tt[2][16];
+  auto xform1 = [&](auto role_c) {
     constexpr int ROLE = decltype(role_c)::value;
-    if constexpr (ROLE == 0 && UPS) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float sp[9], t[9], v[16];
+    for (int k = 0; k < 2; ++k) {
+      if constexpr (ROLE == 0 && UPS) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sp[e] = raw[e][k];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          t[0 * 3 + q] = sp[0 * 3 + q] - sp[1 * 3 + q];
-          t[1 * 3 + q] = sp[1 * 3 + q] + sp[1 * 3 + q];
-          t[2 * 3 + q] = sp[1 * 3 + q] - sp[2 * 3 + q];
+        for (int q = 0; q < 3; ++q) {  // T s (columns q), T = [1 -1 0; 0 2 0; 0 1 -1]
+          tt[k][0 * 3 + q] = raw[0 * 3 + q][k] - raw[1 * 3 + q][k];
+          tt[k][1 * 3 + q] = raw[1 * 3 + q][k] + raw[1 * 3 + q][k];
+          tt[k][2 * 3 + q] = raw[1 * 3 + q][k] - raw[2 * 3 + q][k];
         }
+      } else if constexpr (ROLE == 0) {
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
+        for (int q = 0; q < 4; ++q) {  // B^T d
+          tt[k][0 * 4 + q] = raw[0 * 4 + q][k] - raw[2 * 4 + q][k];
+          tt[k][1 * 4 + q] = raw[1 * 4 + q][k] + raw[2 * 4 + q][k];
+          tt[k][2 * 4 + q] = raw[2 * 4 + q][k] - raw[1 * 4 + q][k];
+          tt[k][3 * 4 + q] = raw[1 * 4 + q][k] - raw[3 * 4 + q][k];
+        }
+      } else if constexpr (ROLE == 1) {
+        // A dY with A = [1 0; 1 1; 1 -1; 0 -1]: dY = [a b; c d] (rows 4t .. 4t+3 of the quad in Morton order)
+        const float qa = raw[0][k], qb = raw[1][k], qc = raw[2][k], qd = raw[3][k];
+        tt[k][0] = qa; tt[k][1] = qb; tt[k][2] = qa + qc; tt[k][3] = qb + qd;
+        tt[k][4] = qa - qc; tt[k][5] = qb - qd; tt[k][6] = -qc; tt[k][7] = -qd;
+      }
+    }
+  };
+  auto xform2 = [&](int st, auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float v[16];
+      if constexpr (ROLE == 0 && UPS) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {  // (.) T^T: row x -> transform row (0, 1, 3)[x]
           const int xr = x == 2 ? 3 : x;
-          v[xr * 4 + 0] = t[x * 3 + 0] - t[x * 3 + 1];
-          v[xr * 4 + 1] = t[x * 3 + 1] + t[x * 3 + 1];
+          v[xr * 4 + 0] = tt[k][x * 3 + 0] - tt[k][x * 3 + 1];
+          v[xr * 4 + 1] = tt[k][x * 3 + 1] + tt[k][x * 3 + 1];
           v[xr * 4 + 2] = 0.f;
-          v[xr * 4 + 3] = t[x * 3 + 1] - t[x * 3 + 2];
+          v[xr * 4 + 3] = tt[k][x * 3 + 1] - tt[k][x * 3 + 2];
         }
         v[8] = v[9] = v[10] = v[11] = 0.f;
         store_entry(st, k, v);
-      }
-    } else if constexpr (ROLE == 0) {
+      } else if constexpr (ROLE == 0) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        float d[16], t[16], v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) d[e] = raw[e][k];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          t[0 * 4 + q] = d[0 * 4 + q] - d[2 * 4 + q];
-          t[1 * 4 + q] = d[1 * 4 + q] + d[2 * 4 + q];
-          t[2 * 4 + q] = d[2 * 4 + q] - d[1 * 4 + q];
-          t[3 * 4 + q] = d[1 * 4 + q] - d[3 * 4 + q];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          v[x * 4 + 0] = t[x * 4 + 0] - t[x * 4 + 2];
-          v[x * 4 + 1] = t[x * 4 + 1] + t[x * 4 + 2];
-          v[x * 4 + 2] = t[x * 4 + 2] - t[x * 4 + 1];
-          v[x * 4 + 3] = t[x * 4 + 1] - t[x * 4 + 3];
+        for (int x = 0; x < 4; ++x) {  // (.) B
+          v[x * 4 + 0] = tt[k][x * 4 + 0] - tt[k][x * 4 + 2];
+          v[x * 4 + 1] = tt[k][x * 4 + 1] + tt[k][x * 4 + 2];
+          v[x * 4 + 2] = tt[k][x * 4 + 2] - tt[k][x * 4 + 1];
+          v[x * 4 + 3] = tt[k][x * 4 + 1] - tt[k][x * 4 + 3];
         }
         store_entry(st, k, v);
-      }
-    } else if constexpr (ROLE == 1) {
+      } else if constexpr (ROLE == 1) {  // (.) A^T
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float qa = raw[0][k], qb = raw[1][k], qc = raw[2][k], qd = raw[3][k];
-        const float p0 = qa, q0 = qb, p1 = qa + qc, q1 = qb + qd, p2 = qa - qc, q2 = qb - qd, p3 = -qc, q3 = -qd;
-        float v[16];
-        v[0] = p0; v[1] = p0 + q0; v[2] = p0 - q0; v[3] = -q0;
-        v[4] = p1; v[5] = p1 + q1; v[6] = p1 - q1; v[7] = -q1;
-        v[8] = p2; v[9] = p2 + q2; v[10] = p2 - q2; v[11] = -q2;
-        v[12] = p3; v[13] = p3 + q3; v[14] = p3 - q3; v[15] = -q3;
+        for (int x = 0; x < 4; ++x) {
+          const float pp = tt[k][2 * x], qq = tt[k][2 * x + 1];
+          v[4 * x] = pp; v[4 * x + 1] = pp + qq; v[4 * x + 2] = pp - qq; v[4 * x + 3] = -qq;
+        }
         store_entry(st, k, v);
       }
     }
@@ -479,8 +225,9 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad8_kernel(WinoWgradArgs a) 
     constexpr int PSC = decltype(psc)::value;  // -1: either set (plain layers: the sets differ in addresses only)
     if (nchunks <= 0) return;
     issue_loads(0, role_c);
-    transform(0, role_c);
+    xform1(role_c);
     issue_loads(1, role_c);
+    xform2(0, role_c);
     __syncthreads();
     // groups of a chunk: g = 2 ks + i (k-step ks, transform row 2 ps + i); behind the upsample row 2 is identically zero:
     // set 1 runs the odd groups only, and position nu = 2 is skipped everywhere
@@ -497,32 +244,53 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad8_kernel(WinoWgradArgs a) 
       load_grp(G0, ca, cb);
       na = ca; nb = cb;
       __builtin_amdgcn_sched_barrier(0);
-      // first half of the chunk's MFMAs || the transform of the next chunk's raw rows -> the other stage
+      // first half of the chunk's MFMAs in two quarters: quarter 1 || phase 1 of the transform of the NEXT chunk's raw
+      // rows (they were loaded a quarter into the previous chunk), then the loads of the chunk after next, then quarter
+      // 2 || phase 2 and its stores into the other stage
+      constexpr int NQ1 = NH / 2;
+      constexpr int NV1 = ROLE == 0 ? (UPS ? 18 : 32) : (ROLE == 1 ? 12 : 0);   // vector instructions of phase 1 (about)
+      constexpr int NV2 = ROLE == 0 ? (UPS ? 18 : 32) : (ROLE == 1 ? 28 : 0);   // ... of phase 2
+      constexpr int NST = ROLE == 2 ? 0 : (UPS && ROLE == 0 ? 6 : 8);           // its LDS stores
+      auto mfma_groups = [&](int e0, int e1) {
 #pragma unroll
-      for (int e = 0; e < NH; ++e) {
-        const int g = G0 + e * GSTEP;
-        load_grp(g + GSTEP, na, nb);
+        for (int e = e0; e < e1; ++e) {
+          const int g = G0 + e * GSTEP;
+          if (e + 1 < NGRP) load_grp(g + GSTEP, na, nb);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (!UPS || m != 2)
-            acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
-        ca = na; cb = nb;
-      }
-      transform(st ^ 1, role_c);
-      constexpr int NM = NH * MPG;                                         // MFMAs of the first half
-      constexpr int NVI = ROLE == 0 ? 2 * 64 : (ROLE == 1 ? 2 * 28 : 0);  // vector instructions of the transform (about)
-      constexpr int NST = ROLE == 2 ? 0 : (UPS && ROLE == 0 ? 6 : 8);     // its LDS stores
-      constexpr int VPM = (NVI + NM - 1) / NM;
+          for (int m = 0; m < 4; ++m)
+            if (!UPS || m != 2)
+              acc[4 * (g & 1) + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], cb[m], acc[4 * (g & 1) + m], 0, 0, 0);
+          ca = na; cb = nb;
+        }
+      };
+      mfma_groups(0, NQ1);
+      xform1(role_c);
+      {
+        constexpr int NM = NQ1 * MPG, VPM = NM > 0 ? (NV1 + NM - 1) / NM : 0;
 #pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        if (i % MPG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next group's operand reads
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-        if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores, spread evenly
-        if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        for (int i = 0; i < NM; ++i) {
+          if (i % MPG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next group's operand reads
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       issue_loads(ch + 2, role_c);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_groups(NQ1, NH);
+      xform2(st ^ 1, role_c);
+      {
+        constexpr int NM = (NH - NQ1) * MPG, VPM = (NV2 + NM - 1) / NM;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          if (i % MPG == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (VPM > 0) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+          if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // transform stores, spread evenly
+          if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (NST > 0 && ((i + 1) * NST) / NM - (i * NST) / NM >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = NH; e < NGRP; ++e) {
@@ -677,17 +445,6 @@ static int launch_wino_wgrad8_cfg(const WinoWgradArgs& a, double flops, dim3 gri
   return DVG_OK;
 }
 
-template <int WA, int WB, bool UPS>
-static int launch_wino_wgrad_cfg(const WinoWgradArgs& a, double flops, dim3 grid, hipStream_t s) {
-  if (opt(OPT_WINO_WAVES) >= 8) return launch_wino_wgrad8_cfg<WA, WB, UPS>(a, flops, grid, s);
-  using C = WinoWgradCfg<WA, WB>;
-  auto kern = conv_wino_wgrad_kernel<WA, WB, UPS>;
-  DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-  const unsigned wgs = grid.x * grid.y * grid.z;  // (one workgroup per CU)
-  DVG_LAUNCH_WORK_SHARE(K_WGRAD_WINO, flops, (float)(wgs > 256u ? 256u : wgs) / 256.0f, kern, grid, dim3(256), C::LDS_BYTES, s, a);
-  return DVG_OK;
-}
-
 // ups = 1: `in` is the SOURCE map of an Upsample(x2) + 3x3 layer ([M / 4][Cin]); M, L describe the layer's OUTPUT grid
 int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
                            const WeightMap& map, float* grad_w, hipStream_t s, int ups, int cus) {
@@ -704,11 +461,11 @@ int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin,
   const int cfg = (Cin % 64 == 0 ? 2 : 0) + (Cout % 64 == 0 ? 1 : 0);  // 3: 64x64, 1: 32x64, 2: 64x32
   int rc;
   if (ups) {
-    rc = cfg == 3 ? launch_wino_wgrad_cfg<2, 2, true>(a, flops, grid, s)
-       : cfg == 1 ? launch_wino_wgrad_cfg<1, 2, true>(a, flops, grid, s) : launch_wino_wgrad_cfg<2, 1, true>(a, flops, grid, s);
+    rc = cfg == 3 ? launch_wino_wgrad8_cfg<2, 2, true>(a, flops, grid, s)
+       : cfg == 1 ? launch_wino_wgrad8_cfg<1, 2, true>(a, flops, grid, s) : launch_wino_wgrad8_cfg<2, 1, true>(a, flops, grid, s);
   } else {
-    rc = cfg == 3 ? launch_wino_wgrad_cfg<2, 2, false>(a, flops, grid, s)
-       : cfg == 1 ? launch_wino_wgrad_cfg<1, 2, false>(a, flops, grid, s) : launch_wino_wgrad_cfg<2, 1, false>(a, flops, grid, s);
+    rc = cfg == 3 ? launch_wino_wgrad8_cfg<2, 2, false>(a, flops, grid, s)
+       : cfg == 1 ? launch_wino_wgrad8_cfg<1, 2, false>(a, flops, grid, s) : launch_wino_wgrad8_cfg<2, 1, false>(a, flops, grid, s);
   }
   DVG_TRY(rc);
   const int64_t pairs = (int64_t)Cin * Cout;

@@ -83,18 +83,16 @@ DecPlan dec_plan(int64_t N, int n) {
     p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 &&
                   conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO_WGRAD) > 0 || N >= 8192);
     {
-      // option dec_wino: -1 (default) the FORWARD launches from 8192 decoder rows up; 1 forward and data gradient
-      // whenever the shape allows, 2 / 3 forward / data gradient only, 0 never.  (The data gradient in this form measured
-      // neutral to slower inside the c3 step: it is a whole-CU kernel beside the whole-CU Winograd weight gradients,
-      // where the folded direct kernel shares CUs -- 9.74 ms with the forward alone, 9.80 with both at any split of the
-      // CUs between them.)
+      // option dec_wino: -1 (default) forward AND data gradient from 8192 decoder rows up; 1 both whenever the shape
+      // allows, 2 / 3 forward / data gradient only, 0 never.  (Round 4's one-wave-per-SIMD data gradient measured neutral
+      // inside the c3 step and stayed off; the two-waves-per-SIMD kernel of round 5 pays: 8.48 -> 8.32 ms, same box.)
       const int64_t o = opt(OPT_DEC_WINO);
       // (strict float32 arithmetic: also the faster form in the f32x3 mode -- 4/9 of the multiplications at f32 rate
       // against 6/16 of the matrix time plus the split arithmetic -- and at least as exact; the bf16-input mode keeps
       // the direct kernel on the bf16 MFMA)
       const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() != 1 && (o > 0 || N >= 8192);
       p.wino_f[l] = on && o != 3 && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
-      p.wino_d[l] = on && (o == 1 || o == 3) && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
+      p.wino_d[l] = on && o != 2 && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
     }
     p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]

@@ -43,12 +43,11 @@ const OptDef kDefs[OPT_COUNT] = {
     {"enc_wino_cus_w", 128, "CUs the Winograd weight-gradient launches are sized for (whole-CU workgroups; the data-gradient chain runs beside them; measured at c3 with enc_wino_cus_d: (128, 128) 9.40 ms, (160, 96) 9.64, (192, 64) 10.09, (192, 128) 9.41, (256, 128) 9.45; a budget of its own for layer 1's launch, the last of the step: neutral)"},
     {"dec_wino_wgrad", -1, "decoder Upsample(x2) + 3x3 layers: weight gradient in the Winograd form (9 of 16 transform positions; conv_wino_wgrad.hip): -1 from 8192 decoder rows up, 0 never, 1 whenever the shape allows"},
     {"dec_wino_cus_w", 256, "CUs those launches are sized for"},
-    {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions; conv_wino.hip): -1 the forward launches from 8192 decoder rows up (default), 0 never, 1 forward and data gradient whenever the shape allows, 2 / 3 forward / data gradient only"},
+    {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions; conv_wino.hip): -1 forward and data-gradient launches from 8192 decoder rows up (default), 0 never, 1 whenever the shape allows, 2 / 3 forward / data gradient only"},
     {"dec_wino_cus", 256, "CUs the decoder's Winograd forward launches are sized for"},
     {"dec_wino_cus_d", 256, "... its data-gradient launches"},
     {"wino_min_blocks", 512, "encoder Winograd launches of a training call (enc_wino = -1): from this many workgroups' worth of tiles up (measured, n = 512 model: 1024 / 512 / 256 -> B = 512: 2.16 / 2.13 / 2.06 ms, B = 1024: 3.03 / 2.82 / 2.82, B = 2048: 4.67 / 4.60 / 4.53; c2: 0.920 / 0.924 / 0.953 -- 512 is the lowest value that costs c2 nothing)"},
     {"wino_dynamic", 1, "Winograd forward / data-gradient launches deal their tile blocks dynamically (an atomic counter per grid row) instead of round-robin: a workgroup that gets its CU late takes fewer blocks (1 default, 0 = the static deal of rounds 3-4)"},
-    {"wino_waves", 8, "Winograd forward / data-gradient kernels: 8 = two waves per SIMD, the transform positions of a sub-tile split over a wave pair (round 5, default), 4 = one wave per SIMD with all 16 positions (rounds 3-4; A/B reference)"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;

@@ -78,13 +78,12 @@ def test_winograd_form_of_the_3x3_layers(N, Cin, Cout, side):
     assert _rel(s[:, 0], y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y64 ** 2).sum((0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("N,Cin,Cout,side,ups", [(64, 32, 64, 16, 0), (256, 64, 128, 8, 0), (512, 128, 512, 4, 0),  # the encoder's layers 1-3
                                                  (37, 64, 64, 8, 0), (5, 32, 64, 4, 0),                             # ragged image counts
                                                  (256, 128, 64, 8, 1), (64, 64, 32, 16, 1), (24, 64, 64, 4, 1)])    # behind the x2 upsample
-def test_winograd_weight_gradient_kernel(N, Cin, Cout, side, ups, waves):
-    """conv_wino_wgrad_kernel / conv_wino_wgrad8_kernel (csrc/conv_wino_wgrad.hip) alone, all six instantiations
-    (<2,2>, <1,2>, <2,1> tiles, plain and behind the Upsample(x2): 9 of 16 positions), both wave counts, against a float64
+def test_winograd_weight_gradient_kernel(N, Cin, Cout, side, ups):
+    """conv_wino_wgrad8_kernel (csrc/conv_wino_wgrad.hip) alone, all six instantiations
+    (<2,2>, <1,2>, <2,1> tiles, plain and behind the Upsample(x2): 9 of 16 positions) against a float64
     weight gradient of the same layer: within 2x the direct kernel's own distance (+ 1e-7: a handful of extra roundings
     in the transforms), i.e. float32 summation noise -- the whole-network tests hold these kernels to 1e-4 .. 5e-3 only."""
     from image_generation_amd import _lib
@@ -104,16 +103,14 @@ def test_winograd_weight_gradient_kernel(N, Cin, Cout, side, ups, waves):
         ref = torch.nn.grad.conv2d_weight(x.double(), shape, gy.double(), padding=1)
         xm, mode = dev.nchw_to_morton(x).cuda(), 0
     gym = dev.nchw_to_morton(gy).cuda()
-    with _lib.option_scope(wino_waves=waves):
-        gw = dev.conv_wino_wgrad(xm, gym, mode, shape, M, Cin, Cout, L, ups=ups)
+    gw = dev.conv_wino_wgrad(xm, gym, mode, shape, M, Cin, Cout, L, ups=ups)
     assert gw is not None
     gd = dev.conv_wgrad(xm, gym, mode, shape, M, Cin, Cout, L, ups=ups)
     rel = lambda a: float((a.cpu().double() - ref).norm() / ref.norm())
     e_w, e_d = rel(gw), rel(gd)
     assert e_w < 2 * e_d + 1e-7 and e_w < 2e-6, (e_w, e_d)
     # twice the same launch: the slab sums are fixed-order, so the bits repeat
-    with _lib.option_scope(wino_waves=waves):
-        gw2 = dev.conv_wino_wgrad(xm, gym, mode, shape, M, Cin, Cout, L, ups=ups)
+    gw2 = dev.conv_wino_wgrad(xm, gym, mode, shape, M, Cin, Cout, L, ups=ups)
     assert torch.equal(gw, gw2)
 
 
