@@ -85,9 +85,9 @@ enum KernelId : int {
 
 // Kernel-form options (options.cpp): set through dvg_set_option, read per call.
 enum Opt : int {
-  OPT_IGEMM_DMA = 0, OPT_IGEMM_POSMAJOR, OPT_IGEMM_THR128, OPT_IGEMM_THR64, OPT_IGEMM_THR32, OPT_IGEMM_NO32, OPT_WGRAD_DMA,
-  OPT_DEC_FOLD, OPT_DEC_D22, OPT_DEC_LC0, OPT_MMD_W128, OPT_MMD_D256, OPT_MMD_BLOCKS, OPT_GIBBS_GENERIC, OPT_GIBBS_WAVES,
-  OPT_GIBBS_WAVES_PER_CHAIN, OPT_SIDE_STREAM, OPT_ENC_WINO, OPT_ENC_WINO_MASK, OPT_ENC_L0_FUSED, OPT_DEC_TAIL_FUSED, OPT_ENC_WINO_CUS, OPT_ENC_WINO_CUS_D, OPT_ENC_WINO_WGRAD, OPT_ENC_WINO_CUS_W, OPT_DEC_WINO_WGRAD, OPT_DEC_WINO_CUS_W, OPT_DEC_WINO, OPT_DEC_WINO_CUS, OPT_DEC_WINO_CUS_D, OPT_WINO_MIN_BLOCKS, OPT_WINO_DYNAMIC, OPT_COUNT
+  OPT_IGEMM_DMA = 0, OPT_IGEMM_POSMAJOR, OPT_IGEMM_THR128, OPT_WGRAD_DMA, OPT_DEC_FOLD, OPT_DEC_D22, OPT_DEC_LC0, OPT_MMD_W128,
+  OPT_MMD_D256, OPT_GIBBS_GENERIC, OPT_SIDE_STREAM, OPT_ENC_WINO, OPT_DEC_WINO, OPT_ENC_L0_FUSED, OPT_DEC_TAIL_FUSED,
+  OPT_WINO_DYNAMIC, OPT_COUNT
 };
 int64_t opt(Opt id);
 

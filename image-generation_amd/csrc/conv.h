@@ -166,6 +166,15 @@ struct ConvArgs {
   // grid: 9 of 16 transform positions), 2 = data gradient (`out` = the source map's gradient, one row per output quad)
   int wino_um = 0;
 };
+// CU budgets of the Winograd launches of a TRAINING call (whole-CU persistent grids: a launch is sized to the CUs its
+// neighbours leave).  Measured at c3, both wave forms: the encoder's data gradient and weight gradient side
+// by side on half the chip each -- (128, 128) 8.41 ms, (144, 112) 8.65, (112, 144) 8.64, (160, 96) 8.7-8.8, (96, 160)
+// 8.86 (round 5) -- the decoder's launches at the whole chip (its weight gradient at 128 / 192: 8.49 / 8.46 against 8.41).
+constexpr int WINO_CUS_ENC_DGRAD = 128, WINO_CUS_ENC_WGRAD = 128, WINO_CUS_DEC = 256;
+// encoder Winograd launches of a training call: from this many workgroups' worth of tile blocks up (measured, n = 512
+// model: 1024 / 512 / 256 -> B = 512: 2.16 / 2.13 / 2.06 ms, B = 1024: 3.03 / 2.82 / 2.82, B = 2048: 4.67 / 4.60 / 4.53;
+// c2: 0.920 / 0.924 / 0.953 -- 512 is the lowest value that costs c2 nothing)
+constexpr int WINO_MIN_BLOCKS = 512;
 // process-wide precision of the forward / data-gradient GEMMs (set through the ABI only: dvg_set_conv_precision; the library reads no environment variable)
 bool conv_precision_bf16();
 int conv_precision_mode();  // 0 f32, 1 bf16 inputs, 2 f32 as three bf16 pieces

@@ -637,20 +637,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Tile configuration: 0 = 128x64, 4 = 128x128 (large launches), 1 = 64x64, 2 = 128x32 (Cout = 32), 3 = 32x64 (two waves) for launches whose 64-row
 // tiling would leave most CUs without a block (small-M layers: a finer tiling fills the chip without the split-K slabs
-// and their reduce pass).  option igemm_no32 = 1 disables 3 (A/B runs).
+// and their reduce pass).
 static int igemm_cfg(int64_t M, int Cout) {
-  const bool no32 = opt(OPT_IGEMM_NO32) != 0;
   if (Cout % 64) return 2;
   // 4 = 128x128 (wave tile 64x64: half the LDS operand reads and half the L2 -> LDS bytes per FLOP of 128x64) once
   // the launch still has >= 512 blocks of that size (two per CU are resident: 79 KB of LDS, 231 VGPRs).  c3: the
   // launches that qualify run at 82 instead of 59 TFLOP/s in-situ, step 22.9 -> 22.55 ms; 256 / 128 measured no
-  // better, c2 has no such launch.  (option igemm_thr128 overrides: tuning runs.)
+  // better, c2 has no such launch.  (option igemm_thr128 overrides the 512: the tests send small fixtures through the tile)
   const int64_t thr128 = opt(OPT_IGEMM_THR128);
   if (Cout % 128 == 0 && ceil_div(M, 128) * (Cout / 128) >= thr128) return 4;
-  const int64_t thr64 = opt(OPT_IGEMM_THR64);
-  if (ceil_div(M, 128) * (Cout / 64) >= thr64) return 0;
-  const int64_t thr32 = opt(OPT_IGEMM_THR32);
-  if (ceil_div(M, 64) * (Cout / 64) >= thr32 || no32) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
+  if (ceil_div(M, 128) * (Cout / 64) >= 512) return 0;
+  if (ceil_div(M, 64) * (Cout / 64) >= 96) return 1;  // (>= 192: unsplit; 96..191: split-K beats finer tiles at c2)
   return 3;
 }
 template <int BM, int BN, int WM, int WN, int WK, int PM = 0>

@@ -586,17 +586,16 @@ static bool wino_shape_ok(int64_t M, int Cin, int Cout, int L) {
 
 bool conv_wino_shape(int64_t M, int Cin, int Cout, int L) { return wino_shape_ok(M, Cin, Cout, L); }
 
-// kind: 0 forward launch of a training call, 1 data-gradient launch, 2 forward launch of an evaluation call.
-// option enc_wino: -1 (default) every launch of 256 workgroups' worth of tile blocks or more (small launches keep the
-// direct form's finer tiles), 0 never, 1 every launch the shape allows, 2 / 3 like 1 for the forward / the data-gradient
-// launches only (A/B measurements).  Rounds 3 ran the form by default in evaluation-mode forward calls only: inside a
-// training step its whole-CU workgroups (512 registers per lane, 145 KB of LDS) measured neutral to slower.  The cause
-// was the GRID, not the form: 256 persistent workgroups beside the sampler's 64 resident workgroups leave 64 of them
-// waiting for a CU for a whole round.  Sized to the CUs the launch can actually get (ConvArgs.wino_cus; options
-// enc_wino_cus / enc_wino_cus_d) the form pays inside the step too: c3 10.54 -> 10.16 ms (round 4).
+// kind: 0 forward launch of a training call, 1 data-gradient launch, 2 forward launch of an evaluation call, 3 weight
+// gradient.  option enc_wino: -1 (default) by size -- evaluation-mode forward launches of 256 workgroups' worth of tile
+// blocks or more, training launches of WINO_MIN_BLOCKS or more (small launches keep the direct form's finer tiles) -- 0
+// never, 1 every launch the shape allows.  (Round 3 ran the form in evaluation calls only: inside a training step its
+// whole-CU workgroups measured neutral to slower.  The cause was the GRID, not the form: 256 persistent workgroups
+// beside the sampler's 64 resident workgroups leave 64 of them waiting for a CU for a whole round; sized to the CUs the
+// launch can actually get -- ConvArgs.wino_cus, the WINO_CUS_* constants of conv.h -- the form pays inside the step.)
 bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   const int64_t o = opt(OPT_ENC_WINO);
-  if (o == 0 || (o == 2 && kind == 1) || (o == 3 && kind != 1) || !wino_shape_ok(M, Cin, Cout, L)) return false;
+  if (o == 0 || !wino_shape_ok(M, Cin, Cout, L)) return false;
   // (the bf16-input mode means bf16-rounded operands for every forward / data-gradient launch: the float32 Winograd form
   // would silently compute those layers in float32, forced or not; weight gradients -- kind 3 -- are float32 in every mode)
   if (kind != 3 && conv_precision_mode() == 1) return false;
@@ -609,8 +608,8 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   // (512) up -- all of c3's launches, the larger ones of mid-size batches; a c2 step with its one 256-block launch
   // switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the persistent grid 128 CUs there)
   // (kind 3: a weight gradient -- float32 in every operand mode; forward / data gradient: not in the bf16-input mode)
-  if (kind == 3) return blocks >= opt(OPT_WINO_MIN_BLOCKS);
-  return kind == 2 ? blocks >= 256 : blocks >= opt(OPT_WINO_MIN_BLOCKS);
+  if (kind == 3) return blocks >= WINO_MIN_BLOCKS;
+  return kind == 2 ? blocks >= 256 : blocks >= WINO_MIN_BLOCKS;
 }
 
 int conv_wino_stats_blocks(int64_t M, int Cout) { return (int)(M / 4 / wino_tblk(wino_cfg(Cout))); }

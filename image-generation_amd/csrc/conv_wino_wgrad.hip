@@ -420,12 +420,12 @@ static WinoWgradGeom wino_wgrad_geom(int64_t M, int Cin, int Cout, int L, int cu
   return g;
 }
 
-// kind of launch the policy is asked about: the weight gradient of a training call (option enc_wino_wgrad: -1 = with the
-// other training launches, i.e. from option wino_min_blocks workgroups' worth of tile blocks up -- in every operand mode:
-// weight gradients are float32 in all of them; 0 never; 1 whenever the shape allows)
+// the weight gradient of a training call takes the Winograd form with the layer's other training launches (option enc_wino:
+// -1 from WINO_MIN_BLOCKS workgroups' worth of tile blocks up -- in every operand mode: weight gradients are float32 in
+// all of them; 0 never; 1 whenever the shape allows)
 bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
-  const int64_t o = opt(OPT_ENC_WINO_WGRAD);
-  if (o == 0 || opt(OPT_ENC_WINO) == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
+  const int64_t o = opt(OPT_ENC_WINO);
+  if (o == 0 || !wino_wgrad_shape_ok(M, Cin, Cout, L)) return false;
   if (o >= 1) return true;
   return conv_wino_ok(M, Cin, Cout, L, 3);
 }
@@ -450,7 +450,7 @@ int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin,
                            const WeightMap& map, float* grad_w, hipStream_t s, int ups, int cus) {
   DVG_REQUIRE(wino_wgrad_shape_ok(M, Cin, Cout, L), "conv_wino_wgrad: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)",
               (long long)M, Cin, Cout, L);
-  if (cus <= 0) cus = (int)opt(OPT_ENC_WINO_CUS_W);
+  if (cus <= 0) cus = WINO_CUS_ENC_WGRAD;
   if (cus < 1) cus = 1;
   if (cus > 256) cus = 256;
   const WinoWgradGeom g = wino_wgrad_geom(M, Cin, Cout, L, cus);

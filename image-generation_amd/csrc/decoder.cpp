@@ -80,19 +80,19 @@ DecPlan dec_plan(int64_t N, int n) {
     const int C = ch[l + 1];
     p.fold[l] = (l == 1 || l == 2) && fold_enabled() && conv_fold_ok(p.M[l] / 4);
     // (weight gradients are float32 in every operand mode, so this form serves all three)
-    p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO_WGRAD) != 0 &&
-                  conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO_WGRAD) > 0 || N >= 8192);
+    p.wino_w[l] = (l == 1 || l == 2) && opt(OPT_DEC_WINO) != 0 &&
+                  conv_wino_wgrad_shape(p.M[l], ch[l], C, p.L[l]) && (opt(OPT_DEC_WINO) > 0 || N >= 8192);
     {
-      // option dec_wino: -1 (default) forward AND data gradient from 8192 decoder rows up; 1 both whenever the shape
-      // allows, 2 / 3 forward / data gradient only, 0 never.  (Round 4's one-wave-per-SIMD data gradient measured neutral
-      // inside the c3 step and stayed off; the two-waves-per-SIMD kernel of round 5 pays: 8.48 -> 8.32 ms, same box.)
+      // option dec_wino: -1 (default) forward, data gradient and weight gradient from 8192 decoder rows up; 1 whenever
+      // the shape allows, 0 never.  (Round 4's one-wave-per-SIMD data gradient measured neutral inside the c3 step and
+      // stayed off; the two-waves-per-SIMD kernel of round 5 pays: 8.48 -> 8.32 ms, same box.)
       const int64_t o = opt(OPT_DEC_WINO);
       // (strict float32 arithmetic: also the faster form in the f32x3 mode -- 4/9 of the multiplications at f32 rate
       // against 6/16 of the matrix time plus the split arithmetic -- and at least as exact; the bf16-input mode keeps
       // the direct kernel on the bf16 MFMA)
       const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() != 1 && (o > 0 || N >= 8192);
-      p.wino_f[l] = on && o != 3 && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
-      p.wino_d[l] = on && o != 2 && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
+      p.wino_f[l] = on && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
+      p.wino_d[l] = on && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
     }
     p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]
@@ -329,7 +329,7 @@ extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const fl
       }
       a.splitk_ws = W + pl.splitk;
       if (pl.wino_f[l]) {  // Winograd on the upsampled map: 9 of 16 transform positions (conv_wino.hip, UM = 1)
-        a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.fold = 0; a.wino_um = 1; a.wino_cus = (int)opt(OPT_DEC_WINO_CUS);
+        a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.fold = 0; a.wino_um = 1; a.wino_cus = WINO_CUS_DEC;
         DVG_TRY(launch_conv_wino(a, s));
       } else {
         DVG_TRY(launch_conv_igemm(a, s));
@@ -488,7 +488,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     if (d22) { a.M = N; a.Cin = 4 * C; a.Cout = 4 * Cin; a.L = 0; a.ntaps = 1; a.poolsum = 0; }
     a.splitk_ws = W + pl.splitk;
     if (pl.wino_d[l]) {  // fine-grid Winograd data gradient with the 2x2 sum folded into its output transform (UM = 2)
-      a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.poolsum = 0; a.fold = 0; a.wino_um = 2; a.wino_cus = (int)opt(OPT_DEC_WINO_CUS_D);
+      a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.poolsum = 0; a.fold = 0; a.wino_um = 2; a.wino_cus = WINO_CUS_DEC;
       DVG_TRY(launch_conv_wino(a, s));
     } else {
       DVG_TRY(launch_conv_igemm(a, s));
@@ -505,7 +505,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       DVG_TRY(launch_wgrad_d22_reduce(W + pl.slabs, pl.ksplit[l], Cin, C, g->conv_w[l], s2));
     } else if (pl.wino_w[l]) {
       DVG_TRY(launch_conv_wino_wgrad(xin, dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONVT_FWD, Cin, C, 9},
-                                     g->conv_w[l], s2, 1, (int)opt(OPT_DEC_WINO_CUS_W)));
+                                     g->conv_w[l], s2, 1, WINO_CUS_DEC));
     } else if (pl.fold[l]) {
       wa.M = pl.M[l] / 4; wa.L = pl.L[l] - 1; wa.ntaps = 16; wa.ups = 0; wa.fold = 1;
       DVG_TRY(launch_conv_wgrad(wa, s2));

@@ -50,10 +50,6 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
     if (C > cmax) cmax = C;
     p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l], training ? 0 : 2);
     p.wino_d[l] = l > 0 && training && conv_wino_ok(p.M[l], C, ch[l], p.L[l], 1);
-    if (const int64_t mask = opt(OPT_ENC_WINO_MASK); mask != 0 && l > 0) {
-      p.wino_f[l] = p.wino_f[l] && ((mask >> (l - 1)) & 1);
-      p.wino_d[l] = p.wino_d[l] && ((mask >> (2 + l)) & 1);
-    }
     p.wino_w[l] = l > 0 && training && conv_wino_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
     p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
@@ -180,10 +176,10 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a.stats = training ? W + pl.stats[l] : nullptr;
       a.M = pl.M[l]; a.Cin = Cin; a.Cout = C; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
       a.splitk_ws = W + pl.splitk;
-      // (a training call's forward runs beside the step's sampler draw, which holds its CUs: with the static deal of tile
-      // blocks the grid is sized to the rest; with the dynamic deal -- option wino_dynamic, the default -- it is sized to
-      // the chip and the workgroups that get their CU late, when the draw ends, take what is left)
-      a.wino_cus = (training && opt(OPT_WINO_DYNAMIC) == 0) ? (int)opt(OPT_ENC_WINO_CUS) : 0;
+      // (a training call's forward runs beside the step's sampler draw, which holds its CUs: the tile blocks are dealt
+      // dynamically, so the grid is sized to the chip and the workgroups that get their CU late, when the draw ends,
+      // take what is left; under option wino_dynamic = 0 -- the static deal, A/B -- a quarter of the chip is left out)
+      a.wino_cus = (training && opt(OPT_WINO_DYNAMIC) == 0) ? 192 : 0;
       if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
       else DVG_TRY(launch_conv_igemm(a, s));
     }
@@ -231,16 +227,6 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.dXp = dX;
-      if (opt(OPT_ENC_L0_FUSED) == 2) {  // two passes (A/B reference of the one-pass form)
-        a0.part = partA;
-        DVG_TRY(launch_enc_l0(2, a0, s));
-        DVG_TRY(launch_colsum2(partA, enc_l0_blocks(B), 2 * C, C, g->bn_b[0], C, g->bn_g[0], s));
-        a0.sum_dz = g->bn_b[0]; a0.sum_dzzh = g->bn_g[0]; a0.inv_m = (float)(1.0 / ((double)B * 1024.0));
-        a0.part = W + pl.part320;
-        DVG_TRY(launch_enc_l0(3, a0, s));
-        DVG_TRY(launch_colsum2(W + pl.part320, enc_l0_blocks(B), 320, 288, g->conv_w[0], 32, g->conv_b[0], s));
-        break;
-      }
       // one pass: S, T2, T1 and sum dz zhat per block, their column sums, then every gradient of the stage from the sums
       a0.part = W + pl.part320;
       DVG_TRY(launch_enc_l0(4, a0, s));
@@ -268,7 +254,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
-    a.wino_cus = (int)opt(OPT_ENC_WINO_CUS_D);  // (the layer's weight-gradient chain runs beside it on the side stream)
+    a.wino_cus = WINO_CUS_ENC_DGRAD;  // (the layer's weight-gradient chain runs beside it on the side stream)
     if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
     else DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));

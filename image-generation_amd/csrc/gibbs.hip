@@ -216,14 +216,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 //   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends,
 //     instead of being recomputed every sweep.
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
-//   * (round 3) WPC = 2: TWO waves per chain (LPC = 64): a colour class of up to 128 spins is one pass of 128 lanes
-//     instead of two passes of 64, which halves the dependent slot-steps of a sweep.  With few chains (c3: 256) the draw is
-//     one instruction stream per chain on a quarter of the chip's SIMDs, issue-bound at one wave per SIMD; it runs beside
-//     the encoder forward and the MMD cannot start before it ends.  The two waves of a chain meet at a workgroup barrier
-//     per colour class (every wave of the workgroup runs the same classes).
-template <int LPC, int WAVES, int MAXS = GIBBS_MAXS, int WPC = 1>
+// (A two-waves-per-chain form of rounds 3-4 -- a class of 65..128 spins as one pass of 128 lanes -- was the faster draw
+// alone and lost inside the training step, twice the workgroups beside the encoder: deleted in round 5.)
+template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
-  static_assert(WPC == 1 || (LPC == 64 && WAVES % WPC == 0 && MAXS <= GIBBS_MAXS), "two waves per chain: 64-lane chains only");
   extern __shared__ __align__(16) unsigned char smem[];
   const int n = a.n;
   const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
@@ -232,12 +228,12 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   gibbs_stage<WAVES * 64>(a, L, tid);
 
   constexpr int CPW = 64 / LPC;
-  constexpr int LPCE = LPC * WPC;  // lanes that work on one chain
+  constexpr int LPCE = LPC;  // lanes that work on one chain
   const int wave = tid >> 6, lane = tid & 63;
-  const int sub = lane / LPC, l = WPC == 1 ? lane % LPC : lane + 64 * (wave % WPC);
-  const int chain = WPC == 1 ? (blockIdx.x * WAVES + wave) * CPW + sub : blockIdx.x * (WAVES / WPC) + wave / WPC;
+  const int sub = lane / LPC, l = lane % LPC;
+  const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
   const bool valid = chain < a.n_chains;
-  _Float16* st = L.state + (size_t)(WPC == 1 ? wave * CPW + sub : wave / WPC) * n_pad;
+  _Float16* st = L.state + (size_t)(wave * CPW + sub) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
   // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
@@ -254,13 +250,9 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
       for (int i = l; i < n; i += LPCE) st[i] = (_Float16)(float)src[i];
     }
   }
-  if constexpr (WPC > 1) {
-    __syncthreads();  // (both waves of a chain wrote its start state; invalid chains keep the barriers company below)
-  } else {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (!valid) return;
-  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (!valid) return;
 
   const int passes = a.passes, n_slots = a.n_colours * passes;
   {
@@ -295,14 +287,10 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
           const float f = gibbs_field(hs[k], row[k], L, st, a.n_batches, a.max_batches);
           st[sp[k]] = gibbs_decide(f, a.two_beta, pick(rr[k], tw));
         }
-        // the next class reads what this one wrote (same wave, or the chain's two waves): order LDS traffic.  (Passes of
-        // one class are independent of each other, so a fence between them is harmless.)
-        if constexpr (WPC > 1) {
-          __syncthreads();
-        } else {
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-        }
+        // the next class reads what this one wrote (same wave): order LDS traffic.  (Passes of one class are independent
+        // of each other, so a fence between them is harmless.)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -324,20 +312,6 @@ static size_t gibbs_lds_bytes(int n, int n_batches, int n_colours, int chains_pe
 // dvg_gibbs_launch_info: the dispatch below runs with a probe set and reports its launch geometry instead of launching
 struct GibbsProbe { int workgroups; int threads; size_t lds; };
 static thread_local GibbsProbe* g_gibbs_probe = nullptr;
-
-// two waves per chain (fast kernel only): 4-wave workgroups of two chains
-static int launch_gibbs_wpc2(GibbsArgs a, hipStream_t s, int max_class) {
-  constexpr int WAVES = 4, CPB = 2;
-  a.passes = (max_class + 127) / 128;
-  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CPB);
-  auto kern = gibbs_fast_kernel<64, WAVES, GIBBS_MAXS, 2>;
-  if (lds > 64 * 1024)
-    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)ceil_div(a.n_chains, CPB);
-  if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
-  DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
-  return DVG_OK;
-}
 
 template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
 static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
@@ -412,24 +386,18 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
   const bool force_generic = opt(OPT_GIBBS_GENERIC) != 0;
   const bool fast = !force_generic;
-  // Waves per workgroup (option gibbs_waves = 1, 2, 4 or 8 overrides for tuning runs).  Measured on the c2 step with the
-  // draw overlapped with the encoder forward: 4 -> 1.237 ms, 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for
-  // issue slots, fatter workgroups do not pay for the CUs they free.
-  const int waves_env = (int)opt(OPT_GIBBS_WAVES);
+  // Waves per workgroup.  Measured on the c2 step with the draw overlapped with the encoder forward: 4 -> 1.237 ms,
+  // 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for issue slots, fatter workgroups do not pay for the CUs they free.
   // Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one wave per
   // workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger
   // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
   // encoder's convolutions that run beside the draw (c3: 19.15 ms with four waves, 19.4 with two, 19.7 with one).
   const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
-  const int waves = waves_env ? waves_env : (small ? 1 : 4);
+  const int waves = small ? 1 : 4;
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
   // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw)
   if (big) {
-    const int wv = waves_env ? waves_env : 16;
-    if (wv <= 2) return launch_gibbs<64, 2>(a, s, fast, mc);
-    if (wv <= 4) return launch_gibbs<64, 4>(a, s, fast, mc);
-    if (wv <= 8) return launch_gibbs<64, 8>(a, s, fast, mc);
     // (An 8-wave register-resident form of the fast schedule for these graphs -- 24 slots, `gibbs_bigfast` -- existed in
     // rounds 2-3: the faster draw alone, 1.49 against 2.20 ms at the c5 slice, but its ~110 KB LDS footprint on EVERY CU
     // starved the convolutions beside it: c5 step 5.0 against 4.0 ms.  Retired in round 4.)
@@ -438,17 +406,8 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
 #define DVG_GIBBS_DISPATCH(LPC)                                              \
   switch (waves) {                                                           \
     case 1: return launch_gibbs<LPC, 1>(a, s, fast, mc);                     \
-    case 2: return launch_gibbs<LPC, 2>(a, s, fast, mc);                     \
-    case 8: return launch_gibbs<LPC, 8>(a, s, fast, mc);                     \
     default: return launch_gibbs<LPC, 4>(a, s, fast, mc);                    \
   }
-  // classes of 65..128 spins with few chains (c3: 512 spins, 256 chains): two waves per chain, one pass per class --
-  // option gibbs_waves_per_chain = 2.  Alone it is the faster draw (1.79 -> 1.38 ms); inside a training step it runs
-  // beside the encoder forward on twice the workgroups and the STEP does not move (c3 11.74 vs 11.76 ms, the encoder's
-  // GEMMs 433 -> 450-500 us each in-situ), so the default stays one wave per chain.
-  if (fast && !waves_env && mc > 64 && mc <= 128 && g->n_colours <= GIBBS_MAXS && n_chains <= 1024 &&
-      gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 2) <= 80 * 1024 && opt(OPT_GIBBS_WAVES_PER_CHAIN) == 2)
-    return launch_gibbs_wpc2(a, s, mc);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
   if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }
   DVG_GIBBS_DISPATCH(64)

@@ -1860,11 +1860,8 @@ static int mmd_w128_env() {  // (read per call: the tests flip it inside one pro
   return v < 0 ? -1 : (v ? 1 : 0);
 }
 
-// column splits of the pair kernel aim for this many blocks (option mmd_blocks: tuning runs)
-static int64_t mmd_target_blocks() {
-  const int64_t v = opt(OPT_MMD_BLOCKS);
-  return v < 1 ? 1 : v;
-}
+// column splits of the pair kernel aim for this many blocks
+static int64_t mmd_target_blocks() { return 256; }
 
 static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   MmdPlan p;

@@ -303,8 +303,7 @@ int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
   switch (mode) {
     case 0: DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_kernel<0>, g0, dim3(256), 0, s, a); break;
     case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
-    case 2: DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_l0_kernel<2>, g, dim3(256), 0, s, a); break;
-    case 3: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<3>, g, dim3(256), 0, s, a); break;
+    // (MODE 2 / 3 -- the backward in two passes, the A/B reference of round 3 -- are no longer instantiated)
     default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
   }
   return DVG_OK;

@@ -226,7 +226,6 @@ class ModelWrapper:
         grbm = GraphRestrictedBoltzmannMachine(list(range(n)), list(zip(ei.tolist(), ej.tolist())))
         self._grbm = grbm.to(self._device)
         self._make_optimizers()
-        self._size_side_by_side_launches()
 
     # ------------------------------------------------------------------ construction
     def setup(self) -> None:
@@ -266,26 +265,6 @@ class ModelWrapper:
         self._dvae.decoder.dropout_seed = int(self.RANDOM_SEED) + 104729 * rank
         self._make_optimizers()
         self.sync_replicas()
-        self._size_side_by_side_launches()
-
-    def _size_side_by_side_launches(self) -> None:
-        """What runs BESIDE the step's sampler draw is sized for the CUs the draw leaves: the encoder forward's Winograd
-        launches are persistent grids of whole-CU workgroups (library option ``enc_wino_cus``), and a workgroup that finds
-        no free CU starts a whole round late (c3: 200 of them beside the draw's 64 workgroups cost 0.6 ms, 192 gain 0.25).
-        A draw of more than 128 workgroups (c5: one per 16 chains) leaves too little: those launches then take the whole
-        chip and queue behind the draw's first workgroups like any other kernel.  (Read by the library only under option
-        ``wino_dynamic = 0``: with the dynamic deal of tile blocks, the default since round 4, the forward grids are
-        chip-sized and the workgroups that wait for the draw's CUs take what is left when they start.)"""
-        if self._device is None or self._device.type != "cuda" or self.sampler is None or not hasattr(self.sampler, "launch_info"):
-            return
-        from . import _lib
-
-        cus = 256
-        if self.overlap_sampler:
-            wg = int(self.sampler.launch_info(self.local_num_reads())["workgroups"])
-            if wg <= 128:
-                cus = 256 - wg
-        _lib.set_option("enc_wino_cus", cus)
 
     # ------------------------------------------------------------------ data-parallel replica consistency
     def _bn_buffers(self):

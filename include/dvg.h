@@ -21,13 +21,16 @@
  *     (3) one library-owned side stream + event ring per device, created under
  *     a mutex by the first *_workspace_bytes query or backward call on that
  *     device and used for the fork/join inside dvg_encoder_bwd /
- *     dvg_decoder_bwd, (4) the kernel-form options (dvg_set_option: named
- *     integers, relaxed atomics, read per call).  RULE: options are ONE
- *     configuration per process -- two models in one process cannot run under
- *     different options concurrently (the plan-shaping ones are recorded per
- *     workspace by a forward call, and a backward call under another plan fails
- *     with DVG_E_INVALID instead of reading what its forward never wrote; the
- *     grid-sizing ones -- enc_wino_cus and friends -- only move performance),
+ *     dvg_decoder_bwd, (4) sixteen kernel-form switches (dvg_set_option: named
+ *     integers, relaxed atomics, read per call), each selecting between two
+ *     TESTED forms of the same function; the product path is every switch's
+ *     default and no caller in this repository sets one outside tests and A/B
+ *     measurements (round 4 had 32, among them grid-sizing knobs that
+ *     ModelWrapper set per model: those are compile-time constants now).  A
+ *     switch is process-wide: flipping one between a forward call and its
+ *     backward call is caught per workspace (the forward records the plan, a
+ *     backward under another plan fails with DVG_E_INVALID instead of reading
+ *     what its forward never wrote),
  *     (5) host-side bookkeeping keyed by workspace pointer: the mode and plan a
  *     forward call ran under (checked by its backward call) and the mark of a
  *     dvg_decoder_prepare in flight (one event per workspace), (6) per device, a

@@ -63,9 +63,11 @@ def test_kernel_form_options_live_in_the_abi_not_in_the_environment():
     assert _lib.get_option("dec_lc0") == -1 and _lib.get_option("igemm_posmajor") == 1
     with pytest.raises(_lib.DvgError, match="unknown option"):
         _lib.set_option("no_such_option", 1)
-    _lib.set_option("mmd_blocks", 128)
+    _lib.set_option("igemm_thr128", 128)
     _lib.check(_lib.lib().dvg_reset_options())
-    assert _lib.get_option("mmd_blocks") == 256
+    assert _lib.get_option("igemm_thr128") == 512
+    # round 5: the tuning knobs and the forms that lost their A/B are gone -- at most 16 switches are left
+    assert len(opts) <= 16, sorted(opts)
     src = os.path.join(ROOT, "image-generation_amd", "csrc")
     offenders = [f for f in os.listdir(src) if os.path.isfile(os.path.join(src, f))
                  and "getenv(" in open(os.path.join(src, f)).read().replace("getenv() sites", "")]

@@ -197,39 +197,3 @@ def test_gibbs_full_size_bit_exact(n, C, sweeps, calls):
         want = cref.gibbs_sweeps(want, ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
                                  plan.adj_eid, seed, call * sweeps, sweeps)
         assert int((got != want.astype(np.float32)).sum()) == 0
-
-
-def test_gibbs_two_waves_per_chain_form_is_bit_exact():
-    """Option gibbs_waves_per_chain = 2 (csrc/gibbs.hip: a colour class of 65..128 spins updated by the 128 lanes of TWO
-    waves, a workgroup barrier per class): c3's draw, twice on persistent chains, every spin against the C restatement."""
-    from image_generation_amd import _lib
-
-    n, C, sweeps = 512, 256, 200
-    seed = 775321899904
-    mg, _ = graphs.get_graph_mapping(graphs.greedy_get_subgraph(n, seed, graphs.zephyr_graph(12)))
-    nodes, ei, ej = graphs.edges_of(mg)
-    plan = graphs.build_plan(n, ei, ej)
-    assert 64 < int(np.diff(plan.class_ptr).max()) <= 128  # (the shape the form serves)
-    rng = np.random.default_rng(2)
-    h = (0.05 * rng.uniform(-1, 1, n)).astype(np.float32)
-    J = (5.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)
-    lin, quad = torch.from_numpy(h).cuda(), torch.from_numpy(J).cuda()
-    hs, Js = gibbs.scaled_fields(h, J, 0.05, (-4, 4), (-1, 1))
-    ids = np.arange(C, dtype=np.uint32)
-    want = cref.init_state(ids, n, seed)
-    with _lib.option_scope(gibbs_waves_per_chain=2):
-        s = smp.GibbsSampler(plan, nodes, beta=20.0, sweeps=sweeps, seed=seed, persistent=True, chain_offset=0,
-                             h_range=(-4, 4), j_range=(-1, 1))
-        for call in range(2):
-            got = s.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
-            want = cref.gibbs_sweeps(want, ids, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
-                                     plan.adj_eid, seed, call * sweeps, sweeps)
-            assert int((got != want.astype(np.float32)).sum()) == 0
-        # a ragged chain count (the last workgroup holds one chain and one idle wave pair)
-        s2 = smp.GibbsSampler(plan, nodes, beta=20.0, sweeps=3, seed=seed, persistent=False, chain_offset=7,
-                              h_range=(-4, 4), j_range=(-1, 1))
-        got = s2.sample_native(lin, quad, 0.05, (-4, 4), (-1, 1), num_reads=5).cpu().numpy()
-    ids5 = np.arange(5, dtype=np.uint32) + 7
-    want5 = cref.gibbs_sweeps(cref.init_state(ids5, n, seed), ids5, hs, Js, 20.0, plan.order, plan.class_ptr, plan.adj_ptr,
-                              plan.adj_idx, plan.adj_eid, seed, 0, 3)
-    assert int((got != want5.astype(np.float32)).sum()) == 0

@@ -122,39 +122,47 @@ def test_decoder_tail_fused_equals_separate_passes():
         assert rel(out[1][3][k], g) < 5e-5, (k, rel(out[1][3][k], g))
 
 
-def test_encoder_winograd_form_matches_direct_form():
-    """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip) against the direct implicit GEMM, on whole
-    networks: evaluation-mode forward and training-mode forward + backward under the default (option enc_wino = -1:
-    evaluation launches of 256 workgroups' worth or more, training launches -- forward and data gradient -- of
-    `wino_min_blocks` = 512 or more: at this size the first two 3x3 layers' launches) and with every launch switched (enc_wino = 1)."""
-    from image_generation_amd import _lib
+def test_encoder_winograd_form_and_direct_form_match_the_float64_oracle():
+    """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip, conv_wino_wgrad.hip) and as the direct implicit
+    GEMM, on whole networks at B = 1024 -- evaluation-mode forward and training-mode forward + backward -- EACH against the
+    float64 oracle (oracle/nets.py), under the three policies: never (enc_wino = 0), the default (-1: evaluation launches
+    of 256 workgroups' worth or more, training launches of 512 or more: at this size the first two 3x3 layers) and every
+    launch (1).  Bars: logits 3e-5 of their range; gradients 5e-3 relative L2, the bar of the full-size step test (the first
+    layers' gradients pass through three BatchNorm backward passes, and at 1024 x 341 pooling windows no batch is free of
+    float32 near-ties whose routing is rounding noise on either side) -- and no form farther from float64 than 1.5x the
+    direct form + 1e-4."""
     n, B = 128, 1024
     params = gen.make_params(n, "encoder", 111)
-    x = torch.from_numpy(gen.make_images(B, 222)).cuda()
-    gl = torch.from_numpy(np.random.default_rng(333).standard_normal((B, n)).astype(np.float32)).cuda()
+    x = torch.from_numpy(gen.make_images(B, 222))
+    gl = torch.from_numpy(np.random.default_rng(333).standard_normal((B, n)).astype(np.float32))
+    p = {k: (torch.from_numpy(np.array(v)).double().requires_grad_("running" not in k) if np.array(v).dtype == np.float32
+             else torch.from_numpy(np.array(v))) for k, v in params.items()}
+    with torch.no_grad():
+        p_eval = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in p.items()}
+        want_ev = nets.encoder_forward(p_eval, x.double(), training=False)
+    want = nets.encoder_forward(p, x.double(), training=True)
+    (want * gl.double()).sum().backward()
     out = {}
     for mode in (0, -1, 1):
-        # (enc_wino = 1 also switches the weight gradients to their Winograd form, conv_wino_wgrad.hip)
-        with _lib.option_scope(enc_wino=mode, enc_wino_wgrad=1 if mode == 1 else -1):
+        with _lib.option_scope(enc_wino=mode):
             enc = _load(Encoder(n), params).eval()
-            ev = enc(x).detach().cpu()
+            ev = enc(x.cuda()).detach().cpu()
             enc = _load(Encoder(n), params).train()
-            lg = enc(x)
-            (lg * gl).sum().backward()
+            lg = enc(x.cuda())
+            (lg * gl.cuda()).sum().backward()
             out[mode] = (ev, lg.detach().cpu(), {k: v.grad.detach().cpu() for k, v in enc.named_parameters()})
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-    assert rel(out[-1][0], out[0][0]) < 2e-6 and rel(out[1][0], out[0][0]) < 2e-6
     assert not torch.equal(out[-1][0], out[0][0])            # (the default DID take the other kernel for the evaluation call)
     assert not torch.equal(out[-1][1], out[0][1])            # ... and for the large launches of the training call
     assert not torch.equal(out[-1][1], out[1][1])            # ... but not for all of them
-    assert rel(out[1][1], out[0][1]) < 5e-6 and rel(out[-1][1], out[0][1]) < 5e-6
-    for mode in (-1, 1):
-        for k, g in out[0][2].items():
-            if k.startswith("conv") and k.endswith("bias") or ".bias" in k and "conv" in k:
+    for mode in (0, -1, 1):
+        _close(out[mode][0], want_ev, 3e-5, f"evaluation logits, enc_wino={mode}")
+        _close(out[mode][1], want.detach(), 3e-5, f"training logits, enc_wino={mode}")
+        for k, g in out[mode][2].items():
+            if k.startswith("conv") and k.endswith("bias"):
                 continue  # conv biases in front of a BatchNorm: zero true gradient, rounding noise only
-            # (5e-3: the bar of the full-size step test against float64 -- the first layers' gradients pass through three
-            # BatchNorm backward passes, whose cancellations amplify any float32 rounding difference to ~1e-3)
-            assert rel(out[mode][2][k], g) < 5e-3, (mode, k, rel(out[mode][2][k], g))
+            e, e0 = rel(g, p[k].grad), rel(out[0][2][k], p[k].grad)
+            assert e < 5e-3 and e < 1.5 * e0 + 1e-4, (mode, k, e, e0)
 
 
 def test_winograd_dynamic_tile_deal_is_bit_identical():
@@ -289,10 +297,10 @@ def test_decoder_matches_oracle_full_gradients(n, B, R):
 def test_decoder_winograd_forms_match_oracle_full_gradients(n, B, R):
     """The Upsample(x2) + ConvTranspose2d 3x3 layers in the Winograd form -- forward, data gradient and weight gradient
     with 9 of the 16 transform positions (csrc/conv_wino.hip UM = 1 / 2, conv_wino_wgrad.hip UPS): the same float64
-    oracle comparison as the direct forms, same bars (options dec_wino / dec_wino_wgrad = 1 force the forms at these
+    oracle comparison as the direct forms, same bars (option dec_wino = 1 forces the forms at these
     sizes; by default they serve decoder batches of 8192 rows or more)."""
     from image_generation_amd import _lib
-    with _lib.option_scope(dec_wino=1, dec_wino_wgrad=1):
+    with _lib.option_scope(dec_wino=1):
         _decoder_vs_oracle(n, B, R)
 
 
