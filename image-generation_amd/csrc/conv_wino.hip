@@ -316,8 +316,7 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
         for (int r = 0; r < 16; ++r) py0[r] = y[r] + bias;
       }
       pblk = blk;
-      __syncthreads();  // (the slots are rewritten by the next chunk's transform)
-      return;
+      return;  // (the barrier behind the read is the caller's)
     }
     // column half of the output transform on the wave's own rows: C_i[b] = sum_nu M[2 ps + i][nu] A[nu][b]
     f32x16 c00 = {0}, c01 = {0}, c10, c11;  // c<i><b>
@@ -329,28 +328,46 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       c10 = (acc[4] + acc[5]) + acc[6]; c11 = (acc[5] - acc[6]) - acc[7];
     }
     // the pair swaps one row: set 0 gives C_1 (its i = 1) and takes C_2; set 1 gives C_2 (its i = 0) and takes C_1.
-    // (UM = 1: C_2 = 0 -- set 1 gives nothing)
+    // (UM = 1: C_2 = 0 -- set 1 gives nothing.)  Both halves b of the row in ONE round where the free LDS holds 8 KB per
+    // wave (the 64 x 64 tile: the transformed-input and the weight stage the last chunk finished with, 32 KB each), else
+    // in two rounds of 4 KB.  The barrier behind the LAST read is the caller's (run: shared with the block hand-over).
     f32x16 y0, y1;  // the wave's output row a = PSC: pixels 2 a + 0, 2 a + 1 of every quad
-    const uint32_t mine = xaddr + (uint32_t)(wave * 4096), theirs = xaddr + (uint32_t)((wave ^ 4) * 4096);
+    constexpr bool ONE_ROUND = C::V_B >= 4 * 8192 && C::U_B >= 4 * 8192;
+    auto slot_of = [&](int w) -> uint32_t {  // exchange slot of wave w (its lane's 16 bytes of piece 0)
+      if constexpr (ONE_ROUND) return lds0 + (uint32_t)((w < 4 ? C::OFF_V + C::V_B : C::OFF_U + C::U_B) + (w & 3) * 8192 + lane * 16);
+      else return xaddr + (uint32_t)(w * 4096);
+    };
+    const uint32_t mine = slot_of(wave), theirs = slot_of(wave ^ 4);
+    auto put = [&](const f32x16& give, int off) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 o = {give[4 * r4], give[4 * r4 + 1], give[4 * r4 + 2], give[4 * r4 + 3]};
+        *reinterpret_cast<lds_f32x4*>((uintptr_t)(mine + off + r4 * 1024)) = o;
+      }
+    };
+    auto take = [&](int off) -> f32x16 {
+      f32x16 got;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 o = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(theirs + off + r4 * 1024));
+        got[4 * r4] = o[0]; got[4 * r4 + 1] = o[1]; got[4 * r4 + 2] = o[2]; got[4 * r4 + 3] = o[3];
+      }
+      return got;
+    };
+    constexpr bool GIVES = !(UM == 1 && PSC == 1), TAKES = !(UM == 1 && PSC == 0);
+    if constexpr (ONE_ROUND) {
+      if constexpr (GIVES) { put(PSC == 0 ? c10 : c00, 0); put(PSC == 0 ? c11 : c01, 4096); }
+      __syncthreads();
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const f32x16& give = PSC == 0 ? (b == 0 ? c10 : c11) : (b == 0 ? c00 : c01);
-      if (!(UM == 1 && PSC == 1)) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const f32x4 o = {give[4 * r4], give[4 * r4 + 1], give[4 * r4 + 2], give[4 * r4 + 3]};
-          *reinterpret_cast<lds_f32x4*>((uintptr_t)(mine + r4 * 1024)) = o;
-        }
+      if constexpr (!ONE_ROUND) {
+        if (b == 1) __syncthreads();  // (round 0's slots are read: they may be rewritten)
+        if constexpr (GIVES) put(PSC == 0 ? (b == 0 ? c10 : c11) : (b == 0 ? c00 : c01), 0);
+        __syncthreads();
       }
-      __syncthreads();
       f32x16 got;
-      if (!(UM == 1 && PSC == 0)) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const f32x4 o = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(theirs + r4 * 1024));
-          got[4 * r4] = o[0]; got[4 * r4 + 1] = o[1]; got[4 * r4 + 2] = o[2]; got[4 * r4 + 3] = o[3];
-        }
-      }
+      if constexpr (TAKES) got = take(ONE_ROUND ? b * 4096 : 0);
       f32x16 yb;
       if constexpr (UM == 1) {
         if constexpr (PSC == 0) yb = (b == 0 ? c00 : c01) + (b == 0 ? c10 : c11);  // Y[0][b] = C_0 + C_1
@@ -360,7 +377,6 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
         else yb = (got - (b == 0 ? c00 : c01)) - (b == 0 ? c10 : c11);                      // Y[1][b] = (C_1 - C_2) - C_3
       }
       if (b == 0) y0 = yb; else y1 = yb;
-      __syncthreads();  // (the slots are rewritten by round 1 / by the next chunk's transform)
     }
     // (+ bias; the stores wait: they are issued beside the MFMAs of the next tile block's first chunk -- store_pending --
     // all workgroups reach their epilogues together, and 64 KB per workgroup stored at once is a burst the memory
@@ -374,20 +390,22 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       s1 += v1; s2 = fmaf(v1, v1, s2);
     }
     pblk = blk;
-    if (a.stats) {
+    if (a.stats) {  // (the per-wave column sums; summed over the block behind the caller's barrier: stats_finish)
       float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       const int slot = ((PSC * WM + wm) * CB + wn * 32 + c) * 2;
       if (hh == 0) { red[slot] = s1; red[slot + 1] = s2; }
-      __syncthreads();
-      if (tid < CB) {  // (waves 0 .. CB / 64 - 1: set 0)
-        float t1 = 0.f, t2 = 0.f;
+    }
+  };
+  auto stats_finish = [&](int blk) {
+    if (a.stats && tid < CB) {  // (waves 0 .. CB / 64 - 1: set 0)
+      const float* red = reinterpret_cast<const float*>(wsm + C::OFF_RED);
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 2 * WM; ++w) { t1 += red[(w * CB + tid) * 2]; t2 += red[(w * CB + tid) * 2 + 1]; }
-        float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
-        dst[0] = t1; dst[1] = t2;
-      }
+      for (int w = 0; w < 2 * WM; ++w) { t1 += red[(w * CB + tid) * 2]; t2 += red[(w * CB + tid) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
+      dst[0] = t1; dst[1] = t2;
     }
   };
 
@@ -527,16 +545,19 @@ __device__ __forceinline__ void conv_wino8_body(const WinoArgs& a, unsigned char
       }
       epilogue(blk_cur, psc);
       pend = true;
-      go = has_next;
-      blk_cur = blk_nxt;
+      // ONE barrier per tile block behind the epilogue: the exchange slots have been read (the next chunk's transform and
+      // weight DMA overwrite them), the per-wave BatchNorm partials are in LDS, the next block's id is handed round
+      // (dynamic deal: two slots in turn, a slot is rewritten two blocks later)
       if (dynq) {
         par ^= 1;
         if (tid == 0) nslot[par] = fetched;
-        __syncthreads();
-        blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
-      } else {
-        blk_nxt = blk_cur + (int)gridDim.x;
       }
+      __syncthreads();
+      stats_finish(blk_cur);
+      go = has_next;
+      blk_cur = blk_nxt;
+      if (dynq) blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
+      else blk_nxt = blk_cur + (int)gridDim.x;
       has_next = blk_nxt < a.nblk;
     }
     if constexpr (!(UM == 2 && PSC == 1)) {
