@@ -77,14 +77,15 @@ def net_flops_per_image(n, R):
 # form the library launches, or 0, the register-staged one -- are the ones priced)
 _NORM = lambda s_: s_.replace(" ", "").replace("voiddvg::", "").replace("dvg::", "").split("(")[0].replace(",false>", ">").replace(",1,0>", ",1>").replace(",1,3>", ",1>")  # noqa: E731
 # name of the rocprof kernel behind a library profiler id that is not itself a kernel name
-PROF_TO_ROCPROF = {"mmd_pm1": "mmd_pair", "gibbs_sweeps": "gibbs_"}
+PROF_TO_ROCPROF = {"mmd_pm1": "mmd_pair", "gibbs_sweeps": "gibbs_", "conv_wino_kernel": "conv_wino8_kernel",
+                   "conv_wino_wgrad_kernel": "conv_wino_wgrad8_kernel"}
 
 
 def _profile(kind, config, lib_hash):
     """A committed profiles/ JSON of this round, or None when it was measured on a different build of the kernels:
     every file carries `kernels_hash` = dvg_source_hash() of the library it was measured on (tools/make_profiles.sh),
     and a number from another build would survive a kernel regression unchanged."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{kind}_{config}.json")
         if os.path.exists(path):
             d = json.load(open(path))

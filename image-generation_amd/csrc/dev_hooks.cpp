@@ -58,7 +58,7 @@ extern "C" size_t dvg_dev_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, i
 }
 
 extern "C" int dvg_dev_conv_wino_wgrad(const float* in, const float* dy, float* slabs, float* grad_w, int mode, int64_t M,
-                                       int Cin, int Cout, int L, int ups, dvg_stream_t stream) {
+                                       int Cin, int Cout, int L, int ups, int cus, dvg_stream_t stream) {
   DVG_REQUIRE(in && dy && slabs && grad_w, "dev_conv_wino_wgrad: null argument");
-  return launch_conv_wino_wgrad(in, dy, M, Cin, Cout, L, slabs, WeightMap{mode, Cin, Cout, 9}, grad_w, (hipStream_t)stream, ups);
+  return launch_conv_wino_wgrad(in, dy, M, Cin, Cout, L, slabs, WeightMap{mode, Cin, Cout, 9}, grad_w, (hipStream_t)stream, ups, cus);
 }

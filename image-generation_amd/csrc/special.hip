@@ -104,20 +104,28 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
 // so pooling, arg-max and the BatchNorm backward are lane-local.  HBM traffic of the stage at c3: 2.9 GB -> 0.45 GB.
 //   MODE 0  per-block (sum, sum of squares) partials for BatchNorm           (replaces the store of Y0)
 //   MODE 1  Xp = LeakyReLU(MaxPool(BN(y)))                                    (replaces enc_bn_pool_fwd's read of Y0)
-//   MODE 2  per-block (sum dz, sum dz zhat) partials                          (replaces enc_bn_pool_bwd reduce)
-//   MODE 3  dW[co][t] = sum_m dY[m][co] in_t[m], db = sum_m dY: dY formed in registers and fed to the MFMA as the A
-//           operand of the pixel pair (crow(r,0), crow(r,1))                  (replaces the apply pass, dY0 and the wgrad's reads)
-//   MODE 4  modes 2 and 3 in ONE pass.  dY = gi (delta dz - m1 - zhat m2) is linear in the two batch means m1, m2, so the
+//   (MODE 2 / 3 of round 3 -- the backward in two passes: per-block (sum dz, sum dz zhat), then the weight gradient with
+//   dY formed in registers -- were the A/B reference of MODE 4 and are gone since round 5)
+//   MODE 4  the whole backward of the stage in ONE pass.  dY = gi (delta dz - m1 - zhat m2) is linear in the two batch means m1, m2, so the
 //           weight gradient is gi (S - m1 T1 - m2 T2) with S = sum delta dz (x) in_t, T2 = sum zhat (x) in_t (two MFMA
 //           accumulations over the same B operand) and T1 = sum in_t: none of the three needs m1 or m2, which enter in
 //           enc_l0_combine_kernel after the partials are summed.  part [blocks][ENC_L0_ROW]: S (320), T2 (320), T1 (10),
 //           sum dz zhat (32).
 
 constexpr int ENC_L0_ROW = 704;  // floats per block of MODE 4's partials: S [0, 320), T2 [320, 640), T1 [640, 650), sum dz zhat [650, 682)
+// MODE 4's two weight-space accumulations run on v_mfma_f32_16x16x4_f32 (round 5): the products are [32 channels] x [10
+// tap columns] over the pixels, and a 32x32x2 MFMA spends 64 cycles on 32 columns of which 10 are used; the 16 x 16 tile
+// spends 32 on 16.  Its A operand wants 16 channels x 4 pixels per instruction where the recomputed tile (a 32x32
+// accumulator) holds 32 channels x 2 pixels per register: ONE v_permlane16_swap of two registers (pixel rows r, r + 1)
+// gives the low-channel and the high-channel operand of the 4 pixels (r, r + 1) x (hh = 0, 1) -- which are x = 0..3 of
+// one row of the 8 x 4 tile, so a lane's B value (tap t = lane & 15 of pixel slot k = lane >> 4) is a fixed offset from
+// one per-lane base.  32 MFMAs of 32 cycles per tile instead of 32 of 64, half the B loads.
+typedef float f32x4c __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
+  static_assert(MODE == 0 || MODE == 1 || MODE == 4, "BatchNorm statistics, BN -> pool -> LeakyReLU, the backward in one pass");
   __shared__ double redd[MODE == 0 ? 2 * 4 * 32 : 1];
-  __shared__ float redf[MODE >= 3 ? 4 * 32 * 33 : (MODE == 2 ? 2 * 4 * 32 : 1)];
+  __shared__ float redf[MODE == 4 ? 4 * 32 * 33 : 1];
   __shared__ float redg[MODE == 4 ? 4 * 32 * 33 : 1];
   __shared__ float redh[MODE == 4 ? 2 * 4 * 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
@@ -130,20 +138,21 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
     dy[j] = t < 9 ? t / 3 - 1 : 0;
     dx[j] = t < 9 ? t % 3 - 1 : 0;
   }
-  float mu = 0.f, is = 0.f, gm = 0.f, bt = 0.f, m1 = 0.f, m2 = 0.f, gi = 0.f;
+  float mu = 0.f, is = 0.f, gm = 0.f, bt = 0.f;
   if (MODE >= 1) { mu = a.mean[c]; is = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
-  if (MODE == 3) { m1 = a.sum_dz[c] * a.inv_m; m2 = a.sum_dzzh[c] * a.inv_m; gi = gm * is; }
-  const int tdy = c < 9 ? c / 3 - 1 : 0, tdx = c < 9 ? c % 3 - 1 : 0;  // MODE 3, 4: this lane's tap column of the B operand
-  f32x16c tacc = {0};  // MODE 4: T2
-  float t1 = 0.f;      // MODE 4: this lane's share of T1[c]
+  // MODE 4: this lane's column of the 16x16x4 B operand: tap tq of pixel slot kq (tq = 9: the column of ones that
+  // carries the bias gradient, 10..15: zero)
+  const int tq = lane & 15, kq = lane >> 4;
+  const int tdy = tq < 9 ? tq / 3 - 1 : 0, tdx = tq < 9 ? tq % 3 - 1 : 0;
+  f32x4c s_lo = {0}, s_hi = {0}, t_lo = {0}, t_hi = {0};  // S and T2, channels 0-15 / 16-31: rows 4 kq + reg, column tq
+  float t1 = 0.f;      // MODE 4: this lane's share of T1[tq]
   const int cy = (int)morton_y((uint32_t)c), cx = (int)morton_x((uint32_t)c);  // pixel c of a tile, inside the tile
   const int64_t tiles = a.B * 32;
   double s1 = 0.0, s2 = 0.0;
-  float r1 = 0.f, r2 = 0.f;
-  f32x16c wacc = {0};
+  float r2 = 0.f;
   constexpr int TU = 2;
   for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
-    float av[TU][5], gov[TU][4];
+    float av[TU][5], gov[TU][4], bq[TU][8];
     bool ok[TU][5];
     // every load of the TU tiles goes out before the first MFMA needs one (clamped, always-valid addresses)
 #pragma unroll
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
       // a tile = 32 consecutive Morton indices = an 8 (x) by 4 (y) block of its image: corner from the tile index
       // (wave-uniform scalar work), the pixel's place inside from the lane (constants)
       const int ti = (int)(tile & 31);
-      const int y = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)) + cy;
-      const int x = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1)) + cx;
+      const int ty0 = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)), tx0 = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1));
+      const int y = ty0 + cy, x = tx0 + cx;
       const float* im = a.img + (tile >> 5) * 1024;
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
@@ -161,9 +170,17 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
         ok[u][j] = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
         av[u][j] = im[ok[u][j] ? yy * 32 + xx : 0];
       }
-      if (MODE >= 2) {
+      if (MODE == 4) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) gov[u][g] = a.dXp[(tile * 8 + 2 * g + hh) * 32 + c];
+        // B operand of pixel-row pair q: the pixel at (row q & 3, x = 4 (q >> 2) + kq) of the tile, shifted by tap tq
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int yy = ty0 + (q & 3) + tdy, xx = tx0 + 4 * (q >> 2) + kq + tdx;
+          const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+          const float v = im[inb ? yy * 32 + xx : 0];
+          bq[u][q] = tq == 9 ? 1.0f : ((tq < 9 && inb) ? v : 0.f);
+        }
       }
     }
 #pragma unroll
@@ -177,34 +194,21 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bw[j], acc, 0, 0, 0);
       }
       if (MODE == 0) {
+        // the tile's 16 values per lane in float32 (two independent chains of 8), the running sums over the ~700 tiles
+        // of a lane in double: the double running sums are what keeps 1 / sigma exact on binary images (a
+        // float32 chain over all of a lane's values was 2e-5 off); a 16-term float32 partial is 1e-7 of ITS sum and the
+        // partials' errors are independent.  48 double-precision instructions per tile were most of this kernel's time.
+        float p1a = 0.f, p1b = 0.f, p2a = 0.f, p2b = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s1 += (double)acc[r];
-          s2 = fma((double)acc[r], (double)acc[r], s2);
+        for (int r = 0; r < 8; ++r) {
+          p1a += acc[r]; p2a = fmaf(acc[r], acc[r], p2a);
+          p1b += acc[8 + r]; p2b = fmaf(acc[8 + r], acc[8 + r], p2b);
         }
+        s1 += (double)p1a + (double)p1b;
+        s2 += (double)p2a + (double)p2b;
         continue;
       }
-      float go[4] = {0.f, 0.f, 0.f, 0.f};
-      if (MODE >= 2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) go[g] = gov[u][g];
-      }
-      float bimg[16];
-      if (MODE >= 3) {  // B operand of the weight-gradient MFMA r: in_t[pixel crow(r, hh)], t = this lane's column
-        const int ti = (int)(tile & 31);
-        const int y0 = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)) + tdy;
-        const int x0 = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1)) + tdx + 2 * hh;
-        const float* im = a.img + (tile >> 5) * 1024;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // pixel crow(r, hh) = (r & 3) + 4 hh + 8 (r >> 2) of the tile: x = (r & 1) + 2 hh + 4 (r >> 3), y = ((r >> 1) & 1) + 2 ((r >> 2) & 1)
-          const int yy = y0 + ((r >> 1) & 1) + 2 * ((r >> 2) & 1), xx = x0 + (r & 1) + 4 * (r >> 3);
-          const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
-          const float v = im[inb ? yy * 32 + xx : 0];
-          bimg[r] = c == 9 ? 1.0f : ((c < 9 && inb) ? v : 0.f);
-          if (MODE == 4) t1 += bimg[r];
-        }
-      }
+      float a1[16], zv[16];  // MODE 4: per pixel row r of the accumulator: delta dz (dz at the window's arg-max, else 0), zhat
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // the window of enc_bn_pool_*: zhat, arg-max (first maximum wins), LeakyReLU slope at the pooled value
@@ -220,24 +224,23 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           a.Xp[(tile * 8 + 2 * g + hh) * 32 + c] = best < 0.f ? best * LRELU_SLOPE : best;
         } else {
           const float slope = !(best > 0.f) ? LRELU_SLOPE : 1.0f;
-          const float dz = go[g] * slope;
-          if (MODE == 2) {
-            r1 += dz;
-            r2 = fmaf(dz, zh[arg], r2);
-          } else if (MODE == 3) {
+          const float dz = gov[u][g] * slope;
+          r2 = fmaf(dz, zh[arg], r2);
 #pragma unroll
-            for (int sq = 0; sq < 4; ++sq) {
-              const float dyv = gi * (((sq == arg) ? dz : 0.f) - m1 - zh[sq] * m2);
-              wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, bimg[4 * g + sq], wacc, 0, 0, 0);
-            }
-          } else {
-            r2 = fmaf(dz, zh[arg], r2);
+          for (int sq = 0; sq < 4; ++sq) { a1[4 * g + sq] = (sq == arg) ? dz : 0.f; zv[4 * g + sq] = zh[sq]; }
+        }
+      }
+      if (MODE == 4) {
 #pragma unroll
-            for (int sq = 0; sq < 4; ++sq) {
-              wacc = __builtin_amdgcn_mfma_f32_32x32x2f32((sq == arg) ? dz : 0.f, bimg[4 * g + sq], wacc, 0, 0, 0);
-              tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(zh[sq], bimg[4 * g + sq], tacc, 0, 0, 0);
-            }
-          }
+        for (int q = 0; q < 8; ++q) {
+          const auto sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(a1[2 * q]), __float_as_uint(a1[2 * q + 1]), false, false);
+          const auto sz = __builtin_amdgcn_permlane16_swap(__float_as_uint(zv[2 * q]), __float_as_uint(zv[2 * q + 1]), false, false);
+          const float b = bq[u][q];
+          t1 += b;
+          s_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sa[0]), b, s_lo, 0, 0, 0);
+          s_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sa[1]), b, s_hi, 0, 0, 0);
+          t_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sz[0]), b, t_lo, 0, 0, 0);
+          t_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sz[1]), b, t_hi, 0, 0, 0);
         }
       }
     }
@@ -253,48 +256,37 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           (float)((redd[128 + tid] + redd[160 + tid]) + (redd[192 + tid] + redd[224 + tid]));
     }
   }
-  if (MODE == 2) {
-    r1 += __shfl_xor(r1, 32, 64);
-    r2 += __shfl_xor(r2, 32, 64);
-    if (hh == 0) { redf[wave * 32 + c] = r1; redf[128 + wave * 32 + c] = r2; }
-    __syncthreads();
-    if (tid < 64) {
-      const int k = tid >> 5, cc = tid & 31;
-      a.part[(size_t)blockIdx.x * 64 + tid] =
-          (redf[k * 128 + cc] + redf[k * 128 + 32 + cc]) + (redf[k * 128 + 64 + cc] + redf[k * 128 + 96 + cc]);
-    }
-  }
-  if (MODE >= 3) {
-    // D[row = co][col = t]: lane holds column c, rows crow(r, hh)
-    constexpr int ROW = MODE == 4 ? ENC_L0_ROW : 320;
+  if (MODE == 4) {
+    // D[row = co][col = t]: a lane holds column tq, rows 4 kq + reg (channels 0-15 in *_lo, 16-31 in *_hi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      redf[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = wacc[r];
-      if (MODE == 4) redg[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + c] = tacc[r];
+    for (int r = 0; r < 4; ++r) {
+      redf[(wave * 32 + 4 * kq + r) * 33 + tq] = s_lo[r];
+      redf[(wave * 32 + 16 + 4 * kq + r) * 33 + tq] = s_hi[r];
+      redg[(wave * 32 + 4 * kq + r) * 33 + tq] = t_lo[r];
+      redg[(wave * 32 + 16 + 4 * kq + r) * 33 + tq] = t_hi[r];
     }
-    if (MODE == 4) {
-      t1 += __shfl_xor(t1, 32, 64);
-      r2 += __shfl_xor(r2, 32, 64);
-      if (hh == 0) { redh[wave * 32 + c] = t1; redh[128 + wave * 32 + c] = r2; }
-    }
+    t1 += __shfl_xor(t1, 16, 64);
+    t1 += __shfl_xor(t1, 32, 64);
+    r2 += __shfl_xor(r2, 32, 64);
+    if (lane < 16) redh[wave * 32 + lane] = t1;
+    if (hh == 0) redh[128 + wave * 32 + c] = r2;
     __syncthreads();
     for (int w = tid; w < 320; w += 256) {
       const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
-      a.part[(size_t)blockIdx.x * ROW + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
-                                             (redf[(2 * 32 + co) * 33 + t] + redf[(3 * 32 + co) * 33 + t]);
-      if (MODE == 4)
-        a.part[(size_t)blockIdx.x * ROW + 320 + w] = (redg[(0 * 32 + co) * 33 + t] + redg[(1 * 32 + co) * 33 + t]) +
-                                                     (redg[(2 * 32 + co) * 33 + t] + redg[(3 * 32 + co) * 33 + t]);
+      a.part[(size_t)blockIdx.x * ENC_L0_ROW + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
+                                                    (redf[(2 * 32 + co) * 33 + t] + redf[(3 * 32 + co) * 33 + t]);
+      a.part[(size_t)blockIdx.x * ENC_L0_ROW + 320 + w] = (redg[(0 * 32 + co) * 33 + t] + redg[(1 * 32 + co) * 33 + t]) +
+                                                          (redg[(2 * 32 + co) * 33 + t] + redg[(3 * 32 + co) * 33 + t]);
     }
-    if (MODE == 4 && tid < 42) {
+    if (tid < 42) {
       const int k = tid < 10 ? 0 : 1, cc = tid < 10 ? tid : tid - 10;  // T1[0..9], then sum dz zhat [0..31]
-      a.part[(size_t)blockIdx.x * ROW + (k ? 650 : 640) + cc] =
+      a.part[(size_t)blockIdx.x * ENC_L0_ROW + (k ? 650 : 640) + cc] =
           (redh[k * 128 + cc] + redh[k * 128 + 32 + cc]) + (redh[k * 128 + 64 + cc] + redh[k * 128 + 96 + cc]);
     }
   }
 }
 
-// blocks: MODE 0 enc_conv0_blocks(B) (the BatchNorm partial rows); MODE 2, 3: enc_l0_blocks(B) rows of `part`
+// blocks: MODE 0 enc_conv0_blocks(B) (the BatchNorm partial rows); MODE 4: enc_l0_blocks(B) rows of `part`
 // (2048 rows: the passes are bound by load latency, and 512 blocks are two per CU)
 int enc_l0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > STREAM_BLOCKS ? STREAM_BLOCKS : b); }
 
@@ -303,7 +295,6 @@ int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
   switch (mode) {
     case 0: DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_kernel<0>, g0, dim3(256), 0, s, a); break;
     case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
-    // (MODE 2 / 3 -- the backward in two passes, the A/B reference of round 3 -- are no longer instantiated)
     default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
   }
   return DVG_OK;

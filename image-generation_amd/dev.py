@@ -21,7 +21,7 @@ _SIGS = {
                            [ctypes.c_void_p]),
     "dvg_dev_encoder_layout": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "dvg_dev_wino_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "dvg_dev_conv_wino_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 4 +
+    "dvg_dev_conv_wino_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 5 +
                                 [ctypes.c_void_p]),
 }
 _bound = False
@@ -105,8 +105,9 @@ def conv_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ntaps=9, ups=0):
     return gw
 
 
-def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ups=0):
-    """The 3x3 weight gradient in the Winograd form (csrc/conv_wino_wgrad.hip), or None when the shape does not qualify."""
+def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ups=0, cus=0):
+    """The 3x3 weight gradient in the Winograd form (csrc/conv_wino_wgrad.hip), or None when the shape does not qualify.
+    ``cus``: CUs the persistent grid is sized for (0: the budget the training step gives the launch)."""
     Lb = lib()
     dev = x_m.device
     nf = Lb.dvg_dev_wino_wgrad_slab_floats(M, Cin, Cout, L)
@@ -115,7 +116,7 @@ def conv_wino_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, ups=0):
     slabs = torch.empty(nf, device=dev)
     gw = torch.empty(w_shape, device=dev)
     _lib.check(Lb.dvg_dev_conv_wino_wgrad(x_m.data_ptr(), dy.data_ptr(), slabs.data_ptr(), gw.data_ptr(), mode, M, Cin, Cout, L,
-                                          int(ups), _lib.stream_ptr(dev)))
+                                          int(ups), int(cus), _lib.stream_ptr(dev)))
     return gw
 
 

@@ -32,7 +32,7 @@ int dvg_dev_conv_wgrad(const float *in, const float *dy, float *slabs, float *gr
  * dvg_dev_wino_wgrad_slab_floats() floats (0 = the shape does not qualify). */
 size_t dvg_dev_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
 int dvg_dev_conv_wino_wgrad(const float *in, const float *dy, float *slabs, float *grad_w, int mode, int64_t M, int Cin,
-                            int Cout, int L, int ups, dvg_stream_t stream);
+                            int Cout, int L, int ups, int cus, dvg_stream_t stream); /* cus: CUs the grid is sized for (0 = the training step's budget) */
 /* Where the encoder's workspace (dvg_encoder_workspace_bytes) keeps what a forward call saved, as FLOAT offsets:
  * out[0..3] = pre-BatchNorm convolution outputs Y[l] ([B * HW_l][C_l], Morton NHWC), out[4..7] = pooled stage outputs
  * Xp[l], out[8..11] = batch means, out[12..15] = batch inverse standard deviations.  Diagnostics only.  (Y[0] is only

@@ -37,13 +37,12 @@ for name, Cin, Cout, L in (("layer 1", 32, 64, 4), ("layer 2", 64, 128, 3), ("la
     ge = 2.0 * (M / 4) * 16 * Cin * Cout / 1e9  # executed GFLOP of the Winograd form
     print(f"{name} M={M:8d} {Cin:4d}->{Cout:4d}  direct (grid sized for 256 CUs) {t_d:7.1f} us ({gf / t_d * 1e3:6.1f} TFLOP/s direct-form)"
           f"   wino vs direct {float((gw - gd).norm() / gd.norm()):.1e}   vs float64 (B={nb}): wino {rel(gw_s):.1e} direct {rel(gd_s):.1e}")
-    # the Winograd form at the CU budget the training step gives it (option enc_wino_cus_w: 128, beside the data gradient)
+    # the Winograd form at the CU budget the training step gives it (128: WINO_CUS_ENC_WGRAD of csrc/conv.h, beside the data gradient)
     # and on the whole chip; interleaved rounds in one process (minimum of 2); slab reduce included
     ts = {}
     for rnd in range(2):
         for cus in (128, 256):
-            with _lib.option_scope(enc_wino_cus_w=cus):
-                t = timeit(lambda: dev.conv_wino_wgrad(x, dy, 0, shape, M, Cin, Cout, L))
+            t = timeit(lambda: dev.conv_wino_wgrad(x, dy, 0, shape, M, Cin, Cout, L, cus=cus))
             ts[cus] = min(ts.get(cus, 1e30), t)
     for cus in (128, 256):
         print(f"        wino, grid sized for {cus:3d} CUs: {ts[cus]:7.1f} us ({gf / ts[cus] * 1e3:6.1f} TFLOP/s direct-form, {ge / ts[cus] * 1e3 / 157.3:.2f} of the f32 peak executed)")
