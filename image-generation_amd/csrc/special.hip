@@ -194,18 +194,11 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bw[j], acc, 0, 0, 0);
       }
       if (MODE == 0) {
-        // the tile's 16 values per lane in float32 (two independent chains of 8), the running sums over the ~700 tiles
-        // of a lane in double: the double running sums are what keeps 1 / sigma exact on binary images (a
-        // float32 chain over all of a lane's values was 2e-5 off); a 16-term float32 partial is 1e-7 of ITS sum and the
-        // partials' errors are independent.  48 double-precision instructions per tile were most of this kernel's time.
-        float p1a = 0.f, p1b = 0.f, p2a = 0.f, p2b = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          p1a += acc[r]; p2a = fmaf(acc[r], acc[r], p2a);
-          p1b += acc[8 + r]; p2b = fmaf(acc[8 + r], acc[8 + r], p2b);
+        for (int r = 0; r < 16; ++r) {
+          s1 += (double)acc[r];
+          s2 = fma((double)acc[r], (double)acc[r], s2);
         }
-        s1 += (double)p1a + (double)p1b;
-        s2 += (double)p2a + (double)p2b;
         continue;
       }
       float a1[16], zv[16];  // MODE 4: per pixel row r of the accumulator: delta dz (dz at the window's arg-max, else 0), zhat
