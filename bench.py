@@ -179,8 +179,8 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
 
     `cores`: stock PyTorch's intra-op pool does not scale on these layer sizes, so the thread count is MEASURED: a short
     sweep (1 warm-up + 3 timed steps per point, each point a fresh process) over `sweep`, capped at the host's core
-    count; the fastest point's thread count runs the baseline proper (again a fresh process) and the sweep is recorded in
-    the line (`thread_sweep`)."""
+    count; 16 threads run the baseline proper (again a fresh process) unless another point is more than 20 % faster, and
+    the sweep is recorded in the line (`thread_sweep`)."""
     import subprocess
 
     cfg = CONFIGS[config]
@@ -201,7 +201,12 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
     for t in points:
         d = leg(t, 1, 3, 0.0, False)
         thread_sweep[str(t)] = {"ms_per_step": d["times_ms"][len(d["times_ms"]) // 2], "images_per_s": d["batch"] / (d["times_ms"][len(d["times_ms"]) // 2] * 1e-3)}
-    cores = int(min(thread_sweep, key=lambda k: thread_sweep[k]["ms_per_step"]))
+    # (3-step points are noisy: round 4's lines picked 8, 16 and 32 threads on three runs of the same box.  16 threads --
+    # what every earlier round ran -- stays unless another point is more than 20 % faster, so that the baseline is the
+    # same measurement from run to run)
+    best = min(thread_sweep, key=lambda k: thread_sweep[k]["ms_per_step"])
+    pref = str(min(16, host))
+    cores = int(pref if pref in thread_sweep and thread_sweep[pref]["ms_per_step"] <= 1.2 * thread_sweep[best]["ms_per_step"] else best)
     d = leg(cores, 3, 10, seconds, True)
     times, Bc = d["times_ms"], d["batch"]
     med = times[len(times) // 2] * 1e-3
@@ -211,8 +216,8 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
             "thread_sweep": thread_sweep,
             "sample": f"{len(times)} train steps of the {cfg['B']}-image workload's model (n={cfg['n']}, R={cfg['R']}, "
                       f"{cfg['C']} chains x {cfg['sweeps']} sweeps) at B={Bc} images per step on the CPU oracle after 3 "
-                      f"warm-up steps, {cores} threads in a fresh process (the fastest of {points}, each measured in its own "
-                      f"process); median {med * 1e3:.0f} ms/step, min {times[0]:.0f} ms",
+                      f"warm-up steps, {cores} threads in a fresh process (16 unless another of {points}, each measured in its own "
+                      f"process, is > 20 % faster); median {med * 1e3:.0f} ms/step, min {times[0]:.0f} ms",
             "ms_per_step_median": med * 1e3, "ms_per_step_min": times[0]}
 
 
@@ -433,8 +438,9 @@ def main():
     write_yaml(cfg, tmp.name, args.precision)
     model = ModelWrapper(cfg["qpu"], n_latents=cfg["n"], training_parameter_file=tmp.name,
                          dist=dp if (dp.world_size > 1 or dp.force) else None)
-    # synthetic batches resident in HBM (a pool, so no step re-reads the batch it just saw)
-    pool = 16
+    # synthetic batches resident in HBM (a pool of 64, SURVEY.md 8d: no step re-reads a batch that is still in a cache --
+    # c3: 64 x 16.8 MB = 1.07 GB, four times the 256 MiB Infinity Cache)
+    pool = 64
     imgs = synthetic_images(pool * cfg["B"], seed=775321899904 + dp.rank, device=dev).reshape(pool, cfg["B"], 1, 32, 32)
     labels = torch.zeros(cfg["B"], dtype=torch.int64, device=dev)
     batches = [(imgs[k], labels) for k in range(pool)]

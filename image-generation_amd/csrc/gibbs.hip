@@ -393,6 +393,8 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
   // encoder's convolutions that run beside the draw (c3: 19.15 ms with four waves, 19.4 with two, 19.7 with one).
   const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
+  // (round 5, c3: 8 waves -- 32 workgroups instead of 64, 32 more CUs for the encoder beside the draw -- 1.23 ms per draw
+  // against 1.00 and 8.41 ms per step against 8.26)
   const int waves = small ? 1 : 4;
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of

@@ -28,6 +28,19 @@ for t, d in events:
     elif depth >= 2: par += t - last
     last = t; depth += d
 print("idle us", idle / 1e3, "time with >=2 kernels us", par / 1e3)
+# the convolution GEMM kernels (conv_igemm / conv_wino8 / conv_wino_wgrad8 / conv_wgrad*): the SUM of their durations (what
+# bench.py's conv_all divides the executed FLOPs by: two kernels side by side count twice) and the UNION of their
+# intervals (wall time during which at least one runs: executed FLOPs / this = what the chip delivers while they run)
+gemm = sorted((s_, e_) for s_, e_, n_, q_, st_ in step if "conv_igemm" in n_ or "conv_wino" in n_ or "conv_wgrad" in n_)
+tot = sum(e_ - s_ for s_, e_ in gemm); uni = 0; cur_s = cur_e = None
+for s_, e_ in gemm:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None: uni += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+if cur_e is not None: uni += cur_e - cur_s
+print("convolution GEMM kernels:", len(gemm), "launches, sum of durations us", tot / 1e3, "union of their intervals us", uni / 1e3)
 short = lambda n: n.split("(")[0].replace("void dvg::", "").replace("dvg::", "")[:60]
 for s, e, n, q, st in step:
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  q{q} {short(n)}")
