@@ -199,7 +199,7 @@ bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);      // policy (op
 bool conv_wino_wgrad_shape(int64_t M, int Cin, int Cout, int L);   // shape only
 size_t conv_wino_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
 // ups = 1: the decoder's Upsample(x2) + 3x3 layers (`in` = the source map, M / L of the output grid: 9 of the 16 position
-// GEMMs remain); cus = CUs the launch is sized for (0: option enc_wino_cus_w)
+// GEMMs remain); cus = CUs the launch is sized for (0: WINO_CUS_ENC_WGRAD)
 int launch_conv_wino_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
                            const WeightMap& map, float* grad_w, hipStream_t s, int ups = 0, int cus = 0);
 int conv_stats_blocks(int64_t M, int Cout);

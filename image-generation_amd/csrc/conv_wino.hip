@@ -625,7 +625,7 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind) {
   const int64_t blocks = M / 4 / wino_tblk(cfg) * (Cout / (cfg == 0 ? 64 : 32));
   // evaluation-mode forward calls: from 256 workgroups' worth up (round 3).  Training calls: the float32 and f32x3 operand
   // modes (the form is strict float32 arithmetic on 4/9 of the multiplications: faster than the split direct kernel
-  // too; in the bf16-input mode the direct kernel on the bf16 MFMA is the faster one) and from option wino_min_blocks
+  // too; in the bf16-input mode the direct kernel on the bf16 MFMA is the faster one) and from WINO_MIN_BLOCKS
   // (512) up -- all of c3's launches, the larger ones of mid-size batches; a c2 step with its one 256-block launch
   // switched measured 3.5 % slower (the draw's 128 one-wave workgroups leave the persistent grid 128 CUs there)
   // (kind 3: a weight gradient -- float32 in every operand mode; forward / data gradient: not in the bf16-input mode)

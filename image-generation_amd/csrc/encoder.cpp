@@ -200,7 +200,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "encoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
   DVG_REQUIRE(plan_forward_flag(ws, 1u << 31), "encoder_bwd: backward requires a training-mode forward on this workspace (the last forward call here ran in evaluation mode: running statistics, no saved batch statistics)");
-  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl, 1)), "encoder_bwd: a kernel-form option (dvg_set_option: igemm_dma / enc_wino / enc_wino_mask / enc_l0_fused) changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl, 1)), "encoder_bwd: a kernel-form option (dvg_set_option: igemm_dma / enc_wino / enc_l0_fused) changed since the forward call on this workspace");
   DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
   for (int l = 0; l < 4; ++l)
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);

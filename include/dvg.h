@@ -116,8 +116,9 @@ int dvg_gibbs_sample(const dvg_graph_t *g, const float *linear, const float *qua
                      const dvg_step_state_t *dyn, dvg_stream_t stream);
 /* The launch geometry dvg_gibbs_sample uses for n_chains chains on this graph (nothing is launched; any out pointer may
  * be NULL): workgroups, threads per workgroup, LDS bytes per workgroup.  For callers that size what runs BESIDE the draw
- * (ModelWrapper: option enc_wino_cus = the CUs the draw leaves; the reference has no counterpart -- its draw is a QPU
- * call, /root/reference/src/model_wrapper.py:309-316). */
+ * (tools and A/B measurements; since round 5 the Winograd grids beside the draw deal their tile blocks dynamically and
+ * no caller needs it on the product path; the reference has no counterpart -- its draw is a QPU call,
+ * /root/reference/src/model_wrapper.py:309-316). */
 int dvg_gibbs_launch_info(const dvg_graph_t *g, int n_chains, int *workgroups, int *threads, size_t *lds_bytes);
 
 /* ------------------------------------------------------------------ GRBM

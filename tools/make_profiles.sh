@@ -5,7 +5,7 @@
 # Every JSON written by the aggregators carries kernels_hash = dvg_source_hash() of the library measured; bench.py drops
 # profiles whose hash differs from the library it runs.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
@@ -63,6 +63,9 @@ python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut 
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
 python tools/wino_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_alone_c3.txt
 python tools/wino_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_wgrad_alone_c3.txt
+# determinism: two processes, 300 graph-replayed c3 steps each, losses printed to the last digit (dynamic tile deal, pair
+# exchange and fixed-order slab sums included)
+(python tools/soak.py c3 300 2>&1 | tail -3; python tools/soak.py c3 300 2>&1 | tail -3) | grep -v amdgpu > $OUT/${R}_soak_c3_300_steps_twice.txt
 # kernel timeline of one c2 step (eager: under rocprofv3 the captured graph's gaps are the profiler's)
 cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr2 -- python3 $ROOT/bench.py --config c2 --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
 python tools/trace_step.py $(ls $OUT/tr2/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c2_step.txt; rm -rf $OUT/tr2
