@@ -21,7 +21,7 @@ struct EncPlan {
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
   bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
   bool wino_w[4];             // ... its weight gradient too (conv_wino_wgrad.hip)
-  size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, splitk;
+  size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, mom_part, mom, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -87,6 +87,9 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
   for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)EW_BLOCKS * ch[l + 1]);  // per layer: reduced on the side stream
   p.partP = bump(o, (size_t)EW_BLOCKS * 8);
   p.part320 = bump(o, (size_t)STREAM_BLOCKS * ENC_L0_ROW_FLOATS);  // (rows of the one-pass layer-0 backward)
+  // layer 0's patch moments (doubles: two floats each; 256-byte granules keep them aligned): per-block rows, then the sums
+  p.mom_part = bump(o, (size_t)enc_l0_moment_blocks(B) * ENC_L0_MOM_ROW * 2);
+  p.mom = bump(o, (size_t)ENC_L0_MOM_ROW * 2);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -154,16 +157,18 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
   for (int l = 0; l < 4; ++l) {
     const int Cin = pl.ch[l], C = pl.ch[l + 1];
     if (l == 0 && opt(OPT_ENC_L0_FUSED) != 0) {
-      // layer 0 recomputed (special.hip, enc_l0_kernel): statistics pass, finaliser, then BN -> pool -> LeakyReLU from
-      // the images; Y0 is never written
+      // layer 0 recomputed (special.hip): BatchNorm statistics from the moments of the input patches, then BN -> pool ->
+      // LeakyReLU from the images (enc_l0_kernel<1>); Y0 is never written
       EncL0Args a0{};
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.Xp = W + pl.Xp[0];
-      a0.part = W + pl.stats[0];
-      if (training) DVG_TRY(launch_enc_l0(0, a0, s));
-      DVG_TRY(launch_bn_finalize(W + pl.stats[0], pl.nblk[0], C, pl.M[0], training, W + pl.mean[0], W + pl.invstd[0],
-                                 p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
+      if (training)
+        DVG_TRY(launch_enc_l0_moments(images, B, p->conv_w[0], p->conv_b[0], (double*)(W + pl.mom_part), (double*)(W + pl.mom),
+                                      W + pl.mean[0], W + pl.invstd[0], p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
+      else
+        DVG_TRY(launch_bn_finalize(W + pl.stats[0], pl.nblk[0], C, pl.M[0], 0, W + pl.mean[0], W + pl.invstd[0],
+                                   p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
       DVG_TRY(launch_enc_l0(1, a0, s));
       x = W + pl.Xp[0];
       continue;
@@ -227,11 +232,13 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.dXp = dX;
-      // one pass: S, T2, T1 and sum dz zhat per block, their column sums, then every gradient of the stage from the sums
+      // one pass: S and sum dz zhat per block, their column sums, then every gradient of the stage from the sums and the
+      // patch moments the forward call left in the workspace
       a0.part = W + pl.part320;
       DVG_TRY(launch_enc_l0(4, a0, s));
-      DVG_TRY(launch_colsum(W + pl.part320, enc_l0_blocks(B), ENC_L0_ROW_FLOATS, 682, 1.0f, partA, 0, 0, s));
-      DVG_TRY(launch_enc_l0_combine(partA, p->bn_g[0], W + pl.invstd[0], B, g->conv_w[0], g->conv_b[0], g->bn_b[0], g->bn_g[0], s));
+      DVG_TRY(launch_colsum(W + pl.part320, enc_l0_blocks(B), ENC_L0_ROW_FLOATS, ENC_L0_ROW_FLOATS, 1.0f, partA, 0, 0, s));
+      DVG_TRY(launch_enc_l0_combine(partA, (const double*)(W + pl.mom), p->conv_w[0], p->conv_b[0], W + pl.mean[0], p->bn_g[0],
+                                    W + pl.invstd[0], B, g->conv_w[0], g->conv_b[0], g->bn_b[0], g->bn_g[0], s));
       break;
     }
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY

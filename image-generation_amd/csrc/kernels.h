@@ -90,18 +90,25 @@ struct EncL0Args {
   const float* img; int64_t B;
   const float* w; const float* bias;                       // conv weight (32,1,3,3), bias (32)
   const float* mean; const float* invstd; const float* gamma; const float* beta;
-  const float* dXp;                                        // gradient wrt the pooled map [B*256][32]          (MODE 2, 3)
-  const float* sum_dz; const float* sum_dzzh; float inv_m; // BatchNorm backward sums over the batch, 1 / (B*1024) (MODE 3)
+  const float* dXp;                                        // gradient wrt the pooled map [B*256][32]          (MODE 4)
   float* Xp;                                               // [B*256][32]                                     (MODE 1)
-  float* part;                                             // MODE 0: [blocks][32][2], MODE 2: [blocks][64], MODE 3: [blocks][320]
+  float* part;                                             // MODE 4: [enc_l0_blocks(B)][ENC_L0_ROW_FLOATS]
 };
 int enc_l0_blocks(int64_t B);
-int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s);
-// mode 4 (both backward passes in one): partial rows of ENC_L0_ROW_FLOATS floats; their column sums `tot` go through
-// launch_enc_l0_combine, which writes the four gradients of the stage
-constexpr int ENC_L0_ROW_FLOATS = 704;
-int launch_enc_l0_combine(const float* tot, const float* gamma, const float* invstd, int64_t B, float* gw, float* gb,
-                          float* g_bn_b, float* g_bn_g, hipStream_t s);
+int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s);  // mode 1 or 4
+// The layer's BatchNorm statistics from the first and second moments of the 3x3 input patches (no pass over the layer's
+// output): part [enc_l0_moment_blocks(B)][ENC_L0_MOM_ROW] doubles of scratch, mom [ENC_L0_MOM_ROW] doubles = the summed
+// moments, which the backward call's launch_enc_l0_combine reads.  Also updates the running statistics and the batch counter.
+constexpr int ENC_L0_MOM = 54, ENC_L0_MOM_ROW = 64;
+int enc_l0_moment_blocks(int64_t B);
+int launch_enc_l0_moments(const float* images, int64_t B, const float* w, const float* bias, double* part, double* mom,
+                          float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s);
+// mode 4 (both backward passes in one): partial rows of ENC_L0_ROW_FLOATS floats (S: 320, sum dz zhat: 32); their column
+// sums `tot` go through launch_enc_l0_combine, which writes the four gradients of the stage
+constexpr int ENC_L0_ROW_FLOATS = 352;
+int launch_enc_l0_combine(const float* tot, const double* mom, const float* w, const float* bias, const float* mean,
+                          const float* gamma, const float* invstd, int64_t B, float* gw, float* gb, float* g_bn_b,
+                          float* g_bn_g, hipStream_t s);
 // part: [EW_BLOCKS][320]: 288 weight-gradient entries in checkpoint order, then 32 bias-gradient entries
 int launch_enc_conv0_wgrad(const float* images, int64_t B, const float* dY, float* part, hipStream_t s);
 // Linear(4,1) over the 2x2 pooled map: P (B,4,n) -> logits (B,n)

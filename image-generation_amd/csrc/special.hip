@@ -102,32 +102,35 @@ int launch_enc_conv0_fwd(const float* images, int64_t B, const float* w, const f
 // the weight gradient -- recomputes the 32-pixel tile with the same five MFMAs (bit-identical every time) and works on
 // the accumulator registers: a lane holds channel c of pixels crow(r, hh), i.e. FOUR WHOLE pooling quads (r = 4g .. 4g+3),
 // so pooling, arg-max and the BatchNorm backward are lane-local.  HBM traffic of the stage at c3: 2.9 GB -> 0.45 GB.
-//   MODE 0  per-block (sum, sum of squares) partials for BatchNorm           (replaces the store of Y0)
+//   moments  (enc_l0_moments_kernel, below) the BatchNorm statistics of the layer WITHOUT making its output: y = w . patch + b
+//           is linear in the nine shifted copies in_t of the one input channel, so sum y and sum y^2 over the batch are
+//           w^T S + M b and quadratic forms w^T P w in the first and second moments S[t] = sum in_t, P[t][t'] = sum in_t in_t'
+//           of the 3x3 patches: 54 numbers that do not depend on the channel (round 5; MODE 0 of rounds 3-5 redid the five
+//           MFMAs per tile and summed the 32 x 32 accumulator in double: 63 us alone at c3, 123 us beside the draw)
 //   MODE 1  Xp = LeakyReLU(MaxPool(BN(y)))                                    (replaces enc_bn_pool_fwd's read of Y0)
 //   (MODE 2 / 3 of round 3 -- the backward in two passes: per-block (sum dz, sum dz zhat), then the weight gradient with
 //   dY formed in registers -- were the A/B reference of MODE 4 and are gone since round 5)
 //   MODE 4  the whole backward of the stage in ONE pass.  dY = gi (delta dz - m1 - zhat m2) is linear in the two batch means m1, m2, so the
-//           weight gradient is gi (S - m1 T1 - m2 T2) with S = sum delta dz (x) in_t, T2 = sum zhat (x) in_t (two MFMA
-//           accumulations over the same B operand) and T1 = sum in_t: none of the three needs m1 or m2, which enter in
-//           enc_l0_combine_kernel after the partials are summed.  part [blocks][ENC_L0_ROW]: S (320), T2 (320), T1 (10),
-//           sum dz zhat (32).
+//           weight gradient is gi (S - m1 T1 - m2 T2) with S = sum delta dz (x) in_t, T2 = sum zhat (x) in_t and T1 = sum in_t.
+//           T1 and T2 need no pass over the pixels at all: T1 is the first moment and, zhat being (y - mu) invstd with y linear
+//           in the patch, T2[co][t] = invstd (sum_t' w[co][t'] P[t'][t] + (b - mu) S[t]) -- both come from the 54 moments the
+//           forward call left in the workspace (enc_l0_combine_kernel, in double).  The pass accumulates S (one MFMA
+//           accumulation) and sum dz zhat.  part [blocks][ENC_L0_ROW]: S (320), sum dz zhat (32).
 
-constexpr int ENC_L0_ROW = 704;  // floats per block of MODE 4's partials: S [0, 320), T2 [320, 640), T1 [640, 650), sum dz zhat [650, 682)
-// MODE 4's two weight-space accumulations run on v_mfma_f32_16x16x4_f32 (round 5): the products are [32 channels] x [10
+constexpr int ENC_L0_ROW = ENC_L0_ROW_FLOATS;  // floats per block of MODE 4's partials: S [0, 320), sum dz zhat [320, 352)
+// MODE 4's weight-space accumulation runs on v_mfma_f32_16x16x4_f32 (round 5): the product is [32 channels] x [10
 // tap columns] over the pixels, and a 32x32x2 MFMA spends 64 cycles on 32 columns of which 10 are used; the 16 x 16 tile
 // spends 32 on 16.  Its A operand wants 16 channels x 4 pixels per instruction where the recomputed tile (a 32x32
 // accumulator) holds 32 channels x 2 pixels per register: ONE v_permlane16_swap of two registers (pixel rows r, r + 1)
 // gives the low-channel and the high-channel operand of the 4 pixels (r, r + 1) x (hh = 0, 1) -- which are x = 0..3 of
 // one row of the 8 x 4 tile, so a lane's B value (tap t = lane & 15 of pixel slot k = lane >> 4) is a fixed offset from
-// one per-lane base.  32 MFMAs of 32 cycles per tile instead of 32 of 64, half the B loads.
+// one per-lane base.  16 MFMAs of 32 cycles per tile (32 while T2 was accumulated here, 32 of 64 cycles before that).
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
-  static_assert(MODE == 0 || MODE == 1 || MODE == 4, "BatchNorm statistics, BN -> pool -> LeakyReLU, the backward in one pass");
-  __shared__ double redd[MODE == 0 ? 2 * 4 * 32 : 1];
+  static_assert(MODE == 1 || MODE == 4, "BN -> pool -> LeakyReLU, the backward in one pass");
   __shared__ float redf[MODE == 4 ? 4 * 32 * 33 : 1];
-  __shared__ float redg[MODE == 4 ? 4 * 32 * 33 : 1];
-  __shared__ float redh[MODE == 4 ? 2 * 4 * 32 : 1];
+  __shared__ float redh[MODE == 4 ? 4 * 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, c = lane & 31;
   float bw[5];
   int dy[5], dx[5];
@@ -144,11 +147,9 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
   // carries the bias gradient, 10..15: zero)
   const int tq = lane & 15, kq = lane >> 4;
   const int tdy = tq < 9 ? tq / 3 - 1 : 0, tdx = tq < 9 ? tq % 3 - 1 : 0;
-  f32x4c s_lo = {0}, s_hi = {0}, t_lo = {0}, t_hi = {0};  // S and T2, channels 0-15 / 16-31: rows 4 kq + reg, column tq
-  float t1 = 0.f;      // MODE 4: this lane's share of T1[tq]
+  f32x4c s_lo = {0}, s_hi = {0};  // S, channels 0-15 / 16-31: rows 4 kq + reg, column tq
   const int cy = (int)morton_y((uint32_t)c), cx = (int)morton_x((uint32_t)c);  // pixel c of a tile, inside the tile
   const int64_t tiles = a.B * 32;
-  double s1 = 0.0, s2 = 0.0;
   float r2 = 0.f;
   constexpr int TU = 2;
   for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
@@ -193,15 +194,7 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
         const float av_ = (2 * j + hh == 9) ? 1.0f : (ok[u][j] ? av[u][j] : 0.f);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bw[j], acc, 0, 0, 0);
       }
-      if (MODE == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s1 += (double)acc[r];
-          s2 = fma((double)acc[r], (double)acc[r], s2);
-        }
-        continue;
-      }
-      float a1[16], zv[16];  // MODE 4: per pixel row r of the accumulator: delta dz (dz at the window's arg-max, else 0), zhat
+      float a1[16];  // MODE 4: per pixel row r of the accumulator: delta dz (dz at the window's arg-max, else 0)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // the window of enc_bn_pool_*: zhat, arg-max (first maximum wins), LeakyReLU slope at the pooled value
@@ -220,97 +213,233 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
           const float dz = gov[u][g] * slope;
           r2 = fmaf(dz, zh[arg], r2);
 #pragma unroll
-          for (int sq = 0; sq < 4; ++sq) { a1[4 * g + sq] = (sq == arg) ? dz : 0.f; zv[4 * g + sq] = zh[sq]; }
+          for (int sq = 0; sq < 4; ++sq) a1[4 * g + sq] = (sq == arg) ? dz : 0.f;
         }
       }
       if (MODE == 4) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const auto sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(a1[2 * q]), __float_as_uint(a1[2 * q + 1]), false, false);
-          const auto sz = __builtin_amdgcn_permlane16_swap(__float_as_uint(zv[2 * q]), __float_as_uint(zv[2 * q + 1]), false, false);
           const float b = bq[u][q];
-          t1 += b;
           s_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sa[0]), b, s_lo, 0, 0, 0);
           s_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sa[1]), b, s_hi, 0, 0, 0);
-          t_lo = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sz[0]), b, t_lo, 0, 0, 0);
-          t_hi = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(sz[1]), b, t_hi, 0, 0, 0);
         }
       }
     }
   }
-  if (MODE == 0) {
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (hh == 0) { redd[wave * 32 + c] = s1; redd[128 + wave * 32 + c] = s2; }
-    __syncthreads();
-    if (tid < 32) {
-      a.part[((size_t)blockIdx.x * 32 + tid) * 2] = (float)((redd[tid] + redd[32 + tid]) + (redd[64 + tid] + redd[96 + tid]));
-      a.part[((size_t)blockIdx.x * 32 + tid) * 2 + 1] =
-          (float)((redd[128 + tid] + redd[160 + tid]) + (redd[192 + tid] + redd[224 + tid]));
-    }
-  }
   if (MODE == 4) {
-    // D[row = co][col = t]: a lane holds column tq, rows 4 kq + reg (channels 0-15 in *_lo, 16-31 in *_hi)
+    // D[row = co][col = t]: a lane holds column tq, rows 4 kq + reg (channels 0-15 in s_lo, 16-31 in s_hi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       redf[(wave * 32 + 4 * kq + r) * 33 + tq] = s_lo[r];
       redf[(wave * 32 + 16 + 4 * kq + r) * 33 + tq] = s_hi[r];
-      redg[(wave * 32 + 4 * kq + r) * 33 + tq] = t_lo[r];
-      redg[(wave * 32 + 16 + 4 * kq + r) * 33 + tq] = t_hi[r];
     }
-    t1 += __shfl_xor(t1, 16, 64);
-    t1 += __shfl_xor(t1, 32, 64);
     r2 += __shfl_xor(r2, 32, 64);
-    if (lane < 16) redh[wave * 32 + lane] = t1;
-    if (hh == 0) redh[128 + wave * 32 + c] = r2;
+    if (hh == 0) redh[wave * 32 + c] = r2;
     __syncthreads();
     for (int w = tid; w < 320; w += 256) {
       const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
       a.part[(size_t)blockIdx.x * ENC_L0_ROW + w] = (redf[(0 * 32 + co) * 33 + t] + redf[(1 * 32 + co) * 33 + t]) +
                                                     (redf[(2 * 32 + co) * 33 + t] + redf[(3 * 32 + co) * 33 + t]);
-      a.part[(size_t)blockIdx.x * ENC_L0_ROW + 320 + w] = (redg[(0 * 32 + co) * 33 + t] + redg[(1 * 32 + co) * 33 + t]) +
-                                                          (redg[(2 * 32 + co) * 33 + t] + redg[(3 * 32 + co) * 33 + t]);
     }
-    if (tid < 42) {
-      const int k = tid < 10 ? 0 : 1, cc = tid < 10 ? tid : tid - 10;  // T1[0..9], then sum dz zhat [0..31]
-      a.part[(size_t)blockIdx.x * ENC_L0_ROW + (k ? 650 : 640) + cc] =
-          (redh[k * 128 + cc] + redh[k * 128 + 32 + cc]) + (redh[k * 128 + 64 + cc] + redh[k * 128 + 96 + cc]);
-    }
+    if (tid < 32) a.part[(size_t)blockIdx.x * ENC_L0_ROW + 320 + tid] = (redh[tid] + redh[32 + tid]) + (redh[64 + tid] + redh[96 + tid]);
   }
 }
 
-// blocks: MODE 0 enc_conv0_blocks(B) (the BatchNorm partial rows); MODE 4: enc_l0_blocks(B) rows of `part`
-// (2048 rows: the passes are bound by load latency, and 512 blocks are two per CU)
+// blocks: MODE 4: enc_l0_blocks(B) rows of `part` (2048 rows: the passes are bound by load latency, and 512 blocks are
+// two per CU)
 int enc_l0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > STREAM_BLOCKS ? STREAM_BLOCKS : b); }
 
 int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
-  const dim3 g0((unsigned)enc_conv0_blocks(a.B)), g((unsigned)enc_l0_blocks(a.B));
+  const dim3 g((unsigned)enc_l0_blocks(a.B));
   switch (mode) {
-    case 0: DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_kernel<0>, g0, dim3(256), 0, s, a); break;
     case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
-    default: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
+    case 4: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
+    default: set_error("launch_enc_l0: mode %d", mode); return DVG_E_INVALID;
   }
   return DVG_OK;
 }
 
-// tot [ENC_L0_ROW]: the column sums of MODE 4's partials.  One block: every gradient of the stage.
-__global__ __launch_bounds__(320) void enc_l0_combine_kernel(const float* __restrict__ tot, const float* __restrict__ gamma,
-                                                             const float* __restrict__ invstd, float inv_m,
+// ---- first and second moments of the 3x3 patches of the batch (the statistics pass of the recomputed layer 0)
+// Term k of the ENC_L0_MOM = 54: k < 9: S[t = k] = sum in_t;  k >= 9: P[t][t'] = sum in_t in_t' for the k-th pair t <= t'
+// in row order ((0,0), (0,1), .., (0,8), (1,1), ..).  in_t of a pixel = the image at (y + t / 3 - 1, x + t % 3 - 1), zero
+// outside (the zero padding of the convolution).  Double sums: a product of two floats is exact in double, so the
+// moments carry nothing but the summation error of 10^6..10^7 terms in double -- the statistics that come out of them
+// are those of the EXACT layer output (the float32 accumulator of the MFMA form rounds each y first).
+// A block stages an image in LDS (zero halo, rows of 40 floats with the interior at column 4: 16-byte rows), one float4
+// per thread, the next image's load in flight meanwhile.  Wave w owns the terms k = w (mod 4) -- 14 or 13 double
+// accumulators per lane instead of 54 -- for ALL pixels of the image: a lane walks four 1 x 4 strips (three 6-wide rows
+// each = 3 x (b32, b128, b32) LDS reads).  part [blocks][ENC_L0_MOM_ROW] doubles.
+__host__ __device__ constexpr int enc_l0_pair_index(int t, int u) { return 9 + t * 9 - t * (t - 1) / 2 + (u - t); }  // t <= u
+
+template <int ROLE>
+__device__ __forceinline__ void enc_l0_moments_strip(const float* __restrict__ T, int y, int x0, double (&acc)[14]) {
+  double d[3][6];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* row = T + (y + r) * 40 + 3 + x0;
+    const f32x4c mid = *reinterpret_cast<const f32x4c*>(row + 1);
+    d[r][0] = (double)row[0]; d[r][1] = (double)mid[0]; d[r][2] = (double)mid[1]; d[r][3] = (double)mid[2];
+    d[r][4] = (double)mid[3]; d[r][5] = (double)row[5];
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if ((t & 3) == ROLE) acc[t >> 2] += d[t / 3][px + t % 3];
+#pragma unroll
+      for (int u = t; u < 9; ++u) {
+        const int k = enc_l0_pair_index(t, u);
+        if ((k & 3) == ROLE) acc[k >> 2] = fma(d[t / 3][px + t % 3], d[u / 3][px + u % 3], acc[k >> 2]);
+      }
+    }
+  }
+}
+
+template <int ROLE>
+__device__ __forceinline__ void enc_l0_moments_wave(const float* __restrict__ T, int lane, double (&acc)[14]) {
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp) {
+    const int strip = lane + 64 * sp;  // 256 strips of an image: row strip >> 3, columns 4 (strip & 7) ..
+    enc_l0_moments_strip<ROLE>(T, strip >> 3, 4 * (strip & 7), acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void enc_l0_moments_kernel(const float* __restrict__ img, int64_t B, double* __restrict__ part) {
+  __shared__ __align__(16) float tile[2][34 * 40];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * 34 * 40; i += 256) (&tile[0][0])[i] = 0.f;
+  double acc[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] = 0.0;
+  int64_t b = blockIdx.x;
+  f32x4c cur = {0.f, 0.f, 0.f, 0.f};
+  if (b < B) cur = *reinterpret_cast<const f32x4c*>(img + b * 1024 + tid * 4);
+  __syncthreads();
+  for (int it = 0; b < B; b += gridDim.x, ++it) {
+    float* T = tile[it & 1];
+    // (the buffer was last read two images ago: every thread has passed the barrier of the image in between since)
+    *reinterpret_cast<f32x4c*>(T + ((tid >> 3) + 1) * 40 + 4 + 4 * (tid & 7)) = cur;
+    __syncthreads();
+    if (b + gridDim.x < B) cur = *reinterpret_cast<const f32x4c*>(img + (b + gridDim.x) * 1024 + tid * 4);
+    if (wave == 0) enc_l0_moments_wave<0>(T, lane, acc);
+    else if (wave == 1) enc_l0_moments_wave<1>(T, lane, acc);
+    else if (wave == 2) enc_l0_moments_wave<2>(T, lane, acc);
+    else enc_l0_moments_wave<3>(T, lane, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0 && 4 * i + wave < ENC_L0_MOM_ROW) part[(size_t)blockIdx.x * ENC_L0_MOM_ROW + 4 * i + wave] = v;
+  }
+}
+
+int enc_l0_moment_blocks(int64_t B) { return (int)(B < 512 ? B : 512); }
+
+// One block: the moments summed over the blocks (fixed order, double) -> mom [ENC_L0_MOM_ROW] (kept for the backward call's
+// combine kernel), then per channel the batch mean and variance of y = w . patch + b:
+//   mean = b + sum_t w_t S_t / M,   var = sum_{t,t'} w_t w_t' (P_tt' / M - S_t S_t' / M^2)   (biased, as BatchNorm normalises)
+// and the running statistics as bn_finalize_kernel updates them.
+__global__ __launch_bounds__(1024) void enc_l0_moments_finalize_kernel(const double* __restrict__ part, int nblk, double M,
+                                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                                       double* __restrict__ mom, float* __restrict__ mean,
+                                                                       float* __restrict__ invstd, float* __restrict__ rm,
+                                                                       float* __restrict__ rv, int64_t* __restrict__ nbt) {
+  __shared__ double red[16][ENC_L0_MOM_ROW];
+  __shared__ double em[ENC_L0_MOM_ROW];  // the moments over M: E[in_t], E[in_t in_t']
+  const int tid = threadIdx.x, j = tid & 63, g = tid >> 6;  // column j, row group g of 16
+  double sum = 0.0;
+  for (int r0 = g; r0 < nblk; r0 += 32 * 16) {  // (enc_l0_moment_blocks: at most 512 rows = one round, 32 loads in flight)
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = r0 + 16 * u < nblk ? part[(size_t)(r0 + 16 * u) * ENC_L0_MOM_ROW + j] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) sum += v[u];
+  }
+  red[g][j] = sum;
+  __syncthreads();
+  if (tid < ENC_L0_MOM_ROW) {
+    double t = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t += red[u][tid];
+    if (tid >= ENC_L0_MOM) t = 0.0;
+    mom[tid] = t;
+    em[tid] = t / M;
+  }
+  __syncthreads();
+  if (tid == 0 && nbt) *nbt += 1;
+  if (tid >= 32) return;
+  const int c = tid;
+  double wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = (double)w[c * 9 + t];
+  double lin = 0.0, quad = 0.0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    lin += wt[t] * em[t];
+#pragma unroll
+    for (int u = t; u < 9; ++u) {
+      const double cov = em[enc_l0_pair_index(t, u)] - em[t] * em[u];
+      quad += (u == t ? 1.0 : 2.0) * wt[t] * wt[u] * cov;
+    }
+  }
+  const double mu = lin + (double)bias[c];
+  const double var = quad < 0.0 ? 0.0 : quad;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+  if (rm) {  // torch: running = (1 - momentum) * running + momentum * batch, unbiased variance
+    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+    rm[c] = (float)((1.0 - (double)BN_MOMENTUM) * (double)rm[c] + (double)BN_MOMENTUM * mu);
+    rv[c] = (float)((1.0 - (double)BN_MOMENTUM) * (double)rv[c] + (double)BN_MOMENTUM * unbiased);
+  }
+}
+
+int launch_enc_l0_moments(const float* images, int64_t B, const float* w, const float* bias, double* part, double* mom,
+                          float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s) {
+  const int nblk = enc_l0_moment_blocks(B);
+  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_moments_kernel, dim3((unsigned)nblk), dim3(256), 0, s, images, B, part);
+  DVG_LAUNCH(K_BN_FINALIZE, enc_l0_moments_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, nblk,
+             (double)B * 1024.0, w, bias, mom, mean, invstd, rm, rv, nbt);
+  return DVG_OK;
+}
+
+// tot [ENC_L0_ROW]: the column sums of MODE 4's partials; mom: the patch moments of the forward call.  One block: every
+// gradient of the stage.  T1[t] = S[t] (t = 9, the bias column of ones: M);
+// T2[co][t] = sum zhat[co] in_t = invstd (sum_t' w[co][t'] P[t'][t] + (b - mu) S[t])  (t = 9: invstd (w . S + (b - mu) M))
+__global__ __launch_bounds__(320) void enc_l0_combine_kernel(const float* __restrict__ tot, const double* __restrict__ mom,
+                                                             const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                             const float* __restrict__ mean, const float* __restrict__ gamma,
+                                                             const float* __restrict__ invstd, double M,
                                                              float* __restrict__ gw, float* __restrict__ gb,
                                                              float* __restrict__ g_bn_b, float* __restrict__ g_bn_g) {
   const int w = threadIdx.x;  // [0, 288): weight (co, t) = (w / 9, w % 9); [288, 320): bias of co = w - 288 (column 9)
   const int co = w < 288 ? w / 9 : w - 288, t = w < 288 ? w % 9 : 9;
-  const float sum_dz = tot[288 + co], sum_dzzh = tot[650 + co];
-  const float m1 = sum_dz * inv_m, m2 = sum_dzzh * inv_m, gi = gamma[co] * invstd[co];
-  const float v = gi * (tot[w] - m1 * tot[640 + t] - m2 * tot[320 + w]);
+  const float sum_dz = tot[288 + co], sum_dzzh = tot[320 + co];
+  const double m1 = (double)sum_dz / M, m2 = (double)sum_dzzh / M;
+  const double shift = (double)bias[co] - (double)mean[co];
+  double t1, t2 = 0.0;
+  if (t < 9) {
+    t1 = mom[t];
+    for (int u = 0; u < 9; ++u) t2 += (double)wgt[co * 9 + u] * mom[u <= t ? enc_l0_pair_index(u, t) : enc_l0_pair_index(t, u)];
+    t2 += shift * mom[t];
+  } else {
+    t1 = M;
+    for (int u = 0; u < 9; ++u) t2 += (double)wgt[co * 9 + u] * mom[u];
+    t2 += shift * M;
+  }
+  t2 *= (double)invstd[co];
+  const float v = (float)((double)gamma[co] * (double)invstd[co] * ((double)tot[w] - m1 * t1 - m2 * t2));
   if (w < 288) gw[w] = v;
   else { gb[co] = v; g_bn_b[co] = sum_dz; g_bn_g[co] = sum_dzzh; }
 }
 
-int launch_enc_l0_combine(const float* tot, const float* gamma, const float* invstd, int64_t B, float* gw, float* gb,
-                          float* g_bn_b, float* g_bn_g, hipStream_t s) {
-  DVG_LAUNCH(K_MISC, enc_l0_combine_kernel, dim3(1), dim3(320), 0, s, tot, gamma, invstd, (float)(1.0 / ((double)B * 1024.0)), gw,
-             gb, g_bn_b, g_bn_g);
+int launch_enc_l0_combine(const float* tot, const double* mom, const float* w, const float* bias, const float* mean,
+                          const float* gamma, const float* invstd, int64_t B, float* gw, float* gb, float* g_bn_b,
+                          float* g_bn_g, hipStream_t s) {
+  DVG_LAUNCH(K_MISC, enc_l0_combine_kernel, dim3(1), dim3(320), 0, s, tot, mom, w, bias, mean, gamma, invstd, (double)B * 1024.0,
+             gw, gb, g_bn_b, g_bn_g);
   return DVG_OK;
 }
 

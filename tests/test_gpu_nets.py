@@ -66,8 +66,11 @@ def test_encoder_matches_reference_fixture(fx):
 
 def test_encoder_layer0_recomputed_equals_stored():
     """Layer 0 recomputed by every pass (option enc_l0_fused = 1, the default: csrc/special.hip enc_l0_kernel) against the
-    stored form of rounds 1-2: the forward is the same arithmetic in the same order (bit-identical logits, training and
-    evaluation mode, and the same running statistics); the backward sums run over another partition of the pixels."""
+    stored form of rounds 1-2.  Evaluation mode: the same arithmetic in the same order, bit-identical logits.  Training
+    mode: the recomputed form takes the layer's batch statistics from the first and second moments of the 3x3 input patches
+    (double; the statistics of the exact layer output) where the stored form sums its float32 output, so mean and variance
+    agree to float32 rounding, not bit for bit; the backward sums run over another partition of the pixels and take
+    sum zhat (x) in_t from the same moments."""
     n, B = 64, 96
     params = gen.make_params(n, "encoder", 121)
     x = torch.from_numpy(gen.make_images(B, 232)).cuda()
@@ -81,13 +84,17 @@ def test_encoder_layer0_recomputed_equals_stored():
             lg = enc(x)
             (lg * gl).sum().backward()
             out[fused] = (ev, lg.detach().cpu(), {k: v.grad.detach().cpu() for k, v in enc.named_parameters()},
-                          {k: v.detach().cpu() for k, v in enc.state_dict().items() if "running" in k})
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
-    for k, v in out[0][3].items():
-        assert torch.equal(v, out[1][3][k]), k
+                          {k: v.detach().cpu() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k})
+    assert torch.equal(out[0][0], out[1][0])
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(out[1][1], out[0][1]) < 2e-6, rel(out[1][1], out[0][1])
+    for k, v in out[0][3].items():
+        if "num_batches" in k:
+            assert torch.equal(v, out[1][3][k]), k
+        else:
+            assert float((v.double() - out[1][3][k].double()).abs().max()) <= 2e-7 * float(v.double().abs().max()) + 1e-9, k
     for k, g in out[0][2].items():
-        if k == "conv.0.bias":
+        if k.startswith("conv.") and k.endswith(".bias"):
             continue  # a conv bias in front of a BatchNorm: zero true gradient, rounding noise only
         assert rel(out[1][2][k], g) < 2e-5, (k, rel(out[1][2][k], g))
 
