@@ -757,7 +757,7 @@ __device__ __forceinline__ void mmd_main_body(const MmdArgs& a, float* smem, int
 //     +-1 are exact and accumulation is f32, i.e. the same arithmetic as the f32 path at 16x the MFMA rate.
 // The weights never leave registers: the Gram accumulator layout (row j = (r&3) + 8(r>>2) + 4h, col i = lane&31) is
 // reused as the B operand of the gradient GEMM under the k-permutation j = 16s + 8(e>>2) + 4h + (e&3); the A operand
-// comes from a bf16 copy of the rows written transposed and in that same k order (mmd_prep_zt_kernel).
+// comes from a bf16 copy of the rows written transposed and in that same k order (mmd_prep_fused_kernel).
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -822,39 +822,76 @@ __global__ __launch_bounds__(256) void mmd_bandwidth_table_kernel(MmdArgs a, con
   for (int h = threadIdx.x; h <= a.d; h += 256) mmd_table_entry(a, ck, h, tab);
 }
 
-// bf16 transposed copy: zt[(jb * d + f) * 32 + 16 s + 8 h + e] = row[32 jb + 16 s + 8 (e>>2) + 4 h + (e&3)][f]
-// (zero beyond the last row).  One thread per (jb, f): 32 strided reads, coalesced over f, one 64-byte write.
-__global__ __launch_bounds__(256) void mmd_prep_zt_kernel(MmdArgs a, uint16_t* __restrict__ zt, int zero_loss_parts) {
-  // (the loss partials the pair kernels of this call will NOT write must read as zero in the final sum: cleared here
-  // rather than by a memset node of its own)
-  for (int64_t e = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; e < 3 * (int64_t)zero_loss_parts;
-       e += (int64_t)gridDim.x * gridDim.y * 256)
+// Both preparation passes in one (plans with the +-1 path, d <= 1024): block jb owns the 32 rows of zt block jb.  Wave w
+// takes rows w, w + 4, ..: the loads of its eight rows go out together (the one-row-per-wave form of mmd_prep_kernel had
+// two 16-byte loads in flight per lane: 1.2 TB/s, and the transposed copy then re-read the int8 rows byte by byte:
+// 54 + 71 us at the head of c3's MMD chain, which IS the step's critical chain).  Row norms: the arithmetic and the
+// order of mmd_prep_kernel (same bits).  The int8 signs go to global memory and to LDS, from where thread f gathers
+// its 32 rows for the bf16 block.  (The transposed copy is written whatever the rows hold: it is only read when the
+// flag says +-1.)
+__global__ __launch_bounds__(256) void mmd_prep_fused_kernel(MmdArgs a, float* __restrict__ sq, int8_t* __restrict__ zi8,
+                                                             int* __restrict__ not_pm1, uint16_t* __restrict__ zt,
+                                                             int zero_loss_parts) {
+  extern __shared__ __align__(16) unsigned char prep_smem[];  // int8 signs [32][d + 16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = a.d, pitch = d + 16;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + tid; e < 3 * (int64_t)zero_loss_parts; e += (int64_t)gridDim.x * 256)
     a.loss_part[e] = 0.0;
-  if (*a.not_pm1 != 0) return;
-  const int64_t jb = blockIdx.y;
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= a.d) return;
+  const int64_t jb = blockIdx.x;
   const bool is_x = jb < a.ztb_y;
-  const int8_t* z8 = is_x ? a.zi8 : a.zi8 + a.nx * (int64_t)a.d;
-  const int64_t cnt = is_x ? a.nx : a.ny;
-  const int64_t row0 = (is_x ? jb : jb - a.ztb_y) * 32;
-  uint32_t packed[16];
+  const int64_t cnt = is_x ? a.nx : a.ny, row0 = (is_x ? jb : jb - a.ztb_y) * 32, goff = is_x ? 0 : a.nx;
+  const float* src = is_x ? a.x : a.y;
+  float acc[8];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    uint32_t v = 0;
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  bool bad = false;
+  for (int k = lane; k < d / 4; k += 64) {
+    float4 v[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int k = 2 * q + half, s = k >> 4, hh = (k >> 3) & 1, e = k & 7;
-      const int64_t row = row0 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3);
-      // (+-1 rows -- the kernel has returned otherwise: bf16(+-1) from the sign of the int8 copy, a quarter of the bytes)
-      const uint32_t b = row < cnt ? (z8[row * a.d + f] > 0 ? 0x3f80u : 0xbf80u) : 0u;
-      v |= b << (16 * half);
+    for (int u = 0; u < 8; ++u) {
+      const int64_t row = row0 + wave + 4 * u;
+      v[u] = row < cnt ? *reinterpret_cast<const float4*>(src + row * d + 4 * k) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    packed[q] = v;
-  }
-  uint4* dst = reinterpret_cast<uint4*>(zt + (jb * a.d + f) * 32);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+    for (int u = 0; u < 8; ++u) {
+      const int64_t row = row0 + wave + 4 * u;
+      const float4 w = v[u];
+      acc[u] = fmaf(w.x, w.x, acc[u]); acc[u] = fmaf(w.y, w.y, acc[u]); acc[u] = fmaf(w.z, w.z, acc[u]); acc[u] = fmaf(w.w, w.w, acc[u]);
+      bad |= !(w.x == 1.0f || w.x == -1.0f) | !(w.y == 1.0f || w.y == -1.0f) | !(w.z == 1.0f || w.z == -1.0f) | !(w.w == 1.0f || w.w == -1.0f);
+      const uint32_t z = (w.x > 0.f ? 0x01u : 0xffu) | (w.y > 0.f ? 0x0100u : 0xff00u) | (w.z > 0.f ? 0x010000u : 0xff0000u) |
+                         (w.w > 0.f ? 0x01000000u : 0xff000000u);
+      *reinterpret_cast<uint32_t*>(prep_smem + (wave + 4 * u) * pitch + 4 * k) = z;
+      if (row < cnt) reinterpret_cast<uint32_t*>(zi8 + (goff + row) * d)[k] = z;
+    }
+  }
+  if (__any(bad) && lane == 0) atomicOr(not_pm1, 1);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    float t = acc[u];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    const int64_t row = row0 + wave + 4 * u;
+    if (lane == 0 && row < cnt) sq[goff + row] = t;
+  }
+  __syncthreads();
+  // zt[(jb * d + f) * 32 + 16 s + 8 h + e] = row[32 jb + 16 s + 8 (e >> 2) + 4 h + (e & 3)][f]  (zero beyond the last row)
+  for (int f = tid; f < d; f += 256) {
+    uint32_t packed[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int k = 2 * q + half, sgrp = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+        const int r = 16 * sgrp + 8 * (e >> 2) + 4 * hh + (e & 3);
+        const uint32_t b = row0 + r < cnt ? ((int8_t)prep_smem[r * pitch + f] > 0 ? 0x3f80u : 0xbf80u) : 0u;
+        v |= b << (16 * half);
+      }
+      packed[q] = v;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(zt + (jb * d + f) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+  }
 }
 
 template <int NFB>
@@ -2085,8 +2122,6 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   // Two implementations of the pair kernels are enqueued back to back and gate themselves on a device flag the prep
   // kernel writes (are all entries exactly +-1?), so no host synchronisation is needed to choose between them.
   DVG_CHECK_HIP(hipMemsetAsync(w + p.off_flag, 0, sizeof(int), s));
-  DVG_LAUNCH(K_MMD_PREP, mmd_prep_kernel, dim3((unsigned)ceil_div(nx + ny, 4)), dim3(256), 0, s, x, nx, y, ny, dim,
-             (float*)(w + p.off_sq), (int8_t*)(w + p.off_zi8), (int*)(w + p.off_flag));
   int loss_parts = (int)(p.S * (p.rbx + p.rby));
   if (p.w128) {
     // (the 128-row-block pair kernel and the float32 kernel behind it number their loss partials by their own grids and
@@ -2094,9 +2129,14 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
     if ((int)(p.S2 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * (p.rb128x + p.rb128y));
     if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
   }
-  if (p.pm1_ok)
-    DVG_LAUNCH(K_MMD_PREP, mmd_prep_zt_kernel, dim3((unsigned)ceil_div(dim, 256), (unsigned)(p.ztb_x + p.ztb_y)),
-               dim3(256), 0, s, a, (uint16_t*)(w + p.off_zt), p.w128 ? loss_parts : 0);
+  if (p.pm1_ok) {  // row norms, int8 copy, +-1 flag and the transposed bf16 copy in one pass over the rows
+    DVG_LAUNCH(K_MMD_PREP, mmd_prep_fused_kernel, dim3((unsigned)(p.ztb_x + p.ztb_y)), dim3(256), (size_t)32 * (dim + 16), s, a,
+               (float*)(w + p.off_sq), (int8_t*)(w + p.off_zi8), (int*)(w + p.off_flag), (uint16_t*)(w + p.off_zt),
+               p.w128 ? loss_parts : 0);
+  } else {
+    DVG_LAUNCH(K_MMD_PREP, mmd_prep_kernel, dim3((unsigned)ceil_div(nx + ny, 4)), dim3(256), 0, s, x, nx, y, ny, dim,
+               (float*)(w + p.off_sq), (int8_t*)(w + p.off_zi8), (int*)(w + p.off_flag));
+  }
   int ndist = 0;
   if (!(cfg->bandwidth > 0.f)) {
     ndist = (int)(p.S1 * p.GX1);
