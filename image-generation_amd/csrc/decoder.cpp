@@ -158,7 +158,7 @@ DecPlan dec_plan(int64_t N, int n) {
   p.slabs = bump(o, max_slab);
   p.partA = bump(o, (size_t)EW_BLOCKS * 2 * cmax);
   // one bias-gradient partial buffer per layer: their column sums run on the side stream, behind the main chain
-  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)(l == 2 ? STREAM_BLOCKS : EW_BLOCKS) * ch[l + 1]);  // (l = 2: rows of the fused tail)
+  for (int l = 0; l < 4; ++l) p.partB[l] = bump(o, (size_t)(l >= 2 ? STREAM_BLOCKS : EW_BLOCKS) * ch[l + 1]);  // (l = 2, 3: rows of the fused tail)
   p.partL = bump(o, (size_t)EW_BLOCKS * cmax);
   p.partF = bump(o, (size_t)EW_BLOCKS * 10);
   p.partW = bump(o, (size_t)STREAM_BLOCKS * 288);
@@ -343,12 +343,17 @@ extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const fl
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
                                p->bn_rm[l], p->bn_rv[l], p->bn_nbt[l], s));
     const float* mask = training ? W + pl.mask[l] : nullptr;
-    if (l == 2 && pl.tail) continue;
+    if ((l == 2 || l == 3) && pl.tail) continue;  // (activated by the next layer's kernels while they stage their input)
     DVG_TRY(launch_dec_bn_act_fwd(W + pl.Y[l], pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                   p->bn_b[l], mask, W + pl.Xs[l], s));
     x = W + pl.Xs[l];
   }
-  DVG_TRY(launch_dec_final_fwd(x, N, p->conv_w[4], p->conv_b[4], out, s));
+  if (pl.tail) {
+    const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], training ? W + pl.mask[3] : nullptr};
+    DVG_TRY(launch_dec_final_fwd_act(in3, N, p->conv_w[4], p->conv_b[4], out, s));
+  } else {
+    DVG_TRY(launch_dec_final_fwd(x, N, p->conv_w[4], p->conv_b[4], out, s));
+  }
   return DVG_OK;
 }
 
@@ -394,14 +399,15 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
   {
     hipEvent_t start = nullptr;
     if (s2 != s) DVG_TRY(stream_mark(s, &start));
-    if (pl.tail) {  // ... with the 1-channel stage's BatchNorm-backward sums formed on the way (no reduce pass below)
-      const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
-      DVG_TRY(launch_dec_final_dgrad_bn(grad_out, N, p->conv_w[4], dX, in3, partA, s));
+    const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
+    if (pl.tail) {  // ... as the 1-channel stage's BatchNorm-backward sums (no reduce pass below; dX itself is not stored)
+      DVG_TRY(launch_dec_final_dgrad_bn(grad_out, N, p->conv_w[4], in3, partA, s));
     } else {
       DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
     }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, start));
-    DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
+    if (pl.tail) DVG_TRY(launch_dec_final_wgrad_act(in3, N, grad_out, W + pl.partF, s2));  // (Xs[3] does not exist)
+    else DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
     DVG_REQUIRE(sums.add2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4]), "decoder_bwd: column-sum batch full");
   }
 
@@ -417,11 +423,15 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       // the (sum dz, sum dz zhat) partials came out of layer 3's fused backward below; dY2 = its second pass
       DVG_TRY(launch_colsum2(partA, dec_tail_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_conv3_bwd_apply(in2, N, W + pl.dYl[3], p->conv_w[3], g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+    } else if (l == 3 && pl.tail) {
+      // the 1-channel stage: its sums came out of the final layer's data-gradient pass above; dY3 = that pass again
+      const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
+      DVG_TRY(launch_colsum2(partA, dec_final_dgrad_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      DVG_TRY(launch_dec_final_dgrad_apply(grad_out, N, p->conv_w[4], in3, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     } else {
-      if (!(l == 3 && pl.tail))
-        DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
-                                             p->bn_b[l], mask, dX, partA, s));
-      DVG_TRY(launch_colsum2(partA, (l == 3 && pl.tail) ? dec_final_dgrad_blocks(N) : EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
+                                           p->bn_b[l], mask, dX, partA, s));
+      DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
       DVG_TRY(launch_dec_bn_act_bwd_apply(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                           p->bn_b[l], mask, dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     }
@@ -475,7 +485,7 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
       const int w3_blocks = stream_blocks(N);  // partial rows of the weight gradient
       if (pl.tail) DVG_TRY(launch_dec_conv3_bwd_reduce(in2, N, dY, p->conv_w[3], partW, partA, s));
       else DVG_TRY(launch_dec_conv3_bwd(xin, N, dY, p->conv_w[3], dX, partW, s));
-      DVG_REQUIRE(sums.add(W + pl.partB[l], EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
+      DVG_REQUIRE(sums.add(W + pl.partB[l], pl.tail ? dec_final_dgrad_blocks(N) : EW_BLOCKS, C, C, 1.0f, g->conv_b[l], 0, 0) &&
                   sums.add(partW, w3_blocks, 288, 288, 1.0f, g->conv_w[3], 32, 9),  // [tap][ci] -> [ci][tap]
                   "decoder_bwd: column-sum batch full");
       continue;

@@ -131,8 +131,11 @@ int launch_dec_conv3_fwd_act(const DecActIn& in, int64_t N, const float* w, cons
 int dec_tail_blocks(int64_t N);
 // the final layer's data gradient with the 1-channel stage's (sum dz, sum dz zhat) partials [dec_final_dgrad_blocks][2]
 int dec_final_dgrad_blocks(int64_t N);
-int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, float* dX, const DecActIn& in, float* part,
-                              hipStream_t s);
+int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, const DecActIn& in, float* part, hipStream_t s);
+// ... and the stage's dY [N*256] once the sums are known (the data gradient is formed again; it is never stored), with the
+// block sums of dY in part_db [dec_final_dgrad_blocks][1]
+int launch_dec_final_dgrad_apply(const float* dOut, int64_t N, const float* w, const DecActIn& in, const float* sum_dz,
+                                 const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);
 int launch_dec_conv3_bwd_reduce(const DecActIn& in, int64_t N, const float* dY3, const float* w, float* part_w, float* part_bn,
                                 hipStream_t s);
 int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, const float* w, const float* sum_dz,
@@ -145,6 +148,10 @@ int dec_conv3_blocks(int64_t N);
 int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float* w, float* dX, float* part, hipStream_t s);
 // decoder final ConvTranspose2d(1,1) at 32x32 from the upsampled 16x16 map; row-major output
 int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s);
+// ... with its input given as the 1-channel stage's pre-BatchNorm output (C = 1 DecActIn; mask [N] or null): activated
+// while it is staged (forward and weight gradient), so that stage's activated map is never written
+int launch_dec_final_fwd_act(const DecActIn& in, int64_t N, const float* w, const float* b, float* out, hipStream_t s);
+int launch_dec_final_wgrad_act(const DecActIn& in, int64_t N, const float* dOut, float* part, hipStream_t s);
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s);
 // part [EW_BLOCKS][10]: d w[0..8], d b
 int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s);

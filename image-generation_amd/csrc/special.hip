@@ -967,10 +967,20 @@ int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, 
 // One image per block iteration, its 16x16 source map in LDS with a zero halo (row-major 18x18): a thread produces 4
 // consecutive output pixels of a row from 3 x 4 source values (the nearest upsample makes neighbouring outputs share
 // them) and stores one float4 -- instead of 36 bounds-checked global gathers.
-__global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restrict__ X, int64_t N,
+// ACT (round 5): the source map arrives as the 1-channel stage's pre-BatchNorm output (DecActIn, C = 1) and is activated
+// while it is staged -- dec_bn_act_fwd's arithmetic, element for element -- so that stage's activated map is never written.
+__device__ __forceinline__ float dec_act1(float y, float mu, float is, float gm, float bt, const float* mask, int64_t img) {
+  float z = fmaf((y - mu) * is, gm, bt);
+  if (mask) z *= mask[img] * (1.0f / DROPOUT_KEEP);
+  return z < 0.f ? z * LRELU_SLOPE : z;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restrict__ X, DecActIn in, int64_t N,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ out) {
   __shared__ float xs[18 * 18];
+  const float mu = ACT ? in.mean[0] : 0.f, is = ACT ? in.invstd[0] : 0.f, gm = ACT ? in.gamma[0] : 0.f, bt = ACT ? in.beta[0] : 0.f;
   const int tid = threadIdx.x;
   float wv[9];
 #pragma unroll
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restr
   const int y = tid >> 3, x0 = (tid & 7) * 4;
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();
-    xs[(sy_ + 1) * 18 + sx_ + 1] = X[img * 256 + tid];
+    xs[(sy_ + 1) * 18 + sx_ + 1] = ACT ? dec_act1(in.y[img * 256 + tid], mu, is, gm, bt, in.mask, img) : X[img * 256 + tid];
     __syncthreads();
     float acc[4] = {bb, bb, bb, bb};
 #pragma unroll
@@ -1000,24 +1010,39 @@ __global__ __launch_bounds__(256) void dec_final_fwd_kernel(const float* __restr
 }
 
 int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float* b, float* out, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, X, N, w, b, out);
+  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel<false>, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, X, DecActIn{},
+             N, w, b, out);
+  return DVG_OK;
+}
+
+int launch_dec_final_fwd_act(const DecActIn& in, int64_t N, const float* w, const float* b, float* out, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_final_fwd_kernel<true>, dim3((unsigned)(N > 2048 ? 2048 : N)), dim3(256), 0, s, nullptr, in, N,
+             w, b, out);
   return DVG_OK;
 }
 
 // dX[q] = sum over the quad's 4 pixels and taps of dOut(y+kh-1, x+kw-1) w[kh][kw]: a 4x4 stencil on dOut around the
 // quad with the taps pre-summed per offset (rows {w0}, {w0+w1}, {w1+w2}, {w2}, same for columns).  The image's dOut sits
 // in LDS with a zero halo (34x34); thread = source pixel.
-// BN = true (round 3): the thread that forms dX[img][q] also takes it through the 1-channel stage's Dropout / LeakyReLU
+// MODE 1 (round 3): the thread that forms dX[img][q] also takes it through the 1-channel stage's Dropout / LeakyReLU
 // backward and adds its (dz, dz zhat) to the block's partials -- dec_bn_act_bwd_reduce's pass over Y, X and dX is gone
 // (the slope from the sign of the recomputed z, as in elementwise.hip).  part [blocks][2].
-template <bool BN>
+// MODE 2 (round 5): the same pass again once the two sums are known: dX is formed a second time (the image's dOut is
+// 4 KB in LDS; the stencil is 16 FMAs) and leaves as the stage's dY = gamma invstd (dz - mean(dz) - zhat mean(dz zhat)),
+// with the block's sum of dY in part [blocks][1] -- dX itself is written by neither pass (MODE 1 stopped storing it), and
+// dec_bn_act_bwd_apply's scalar pass over Y, X and dX (68 us at c3) is gone.  MODE 0: the plain data gradient.
+template <int MODE>
 __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __restrict__ dOut, int64_t N,
                                                               const float* __restrict__ w, float* __restrict__ dX,
-                                                              DecActIn in, float* __restrict__ part) {
+                                                              DecActIn in, const float* __restrict__ sum_dz,
+                                                              const float* __restrict__ sum_dzzh, float inv_m,
+                                                              float* __restrict__ part) {
+  constexpr bool BN = MODE != 0;
   __shared__ float gs[34 * 34];
   __shared__ float red[2 * 4];
   float r1 = 0.f, r2 = 0.f;
   const float mu = BN ? in.mean[0] : 0.f, is = BN ? in.invstd[0] : 0.f, gm = BN ? in.gamma[0] : 0.f, bt = BN ? in.beta[0] : 0.f;
+  const float m1 = MODE == 2 ? sum_dz[0] * inv_m : 0.f, m2 = MODE == 2 ? sum_dzzh[0] * inv_m : 0.f, gi = gm * is;
   const int tid = threadIdx.x;
   float wf[4][4];  // wf[u+1][v+1], u, v in -1..2: offset of the dOut pixel from the quad's top-left pixel
 #pragma unroll
@@ -1051,13 +1076,19 @@ __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __res
 #pragma unroll
       for (int v = 0; v < 4; ++v) acc = fmaf(row[v], wf[u][v], acc);
     }
-    dX[img * 256 + tid] = acc;
+    if (MODE == 0) dX[img * 256 + tid] = acc;
     if (BN) {
       const float zh = (in.y[img * 256 + tid] - mu) * is;
       const float mk = in.mask ? in.mask[img] * (1.0f / DROPOUT_KEEP) : 1.0f;
       const float dz = acc * ((fmaf(zh, gm, bt) > 0.f) ? 1.0f : LRELU_SLOPE) * mk;
-      r1 += dz;
-      r2 = fmaf(dz, zh, r2);
+      if (MODE == 1) {
+        r1 += dz;
+        r2 = fmaf(dz, zh, r2);
+      } else {
+        const float v = gi * (dz - m1 - zh * m2);
+        dX[img * 256 + tid] = v;  // (MODE 2: `dX` is the stage's dY)
+        r1 += v;
+      }
     }
   }
   if (BN) {
@@ -1065,22 +1096,29 @@ __global__ __launch_bounds__(256) void dec_final_dgrad_kernel(const float* __res
     for (int off = 32; off > 0; off >>= 1) { r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64); }
     if ((tid & 63) == 0) { red[tid >> 6] = r1; red[4 + (tid >> 6)] = r2; }
     __syncthreads();
-    if (tid < 2) part[(size_t)blockIdx.x * 2 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+    if (MODE == 1 && tid < 2) part[(size_t)blockIdx.x * 2 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+    if (MODE == 2 && tid == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
 int dec_final_dgrad_blocks(int64_t N) { return (int)(N > 2048 ? 2048 : N); }
 
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<false>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
-             dX, DecActIn{}, nullptr);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<0>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
+             dX, DecActIn{}, nullptr, nullptr, 0.f, nullptr);
   return DVG_OK;
 }
 
-int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, float* dX, const DecActIn& in, float* part,
-                              hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<true>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
-             dX, in, part);
+int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, const DecActIn& in, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<1>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut, N, w,
+             nullptr, in, nullptr, nullptr, 0.f, part);
+  return DVG_OK;
+}
+
+int launch_dec_final_dgrad_apply(const float* dOut, int64_t N, const float* w, const DecActIn& in, const float* sum_dz,
+                                 const float* sum_dzzh, float* dY, float* part_db, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_dgrad_kernel<2>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, dOut,
+             N, w, dY, in, sum_dz, sum_dzzh, (float)(1.0 / ((double)N * 256.0)), part_db);
   return DVG_OK;
 }
 
@@ -1090,9 +1128,11 @@ int launch_dec_final_dgrad_bn(const float* dOut, int64_t N, const float* w, floa
 // all fall in that pixel's 3x3 neighbourhood: 9 LDS reads + 36 FMAs per thread and image, the next image's global
 // loads in flight meanwhile.  (The per-output-pixel form -- 9 guarded, Morton-addressed global gathers per element --
 // took 1.1 ms at c3, 17x its HBM time.)
-__global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __restrict__ X, int64_t N,
+template <bool ACT>
+__global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __restrict__ X, DecActIn in, int64_t N,
                                                               const float* __restrict__ dOut, float* __restrict__ part) {
   __shared__ float Xs[2][18 * 18];
+  const float mu = ACT ? in.mean[0] : 0.f, is = ACT ? in.invstd[0] : 0.f, gm = ACT ? in.gamma[0] : 0.f, bt = ACT ? in.beta[0] : 0.f;
   __shared__ float red[10 * 256];
   const int tid = threadIdx.x;
   for (int e = tid; e < 2 * 18 * 18; e += 256) (&Xs[0][0])[e] = 0.f;  // borders stay zero
@@ -1106,7 +1146,7 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
   float xv = 0.f;
   float2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f};
   if (img < N) {
-    xv = X[img * 256 + tid];
+    xv = ACT ? dec_act1(in.y[img * 256 + tid], mu, is, gm, bt, in.mask, img) : X[img * 256 + tid];
     g0 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i) * 32 + 2 * j);
     g1 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i + 1) * 32 + 2 * j);
   }
@@ -1115,7 +1155,7 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
     const float g[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
     const int64_t nimg = img + gridDim.x;
     if (nimg < N) {
-      xv = X[nimg * 256 + tid];
+      xv = ACT ? dec_act1(in.y[nimg * 256 + tid], mu, is, gm, bt, in.mask, nimg) : X[nimg * 256 + tid];
       g0 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i) * 32 + 2 * j);
       g1 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i + 1) * 32 + 2 * j);
     }
@@ -1153,7 +1193,12 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
 }
 
 int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, X, N, dOut, part);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel<false>, dim3(EW_BLOCKS), dim3(256), 0, s, X, DecActIn{}, N, dOut, part);
+  return DVG_OK;
+}
+
+int launch_dec_final_wgrad_act(const DecActIn& in, int64_t N, const float* dOut, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel<true>, dim3(EW_BLOCKS), dim3(256), 0, s, nullptr, in, N, dOut, part);
   return DVG_OK;
 }
 
