@@ -6,24 +6,25 @@ namespace dvg {
 
 // ---------------------------------------------------------------- Gumbel-softmax, 2 classes
 // Plugin default latent_to_discrete (call site /root/reference/src/model_wrapper.py:184-188, :297).
+// Device-drawn Gumbel noise of element e from its 32-bit words w0, w1.  One Philox call serves TWO elements (e even:
+// words x, y; e odd: z, w): the counter is e >> 1.
+// u = (k + 1/2) 2^-23 with k the top 23 bits: every value is exact in float32 and strictly inside (0, 1), so the
+// Gumbel noise is finite (|g| < 17.4).  A 24-bit k does NOT work: 16777215 + 0.5 rounds to 2^24, u = 1, g = +inf,
+// and (inf - inf) in the softmax below poisons the whole encoder gradient -- a 2^-24 event per draw, i.e. a few
+// per cent per training step at B R n = 2.6e5 (found by a soak run; regression test in tests/test_gpu_losses.py).
+// The noise is a SAMPLE (no counterpart in the reference to agree with bit for bit): the hardware logarithm
+// (v_log_f32, 1 ulp) instead of logf's longer form.  -log u >= 2^-24 for every u above; the clamp keeps a rounding
+// of the hardware result towards zero from reaching log(0).
+__device__ __forceinline__ float gumbel_from_word(uint32_t w) {
+  const float u = __fmul_rn(__uint2float_rn(w >> 9) + 0.5f, 1.1920928955078125e-07f);
+  return -__logf(fmaxf(-__logf(u), 2.98023224e-08f));
+}
+__device__ __forceinline__ u32x4 gumbel_words(int64_t pair, uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi) {
+  return philox4x32_10((uint32_t)pair, off_lo, off_hi ^ (uint32_t)(pair >> 32), STREAM_GUMBEL, k0, k1);
+}
+
 // one element of the Gumbel-softmax (2 classes): spin = argmax, dspin = d p0 / d logit * 2
-__device__ __forceinline__ void gumbel_element(float l, int64_t e, const float* __restrict__ gumbels, uint32_t k0, uint32_t k1,
-                                               uint32_t off_lo, uint32_t off_hi, float tau, float& spin, float& ds) {
-  float g0, g1;
-  if (gumbels) {
-    g0 = gumbels[2 * e];
-    g1 = gumbels[2 * e + 1];
-  } else {
-    const u32x4 r = philox4x32_10((uint32_t)e, off_lo, off_hi ^ (uint32_t)(e >> 32), STREAM_GUMBEL, k0, k1);
-    // u = (k + 1/2) 2^-23 with k the top 23 bits: every value is exact in float32 and strictly inside (0, 1), so the
-    // Gumbel noise is finite (|g| < 17).  A 24-bit k does NOT work: 16777215 + 0.5 rounds to 2^24, u = 1, g = +inf,
-    // and (inf - inf) in the softmax below poisons the whole encoder gradient -- a 2^-24 event per draw, i.e. a few
-    // per cent per training step at B R n = 2.6e5 (found by a soak run; regression test in tests/test_gpu_losses.py).
-    const float u0 = __fmul_rn(__uint2float_rn(r.x >> 9) + 0.5f, 1.1920928955078125e-07f);
-    const float u1 = __fmul_rn(__uint2float_rn(r.y >> 9) + 0.5f, 1.1920928955078125e-07f);
-    g0 = -logf(-logf(u0));
-    g1 = -logf(-logf(u1));
-  }
+__device__ __forceinline__ void gumbel_softmax2(float l, float g0, float g1, float tau, float& spin, float& ds) {
   const float y0 = __fdiv_rn(__fadd_rn(l, g0), tau);
   const float y1 = __fdiv_rn(g1, tau);
   const float m = fmaxf(y0, y1);
@@ -33,7 +34,8 @@ __device__ __forceinline__ void gumbel_element(float l, int64_t e, const float* 
   ds = 2.0f * p0 * (1.0f - p0) / tau;
 }
 
-// four consecutive latent units per thread (n % 4 == 0): one 16-byte load of the logits, two 16-byte stores
+// four consecutive latent units per thread (n % 4 == 0): one 16-byte load of the logits, two 16-byte stores, two Philox
+// calls (or two 16-byte loads of injected noise)
 __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, int64_t B, int n, int R,
                                                          float tau, const float* __restrict__ gumbels,
                                                          uint32_t k0, uint32_t k1, uint32_t off_lo, uint32_t off_hi,
@@ -42,16 +44,28 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict
   if (off_dev) { const uint64_t o = *off_dev; off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32); }
   const int n4 = n >> 2;
   const int64_t total4 = B * R * (int64_t)n4;
+  const bool small = total4 < (int64_t)1 << 31;  // (uniform: 32-bit index arithmetic -- two 64-bit divisions by run-time
+                                                 // values were a fifth of this kernel's instructions)
+  const uint32_t n4u = (uint32_t)n4, n4r = (uint32_t)n4 * (uint32_t)R;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (int64_t)gridDim.x * 256) {
-    const int i4 = (int)(q % n4);
-    const int64_t b = q / ((int64_t)n4 * R);
+    const int i4 = small ? (int)((uint32_t)q % n4u) : (int)(q % n4);
+    const int64_t b = small ? (int64_t)((uint32_t)q / n4r) : q / ((int64_t)n4 * R);
     const float4 l = *reinterpret_cast<const float4*>(logits + b * n + 4 * i4);
     const int64_t e = 4 * q;
+    float g[8];
+    if (gumbels) {
+      const float4 a = *reinterpret_cast<const float4*>(gumbels + 2 * e), c = *reinterpret_cast<const float4*>(gumbels + 2 * e + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = c.x; g[5] = c.y; g[6] = c.z; g[7] = c.w;
+    } else {
+      const u32x4 r0 = gumbel_words(e >> 1, k0, k1, off_lo, off_hi), r1 = gumbel_words((e >> 1) + 1, k0, k1, off_lo, off_hi);
+      g[0] = gumbel_from_word(r0.x); g[1] = gumbel_from_word(r0.y); g[2] = gumbel_from_word(r0.z); g[3] = gumbel_from_word(r0.w);
+      g[4] = gumbel_from_word(r1.x); g[5] = gumbel_from_word(r1.y); g[6] = gumbel_from_word(r1.z); g[7] = gumbel_from_word(r1.w);
+    }
     float4 sp, ds;
-    gumbel_element(l.x, e, gumbels, k0, k1, off_lo, off_hi, tau, sp.x, ds.x);
-    gumbel_element(l.y, e + 1, gumbels, k0, k1, off_lo, off_hi, tau, sp.y, ds.y);
-    gumbel_element(l.z, e + 2, gumbels, k0, k1, off_lo, off_hi, tau, sp.z, ds.z);
-    gumbel_element(l.w, e + 3, gumbels, k0, k1, off_lo, off_hi, tau, sp.w, ds.w);
+    gumbel_softmax2(l.x, g[0], g[1], tau, sp.x, ds.x);
+    gumbel_softmax2(l.y, g[2], g[3], tau, sp.y, ds.y);
+    gumbel_softmax2(l.z, g[4], g[5], tau, sp.z, ds.z);
+    gumbel_softmax2(l.w, g[6], g[7], tau, sp.w, ds.w);
     *reinterpret_cast<float4*>(spins + e) = sp;
     *reinterpret_cast<float4*>(dspin + e) = ds;
   }
@@ -68,8 +82,14 @@ __global__ __launch_bounds__(256) void gumbel_fwd_scalar_kernel(const float* __r
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e % n);
     const int64_t b = e / ((int64_t)n * R);
-    float sp, ds;
-    gumbel_element(logits[b * n + i], e, gumbels, k0, k1, off_lo, off_hi, tau, sp, ds);
+    float sp, ds, g0, g1;
+    if (gumbels) {
+      g0 = gumbels[2 * e]; g1 = gumbels[2 * e + 1];
+    } else {
+      const u32x4 r = gumbel_words(e >> 1, k0, k1, off_lo, off_hi);
+      g0 = gumbel_from_word((e & 1) ? r.z : r.x); g1 = gumbel_from_word((e & 1) ? r.w : r.y);
+    }
+    gumbel_softmax2(logits[b * n + i], g0, g1, tau, sp, ds);
     spins[e] = sp;
     dspin[e] = ds;
   }
@@ -216,7 +236,7 @@ extern "C" int dvg_gumbel_fwd(const float* logits, int64_t B, int n, int R, floa
                               dvg_stream_t stream) {
   DVG_REQUIRE(logits && spins && dspin, "gumbel_fwd: null argument");
   DVG_REQUIRE(B > 0 && n > 0 && R > 0 && tau > 0.f, "gumbel_fwd: B=%lld n=%d R=%d tau=%g", (long long)B, n, R, tau);
-  if (n % 4 != 0 || ((((uintptr_t)logits | (uintptr_t)spins | (uintptr_t)dspin) & 15) != 0)) {  // (e.g. a slice view)
+  if (n % 4 != 0 || ((((uintptr_t)logits | (uintptr_t)spins | (uintptr_t)dspin | (uintptr_t)gumbels) & 15) != 0)) {  // (e.g. a slice view)
     DVG_LAUNCH(K_GUMBEL_FWD, gumbel_fwd_scalar_kernel, dim3(grid_for(B * R * (int64_t)n)), dim3(256), 0, (hipStream_t)stream,
                logits, B, n, R, tau, gumbels, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
                (uint32_t)(offset >> 32), dyn ? &dyn->gumbel_offset : nullptr, spins, dspin);
