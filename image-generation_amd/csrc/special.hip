@@ -790,7 +790,7 @@ int launch_dec_conv3_bwd(const float* X, int64_t N, const float* dY, const float
 //   APPLY = true:  that layer's dY = gamma invstd (dz - mean(dz) - zhat mean(dz zhat)) and its column-sum partials
 // Together they replace dec_conv3_bwd + dec_bn_act_bwd reduce + apply of the 8x8x32 stage: 2.4 GB -> 0.9 GB at c3.
 template <bool APPLY>
-__global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, int64_t N, const float* __restrict__ dY3,
+__global__ __launch_bounds__(256) void dec_conv3_bwd_fused_kernel(DecActIn in, int64_t N, const float* __restrict__ dY3,
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ sum_dz,
                                                                   const float* __restrict__ sum_dzzh, float inv_m,
@@ -802,11 +802,13 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
   __shared__ float ws[9 * 32];  // [tap][ci]
   __shared__ float red[8 * 32 * (APPLY ? 1 : 2)];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 288; i += 288) ws[(i % 9) * 32 + i / 9] = w[i];
-  int gsrc[2][4];
+  for (int i = tid; i < 288; i += 256) ws[(i % 9) * 32 + i / 9] = w[i];
+  // (256 threads since round 5 -- the weight-gradient role no longer needs one thread per (tap, channel): four waves, three
+  // blocks per CU at this kernel's register count where the 288-thread form fitted two)
+  int gsrc[3][4];  // G[e], e = tid + 256 k < 576 = 64 source pixels x 9 taps
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = tid + 288 * k, q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
+  for (int k = 0; k < 3; ++k) {
+    const int e = tid + 256 * k < 576 ? tid + 256 * k : 0, q = e / 9, t = e % 9, kh = t / 3, kw = t % 3;
     const int ys = (int)morton_y((uint32_t)q), xq = (int)morton_x((uint32_t)q);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -814,9 +816,14 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
       gsrc[k][u] = (y >= 0 && y < 16 && x >= 0 && x < 16) ? (int)morton((uint32_t)y, (uint32_t)x) : -1;
     }
   }
-  const int tap = tid >> 5, ci = tid & 31;      // weight-gradient role
   const int q = tid >> 2, cg = (tid & 3) * 8;   // data-gradient role (tid < 256): source pixel q, channels cg .. cg + 7
-  const bool dg = tid < 256;
+  // weight-gradient role (APPLY = false), round 5: dW3[tap][ci] += sum_q G[q][tap] x[q][ci] on v_mfma_f32_16x16x4_f32 --
+  // rows = taps (9 of 16), columns = 16 channels, k = source pixels: wave w < 4 owns pixels 16 w .. 16 w + 15 (four
+  // k-steps x two channel halves = 8 MFMAs and 12 LDS reads per image where every one of the 288 threads ran 64 FMAs
+  // off 128 LDS reads: the kernel was bound by those reads and by its vector instructions, 200 us at c3 for 295 MB)
+  const int lane = tid & 63, wv = tid >> 6, mt = lane & 15, mq = lane >> 4;
+  f32x4c wacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  constexpr bool dg = true;  // (every thread has the data-gradient role)
   // per-channel constants in LDS (read as broadcast float4s where they are used: in registers they made this a 170-VGPR
   // kernel, two waves per SIMD, bound by the latency of its own loads)
   __shared__ __align__(16) float cst[7][32];  // mean, invstd, gamma, beta, gamma invstd, mean(dz), mean(dz zhat)
@@ -826,7 +833,6 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
     cst[5][tid] = APPLY ? sum_dz[tid] * inv_m : 0.f;
     cst[6][tid] = APPLY ? sum_dzzh[tid] * inv_m : 0.f;
   }
-  float acc = 0.f;
   float a1[8], a2[8];  // APPLY: a1 = column sums of dY; else (sum dz, sum dz zhat)
 #pragma unroll
   for (int k = 0; k < 8; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
@@ -876,11 +882,11 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       float g = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) g += gsrc[k][u] >= 0 ? dys[gsrc[k][u]] : 0.f;
-      G[tid + 288 * k] = g;
+      if (tid + 256 * k < 576) G[tid + 256 * k] = g;
     }
     __syncthreads();
     if (dg) {
@@ -910,12 +916,34 @@ __global__ __launch_bounds__(288) void dec_conv3_bwd_fused_kernel(DecActIn in, i
         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
-    if (!APPLY) {
-#pragma unroll 8
-      for (int qq = 0; qq < 64; ++qq) acc = fmaf(G[qq * 9 + tap], xs[qq * 32 + ci], acc);
+    if constexpr (!APPLY) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int qq = 16 * wv + 4 * s4 + mq;
+        const float av = mt < 9 ? G[qq * 9 + mt] : 0.f;
+        const float b0 = xs[qq * 32 + mt], b1 = xs[qq * 32 + 16 + mt];
+        wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, wacc[0], 0, 0, 0);
+        wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, wacc[1], 0, 0, 0);
+      }
     }
   }
-  if (!APPLY) part_w[(size_t)blockIdx.x * 288 + tid] = acc;
+  if constexpr (!APPLY) {
+    // D[row = tap][col = channel]: a lane holds rows 4 mq + r of column mt; the four waves' partial sums meet in LDS
+    __syncthreads();
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * mq + r;
+        if (row < 9) {
+          xs[(wv * 9 + row) * 32 + mt] = wacc[0][r];
+          xs[(wv * 9 + row) * 32 + 16 + mt] = wacc[1][r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 288; e += 256)  // e = tap * 32 + channel
+      part_w[(size_t)blockIdx.x * 288 + e] = (xs[0 * 288 + e] + xs[1 * 288 + e]) + (xs[2 * 288 + e] + xs[3 * 288 + e]);
+  }
   // per-block column sums over the 64 source-pixel threads of each 8-channel group: waves 0-3 hold 16 pixels x 4 groups
   // each; lanes with the same (tid & 3) share a group
   if (dg) {
@@ -950,14 +978,14 @@ int dec_tail_blocks(int64_t N) { return stream_blocks(N); }
 
 int launch_dec_conv3_bwd_reduce(const DecActIn& in, int64_t N, const float* dY3, const float* w, float* part_w, float* part_bn,
                                 hipStream_t s) {
-  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_fused_kernel<false>, dim3((unsigned)dec_tail_blocks(N)), dim3(288), 0, s, in, N, dY3,
+  DVG_LAUNCH(K_DEC_CONV3_BWD, dec_conv3_bwd_fused_kernel<false>, dim3((unsigned)dec_tail_blocks(N)), dim3(256), 0, s, in, N, dY3,
              w, nullptr, nullptr, 0.f, nullptr, part_w, part_bn);
   return DVG_OK;
 }
 
 int launch_dec_conv3_bwd_apply(const DecActIn& in, int64_t N, const float* dY3, const float* w, const float* sum_dz,
                                const float* sum_dzzh, float* dY2, float* part_db, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_conv3_bwd_fused_kernel<true>, dim3((unsigned)dec_tail_blocks(N)), dim3(288), 0, s, in, N,
+  DVG_LAUNCH(K_DEC_BN_ACT_BWD_APPLY, dec_conv3_bwd_fused_kernel<true>, dim3((unsigned)dec_tail_blocks(N)), dim3(256), 0, s, in, N,
              dY3, w, sum_dz, sum_dzzh, (float)(1.0 / ((double)N * 64.0)), dY2, nullptr, part_db);
   return DVG_OK;
 }
