@@ -221,14 +221,23 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
             "ms_per_step_median": med * 1e3, "ms_per_step_min": times[0]}
 
 
-def loss_parity():
+def loss_parity(side_mode=None):
     """The "loss parity vs CPU" half of the metric: 12 training steps on this GPU against the committed fixture of the
     reference's own ``ModelWrapper.step`` driven over the CPU oracle on identical batches, Gumbel noise and dropout
     masks (tests/golden/make_golden.py), and a sampler draw against the C restatement.  Checker only: the timed
-    region above never touches it."""
+    region above never touches it.  `side_mode` ("f32x3" / "bf16"): that operand mode's losses at each of the fixture's
+    12 training states, taken from the float32 trajectory's saved state (``parity_check_by_state``: a free run in a side
+    mode compares chaotic trajectories -- profiles/r05_fixture_knife_edge.txt), with the free run's figures beside."""
     import __graft_entry__ as entry
 
     r = entry.parity_check(steps=12)
+    if side_mode:
+        s = entry.parity_check_by_state(side_mode, steps=12)
+        return {"steps": s["steps"], "max_rel_dev": s["max_rel_dev"], "tolerance": 1e-5, "mode": side_mode,
+                "how": "each step taken from the float32 trajectory's saved training state",
+                "max_rel_dev_free_run": r["max_rel_dev"], "gibbs_spin_mismatches": r["gibbs_spin_mismatches"],
+                "gibbs_spins_checked": r["gibbs_spins_checked"],
+                "against": "tests/golden/step_n64.npz (reference step orchestration over the CPU oracle, B=8, n=64, R=2)"}
     return {"steps": r["steps"], "max_rel_dev": r["max_rel_dev"], "tolerance": 1e-5,
             "gibbs_spin_mismatches": r["gibbs_spin_mismatches"], "gibbs_spins_checked": r["gibbs_spins_checked"],
             "against": "tests/golden/step_n64.npz (reference step orchestration over the CPU oracle, B=8, n=64, R=2)"}
@@ -659,7 +668,8 @@ def main():
                 out["cpu_baseline"] = {"error": repr(exc)}
             out["loss_parity"] = loss_parity()
         if args.parity and args.gpus == 1:
-            out["loss_parity"] = dict(loss_parity(), note="12 fixture steps in this arithmetic mode (every forward / data-gradient launch)")
+            out["loss_parity"] = dict(loss_parity(args.precision if args.precision != "f32" else None),
+                                      note="12 fixture steps in this arithmetic mode (every forward / data-gradient launch)")
         if args.gpus == 1 and not args.child and not args.no_cpu_baseline and args.precision == "f32":
             out["f32x3"] = split3_run(args)
             out["bf16_inputs"] = bf16_inputs_run(args)

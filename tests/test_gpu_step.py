@@ -559,7 +559,7 @@ def test_backward_writes_parameter_gradients_into_the_flat_buffer(golden_dir):
         assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
 
 
-def test_step_losses_match_reference_orchestration_split3_mode(tmp_path, golden_dir, fx):
+def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
     """The 12-step fixture of the reference's own ``ModelWrapper.step`` under DVG_PRECISION_F32_SPLIT3 (float32 operands
     as three bf16 pieces on the bf16 MFMA): the north star's 1e-5 relative on every loss of every step, as in float32 --
     AT EVERY ONE OF THE FIXTURE'S 12 TRAINING STATES.  The float32 run (which test_step_losses_match_reference_orchestration
@@ -574,64 +574,18 @@ def test_step_losses_match_reference_orchestration_split3_mode(tmp_path, golden_
     weights by 2 lr the other way, and eight steps later one spin of 1024 flips (profiles/r05_fixture_knife_edge.txt: the
     probe that found the window).  The free run is kept below with the bars it can robustly carry: the first step exact,
     the rest tracking."""
+    import __graft_entry__ as entry
     from image_generation_amd import _lib
 
-    n, steps = int(fx["n"]), int(fx["steps"])
-    params = os.path.join(golden_dir, "step_params.yaml")
-
-    def fresh():
-        m = ModelWrapper("Advantage_system4", n_latents=n, training_parameter_file=params)
-        B = m.BATCH_SIZE
-        images = torch.from_numpy(gen.make_images(B * steps, seed=909)).reshape(steps, B, 1, 32, 32)
-        m.set_dataloader([(images[k], torch.zeros(B, dtype=torch.int64)) for k in range(steps)])
-        m.train_init(n_epochs=1)
-        m.noise_hook = lambda step: {"gumbels": torch.from_numpy(fx["gumbels"][step]),
-                                     "dropout_masks": [torch.from_numpy(fx[f"masks{l}"][step].astype(np.float32)) for l in range(4)]}
-        return m, images
-
-    def losses_of_last_step(m, k):
-        got = {"mse": m.losses["mse_losses"][-1], "dvae": m.losses["dvae_losses"][-1]}
-        if k % 10 == 0:
-            got["nll"] = float(m.last["nll"])
-        return got
-
-    def want(k):
-        w = {"mse": float(fx["mse"][k]), "dvae": float(fx["dvae"][k])}
-        if k % 10 == 0:
-            w["nll"] = float(fx["nll"][k // 10])
-        return w
-
-    lead, images = fresh()  # the float32 trajectory
-    worst = {}
-    for k in range(steps):
-        lead.save(tmp_path / "state")
-        lead.save_training_state(tmp_path / "state")
-        shadow, _ = fresh()
-        shadow.load(tmp_path / "state")
-        shadow.train_init(n_epochs=1)
-        shadow.load_training_state(tmp_path / "state")
-        _lib.set_conv_precision("f32x3")
-        try:
-            shadow.step((images[k], None), epoch=0)
-            torch.cuda.synchronize()
-        finally:
-            _lib.set_conv_precision("f32")
-        got, ref = losses_of_last_step(shadow, k), want(k)
-        for name in got:
-            dev_ = abs(got[name] - ref[name]) / abs(ref[name])
-            worst[name] = max(worst.get(name, 0.0), dev_)
-            assert dev_ <= 1e-5, (k, name, dev_)
-        del shadow
-        lead.step((images[k], None), epoch=0)
-        got = losses_of_last_step(lead, k)
-        for name in got:  # (the leading trajectory is the one the float32 test pins)
-            assert abs(got[name] - want(k)[name]) <= 1e-5 * abs(want(k)[name]), (k, name)
-    assert set(worst) == {"mse", "dvae", "nll"}
+    r = entry.parity_check_by_state("f32x3", steps=12)
+    assert set(r["max_rel_dev"]) == {"mse", "mse+mmd", "nll"}
+    for name, dev_ in r["max_rel_dev"].items():
+        assert dev_ <= 1e-5, (name, dev_)
+    for name, dev_ in r["max_rel_dev_leading_f32_run"].items():  # (the trajectory the float32 test pins)
+        assert dev_ <= 1e-5, (name, dev_)
 
     # the free run: first step at the exact bar (one forward pass separates it from the reference), every later step
     # tracking the reference (a wrong backward or update would not)
-    import __graft_entry__ as entry
-
     _lib.set_conv_precision("f32x3")
     try:
         r = entry.parity_check(steps=12)
