@@ -21,7 +21,7 @@ struct EncPlan {
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
   bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
   bool wino_w[4];             // ... its weight gradient too (conv_wino_wgrad.hip)
-  size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, mom_part, mom, splitk;
+  size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, mom_part, mom, pimg, splitk;
   int ksplit[4];
   size_t total_floats;
 };
@@ -90,6 +90,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
   // layer 0's patch moments (doubles: two floats each; 256-byte granules keep them aligned): per-block rows, then the sums
   p.mom_part = bump(o, (size_t)enc_l0_moment_blocks(B) * ENC_L0_MOM_ROW * 2);
   p.mom = bump(o, (size_t)ENC_L0_MOM_ROW * 2);
+  p.pimg = bump(o, (size_t)B * ENC_L0_PIMG);  // the zero-padded images the passes that recompute layer 0 read
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -163,9 +164,10 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.Xp = W + pl.Xp[0];
+      a0.pimg = training ? W + pl.pimg : nullptr;
       if (training)
         DVG_TRY(launch_enc_l0_moments(images, B, p->conv_w[0], p->conv_b[0], (double*)(W + pl.mom_part), (double*)(W + pl.mom),
-                                      W + pl.mean[0], W + pl.invstd[0], p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
+                                      W + pl.pimg, W + pl.mean[0], W + pl.invstd[0], p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
       else
         DVG_TRY(launch_bn_finalize(W + pl.stats[0], pl.nblk[0], C, pl.M[0], 0, W + pl.mean[0], W + pl.invstd[0],
                                    p->bn_rm[0], p->bn_rv[0], p->bn_nbt[0], s));
@@ -232,6 +234,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
       a0.img = images; a0.B = B; a0.w = p->conv_w[0]; a0.bias = p->conv_b[0];
       a0.mean = W + pl.mean[0]; a0.invstd = W + pl.invstd[0]; a0.gamma = p->bn_g[0]; a0.beta = p->bn_b[0];
       a0.dXp = dX;
+      a0.pimg = W + pl.pimg;  // (written by the forward call's moments pass: the backward follows a training-mode forward)
       // one pass: S and sum dz zhat per block, their column sums, then every gradient of the stage from the sums and the
       // patch moments the forward call left in the workspace
       a0.part = W + pl.part320;

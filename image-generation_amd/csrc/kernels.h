@@ -90,6 +90,8 @@ struct EncL0Args {
   const float* img; int64_t B;
   const float* w; const float* bias;                       // conv weight (32,1,3,3), bias (32)
   const float* mean; const float* invstd; const float* gamma; const float* beta;
+  const float* pimg;                                       // zero-padded copy of the images [B][ENC_L0_PIMG] written by the moments
+                                                           // pass of a training-mode forward, or null (bounds-tested reads of img)
   const float* dXp;                                        // gradient wrt the pooled map [B*256][32]          (MODE 4)
   float* Xp;                                               // [B*256][32]                                     (MODE 1)
   float* part;                                             // MODE 4: [enc_l0_blocks(B)][ENC_L0_ROW_FLOATS]
@@ -100,9 +102,10 @@ int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s);  // mode 1 or 4
 // output): part [enc_l0_moment_blocks(B)][ENC_L0_MOM_ROW] doubles of scratch, mom [ENC_L0_MOM_ROW] doubles = the summed
 // moments, which the backward call's launch_enc_l0_combine reads.  Also updates the running statistics and the batch counter.
 constexpr int ENC_L0_MOM = 54, ENC_L0_MOM_ROW = 64;
+constexpr int ENC_L0_PIMG = 34 * 40;  // floats per padded image: 34 rows of 40, the 32 x 32 interior at row 1 / column 4
 int enc_l0_moment_blocks(int64_t B);
 int launch_enc_l0_moments(const float* images, int64_t B, const float* w, const float* bias, double* part, double* mom,
-                          float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s);
+                          float* pimg, float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s);
 // mode 4 (both backward passes in one): partial rows of ENC_L0_ROW_FLOATS floats (S: 320, sum dz zhat: 32); their column
 // sums `tot` go through launch_enc_l0_combine, which writes the four gradients of the stage
 constexpr int ENC_L0_ROW_FLOATS = 352;

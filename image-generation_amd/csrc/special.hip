@@ -126,7 +126,13 @@ constexpr int ENC_L0_ROW = ENC_L0_ROW_FLOATS;  // floats per block of MODE 4's p
 // one row of the 8 x 4 tile, so a lane's B value (tap t = lane & 15 of pixel slot k = lane >> 4) is a fixed offset from
 // one per-lane base.  16 MFMAs of 32 cycles per tile (32 while T2 was accumulated here, 32 of 64 cycles before that).
 typedef float f32x4c __attribute__((ext_vector_type(4)));
-template <int MODE>
+// PAD (round 5): the images are read from the zero-padded copy the moments kernel leaves in the workspace ([34][40] floats
+// per image, interior at row 1 / column 4, ones in eight pad cells, zeros in eight others): a tap outside the image reads
+// a zero, the bias column of the operands reads a one, and a load's address is a wave-uniform image base + a per-lane
+// constant + a compile-time offset -- no bounds tests, no selects (they were a third of this kernel's 450 vector
+// instructions per tile).  Evaluation-mode forwards (no moments pass) keep the bounds-tested reads of the plain image.
+constexpr int ENC_L0_ONES = 37, ENC_L0_ZEROS = 38;  // cells c, c + 40 r (r < 4) and those + 4 hold the constant
+template <int MODE, bool PAD>
 __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
   static_assert(MODE == 1 || MODE == 4, "BN -> pool -> LeakyReLU, the backward in one pass");
   __shared__ float redf[MODE == 4 ? 4 * 32 * 33 : 1];
@@ -151,6 +157,12 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
   const int cy = (int)morton_y((uint32_t)c), cx = (int)morton_x((uint32_t)c);  // pixel c of a tile, inside the tile
   const int64_t tiles = a.B * 32;
   float r2 = 0.f;
+  // PAD: this lane's cell of the padded image for tap 2 j + hh of its pixel (tap 9 = the bias column: a one), and for the
+  // B operand's tap tq of pixel slot kq (tq = 9: ones, above: zeros), both relative to the tile's corner
+  int aoff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) aoff[j] = (cy + dy[j] + 1) * 40 + cx + dx[j] + 4;
+  const int boff = (tdy + 1) * 40 + kq + tdx + 4, bconst = tq == 9 ? ENC_L0_ONES : ENC_L0_ZEROS;
   constexpr int TU = 2;
   for (int64_t t0 = ((int64_t)blockIdx.x * 4 + wave) * TU; t0 < tiles; t0 += (int64_t)gridDim.x * 4 * TU) {
     float av[TU][5], gov[TU][4], bq[TU][8];
@@ -164,24 +176,41 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
       const int ti = (int)(tile & 31);
       const int ty0 = 4 * ((ti & 1) + 2 * ((ti >> 2) & 1) + 4 * ((ti >> 4) & 1)), tx0 = 8 * (((ti >> 1) & 1) + 2 * ((ti >> 3) & 1));
       const int y = ty0 + cy, x = tx0 + cx;
-      const float* im = a.img + (tile >> 5) * 1024;
+      if constexpr (PAD) {
+        const float* im = a.pimg + (int64_t)__builtin_amdgcn_readfirstlane((int)(tile >> 5)) * ENC_L0_PIMG;
+        const int toff = ty0 * 40 + tx0;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int yy = y + dy[j], xx = x + dx[j];
-        ok[u][j] = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
-        av[u][j] = im[ok[u][j] ? yy * 32 + xx : 0];
+        for (int j = 0; j < 5; ++j) {
+          ok[u][j] = true;
+          av[u][j] = im[(j == 4 && hh == 1) ? ENC_L0_ONES : toff + aoff[j]];
+        }
+        if (MODE == 4) {
+          const int bidx = tq < 9 ? toff + boff : bconst;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bq[u][q] = im[bidx + (q & 3) * 40 + 4 * (q >> 2)];
+        }
+      } else {
+        const float* im = a.img + (tile >> 5) * 1024;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int yy = y + dy[j], xx = x + dx[j];
+          ok[u][j] = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+          av[u][j] = im[ok[u][j] ? yy * 32 + xx : 0];
+        }
+        if (MODE == 4) {
+          // B operand of pixel-row pair q: the pixel at (row q & 3, x = 4 (q >> 2) + kq) of the tile, shifted by tap tq
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int yy = ty0 + (q & 3) + tdy, xx = tx0 + 4 * (q >> 2) + kq + tdx;
+            const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
+            const float v = im[inb ? yy * 32 + xx : 0];
+            bq[u][q] = tq == 9 ? 1.0f : ((tq < 9 && inb) ? v : 0.f);
+          }
+        }
       }
       if (MODE == 4) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) gov[u][g] = a.dXp[(tile * 8 + 2 * g + hh) * 32 + c];
-        // B operand of pixel-row pair q: the pixel at (row q & 3, x = 4 (q >> 2) + kq) of the tile, shifted by tap tq
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int yy = ty0 + (q & 3) + tdy, xx = tx0 + 4 * (q >> 2) + kq + tdx;
-          const bool inb = yy >= 0 && yy < 32 && xx >= 0 && xx < 32;
-          const float v = im[inb ? yy * 32 + xx : 0];
-          bq[u][q] = tq == 9 ? 1.0f : ((tq < 9 && inb) ? v : 0.f);
-        }
       }
     }
 #pragma unroll
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
       f32x16c acc = {0};
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
-        const float av_ = (2 * j + hh == 9) ? 1.0f : (ok[u][j] ? av[u][j] : 0.f);
+        const float av_ = PAD ? av[u][j] : ((2 * j + hh == 9) ? 1.0f : (ok[u][j] ? av[u][j] : 0.f));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bw[j], acc, 0, 0, 0);
       }
       float a1[16];  // MODE 4: per pixel row r of the accumulator: delta dz (dz at the window's arg-max, else 0)
@@ -251,10 +280,17 @@ __global__ __launch_bounds__(256) void enc_l0_kernel(EncL0Args a) {
 int enc_l0_blocks(int64_t B) { const int64_t b = ceil_div(B * 32, 8); return (int)(b > STREAM_BLOCKS ? STREAM_BLOCKS : b); }
 
 int launch_enc_l0(int mode, const EncL0Args& a, hipStream_t s) {
-  const dim3 g((unsigned)enc_l0_blocks(a.B));
+  const dim3 g((unsigned)enc_l0_blocks(a.B)), g1(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4));
+  const bool pad = a.pimg != nullptr;  // (the padded copy exists: a training-mode forward's moments pass wrote it)
   switch (mode) {
-    case 1: DVG_LAUNCH(K_ENC_BN_POOL_FWD, enc_l0_kernel<1>, dim3(2048 < a.B * 4 ? 2048 : (unsigned)(a.B * 4)), dim3(256), 0, s, a); break;
-    case 4: DVG_LAUNCH(K_ENC_CONV0_WGRAD, enc_l0_kernel<4>, g, dim3(256), 0, s, a); break;
+    case 1:
+      if (pad) DVG_LAUNCH(K_ENC_BN_POOL_FWD, (enc_l0_kernel<1, true>), g1, dim3(256), 0, s, a);
+      else DVG_LAUNCH(K_ENC_BN_POOL_FWD, (enc_l0_kernel<1, false>), g1, dim3(256), 0, s, a);
+      break;
+    case 4:
+      if (pad) DVG_LAUNCH(K_ENC_CONV0_WGRAD, (enc_l0_kernel<4, true>), g, dim3(256), 0, s, a);
+      else DVG_LAUNCH(K_ENC_CONV0_WGRAD, (enc_l0_kernel<4, false>), g, dim3(256), 0, s, a);
+      break;
     default: set_error("launch_enc_l0: mode %d", mode); return DVG_E_INVALID;
   }
   return DVG_OK;
@@ -305,10 +341,17 @@ __device__ __forceinline__ void enc_l0_moments_wave(const float* __restrict__ T,
   }
 }
 
-__global__ __launch_bounds__(256) void enc_l0_moments_kernel(const float* __restrict__ img, int64_t B, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void enc_l0_moments_kernel(const float* __restrict__ img, int64_t B, double* __restrict__ part,
+                                                             float* __restrict__ pimg) {
   __shared__ __align__(16) float tile[2][34 * 40];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 2 * 34 * 40; i += 256) (&tile[0][0])[i] = 0.f;
+  __syncthreads();
+  // the constant cells enc_l0_kernel<., PAD> reads for its bias column (pad columns: the strips below never touch them)
+  if (tid < 16) {
+    const int bf = tid >> 3, r = tid & 3, second = (tid >> 2) & 1;
+    tile[bf][r * 40 + ENC_L0_ONES + 4 * second] = 1.0f;
+  }
   double acc[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) acc[i] = 0.0;
@@ -322,6 +365,9 @@ __global__ __launch_bounds__(256) void enc_l0_moments_kernel(const float* __rest
     *reinterpret_cast<f32x4c*>(T + ((tid >> 3) + 1) * 40 + 4 + 4 * (tid & 7)) = cur;
     __syncthreads();
     if (b + gridDim.x < B) cur = *reinterpret_cast<const f32x4c*>(img + (b + gridDim.x) * 1024 + tid * 4);
+    // the padded image as it stands in LDS goes to the workspace: the two passes that recompute the layer read it from there
+    for (int i = tid; i < ENC_L0_PIMG / 4; i += 256)
+      reinterpret_cast<f32x4c*>(pimg + b * ENC_L0_PIMG)[i] = reinterpret_cast<const f32x4c*>(T)[i];
     if (wave == 0) enc_l0_moments_wave<0>(T, lane, acc);
     else if (wave == 1) enc_l0_moments_wave<1>(T, lane, acc);
     else if (wave == 2) enc_l0_moments_wave<2>(T, lane, acc);
@@ -397,9 +443,9 @@ __global__ __launch_bounds__(1024) void enc_l0_moments_finalize_kernel(const dou
 }
 
 int launch_enc_l0_moments(const float* images, int64_t B, const float* w, const float* bias, double* part, double* mom,
-                          float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s) {
+                          float* pimg, float* mean, float* invstd, float* rm, float* rv, int64_t* nbt, hipStream_t s) {
   const int nblk = enc_l0_moment_blocks(B);
-  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_moments_kernel, dim3((unsigned)nblk), dim3(256), 0, s, images, B, part);
+  DVG_LAUNCH(K_ENC_CONV0_FWD, enc_l0_moments_kernel, dim3((unsigned)nblk), dim3(256), 0, s, images, B, part, pimg);
   DVG_LAUNCH(K_BN_FINALIZE, enc_l0_moments_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part, nblk,
              (double)B * 1024.0, w, bias, mom, mean, invstd, rm, rv, nbt);
   return DVG_OK;
