@@ -258,6 +258,31 @@ def test_encoder_matches_oracle_full_gradients(n, B):
         assert int(enc.state_dict()[f"conv.{4*l+1}.num_batches_tracked"]) == int(p[f"conv.{4*l+1}.num_batches_tracked"])
 
 
+def test_encoder_layer0_moment_statistics_on_real_valued_images():
+    """Layer 0's BatchNorm statistics come from the first / second moments of the 3x3 input patches (csrc/special.hip,
+    enc_l0_moments_kernel) and its backward takes sum zhat (x) in_t from the same moments: nothing in that algebra needs
+    the {0, 1} images of the other tests.  Real-valued images with a large common offset (mean 3, deviation 0.5: the
+    variance is a small difference of large moments) against the float64 oracle: batch statistics through the running
+    buffers, logits, and every gradient of the stage."""
+    n, B = 64, 24
+    params = gen.make_params(n, "encoder", 77)
+    enc = _load(Encoder(n), params).train()
+    p = {k: (torch.from_numpy(np.array(v)).double().requires_grad_("running" not in k) if np.array(v).dtype == np.float32
+             else torch.from_numpy(np.array(v))) for k, v in params.items()}
+    g = torch.Generator().manual_seed(5)
+    x = (3.0 + 0.5 * torch.randn(B, 1, 32, 32, generator=g)).float()
+    gl = torch.randn(B, n, generator=g)
+    want = nets.encoder_forward(p, x.double(), training=True)
+    (want * gl.double()).sum().backward()
+    got = enc(x.cuda())
+    (got * gl.cuda()).sum().backward()
+    for stat in ("running_mean", "running_var"):
+        _close(enc.state_dict()[f"conv.1.{stat}"].cpu(), p[f"conv.1.{stat}"], 2e-6, stat)
+    _close(got.detach().cpu(), want.detach(), 3e-5, "logits")
+    for name in ("conv.0.weight", "conv.1.weight", "conv.1.bias", "conv.4.weight", "projection.weight"):
+        _close(dict(enc.named_parameters())[name].grad.cpu(), p[name].grad, 2e-4, name)
+
+
 def test_encoder_forward_large_batch_folds_bn_partials():
     """B = 288 gives the first layer >= 1024 per-block BatchNorm partial rows, which launch_bn_finalize folds in a
     first pass: forward logits and running statistics against the oracle (forward only: at this many pooling windows
