@@ -155,6 +155,16 @@ SIGNATURES = {
          c_size_t, c_int, c_void_p],
     ),
     "dvg_stream_join_side": (c_int, [c_void_p]),
+    "dvg_decoder_fwd_mse_ex": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, POINTER(c_void_p), c_uint64, c_uint64, c_void_p, c_int, c_float,
+         c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p],
+    ),
+    "dvg_decoder_bwd_mse_ex": (
+        c_int,
+        [POINTER(DecoderParams), c_int, c_void_p, c_int64, c_void_p, c_int, c_float, POINTER(DecoderGrads), c_void_p,
+         c_void_p, c_size_t, c_int, c_void_p],
+    ),
     "dvg_mse_workspace_bytes": (c_size_t, []),
     "dvg_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dvg_adam_step": (

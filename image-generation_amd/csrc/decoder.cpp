@@ -20,7 +20,7 @@ struct DecPlan {
   int nblk[4];
   size_t X0, Y[4], Xs[4], mean[4], invstd[4], stats[4], mask[4];
   size_t wp_lin, wpd_lin, bias_lin, wp[3], wpd[3];
-  size_t dXbuf, dYl[4], slabs, partA, partB[4], partL, partW, partF, splitk;
+  size_t dXbuf, dYl[4], slabs, partA, partB[4], partL, partW, partF, partT, msep, splitk;
   int ksplit_lin, ksplit[3];
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   bool wino_w[4];  // layer's weight gradient runs in the Winograd form (conv_wino_wgrad.hip, 9 of 16 positions)
@@ -162,6 +162,10 @@ DecPlan dec_plan(int64_t N, int n) {
   p.partL = bump(o, (size_t)EW_BLOCKS * cmax);
   p.partF = bump(o, (size_t)EW_BLOCKS * 10);
   p.partW = bump(o, (size_t)STREAM_BLOCKS * 288);
+  // the fused tail (dvg_decoder_fwd_mse_ex): the 1-channel stage's (sum dz, sum dz zhat) partials, written by the FORWARD call
+  // and read by the backward call (a buffer of their own: partA is every other stage's scratch), and the MSE partials (doubles)
+  p.partT = bump(o, (size_t)STREAM_BLOCKS * 2);
+  p.msep = bump(o, (size_t)STREAM_BLOCKS * 2);
   p.splitk = bump(o, max_split);
   p.total_floats = o;
   return p;
@@ -285,14 +289,25 @@ extern "C" int dvg_decoder_prepare(const dvg_decoder_params_t* p, int n, int64_t
   return prep_arm(ws, prologue_signature(p, n, N, training, seed, offset, dyn, pl), s);
 }
 
-extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
-                                  const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
-                                  size_t ws_bytes, const dvg_step_state_t* dyn, int prepared, dvg_stream_t stream) {
+namespace {
+// The MSE against `images` ([N / R][1024]; replica r of image b = decoder row b R + r) fused behind the decoder
+// (dvg_decoder_fwd_mse_ex / dvg_decoder_bwd_mse_ex): the reconstruction and its gradient are never written.
+struct MseTail { const float* images; int R; float grad_scale; float* loss_out; };
+float mse_gscale(const MseTail& mt, int64_t N) { return (float)(2.0 * (double)mt.grad_scale / ((double)N * 1024.0)); }  // (dvg_mse_fwd_bwd's)
+
+int decoder_fwd_impl(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
+                     const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, const MseTail* mt,
+                     void* ws, size_t ws_bytes, const dvg_step_state_t* dyn, int prepared, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   conv_precision_note_forward(ws);
-  plan_note_forward(ws, plan_signature(pl));
-  DVG_REQUIRE(spins && out, "decoder_fwd: null spins/out");
+  plan_note_forward(ws, plan_signature(pl) | (mt ? 1u << 30 : 0u));
+  DVG_REQUIRE(spins && (out || mt), "decoder_fwd: null spins/out");
+  if (mt) {
+    DVG_REQUIRE(training, "decoder_fwd_mse: training-mode calls only (the fused tail produces the backward's sums)");
+    DVG_REQUIRE(pl.tail, "decoder_fwd_mse: needs option dec_tail_fused != 0");
+    DVG_REQUIRE(mt->images && mt->loss_out && mt->R >= 1 && N % mt->R == 0, "decoder_fwd_mse: images / loss_out / R (N=%lld R=%d)", (long long)N, mt->R);
+  }
   hipStream_t s = (hipStream_t)stream;
   float* W = (float*)ws;
   {
@@ -348,13 +363,34 @@ extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const fl
                                   p->bn_b[l], mask, W + pl.Xs[l], s));
     x = W + pl.Xs[l];
   }
-  if (pl.tail) {
+  if (mt) {
+    // final layer -> MSE -> the final layer's data gradient -> the 1-channel stage's backward sums, one pass per image
+    const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
+    DVG_TRY(launch_dec_tail_mse_sums(in3, N, p->conv_w[4], p->conv_b[4], mt->images, mt->R, mse_gscale(*mt, N), W + pl.partT,
+                                     (double*)(W + pl.msep), s));
+    DVG_TRY(launch_mse_final((const double*)(W + pl.msep), dec_final_dgrad_blocks(N), 1.0 / ((double)N * 1024.0), mt->loss_out, s));
+  } else if (pl.tail) {
     const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], training ? W + pl.mask[3] : nullptr};
     DVG_TRY(launch_dec_final_fwd_act(in3, N, p->conv_w[4], p->conv_b[4], out, s));
   } else {
     DVG_TRY(launch_dec_final_fwd(x, N, p->conv_w[4], p->conv_b[4], out, s));
   }
   return DVG_OK;
+}
+}  // namespace
+
+extern "C" int dvg_decoder_fwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
+                                  const float* const dropout_keep[4], uint64_t seed, uint64_t offset, float* out, void* ws,
+                                  size_t ws_bytes, const dvg_step_state_t* dyn, int prepared, dvg_stream_t stream) {
+  return decoder_fwd_impl(p, n, spins, N, training, dropout_keep, seed, offset, out, nullptr, ws, ws_bytes, dyn, prepared, stream);
+}
+
+extern "C" int dvg_decoder_fwd_mse_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
+                                      const float* const dropout_keep[4], uint64_t seed, uint64_t offset, const float* images,
+                                      int R, float grad_scale, float* loss_out, void* ws, size_t ws_bytes,
+                                      const dvg_step_state_t* dyn, int prepared, dvg_stream_t stream) {
+  const MseTail mt{images, R, grad_scale, loss_out};
+  return decoder_fwd_impl(p, n, spins, N, 1, dropout_keep, seed, offset, nullptr, &mt, ws, ws_bytes, dyn, prepared, stream);
 }
 
 extern "C" int dvg_decoder_fwd(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, int training,
@@ -375,14 +411,16 @@ extern "C" int dvg_stream_join_side(dvg_stream_t stream) {
   return DVG_OK;
 }
 
-extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
-                                  const float* grad_out, const dvg_decoder_grads_t* g, float* grad_spins, void* ws,
-                                  size_t ws_bytes, int defer_join, dvg_stream_t stream) {
+namespace {
+int decoder_bwd_impl(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N, const float* grad_out,
+                     const MseTail* mt, const dvg_decoder_grads_t* g, float* grad_spins, void* ws, size_t ws_bytes,
+                     int defer_join, dvg_stream_t stream) {
   const DecPlan pl = dec_plan(N > 0 ? N : 1, (n >= 32 && n % 32 == 0) ? n : 32);
   DVG_TRY(check_common(p, n, N, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "decoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
-  DVG_REQUIRE(plan_matches_forward(ws, plan_signature(pl)), "decoder_bwd: a kernel-form option (dvg_set_option: dec_fold / dec_d22 / dec_lc0 / igemm_dma) changed since the forward call on this workspace");
-  DVG_REQUIRE(spins && grad_out && g, "decoder_bwd: null argument");
+  DVG_REQUIRE(plan_matches_forward(ws, plan_signature(pl) | (mt ? 1u << 30 : 0u)), "decoder_bwd: a kernel-form option (dvg_set_option: dec_fold / dec_d22 / dec_lc0 / igemm_dma) changed since the forward call on this workspace, or the forward call was not of the same kind (dvg_decoder_fwd_ex / dvg_decoder_fwd_mse_ex)");
+  DVG_REQUIRE(spins && (grad_out || mt) && g, "decoder_bwd: null argument");
+  if (mt) DVG_REQUIRE(pl.tail && mt->images && mt->R >= 1 && N % mt->R == 0, "decoder_bwd_mse: images / R (N=%lld R=%d), option dec_tail_fused", (long long)N, mt->R);
   DVG_REQUIRE(g->lin_w && g->lin_b, "decoder_bwd: null linear gradient buffer");
   for (int l = 0; l < 5; ++l) DVG_REQUIRE(g->conv_w[l] && g->conv_b[l], "decoder_bwd: null conv gradient buffer %d", l);
   for (int l = 0; l < 4; ++l) DVG_REQUIRE(g->bn_g[l] && g->bn_b[l], "decoder_bwd: null BN gradient buffer %d", l);
@@ -400,13 +438,16 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     hipEvent_t start = nullptr;
     if (s2 != s) DVG_TRY(stream_mark(s, &start));
     const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
-    if (pl.tail) {  // ... as the 1-channel stage's BatchNorm-backward sums (no reduce pass below; dX itself is not stored)
+    if (mt) {
+      // (the sums are in partT since the forward call: dvg_decoder_fwd_mse_ex)
+    } else if (pl.tail) {  // ... as the 1-channel stage's BatchNorm-backward sums (no reduce pass below; dX itself is not stored)
       DVG_TRY(launch_dec_final_dgrad_bn(grad_out, N, p->conv_w[4], in3, partA, s));
     } else {
       DVG_TRY(launch_dec_final_dgrad(grad_out, N, p->conv_w[4], dX, s));
     }
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, start));
-    if (pl.tail) DVG_TRY(launch_dec_final_wgrad_act(in3, N, grad_out, W + pl.partF, s2));  // (Xs[3] does not exist)
+    if (mt) DVG_TRY(launch_dec_final_wgrad_mse(in3, N, p->conv_w[4], p->conv_b[4], mt->images, mt->R, mse_gscale(*mt, N), W + pl.partF, s2));
+    else if (pl.tail) DVG_TRY(launch_dec_final_wgrad_act(in3, N, grad_out, W + pl.partF, s2));  // (Xs[3] does not exist)
     else DVG_TRY(launch_dec_final_wgrad(W + pl.Xs[3], N, grad_out, W + pl.partF, s2));
     DVG_REQUIRE(sums.add2(W + pl.partF, EW_BLOCKS, 10, 9, g->conv_w[4], 1, g->conv_b[4]), "decoder_bwd: column-sum batch full");
   }
@@ -426,8 +467,12 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     } else if (l == 3 && pl.tail) {
       // the 1-channel stage: its sums came out of the final layer's data-gradient pass above; dY3 = that pass again
       const DecActIn in3{W + pl.Y[3], W + pl.mean[3], W + pl.invstd[3], p->bn_g[3], p->bn_b[3], W + pl.mask[3]};
-      DVG_TRY(launch_colsum2(partA, dec_final_dgrad_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
-      DVG_TRY(launch_dec_final_dgrad_apply(grad_out, N, p->conv_w[4], in3, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
+      DVG_TRY(launch_colsum2(mt ? W + pl.partT : partA, dec_final_dgrad_blocks(N), 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
+      if (mt)
+        DVG_TRY(launch_dec_tail_mse_apply(in3, N, p->conv_w[4], p->conv_b[4], mt->images, mt->R, mse_gscale(*mt, N), g->bn_b[l],
+                                          g->bn_g[l], dY, W + pl.partB[l], s));
+      else
+        DVG_TRY(launch_dec_final_dgrad_apply(grad_out, N, p->conv_w[4], in3, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));
     } else {
       DVG_TRY(launch_dec_bn_act_bwd_reduce(Y, Xs, pl.M[l], C, 2 * pl.L[l], W + pl.mean[l], W + pl.invstd[l], p->bn_g[l],
                                            p->bn_b[l], mask, dX, partA, s));
@@ -551,4 +596,18 @@ extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const fl
     if (!defer_join) DVG_TRY(stream_order_after(s, s2));  // join (deferred: dvg_stream_join_side / the next backward call)
   }
   return DVG_OK;
+}
+}  // namespace
+
+extern "C" int dvg_decoder_bwd_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
+                                  const float* grad_out, const dvg_decoder_grads_t* g, float* grad_spins, void* ws,
+                                  size_t ws_bytes, int defer_join, dvg_stream_t stream) {
+  return decoder_bwd_impl(p, n, spins, N, grad_out, nullptr, g, grad_spins, ws, ws_bytes, defer_join, stream);
+}
+
+extern "C" int dvg_decoder_bwd_mse_ex(const dvg_decoder_params_t* p, int n, const float* spins, int64_t N,
+                                      const float* images, int R, float grad_scale, const dvg_decoder_grads_t* g,
+                                      float* grad_spins, void* ws, size_t ws_bytes, int defer_join, dvg_stream_t stream) {
+  const MseTail mt{images, R, grad_scale, nullptr};
+  return decoder_bwd_impl(p, n, spins, N, nullptr, &mt, g, grad_spins, ws, ws_bytes, defer_join, stream);
 }

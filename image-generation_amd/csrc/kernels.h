@@ -155,6 +155,19 @@ int launch_dec_final_fwd(const float* X, int64_t N, const float* w, const float*
 // while it is staged (forward and weight gradient), so that stage's activated map is never written
 int launch_dec_final_fwd_act(const DecActIn& in, int64_t N, const float* w, const float* b, float* out, hipStream_t s);
 int launch_dec_final_wgrad_act(const DecActIn& in, int64_t N, const float* dOut, float* part, hipStream_t s);
+// The training step's tail in one pass per image (special.hip, dec_tail_mse_kernel): final ConvTranspose forward -> MSE
+// against images [N / R][1024] -> the final layer's data gradient -> the 1-channel stage's backward; the reconstruction
+// and its gradient are never written.  gscale = 2 grad_scale / (N 1024).  _sums: part [dec_final_dgrad_blocks][2] and the
+// squared-error partials mse_part [dec_final_dgrad_blocks] (launch_mse_final sums them); _apply: the stage's dY and
+// part_db [dec_final_dgrad_blocks][1]; _wgrad_mse: the final layer's weight / bias gradient partials [EW_BLOCKS][10].
+int launch_dec_tail_mse_sums(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                             float gscale, float* part, double* mse_part, hipStream_t s);
+int launch_dec_tail_mse_apply(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                              float gscale, const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db,
+                              hipStream_t s);
+int launch_dec_final_wgrad_mse(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                               float gscale, float* part, hipStream_t s);
+int launch_mse_final(const double* partial, int nb, double inv_numel, float* loss, hipStream_t s);  // misc.hip
 int launch_dec_final_dgrad(const float* dOut, int64_t N, const float* w, float* dX, hipStream_t s);
 // part [EW_BLOCKS][10]: d w[0..8], d b
 int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s);

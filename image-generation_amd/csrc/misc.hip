@@ -288,6 +288,13 @@ extern "C" int dvg_heaviside_fwd(const float* logits, int64_t numel, float* spin
   return DVG_OK;
 }
 
+namespace dvg {
+int launch_mse_final(const double* partial, int nb, double inv_numel, float* loss, hipStream_t s) {
+  DVG_LAUNCH(K_MSE, mse_final_kernel, dim3(1), dim3(64), 0, s, partial, nb, inv_numel, loss);
+  return DVG_OK;
+}
+}  // namespace dvg
+
 extern "C" size_t dvg_mse_workspace_bytes(void) { return sizeof(double) * MSE_BLOCKS; }
 
 extern "C" int dvg_mse_fwd_bwd(const float* recon, const float* images, int64_t B, int R, float grad_scale,

@@ -1196,16 +1196,138 @@ int launch_dec_final_dgrad_apply(const float* dOut, int64_t N, const float* w, c
   return DVG_OK;
 }
 
+// ---- the training step's tail in one pass per image (round 5): final ConvTranspose forward -> MSE (value + gradient) ->
+// the final layer's data gradient -> the 1-channel stage's LeakyReLU / Dropout / BatchNorm backward.  The reconstruction
+// (N x 1024 floats: 134 MB at c3) and its gradient never reach memory: the separate kernels wrote and read them five
+// times between them (dec_final_fwd, mse_partial, dec_final_dgrad<1>, <2>, dec_final_wgrad: 1.1 GB -> 0.23 GB, 207 us of
+// the critical chain).  Every value is formed by the arithmetic of the kernel it replaces, in its order: the gradients
+// are those of the separate path bit for bit (the loss's double partial sums are grouped by image instead of by
+// stride: equal to rounding).
+//   MODE 1: (sum dz, sum dz zhat) partials part [blocks][2] + the block's sum of squared differences mse_part [blocks]
+//   MODE 2: the stage's dY [N*256] once the two sums are known (the pass again) + the block sums of dY part [blocks][1]
+// images [N / R][1024] (replica r of image b is row b R + r of the decoder's batch); gscale = 2 grad_scale / numel.
+template <int MODE>
+__global__ __launch_bounds__(256) void dec_tail_mse_kernel(DecActIn in, int64_t N, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ images,
+                                                           int R, float gscale, const float* __restrict__ sum_dz,
+                                                           const float* __restrict__ sum_dzzh, float inv_m,
+                                                           float* __restrict__ dY, float* __restrict__ part,
+                                                           double* __restrict__ mse_part) {
+  __shared__ float xs[18 * 18];
+  __shared__ float gs[34 * 34];
+  __shared__ float red[2 * 4];
+  __shared__ double redd[4];
+  const int tid = threadIdx.x;
+  const float mu = in.mean[0], is = in.invstd[0], gm = in.gamma[0], bt = in.beta[0];
+  const float m1 = MODE == 2 ? sum_dz[0] * inv_m : 0.f, m2 = MODE == 2 ? sum_dzzh[0] * inv_m : 0.f, gi = gm * is;
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = w[t];
+  const float bb = bias[0];
+  float wf[4][4];  // the data gradient's pre-summed taps (dec_final_dgrad_kernel)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float acc = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int sy = (u - 1) - (kh - 1), sx = (v - 1) - (kw - 1);
+          if (sy >= 0 && sy < 2 && sx >= 0 && sx < 2) acc += w[kh * 3 + kw];
+        }
+      wf[u][v] = acc;
+    }
+  for (int e = tid; e < 18 * 18; e += 256) xs[e] = 0.f;
+  for (int e = tid; e < 34 * 34; e += 256) gs[e] = 0.f;
+  const int ys = (int)morton_y((uint32_t)tid), xq = (int)morton_x((uint32_t)tid);  // source pixel `tid` (Morton)
+  const int y = tid >> 3, x0 = (tid & 7) * 4;                                        // output pixels (y, x0 .. x0 + 3)
+  float r1 = 0.f, r2 = 0.f;
+  double msum = 0.0;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    __syncthreads();  // the previous image's readers of xs / gs are done
+    const float yv = in.y[img * 256 + tid];
+    xs[(ys + 1) * 18 + xq + 1] = dec_act1(yv, mu, is, gm, bt, in.mask, img);
+    const float4 tv = *reinterpret_cast<const float4*>(images + (img / R) * 1024 + y * 32 + x0);
+    __syncthreads();
+    float acc[4] = {bb, bb, bb, bb};  // dec_final_fwd_kernel
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* row = xs + (((y + 1 - kh) >> 1) + 1) * 18 + (x0 >> 1);
+      const float v0 = row[0], v1 = row[1], v2 = row[2], v3 = row[3];
+      const float src[6] = {v0, v1, v1, v2, v2, v3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[j] = fmaf(src[j + 2 - kw], wv[kh * 3 + kw], acc[j]);
+    }
+    const float d0 = acc[0] - tv.x, d1 = acc[1] - tv.y, d2 = acc[2] - tv.z, d3 = acc[3] - tv.w;  // mse_partial_kernel
+    if (MODE == 1) msum += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+    float* gd = gs + (y + 1) * 34 + x0 + 1;
+    gd[0] = gscale * d0; gd[1] = gscale * d1; gd[2] = gscale * d2; gd[3] = gscale * d3;
+    __syncthreads();
+    float dx = 0.f;  // dec_final_dgrad_kernel
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = gs + (2 * ys + u) * 34 + 2 * xq;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dx = fmaf(row[v], wf[u][v], dx);
+    }
+    const float zh = (yv - mu) * is;
+    const float mk = in.mask ? in.mask[img] * (1.0f / DROPOUT_KEEP) : 1.0f;
+    const float dz = dx * ((fmaf(zh, gm, bt) > 0.f) ? 1.0f : LRELU_SLOPE) * mk;
+    if (MODE == 1) {
+      r1 += dz;
+      r2 = fmaf(dz, zh, r2);
+    } else {
+      const float v = gi * (dz - m1 - zh * m2);
+      dY[img * 256 + tid] = v;
+      r1 += v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { r1 += __shfl_xor(r1, off, 64); r2 += __shfl_xor(r2, off, 64); msum += __shfl_xor(msum, off, 64); }
+  if ((tid & 63) == 0) { red[tid >> 6] = r1; red[4 + (tid >> 6)] = r2; redd[tid >> 6] = msum; }
+  __syncthreads();
+  if (MODE == 1 && tid < 2) part[(size_t)blockIdx.x * 2 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+  if (MODE == 2 && tid == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (MODE == 1 && tid == 0) mse_part[blockIdx.x] = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+}
+
+int launch_dec_tail_mse_sums(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                             float gscale, float* part, double* mse_part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_FWD, dec_tail_mse_kernel<1>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, in, N, w, bias,
+             images, R, gscale, nullptr, nullptr, 0.f, nullptr, part, mse_part);
+  return DVG_OK;
+}
+
+int launch_dec_tail_mse_apply(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                              float gscale, const float* sum_dz, const float* sum_dzzh, float* dY, float* part_db,
+                              hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_tail_mse_kernel<2>, dim3((unsigned)dec_final_dgrad_blocks(N)), dim3(256), 0, s, in, N, w, bias,
+             images, R, gscale, sum_dz, sum_dzzh, (float)(1.0 / ((double)N * 256.0)), dY, part_db, nullptr);
+  return DVG_OK;
+}
+
 // dw[kh][kw] = sum dOut(y,x) Xup(y+1-kh, x+1-kw); db = sum dOut;  part [EW_BLOCKS][10]
 // One image per block pass: the 16x16 source image goes to LDS (row-major, zero border, double-buffered: one barrier
 // per image); thread (i, j) owns source pixel (i, j), i.e. the 2x2 output quad that upsamples it, whose 4 x 9 taps
 // all fall in that pixel's 3x3 neighbourhood: 9 LDS reads + 36 FMAs per thread and image, the next image's global
 // loads in flight meanwhile.  (The per-output-pixel form -- 9 guarded, Morton-addressed global gathers per element --
 // took 1.1 ms at c3, 17x its HBM time.)
-template <bool ACT>
+// MSE (with ACT): dOut does not exist (dec_tail_mse_kernel): the thread forms its quad of it again -- the final layer's
+// forward over the 3 x 3 neighbourhood it holds anyway, in dec_final_fwd_kernel's order, minus the image, times gscale.
+template <bool ACT, bool MSE>
 __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __restrict__ X, DecActIn in, int64_t N,
-                                                              const float* __restrict__ dOut, float* __restrict__ part) {
+                                                              const float* __restrict__ dOut, float* __restrict__ part,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ images, int R, float gscale) {
   __shared__ float Xs[2][18 * 18];
+  float wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = MSE ? w[t] : 0.f;
+  const float bb = MSE ? bias[0] : 0.f;
   const float mu = ACT ? in.mean[0] : 0.f, is = ACT ? in.invstd[0] : 0.f, gm = ACT ? in.gamma[0] : 0.f, bt = ACT ? in.beta[0] : 0.f;
   __shared__ float red[10 * 256];
   const int tid = threadIdx.x;
@@ -1219,19 +1341,22 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
   int64_t img = blockIdx.x;
   float xv = 0.f;
   float2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f};
+  const float* gsrc = MSE ? images : dOut;  // (MSE: g0 / g1 carry the IMAGE's quad until the neighbourhood is read)
   if (img < N) {
     xv = ACT ? dec_act1(in.y[img * 256 + tid], mu, is, gm, bt, in.mask, img) : X[img * 256 + tid];
-    g0 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i) * 32 + 2 * j);
-    g1 = *reinterpret_cast<const float2*>(dOut + img * 1024 + (2 * i + 1) * 32 + 2 * j);
+    const int64_t gi_ = MSE ? img / R : img;
+    g0 = *reinterpret_cast<const float2*>(gsrc + gi_ * 1024 + (2 * i) * 32 + 2 * j);
+    g1 = *reinterpret_cast<const float2*>(gsrc + gi_ * 1024 + (2 * i + 1) * 32 + 2 * j);
   }
   for (int buf = 0; img < N; img += gridDim.x, buf ^= 1) {
     Xs[buf][spos] = xv;
-    const float g[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
+    float g[2][2] = {{g0.x, g0.y}, {g1.x, g1.y}};
     const int64_t nimg = img + gridDim.x;
     if (nimg < N) {
       xv = ACT ? dec_act1(in.y[nimg * 256 + tid], mu, is, gm, bt, in.mask, nimg) : X[nimg * 256 + tid];
-      g0 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i) * 32 + 2 * j);
-      g1 = *reinterpret_cast<const float2*>(dOut + nimg * 1024 + (2 * i + 1) * 32 + 2 * j);
+      const int64_t gi_ = MSE ? nimg / R : nimg;
+      g0 = *reinterpret_cast<const float2*>(gsrc + gi_ * 1024 + (2 * i) * 32 + 2 * j);
+      g1 = *reinterpret_cast<const float2*>(gsrc + gi_ * 1024 + (2 * i + 1) * 32 + 2 * j);
     }
     __syncthreads();
     float sn[3][3];  // source pixels (i-1 .. i+1, j-1 .. j+1)
@@ -1241,6 +1366,23 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
       for (int c = 0; c < 3; ++c) sn[r][c] = Xs[buf][(i + r) * 18 + j + c];
     // output (2i+a, 2j+b), tap (kh, kw) reads upsampled (2i+a+1-kh, 2j+b+1-kw) = source ((2i+a+1-kh)>>1, ...):
     // neighbourhood row 1,1,0 for a = 0 and 2,1,1 for a = 1 (kh = 0,1,2); same along the columns
+    if (MSE) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          float rec = bb;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int r = a == 0 ? (kh == 2 ? 0 : 1) : (kh == 0 ? 2 : 1);
+              const int c = b == 0 ? (kw == 2 ? 0 : 1) : (kw == 0 ? 2 : 1);
+              rec = fmaf(sn[r][c], wv[kh * 3 + kw], rec);
+            }
+          g[a][b] = gscale * (rec - g[a][b]);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1267,12 +1409,21 @@ __global__ __launch_bounds__(256) void dec_final_wgrad_kernel(const float* __res
 }
 
 int launch_dec_final_wgrad(const float* X, int64_t N, const float* dOut, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel<false>, dim3(EW_BLOCKS), dim3(256), 0, s, X, DecActIn{}, N, dOut, part);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, (dec_final_wgrad_kernel<false, false>), dim3(EW_BLOCKS), dim3(256), 0, s, X, DecActIn{}, N, dOut, part,
+             nullptr, nullptr, nullptr, 1, 0.f);
   return DVG_OK;
 }
 
 int launch_dec_final_wgrad_act(const DecActIn& in, int64_t N, const float* dOut, float* part, hipStream_t s) {
-  DVG_LAUNCH(K_DEC_FINAL_BWD, dec_final_wgrad_kernel<true>, dim3(EW_BLOCKS), dim3(256), 0, s, nullptr, in, N, dOut, part);
+  DVG_LAUNCH(K_DEC_FINAL_BWD, (dec_final_wgrad_kernel<true, false>), dim3(EW_BLOCKS), dim3(256), 0, s, nullptr, in, N, dOut, part,
+             nullptr, nullptr, nullptr, 1, 0.f);
+  return DVG_OK;
+}
+
+int launch_dec_final_wgrad_mse(const DecActIn& in, int64_t N, const float* w, const float* bias, const float* images, int R,
+                               float gscale, float* part, hipStream_t s) {
+  DVG_LAUNCH(K_DEC_FINAL_BWD, (dec_final_wgrad_kernel<true, true>), dim3(EW_BLOCKS), dim3(256), 0, s, nullptr, in, N, nullptr, part,
+             w, bias, images, R, gscale);
   return DVG_OK;
 }
 

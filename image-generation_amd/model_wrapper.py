@@ -90,6 +90,9 @@ class ModelWrapper:
         # prepare_decoder: enqueue the decoder's weight-only prologue at the start of the step, beside the encoder
         # (None: from PREPARE_DECODER_ROWS decoder rows up; True / False force it)
         self.prepare_decoder = None
+        # fuse_decoder_mse: Decoder.forward_mse in the training step (the reconstruction is never written) -- None: from
+        # FUSE_DECODER_MSE_ROWS decoder rows (B * R) up; True / False: always / never (A/B runs, tests)
+        self.fuse_decoder_mse = None
         self._prep_stream = None
         # Replayed steps write their losses into the graph's static output tensors.  keep_step_losses = True (default)
         # appends a COPY per step to self.losses (two tiny device copies, ~0.5 % of a c2 step), as the reference's lists
@@ -485,8 +488,19 @@ class ModelWrapper:
             # kernel runs 1.4 ms past the decoder forward, which the main stream used to sit out; 23.65 -> 22.93 ms).
             defer = self._defer_mmd_join(flat, samples)
             spins_cut = spins.detach().requires_grad_(True)
-            reconstructed_images = self._dvae.decoder(spins_cut)
-            mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
+            dec = self._dvae.decoder
+            # fuse_decoder_mse: the reconstruction loss behind the decoder in one pair of library calls -- the reconstruction
+            # and its gradient are never written (Decoder.forward_mse; same loss to rounding, same gradients bit for bit)
+            n_rows = int(spins.shape[0]) * int(spins.shape[1])
+            want = self.fuse_decoder_mse if self.fuse_decoder_mse is not None else n_rows >= self.FUSE_DECODER_MSE_ROWS
+            fused = bool(want) and _lib.get_option("dec_tail_fused") != 0
+            if fused:
+                mse_loss = dec.forward_mse(spins_cut, images)
+                seed_t, seed_g = [mse_loss], None
+            else:
+                reconstructed_images = dec(spins_cut)
+                mse_loss, g_recon = F.replicated_mse_loss_and_grad(reconstructed_images, images)
+                seed_t, seed_g = [reconstructed_images], [g_recon]
             if not defer:
                 self._defer_measure(main, side)
                 main.wait_stream(side)
@@ -494,13 +508,13 @@ class ModelWrapper:
             # would route it through AccumulateGrad of the leaf, which CLONES it (67 MB at c3: an 86 us copy on the critical
             # chain).  The decoder's parameter gradients do not travel through autograd at all here: its backward writes
             # them into the optimizer's flat buffer and sets .grad itself (modules._grad_targets).
-            dec = self._dvae.decoder
             if writes_grads_direct(dec):
-                (g_dec,) = torch.autograd.grad([reconstructed_images], [spins_cut], [g_recon])
+                (g_dec,) = torch.autograd.grad(seed_t, [spins_cut], seed_g)
                 assert all(p.grad is not None for p in dec._trainable()), "decoder backward did not take the direct path"
             else:
-                torch.autograd.backward([reconstructed_images], [g_recon])
+                torch.autograd.backward(seed_t, seed_g)
                 g_dec = spins_cut.grad
+            mse_loss = mse_loss.detach()
             if defer:
                 main.wait_stream(side)
             g_spins.record_stream(main)
@@ -720,6 +734,11 @@ class ModelWrapper:
     # of the captured step costs 40-70 us (measured at B R = 2048 ... 16384), more than the 20-60 us the prologue takes
     # there; at 32768 rows it takes 190 us (the composed Linear o ConvTranspose weights) and the step gains 0.10-0.15 ms.
     PREPARE_DECODER_ROWS = 32768
+
+    # Below this many decoder rows the three separate calls are kept: the fused tail's kernels redo the final layer's forward
+    # in three passes and pay a per-block set-up per image at one image per block (measured: c3, 32768 rows, 8.12 -> 8.05 ms;
+    # c2, 2048 rows, 0.880 -> 0.888 ms)
+    FUSE_DECODER_MSE_ROWS = 8192
 
     def _prepare_decoder(self, images, main) -> None:
         """The decoder's weight-only prologue (packs, composed weights, dropout masks: ``Decoder.prepare``) on a stream

@@ -157,34 +157,53 @@ class Encoder(torch.nn.Module):
 # ------------------------------------------------------------------------------------ decoder
 
 
+def _decoder_call_setup(spins, module, masks, seed, offset, params):
+    """What both decoder forward functions do before their library call: checks, the native parameter struct, the
+    workspace (a prepared prologue's when it was made for exactly this call), the injected dropout masks."""
+    L = lib()
+    x = _lib.require_cuda(spins.detach().float().contiguous(), "spins")
+    if x.dim() != 3 or x.shape[-1] != module.n_latents:
+        raise ValueError(f"Decoder expects (B,R,{module.n_latents}) spins, got {tuple(x.shape)}")
+    B, R, n = x.shape
+    N = B * R
+    st = module._native_struct(params)
+    training = bool(module.training)
+    # a prologue enqueued ahead of time (Decoder.prepare) is used when it was made for exactly this call
+    prep, module._prepared = module._prepared, None
+    prepared = (prep is not None and masks is None and prep["key"] == (N, n, training, int(seed), int(offset), x.device)
+                and all(a.data_ptr() == b.data_ptr() for a, b in zip(prep["params"], params)))
+    ws = prep["ws"] if prepared else _ws(L.dvg_decoder_workspace_bytes(N, n), x.device)
+    mask_arr = (ctypes.c_void_p * 4)()
+    keep = []
+    if training and masks is not None:
+        for l, (m, c) in enumerate(zip(masks, (128, 64, 32, 1))):
+            m = _lib.require_cuda(m.detach().float().contiguous(), f"dropout mask {l}")
+            if m.numel() != N * c:
+                raise ValueError(f"dropout mask {l} must have {N}x{c} elements")
+            keep.append(m)
+            mask_arr[l] = m.data_ptr()
+    return x, (B, R, n), st, training, prep, prepared, ws, mask_arr, keep
+
+
+def _decoder_grad_struct(grads):
+    gs = DecoderGrads()
+    gs.lin_w, gs.lin_b = grads[0].data_ptr(), grads[1].data_ptr()
+    for l in range(4):
+        gs.conv_w[l], gs.conv_b[l] = grads[2 + 4 * l].data_ptr(), grads[3 + 4 * l].data_ptr()
+        gs.bn_g[l], gs.bn_b[l] = grads[4 + 4 * l].data_ptr(), grads[5 + 4 * l].data_ptr()
+    gs.conv_w[4], gs.conv_b[4] = grads[18].data_ptr(), grads[19].data_ptr()
+    return gs
+
+
 class _DecoderFn(torch.autograd.Function):
     """args: spins (B,R,n), module, masks (list or None), seed, offset, then the 28 trainable tensors."""
 
     @staticmethod
     def forward(ctx, spins, module, masks, seed, offset, *params):
         L = lib()
-        x = _lib.require_cuda(spins.detach().float().contiguous(), "spins")
-        if x.dim() != 3 or x.shape[-1] != module.n_latents:
-            raise ValueError(f"Decoder expects (B,R,{module.n_latents}) spins, got {tuple(x.shape)}")
-        B, R, n = x.shape
+        x, (B, R, n), st, training, prep, prepared, ws, mask_arr, keep = _decoder_call_setup(spins, module, masks, seed, offset, params)
         N = B * R
-        st = module._native_struct(params)
         out = torch.empty((B, R, 1, 32, 32), dtype=torch.float32, device=x.device)
-        training = bool(module.training)
-        # a prologue enqueued ahead of time (Decoder.prepare) is used when it was made for exactly this call
-        prep, module._prepared = module._prepared, None
-        prepared = (prep is not None and masks is None and prep["key"] == (N, n, training, int(seed), int(offset), x.device)
-                    and all(a.data_ptr() == b.data_ptr() for a, b in zip(prep["params"], params)))
-        ws = prep["ws"] if prepared else _ws(L.dvg_decoder_workspace_bytes(N, n), x.device)
-        mask_arr = (ctypes.c_void_p * 4)()
-        keep = []
-        if training and masks is not None:
-            for l, (m, c) in enumerate(zip(masks, (128, 64, 32, 1))):
-                m = _lib.require_cuda(m.detach().float().contiguous(), f"dropout mask {l}")
-                if m.numel() != N * c:
-                    raise ValueError(f"dropout mask {l} must have {N}x{c} elements")
-                keep.append(m)
-                mask_arr[l] = m.data_ptr()
         with torch.cuda.device(x.device):
             if prep is not None and not prepared:
                 # made for another call (shape, mode or parameters changed in between): wait it out and do without
@@ -208,12 +227,7 @@ class _DecoderFn(torch.autograd.Function):
         B, R, n = ctx.shape
         st = module._native_struct(params)
         grads, direct = _grad_targets(module, params)
-        gs = DecoderGrads()
-        gs.lin_w, gs.lin_b = grads[0].data_ptr(), grads[1].data_ptr()
-        for l in range(4):
-            gs.conv_w[l], gs.conv_b[l] = grads[2 + 4 * l].data_ptr(), grads[3 + 4 * l].data_ptr()
-            gs.bn_g[l], gs.bn_b[l] = grads[4 + 4 * l].data_ptr(), grads[5 + 4 * l].data_ptr()
-        gs.conv_w[4], gs.conv_b[4] = grads[18].data_ptr(), grads[19].data_ptr()
+        gs = _decoder_grad_struct(grads)
         go = grad_out.contiguous().float()
         gx = torch.empty_like(x) if ctx.need_input_grad else None
         # (deferral only when the gradients land in the optimizer's buffer: handed back as fresh tensors, autograd's
@@ -233,6 +247,56 @@ class _DecoderFn(torch.autograd.Function):
             # it.  The owner of the deferral (ModelWrapper) drops these references AFTER dvg_stream_join_side.
             module._deferred_keep = (ws, go, x, gx, tuple(grads))
         return (gx, None, None, None, None, *_grad_returns(module, grads, direct))
+
+
+class _DecoderMseFn(torch.autograd.Function):
+    """The decoder with the reconstruction loss fused behind it (``dvg_decoder_fwd_mse_ex`` / ``dvg_decoder_bwd_mse_ex``:
+    include/dvg.h): returns ``mse_loss(decoder(spins), images replicated over R)`` without ever writing the
+    reconstruction or its gradient.  args: spins (B,R,n), images (B,1,32,32), module, masks, seed, offset, then the 28
+    trainable tensors.  The gradient the backward call seeds is d loss / d reconstruction itself, fixed at forward time:
+    differentiate the returned loss DIRECTLY (unit upstream gradient) -- a loss that is scaled or combined before it is
+    differentiated has to go through ``Decoder.forward`` and ``replicated_mse_loss``."""
+
+    @staticmethod
+    def forward(ctx, spins, images, module, masks, seed, offset, *params):
+        L = lib()
+        if not module.training:
+            raise _lib.DvgError("Decoder.forward_mse is a training-mode call (batch statistics, backward sums)")
+        x, (B, R, n), st, training, prep, prepared, ws, mask_arr, keep = _decoder_call_setup(spins, module, masks, seed, offset, params)
+        im = _lib.require_cuda(images.detach().float().contiguous(), "images")
+        if im.numel() != B * 1024:
+            raise ValueError(f"forward_mse expects images ({B},1,32,32), got {tuple(images.shape)}")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            if prep is not None and not prepared:
+                torch.cuda.current_stream(x.device).wait_stream(prep["stream"])
+            check(L.dvg_decoder_fwd_mse_ex(ctypes.byref(st), n, x.data_ptr(), B * R, mask_arr if keep else None,
+                                           int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), im.data_ptr(), R, 1.0,
+                                           loss.data_ptr(), ws.data_ptr(), ws.numel(), _lib.DYN, int(prepared),
+                                           stream_ptr(x.device)), "dvg_decoder_fwd_mse_ex")
+        ctx.module, ctx.shape = module, (B, R, n)
+        ctx.need_input_grad = spins.requires_grad
+        ctx.save_for_backward(x, im, ws, *params)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        L = lib()
+        x, im, ws, *params = ctx.saved_tensors
+        module = ctx.module
+        B, R, n = ctx.shape
+        st = module._native_struct(params)
+        grads, direct = _grad_targets(module, params)
+        gs = _decoder_grad_struct(grads)
+        gx = torch.empty_like(x) if ctx.need_input_grad else None
+        defer = bool(getattr(module, "_defer_join", False)) and direct
+        with torch.cuda.device(x.device):
+            check(L.dvg_decoder_bwd_mse_ex(ctypes.byref(st), n, x.data_ptr(), B * R, im.data_ptr(), R, 1.0,
+                                           ctypes.byref(gs), _lib.ptr(gx), ws.data_ptr(), ws.numel(), int(defer),
+                                           stream_ptr(x.device)), "dvg_decoder_bwd_mse_ex")
+        if defer:
+            module._deferred_keep = (ws, im, x, gx, tuple(grads))  # (see _DecoderFn.backward)
+        return (gx, None, None, None, None, None, *_grad_returns(module, grads, direct))
 
 
 class Decoder(torch.nn.Module):
@@ -319,3 +383,12 @@ class Decoder(torch.nn.Module):
         if self.training:
             self._dropout_calls += 1
         return _DecoderFn.apply(x, self, masks, self.dropout_seed, offset, *self._trainable())
+
+    def forward_mse(self, x: torch.Tensor, images: torch.Tensor) -> torch.Tensor:
+        """``mse_loss(self(x), images.unsqueeze(1).repeat(1, R, ...))`` of a training step without the reconstruction
+        ever being written (``_DecoderMseFn``): the same loss to rounding, the same gradients bit for bit, a fifth of the
+        memory traffic of the network's tail.  Training mode; differentiate the returned loss directly."""
+        masks, self._injected_masks = self._injected_masks, None
+        offset = self._dropout_calls
+        self._dropout_calls += 1
+        return _DecoderMseFn.apply(x, images, self, masks, self.dropout_seed, offset, *self._trainable())

@@ -287,6 +287,25 @@ int dvg_decoder_bwd_ex(const dvg_decoder_params_t *p, int n_latents, const float
 /* Orders `stream` behind everything queued so far on the library's side stream of the current device (no-op when the
  * side stream is disabled). */
 int dvg_stream_join_side(dvg_stream_t stream);
+/* The decoder with the reconstruction loss fused behind it -- Decoder.forward + mse_loss of the training step
+ * (/root/reference/src/model_wrapper.py:297-305) as ONE pair of calls.  An addition to the surface above, not a
+ * replacement: dvg_decoder_fwd_ex + dvg_mse_fwd_bwd + dvg_decoder_bwd_ex compute the same loss (to rounding of its double
+ * partial sums) and the same gradients BIT FOR BIT (tests/test_gpu_nets.py); what the pair saves is memory traffic.
+ * The reconstruction (N,1,32,32) and its gradient are never written: the final ConvTranspose2d(1,1), the squared error
+ * against images (N / R, 1024) -- replica r of image b is decoder row b R + r --, the final layer's data gradient and the
+ * 1-channel stage's BatchNorm / Dropout2d / LeakyReLU backward run in one pass per image, and the passes of the backward
+ * call that need the loss gradient form it again from the stage's saved pre-BatchNorm output (1.1 GB -> 0.23 GB of HBM
+ * traffic at N = 32768).  Training mode only; needs option dec_tail_fused != 0 (the default).
+ * loss_out = mean((recon - image)^2); the gradient seeded into the backward is grad_scale * d loss / d recon, as in
+ * dvg_mse_fwd_bwd, and dvg_decoder_bwd_mse_ex must be given the same images, R and grad_scale as the forward call on
+ * this workspace.  Every other argument as in dvg_decoder_fwd_ex / dvg_decoder_bwd_ex. */
+int dvg_decoder_fwd_mse_ex(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                           const float *const dropout_keep[4], uint64_t seed, uint64_t offset, const float *images,
+                           int R, float grad_scale, float *loss_out, void *ws, size_t ws_bytes,
+                           const dvg_step_state_t *dyn, int prepared, dvg_stream_t stream);
+int dvg_decoder_bwd_mse_ex(const dvg_decoder_params_t *p, int n_latents, const float *spins, int64_t N,
+                           const float *images, int R, float grad_scale, const dvg_decoder_grads_t *grads,
+                           float *grad_spins, void *ws, size_t ws_bytes, int defer_join, dvg_stream_t stream);
 
 /* ------------------------------------------------------------------ MSE
  * torch.nn.functional.mse_loss(reconstructed, images.unsqueeze(1).repeat(1,R,...))

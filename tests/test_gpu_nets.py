@@ -129,6 +129,56 @@ def test_decoder_tail_fused_equals_separate_passes():
         assert rel(out[1][3][k], g) < 5e-5, (k, rel(out[1][3][k], g))
 
 
+@pytest.mark.parametrize("n,B,R", [(64, 12, 4), (128, 300, 8), (64, 5, 1)])
+def test_decoder_with_the_mse_fused_behind_it_equals_the_three_separate_calls(n, B, R):
+    """``Decoder.forward_mse`` (dvg_decoder_fwd_mse_ex / dvg_decoder_bwd_mse_ex: the reconstruction and its gradient are
+    never written) against ``Decoder.forward`` + ``replicated_mse_loss`` + the decoder's backward: the loss to the
+    rounding of its double partial sums (they are grouped by image instead of by stride), the gradient wrt the spins and
+    EVERY parameter gradient bit for bit -- each value is formed by the arithmetic of the kernel it replaces, in its
+    order.  Injected and device-drawn dropout masks; B R above and below the 2048 blocks of the tail's grid."""
+    from image_generation_amd import functional as F
+
+    params = gen.make_params(n, "decoder", 414 + n)
+    spins0 = torch.from_numpy(gen.make_spins(B, R, n, 515)).cuda()
+    images = torch.from_numpy(gen.make_images(B, 818)).cuda()
+    for injected in (True, False):
+        masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 616)] if injected else None
+        out = []
+        for fused in (False, True):
+            dec = _load(Decoder(n), params).train()
+            dec.dropout_seed = 4242
+            if masks is not None:
+                dec.inject_dropout_masks(masks)
+            sp = spins0.clone().requires_grad_(True)
+            if fused:
+                loss = dec.forward_mse(sp, images)
+            else:
+                loss = F.replicated_mse_loss(dec(sp), images)
+            loss.backward()
+            out.append((float(loss.detach()), sp.grad.detach().cpu(), {k: v.grad.detach().cpu() for k, v in dec.named_parameters()},
+                        {k: v.detach().cpu() for k, v in dec.state_dict().items() if "running" in k}))
+        assert abs(out[1][0] - out[0][0]) <= 2e-7 * abs(out[0][0]), (out[0][0], out[1][0])
+        assert torch.equal(out[1][1], out[0][1]), "gradient wrt the spins"
+        for k, g in out[0][2].items():
+            assert torch.equal(out[1][2][k], g), k
+        for k, v in out[0][3].items():
+            assert torch.equal(out[1][3][k], v), k
+
+
+def test_decoder_forward_mse_fails_loudly_outside_its_domain():
+    dec = Decoder(64).cuda().eval()
+    sp = torch.from_numpy(gen.make_spins(2, 2, 64, 1)).cuda()
+    im = torch.from_numpy(gen.make_images(2, 2)).cuda()
+    with pytest.raises(_lib.DvgError):
+        dec.forward_mse(sp, im)  # evaluation mode
+    dec.train()
+    with pytest.raises(ValueError):
+        dec.forward_mse(sp, im[:1])  # one image for two rows of spins
+    with _lib.option_scope(dec_tail_fused=0):
+        with pytest.raises(_lib.DvgError):
+            dec.forward_mse(sp, im)  # the fused tail is built on the dec_tail_fused kernels
+
+
 def test_encoder_winograd_form_and_direct_form_match_the_float64_oracle():
     """The encoder's 3x3 layers in the Winograd form (csrc/conv_wino.hip, conv_wino_wgrad.hip) and as the direct implicit
     GEMM, on whole networks at B = 1024 -- evaluation-mode forward and training-mode forward + backward -- EACH against the

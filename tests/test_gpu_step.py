@@ -559,6 +559,35 @@ def test_backward_writes_parameter_gradients_into_the_flat_buffer(golden_dir):
         assert torch.allclose(p.grad, 2 * g, rtol=1e-6, atol=1e-9)
 
 
+def test_step_with_the_decoder_and_the_mse_fused_is_the_same_step(golden_dir, fx):
+    """``ModelWrapper.fuse_decoder_mse`` (the reconstruction never written: Decoder.forward_mse) forced on against forced
+    off over the first five steps of the fixture, eager and graph-replayed: every parameter and the persistent chains
+    bit for bit, the losses to the rounding of the MSE's partial sums."""
+    def run(fused, graph):
+        torch.manual_seed(0)
+        m = ModelWrapper("Advantage_system4", n_latents=int(fx["n"]), training_parameter_file=os.path.join(golden_dir, "step_params.yaml"))
+        B = m.BATCH_SIZE
+        images = torch.from_numpy(gen.make_images(B * 12, seed=909)).reshape(12, B, 1, 32, 32).cuda()
+        m.set_dataloader([(images[k], None) for k in range(12)])
+        m.train_init(n_epochs=1)
+        m.fuse_decoder_mse = fused
+        m.use_graph, m.sync_losses = graph, not graph
+        for k in range(5):
+            m.step((images[k], None), epoch=0)
+        torch.cuda.synchronize()
+        sd = {k: v.clone() for k, v in m._dvae.state_dict().items()}
+        sd.update({"grbm." + k: v.clone() for k, v in m._grbm.state_dict().items()})
+        sd["chains"] = m.sampler._state.clone()
+        return sd, [float(v) for v in m.losses["mse_losses"]], [float(v) for v in m.losses["dvae_losses"]]
+
+    for graph in (False, True):
+        (a, mse_a, tot_a), (b, mse_b, tot_b) = run(False, graph), run(True, graph)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (graph, k)
+        np.testing.assert_allclose(mse_b, mse_a, rtol=3e-7)
+        np.testing.assert_allclose(tot_b, tot_a, rtol=3e-7)
+
+
 def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
     """The 12-step fixture of the reference's own ``ModelWrapper.step`` under DVG_PRECISION_F32_SPLIT3 (float32 operands
     as three bf16 pieces on the bf16 MFMA): the north star's 1e-5 relative on every loss of every step, as in float32 --
