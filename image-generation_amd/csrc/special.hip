@@ -1245,11 +1245,27 @@ __global__ __launch_bounds__(256) void dec_tail_mse_kernel(DecActIn in, int64_t 
   const int y = tid >> 3, x0 = (tid & 7) * 4;                                        // output pixels (y, x0 .. x0 + 3)
   float r1 = 0.f, r2 = 0.f;
   double msum = 0.0;
+  // (the next image's values are requested before this image is computed: an iteration is three barriers long and would
+  // otherwise open with a full global-load latency)
+  float nyv = 0.f, nmk = 1.0f;
+  float4 ntv = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t img) {
+    const int64_t im = img < N ? img : N - 1;
+    nyv = in.y[im * 256 + tid];
+    ntv = *reinterpret_cast<const float4*>(images + (im / R) * 1024 + y * 32 + x0);
+    if (in.mask) nmk = in.mask[im];
+  };
+  fetch(blockIdx.x);
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     __syncthreads();  // the previous image's readers of xs / gs are done
-    const float yv = in.y[img * 256 + tid];
-    xs[(ys + 1) * 18 + xq + 1] = dec_act1(yv, mu, is, gm, bt, in.mask, img);
-    const float4 tv = *reinterpret_cast<const float4*>(images + (img / R) * 1024 + y * 32 + x0);
+    const float yv = nyv, mkv = nmk;
+    const float4 tv = ntv;
+    fetch(img + gridDim.x);
+    {  // dec_act1 with the mask value already in hand
+      float z = fmaf((yv - mu) * is, gm, bt);
+      if (in.mask) z *= mkv * (1.0f / DROPOUT_KEEP);
+      xs[(ys + 1) * 18 + xq + 1] = z < 0.f ? z * LRELU_SLOPE : z;
+    }
     __syncthreads();
     float acc[4] = {bb, bb, bb, bb};  // dec_final_fwd_kernel
 #pragma unroll
@@ -1275,7 +1291,7 @@ __global__ __launch_bounds__(256) void dec_tail_mse_kernel(DecActIn in, int64_t 
       for (int v = 0; v < 4; ++v) dx = fmaf(row[v], wf[u][v], dx);
     }
     const float zh = (yv - mu) * is;
-    const float mk = in.mask ? in.mask[img] * (1.0f / DROPOUT_KEEP) : 1.0f;
+    const float mk = in.mask ? mkv * (1.0f / DROPOUT_KEEP) : 1.0f;
     const float dz = dx * ((fmaf(zh, gm, bt) > 0.f) ? 1.0f : LRELU_SLOPE) * mk;
     if (MODE == 1) {
       r1 += dz;
