@@ -963,13 +963,19 @@ __global__ __launch_bounds__(256) void dec_conv3_bwd_fused_kernel(DecActIn in, i
       }
     }
     if constexpr (!APPLY) {
+      float av[4], b0[4], b1[4];  // every operand read goes out before the first MFMA waits for one
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int qq = 16 * wv + 4 * s4 + mq;
-        const float av = mt < 9 ? G[qq * 9 + mt] : 0.f;
-        const float b0 = xs[qq * 32 + mt], b1 = xs[qq * 32 + 16 + mt];
-        wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, wacc[0], 0, 0, 0);
-        wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, wacc[1], 0, 0, 0);
+        av[s4] = G[qq * 9 + (mt < 9 ? mt : 0)];
+        b0[s4] = xs[qq * 32 + mt];
+        b1[s4] = xs[qq * 32 + 16 + mt];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float a_ = mt < 9 ? av[s4] : 0.f;
+        wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b0[s4], wacc[0], 0, 0, 0);
+        wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b1[s4], wacc[1], 0, 0, 0);
       }
     }
   }
