@@ -165,6 +165,34 @@ def test_decoder_with_the_mse_fused_behind_it_equals_the_three_separate_calls(n,
             assert torch.equal(out[1][3][k], v), k
 
 
+@pytest.mark.parametrize("mode", ["f32x3", "bf16"])
+def test_decoder_with_the_mse_fused_behind_it_in_the_side_operand_modes(mode):
+    """The fused tail is float32 arithmetic in every operand mode (its kernels are not GEMM launches): under f32x3 and under
+    bf16 GEMM inputs ``forward_mse`` still equals the three separate calls bit for bit in every gradient."""
+    from image_generation_amd import functional as F
+
+    n, B, R = 64, 40, 4
+    params = gen.make_params(n, "decoder", 515)
+    spins0 = torch.from_numpy(gen.make_spins(B, R, n, 6)).cuda()
+    images = torch.from_numpy(gen.make_images(B, 9)).cuda()
+    _lib.set_conv_precision(mode)
+    try:
+        out = []
+        for fused in (False, True):
+            dec = _load(Decoder(n), params).train()
+            dec.dropout_seed = 11
+            sp = spins0.clone().requires_grad_(True)
+            loss = dec.forward_mse(sp, images) if fused else F.replicated_mse_loss(dec(sp), images)
+            loss.backward()
+            out.append((float(loss.detach()), sp.grad.detach().cpu(), {k: v.grad.detach().cpu() for k, v in dec.named_parameters()}))
+    finally:
+        _lib.set_conv_precision("f32")
+    assert abs(out[1][0] - out[0][0]) <= 2e-7 * abs(out[0][0])
+    assert torch.equal(out[1][1], out[0][1])
+    for k, g in out[0][2].items():
+        assert torch.equal(out[1][2][k], g), k
+
+
 def test_decoder_forward_mse_fails_loudly_outside_its_domain():
     dec = Decoder(64).cuda().eval()
     sp = torch.from_numpy(gen.make_spins(2, 2, 64, 1)).cuda()
