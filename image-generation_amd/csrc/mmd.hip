@@ -1711,9 +1711,12 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
               __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrct, (lds_void*)(uintptr_t)(cur.ztdst + (i - NZ8) * 1024), 16, ztoff0, cur.ztso + (i - NZ8) * 1024, 0, 0);
           }
         }
-        // the loads above serve the NEXT tile: they must be issued before this tile's MFMAs, not after them (left to
-        // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency)
-        __builtin_amdgcn_sched_barrier(0);
+        // the loads above serve the NEXT tile: they must be issued early in this tile, not after its MFMAs (left to
+        // itself the scheduler sinks them to the end of the tile, where the next tile waits out their full latency) --
+        // but not all in ONE MFMA gap either (round 5): three 16-byte reads per gap and wave saturate the LDS array and
+        // stretch the gap from 32 to 48 cycles (MI355X_MICROARCH.md).  The group barriers at the tile's end ask for two
+        // reads behind the Gram MFMA and one behind each of the first two gradient MFMAs: 1872 -> 1837 us alone at c3
+        // (one read per gap, or all of the rest behind the first gradient MFMA: slower again).
 #pragma unroll
         for (int term = 0; term < NTERM; ++term) {
           G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[0]),
@@ -1735,10 +1738,14 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         ac[0] = an[0]; ac[1] = an[1];
 #pragma unroll
         for (int u = 0; u < GPT; ++u) zc[u] = zn[u];
-        // wanted order inside the tile: an MFMA, a few vector instructions of the lookups, an MFMA, ...
+        // wanted order inside the tile: two of the next tile's reads and the DMA pieces, an MFMA, a read and a few vector
+        // instructions of the lookups, an MFMA, ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
         for (int i = 0; i < 2 * NTERM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // pin the tile order: unpinned, the scheduler hoists every tile's loads (spills)
