@@ -19,6 +19,7 @@ namespace dvg {
 struct GibbsArgs {
   const int32_t *order, *class_ptr, *adj_idx, *adj_eid;
   const int32_t *adj_row, *adj_src4;  // padded-row image (graph.h)
+  const int32_t* lane_src;            // lane-major image (graph.h); null: none for this graph
   const float *linear, *quadratic;
   int n, n_batches, max_batches, n_colours;
   float prefactor, h_lo, h_hi, j_lo, j_hi, two_beta;
@@ -208,32 +209,116 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   }
 }
 
-// Fast path for graphs with at most GIBBS_MAXS (colour class, pass) slots per lane, a pass being LPC spins of a class
-// -- every graph the shipped solvers produce up to 512 spins.  Same arithmetic, same order, same random stream as
-// gibbs_kernel (bit-exact); what changes is the schedule:
-//   * a lane owns the same spin of every slot in every sweep, so its row descriptor, local field offset and spin index
-//     are read from LDS once, before the sweep loop, and live in registers;
-//   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends,
-//     instead of being recomputed every sweep.
+// Fast path for graphs with at most GIBBS_MAXS (colour class, pass) slots per lane, a pass being LPC spins of a class,
+// and at most 4 MB <= 20 neighbours per spin -- every graph the shipped solvers produce up to 512 spins.  Same
+// arithmetic, same order, same random stream as gibbs_kernel (bit-exact); what changes is the schedule and the LDS image:
+//   * a lane owns the same spin of every slot in every sweep, so its spin index and clamped field offset are read once,
+//     before the sweep loop, and live in registers;
+//   * the neighbour tables are stored LANE-MAJOR (graph.h, `lane_src`): batch j of slot k of lane l sits at
+//     ((k MB + j) LPC + l), so a batch read is one ds_read_b128 / ds_read_b64 at an IMMEDIATE offset from a per-lane base
+//     -- consecutive lanes read consecutive 16-byte words (no bank conflicts, where the per-row image scattered them) and
+//     the ~25 compare / select / address instructions per slot of the per-row walk are gone; a lane without a spin in a
+//     slot, or a row shorter than MB batches, finds J = 0 there;
+//   * the two passes of a colour class (PAIRS: classes of 65..128 spins on 64 lanes -- c3) are independent of each other
+//     and are computed side by side: at one wave per SIMD a single row leaves the wave waiting out two LDS round trips
+//     and a chain of 20 dependent adds with nothing else to issue;
+//   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends.
+// (Rounds 3-5 history: the per-row image with register-resident row descriptors, 1.00 ms per c3 draw alone; its passes
+// side by side 0.88; a two-waves-per-chain form, faster alone, lost inside the step -- twice the workgroups beside the
+// encoder -- and so did 8 waves per workgroup.)
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
-// (A two-waves-per-chain form of rounds 3-4 -- a class of 65..128 spins as one pass of 128 lanes -- was the faster draw
-// alone and lost inside the training step, twice the workgroups beside the encoder: deleted in round 5.)
-template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
+
+__host__ __device__ __forceinline__ size_t gibbs_lane_lds_bytes(int slots, int mb, int lpc, int n, int chains) {
+  return (size_t)slots * mb * lpc * 24 + sizeof(_Float16) * (size_t)chains * ((n + 15) & ~15);
+}
+
+// the signed couplings of MB batches, in row order, onto f (one row)
+template <int MB, int LPC>
+__device__ __forceinline__ float gibbs_lane_field(float f, const unsigned char* wl, const unsigned char* ol, int k,
+                                                  const unsigned char* stb) {
+  gf32x4 w[MB];
+  gu32x2 o[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    w[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)(k * MB + j) * LPC * 16);
+    o[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)(k * MB + j) * LPC * 8);
+  }
+  _Float16 h[MB][4];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    h[j][0] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] & 0xffffu));
+    h[j][1] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] >> 16));
+    h[j][2] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] & 0xffffu));
+    h[j][3] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] >> 16));
+  }
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f = gibbs_signed_add(h[j][e], w[j][e], f);
+  }
+  return f;
+}
+
+// two rows (slots k and k + 1) side by side: the same reads and adds per row, in the same order
+template <int MB, int LPC>
+__device__ __forceinline__ void gibbs_lane_field2(float& f0, float& f1, const unsigned char* wl, const unsigned char* ol,
+                                                  int k, const unsigned char* stb) {
+  gf32x4 w0[MB], w1[MB];
+  gu32x2 o0[MB], o1[MB];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    w0[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)(k * MB + j) * LPC * 16);
+    o0[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)(k * MB + j) * LPC * 8);
+    w1[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)((k + 1) * MB + j) * LPC * 16);
+    o1[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)((k + 1) * MB + j) * LPC * 8);
+  }
+  _Float16 h0[MB][4], h1[MB][4];
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+    h0[j][0] = *reinterpret_cast<const _Float16*>(stb + (o0[j][0] & 0xffffu));
+    h0[j][1] = *reinterpret_cast<const _Float16*>(stb + (o0[j][0] >> 16));
+    h0[j][2] = *reinterpret_cast<const _Float16*>(stb + (o0[j][1] & 0xffffu));
+    h0[j][3] = *reinterpret_cast<const _Float16*>(stb + (o0[j][1] >> 16));
+    h1[j][0] = *reinterpret_cast<const _Float16*>(stb + (o1[j][0] & 0xffffu));
+    h1[j][1] = *reinterpret_cast<const _Float16*>(stb + (o1[j][0] >> 16));
+    h1[j][2] = *reinterpret_cast<const _Float16*>(stb + (o1[j][1] & 0xffffu));
+    h1[j][3] = *reinterpret_cast<const _Float16*>(stb + (o1[j][1] >> 16));
+  }
+#pragma unroll
+  for (int j = 0; j < MB; ++j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f0 = gibbs_signed_add(h0[j][e], w0[j][e], f0);
+      f1 = gibbs_signed_add(h1[j][e], w1[j][e], f1);
+    }
+  }
+}
+
+template <int LPC, int WAVES, int MB, bool PAIRS, int MAXS = GIBBS_MAXS>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int n = a.n;
-  const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
-  const int n_pad = (n + 15) & ~15;
+  const int n = a.n, n_pad = (n + 15) & ~15;
+  const int passes = a.passes, n_slots = a.n_colours * passes;
   const int tid = threadIdx.x;
-  gibbs_stage<WAVES * 64>(a, L, tid);
+  // LDS: couplings [n_slots MB][LPC] x 16 B | state offsets [n_slots MB][LPC] x 8 B | state [chains][n_pad] float16
+  float* wimg = reinterpret_cast<float*>(smem);
+  uint16_t* oimg = reinterpret_cast<uint16_t*>(smem + (size_t)n_slots * MB * LPC * 16);
+  _Float16* state = reinterpret_cast<_Float16*>(smem + (size_t)n_slots * MB * LPC * 24);
+  {
+    const int n_ent = n_slots * MB * LPC * 4;
+    for (int q = tid; q < n_ent; q += WAVES * 64) {
+      const int src = a.lane_src[q];
+      wimg[q] = src >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[src]]), a.j_lo, a.j_hi) : 0.0f;
+      oimg[q] = src >= 0 ? (uint16_t)(2 * a.adj_idx[src]) : (uint16_t)0;
+    }
+  }
 
   constexpr int CPW = 64 / LPC;
-  constexpr int LPCE = LPC;  // lanes that work on one chain
   const int wave = tid >> 6, lane = tid & 63;
   const int sub = lane / LPC, l = lane % LPC;
   const int chain = (blockIdx.x * WAVES + wave) * CPW + sub;
   const bool valid = chain < a.n_chains;
-  _Float16* st = L.state + (size_t)(wave * CPW + sub) * n_pad;
+  _Float16* st = state + (size_t)(wave * CPW + sub) * n_pad;
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
 
   // (read before the chains start: a fresh chain's start configuration is keyed by the sweep index it starts at, so
@@ -241,38 +326,39 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if (valid) {
     if (a.init) {
-      for (int i = l; i < n; i += LPCE) {
+      for (int i = l; i < n; i += LPC) {
         u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
         st[i] = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
       }
     } else {
       const int8_t* src = a.state + (size_t)chain * n;
-      for (int i = l; i < n; i += LPCE) st[i] = (_Float16)(float)src[i];
+      for (int i = l; i < n; i += LPC) st[i] = (_Float16)(float)src[i];
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  if (!valid) return;
-
-  const int passes = a.passes, n_slots = a.n_colours * passes;
-  {
-  // this lane's spin in each (colour, pass) slot (-1: none), with its row descriptor and clamped field offset
+  // this lane's spin in each (colour, pass) slot (-1: none) and its clamped field offset
   int sp[MAXS];
-  uint32_t row[MAXS];
   float hs[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) {
-    sp[k] = -1; row[k] = 0; hs[k] = 0.f;
+    sp[k] = -1; hs[k] = 0.f;
     if (k < n_slots) {
       const int col = k / passes, pass = k - col * passes;
-      const int p = L.cls[col] + pass * LPCE + l;
-      if (valid && p < L.cls[col + 1]) {
-        const int i = L.order[p];
-        sp[k] = i; row[k] = L.row[i]; hs[k] = L.hs[i];
+      const int p = a.class_ptr[col] + pass * LPC + l;
+      if (valid && p < a.class_ptr[col + 1]) {
+        sp[k] = a.order[p];
+        hs[k] = clampf(__fmul_rn(a.prefactor, a.linear[sp[k]]), a.h_lo, a.h_hi);
       }
     }
   }
+  __syncthreads();  // the tables are staged
+  if (!valid) return;
+
+  const unsigned char* wl = smem + (size_t)l * 16;
+  const unsigned char* ol = smem + (size_t)n_slots * MB * LPC * 16 + (size_t)l * 8;
+  const unsigned char* stb = reinterpret_cast<const unsigned char*>(st);
   u32x4 rr[MAXS];
+#pragma unroll
+  for (int k = 0; k < MAXS; ++k) rr[k] = u32x4{0u, 0u, 0u, 0u};
   for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
     const uint32_t tq = t >> 2, tw = t & 3u;
     if (t == sweep0 || tw == 0u) {
@@ -280,24 +366,51 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
       for (int k = 0; k < MAXS; ++k)
         if (sp[k] >= 0) rr[k] = philox4x32_10((uint32_t)sp[k], cid, tq, STREAM_GIBBS, a.k0, a.k1);
     }
+    // word tw of a slot's four, as two bit-selects under wave-uniform masks (a uniform `?:` becomes scalar branches,
+    // four per slot and sweep)
+    const uint32_t m1 = 0u - (tw & 1u), m2 = 0u - (tw >> 1);
+#define DVG_GIBBS_WORD(K) (((((rr[K].x & ~m1) | (rr[K].y & m1)) & ~m2)) | (((rr[K].z & ~m1) | (rr[K].w & m1)) & m2))
+    if constexpr (PAIRS) {
 #pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-      if (k < n_slots) {
-        if (sp[k] >= 0) {
-          const float f = gibbs_field(hs[k], row[k], L, st, a.n_batches, a.max_batches);
-          st[sp[k]] = gibbs_decide(f, a.two_beta, pick(rr[k], tw));
+      for (int c = 0; c < MAXS / 2; ++c) {
+        if (2 * c >= n_slots) break;
+        {
+          const int k0 = 2 * c, k1 = 2 * c + 1;
+          if (__builtin_amdgcn_ballot_w64(sp[k1] >= 0) != 0) {
+            float f0 = hs[k0], f1 = hs[k1];
+            gibbs_lane_field2<MB, LPC>(f0, f1, wl, ol, k0, stb);
+            const _Float16 s0 = gibbs_decide(f0, a.two_beta, DVG_GIBBS_WORD(k0));
+            const _Float16 s1 = gibbs_decide(f1, a.two_beta, DVG_GIBBS_WORD(k1));
+            if (sp[k0] >= 0) st[sp[k0]] = s0;
+            if (sp[k1] >= 0) st[sp[k1]] = s1;
+          } else if (sp[k0] >= 0) {
+            const float f = gibbs_lane_field<MB, LPC>(hs[k0], wl, ol, k0, stb);
+            st[sp[k0]] = gibbs_decide(f, a.two_beta, DVG_GIBBS_WORD(k0));
+          }
+          // the next class reads what this one wrote (same wave): order LDS traffic
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
         }
-        // the next class reads what this one wrote (same wave): order LDS traffic.  (Passes of one class are independent
-        // of each other, so a fence between them is harmless.)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k) {
+        if (k >= n_slots) break;
+        {
+          if (sp[k] >= 0) {
+            const float f = gibbs_lane_field<MB, LPC>(hs[k], wl, ol, k, stb);
+            st[sp[k]] = gibbs_decide(f, a.two_beta, DVG_GIBBS_WORD(k));
+          }
+          // (passes of one class are independent of each other, so a fence between them is harmless)
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
   }
-  }
-  if (!valid) return;
+#undef DVG_GIBBS_WORD
   int8_t* dst = a.state + (size_t)chain * n;
-  for (int i = l; i < n; i += LPCE) {
+  for (int i = l; i < n; i += LPC) {
     const float v = (float)st[i];
     dst[i] = (int8_t)v;
     if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
@@ -313,10 +426,8 @@ static size_t gibbs_lds_bytes(int n, int n_batches, int n_colours, int chains_pe
 struct GibbsProbe { int workgroups; int threads; size_t lds; };
 static thread_local GibbsProbe* g_gibbs_probe = nullptr;
 
-template <int LPC, int WAVES, int MAXS = GIBBS_MAXS>
-static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
-  a.passes = (max_class + LPC - 1) / LPC;
-  fast = fast && a.n_colours * a.passes <= MAXS;
+template <int LPC, int WAVES>
+static int launch_gibbs(GibbsArgs a, hipStream_t s) {
   constexpr int CPB = WAVES * (64 / LPC);
   const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CPB);
   if (lds > 160 * 1024) {
@@ -325,10 +436,23 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s, bool fast, int max_class) {
   }
   const int grid = (int)ceil_div(a.n_chains, CPB);
   if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
-  auto kern = fast ? gibbs_fast_kernel<LPC, WAVES, MAXS> : gibbs_kernel<LPC, WAVES>;
+  auto kern = gibbs_kernel<LPC, WAVES>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // work = spin updates of the draw (bench.py's sampler roofline)
+  DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
+  return DVG_OK;
+}
+
+template <int LPC, int WAVES, int MB>
+static int launch_gibbs_fast(GibbsArgs a, hipStream_t s, bool pairs) {
+  constexpr int CPB = WAVES * (64 / LPC);
+  const size_t lds = gibbs_lane_lds_bytes(a.n_colours * a.passes, MB, LPC, a.n, CPB);
+  const int grid = (int)ceil_div(a.n_chains, CPB);
+  if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
+  auto kern = pairs ? gibbs_fast_kernel<LPC, WAVES, MB, true> : gibbs_fast_kernel<LPC, WAVES, MB, false>;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
   return DVG_OK;
 }
@@ -358,6 +482,7 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   a.chain_id0 = chain_id0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
   a.sweep0 = sweep0; a.n_sweeps = n_sweeps; a.init = init;
   a.sweep0_dev = dyn ? &dyn->sweep0 : nullptr;
+  a.lane_src = nullptr; a.passes = 0;
   return gibbs_dispatch(g, a, n_chains, (hipStream_t)stream);
 }
 
@@ -380,36 +505,42 @@ extern "C" int dvg_gibbs_launch_info(const dvg_graph_t* g, int n_chains, int* wo
 }
 
 static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipStream_t s) {
-  // lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass
+  // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one;
+  // 2 = the fast schedule without its two-passes-side-by-side form)
+  const int64_t form = opt(OPT_GIBBS_GENERIC);
+  if (g->lane_src && form != 1) {
+    // Lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass (graph.cpp chose it).
+    // Waves per workgroup.  Measured on the c2 step with the draw overlapped with the encoder forward: 4 -> 1.237 ms,
+    // 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for issue slots, fatter workgroups do not pay for the CUs they
+    // free (round 5, c3: 8 waves -- 32 workgroups instead of 64 -- 1.23 ms per draw against 1.00 and 8.41 ms per step
+    // against 8.26).  Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one
+    // wave per workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 ->
+    // 1.060 ms).  Larger graphs keep four waves: every extra workgroup stages its own copy of the tables.
+    const int lpc = g->lane_lpc, mb = g->lane_mb;
+    a.lane_src = g->lane_src;
+    a.passes = g->lane_passes;
+    const bool pairs = a.passes == 2 && form != 2;
+    const bool small = gibbs_lane_lds_bytes(g->n_colours * a.passes, mb, lpc, g->n, 0) <= 16 * 1024 && n_chains <= 1024;
+#define DVG_GIBBS_FAST(LPC, MB)                                                       \
+  if (lpc == LPC && mb == MB)                                                         \
+    return small ? launch_gibbs_fast<LPC, 1, MB>(a, s, pairs) : launch_gibbs_fast<LPC, 4, MB>(a, s, pairs);
+    DVG_GIBBS_FAST(16, 4) DVG_GIBBS_FAST(16, 5) DVG_GIBBS_FAST(32, 4) DVG_GIBBS_FAST(32, 5)
+    DVG_GIBBS_FAST(64, 4) DVG_GIBBS_FAST(64, 5)
+#undef DVG_GIBBS_FAST
+    set_error("gibbs: lane image with %d lanes per chain and %d batches has no kernel", lpc, mb);
+    return DVG_E_UNSUPPORTED;
+  }
+  // The rolled schedule: graphs without a lane image (more than GIBBS_MAXS slots per lane, more than 20 neighbours).
   const int mc = g->max_class;
-  const bool big = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024;
-  // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one)
-  const bool force_generic = opt(OPT_GIBBS_GENERIC) != 0;
-  const bool fast = !force_generic;
-  // Waves per workgroup.  Measured on the c2 step with the draw overlapped with the encoder forward: 4 -> 1.237 ms,
-  // 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for issue slots, fatter workgroups do not pay for the CUs they free.
-  // Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one wave per
-  // workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger
-  // graphs keep four waves: every extra workgroup stages its own ~50 KB copy of the tables and takes that LDS from the
-  // encoder's convolutions that run beside the draw (c3: 19.15 ms with four waves, 19.4 with two, 19.7 with one).
-  const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
-  // (round 5, c3: 8 waves -- 32 workgroups instead of 64, 32 more CUs for the encoder beside the draw -- 1.23 ms per draw
-  // against 1.00 and 8.41 ms per step against 8.26)
-  const int waves = small ? 1 : 4;
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
-  // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw)
-  if (big) {
-    // (An 8-wave register-resident form of the fast schedule for these graphs -- 24 slots, `gibbs_bigfast` -- existed in
-    // rounds 2-3: the faster draw alone, 1.49 against 2.20 ms at the c5 slice, but its ~110 KB LDS footprint on EVERY CU
-    // starved the convolutions beside it: c5 step 5.0 against 4.0 ms.  Retired in round 4.)
-    return launch_gibbs<64, 16>(a, s, fast, mc);
-  }
-#define DVG_GIBBS_DISPATCH(LPC)                                              \
-  switch (waves) {                                                           \
-    case 1: return launch_gibbs<LPC, 1>(a, s, fast, mc);                     \
-    default: return launch_gibbs<LPC, 4>(a, s, fast, mc);                    \
-  }
+  // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw).
+  // (An 8-wave register-resident form for these graphs -- 24 slots, `gibbs_bigfast` -- existed in rounds 2-3: the
+  // faster draw alone, 1.49 against 2.20 ms at the c5 slice, but its ~110 KB LDS footprint on EVERY CU starved the
+  // convolutions beside it: c5 step 5.0 against 4.0 ms.  Retired in round 4.)
+  if (gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024) return launch_gibbs<64, 16>(a, s);
+  const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
+#define DVG_GIBBS_DISPATCH(LPC) return small ? launch_gibbs<LPC, 1>(a, s) : launch_gibbs<LPC, 4>(a, s);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }
   if (mc <= 32) { DVG_GIBBS_DISPATCH(32) }
   DVG_GIBBS_DISPATCH(64)

@@ -79,6 +79,29 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
   if (rc == DVG_OK) rc = upload(&g->adj_row, row, n);
   if (rc == DVG_OK) rc = upload(&g->adj_src4, src4, (size_t)4 * nb);
   delete[] row; delete[] src4;
+  if (rc == DVG_OK) {  // the lane-major image of the sampler's fast schedule (graph.h)
+    const int lpc = g->max_class <= 16 ? 16 : g->max_class <= 32 ? 32 : 64;
+    const int passes = (g->max_class + lpc - 1) / lpc, slots = n_colours * passes;
+    const int mb = g->max_batches <= 4 ? 4 : 5;
+    if (slots <= 12 && g->max_batches <= 5) {
+      const size_t count = (size_t)slots * mb * lpc * 4;
+      int32_t* img = new (std::nothrow) int32_t[count];
+      if (!img) { dvg_graph_destroy(g); DVG_REQUIRE(false, "graph_create: out of host memory"); }
+      for (size_t q = 0; q < count; ++q) img[q] = -1;
+      for (int k = 0; k < slots; ++k) {
+        const int col = k / passes, pass = k - col * passes;
+        for (int l = 0; l < lpc; ++l) {
+          const int p = class_ptr[col] + pass * lpc + l;
+          if (p >= class_ptr[col + 1]) continue;
+          const int i = order[p], d = adj_ptr[i + 1] - adj_ptr[i];
+          for (int t = 0; t < d; ++t) img[(((size_t)k * mb + t / 4) * lpc + l) * 4 + t % 4] = adj_ptr[i] + t;
+        }
+      }
+      rc = upload(&g->lane_src, img, count);
+      delete[] img;
+      g->lane_lpc = lpc; g->lane_mb = mb; g->lane_passes = passes;
+    }
+  }
   if (rc != DVG_OK) {
     if (rc == DVG_E_UNSUPPORTED) set_error("graph_create: a spin with more than 1020 neighbours");
     dvg_graph_destroy(g);
@@ -98,7 +121,7 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
 extern "C" int dvg_graph_destroy(dvg_graph_t* g) {
   if (!g) return DVG_OK;
   hipFree(g->edge_i); hipFree(g->edge_j); hipFree(g->order); hipFree(g->class_ptr);
-  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid); hipFree(g->adj_row); hipFree(g->adj_src4);
+  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid); hipFree(g->adj_row); hipFree(g->adj_src4); hipFree(g->lane_src);
   delete g;
   return DVG_OK;
 }

@@ -28,6 +28,18 @@ def _model(plan, rng):
                                              ("zephyr", 512, 64, 3), ("zephyr", 1024, 9, 2), ("pegasus", 128, 256, 50),
                                              ("zephyr", 512, 33, 13), ("zephyr", 1024, 41, 5)])  # last: 16-wave workgroups, ragged last one
 def test_gibbs_bit_exact(fam, n, C, sweeps):
+    _bit_exact(fam, n, C, sweeps)
+
+
+@pytest.mark.parametrize("fam,n,C,sweeps", [("zephyr", 512, 70, 6), ("pegasus", 512, 256, 5)])
+def test_gibbs_bit_exact_one_row_at_a_time(fam, n, C, sweeps):
+    """Graphs whose colour classes take two passes of 64 lanes run the passes side by side by default; option
+    gibbs_generic = 2 keeps the same lane-major schedule one row at a time -- same bits."""
+    with _lib.option_scope(gibbs_generic=2):
+        _bit_exact(fam, n, C, sweeps)
+
+
+def _bit_exact(fam, n, C, sweeps):
     plan, nodes = _plan(fam, n)
     rng = np.random.default_rng(n)
     h, J = _model(plan, rng)
@@ -67,7 +79,7 @@ def test_gibbs_bit_exact_on_arbitrary_graphs(n, p_edge, C, sweeps):
     hs, Js = gibbs.scaled_fields(h, J, 0.3, (-4, 4), (-1, 1))
     ids = np.arange(C, dtype=np.uint32) + 7
     lin = torch.from_numpy(h).cuda(); quad = torch.from_numpy(J).cuda()
-    for generic in (0, 1):
+    for generic in (0, 1, 2):
         with _lib.option_scope(gibbs_generic=generic):
             s = smp.GibbsSampler(plan, list(range(n)), beta=1.5, sweeps=sweeps, seed=SEED, persistent=True, chain_offset=7,
                                  h_range=(-4, 4), j_range=(-1, 1))
