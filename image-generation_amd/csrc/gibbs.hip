@@ -229,67 +229,49 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
 
 __host__ __device__ __forceinline__ size_t gibbs_lane_lds_bytes(int slots, int mb, int lpc, int n, int chains) {
-  return (size_t)slots * mb * lpc * 24 + sizeof(_Float16) * (size_t)chains * ((n + 15) & ~15);
+  // tables | one state row per chain | a 64-entry sink per wave (where lanes without a spin in a slot store)
+  return (size_t)slots * mb * lpc * 24 + sizeof(_Float16) * (size_t)chains * ((n + 15) & ~15) +
+         sizeof(_Float16) * 64 * (size_t)((chains * lpc + 63) / 64);
 }
 
-// the signed couplings of MB batches, in row order, onto f (one row)
-template <int MB, int LPC>
-__device__ __forceinline__ float gibbs_lane_field(float f, const unsigned char* wl, const unsigned char* ol, int k,
-                                                  const unsigned char* stb) {
-  gf32x4 w[MB];
-  gu32x2 o[MB];
-#pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    w[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)(k * MB + j) * LPC * 16);
-    o[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)(k * MB + j) * LPC * 8);
-  }
-  _Float16 h[MB][4];
-#pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    h[j][0] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] & 0xffffu));
-    h[j][1] = *reinterpret_cast<const _Float16*>(stb + (o[j][0] >> 16));
-    h[j][2] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] & 0xffffu));
-    h[j][3] = *reinterpret_cast<const _Float16*>(stb + (o[j][1] >> 16));
-  }
+// One colour-class step of the fast schedule: NRUN rows (slots k, k + 1) side by side -- per row the same reads and
+// the same adds, in row order.  The rows' state offsets `o` were read one step AHEAD (they do not depend on the state);
+// this step issues its state reads and coupling reads, then reads the NEXT step's offsets (`ol_next`) while those are in
+// flight, so that of the two dependent LDS round trips per step (tables, then state) only the second one is waited out.
+template <int MB, int LPC, int NR, int NRUN>
+__device__ __forceinline__ void gibbs_lane_class(float (&f)[NR], gu32x2 (&o)[NR][MB], const unsigned char* wlk,
+                                                 const unsigned char* ol_next, const unsigned char* stb) {
+  _Float16 h[NRUN][MB][4];
+  gf32x4 w[NRUN][MB];
+  // (the couplings first: nothing they wait for, and the LDS serves them while the state addresses are computed)
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) f = gibbs_signed_add(h[j][e], w[j][e], f);
+    for (int r = 0; r < NRUN; ++r) w[r][j] = *reinterpret_cast<const gf32x4*>(wlk + (size_t)(r * MB + j) * LPC * 16);
   }
-  return f;
-}
-
-// two rows (slots k and k + 1) side by side: the same reads and adds per row, in the same order
-template <int MB, int LPC>
-__device__ __forceinline__ void gibbs_lane_field2(float& f0, float& f1, const unsigned char* wl, const unsigned char* ol,
-                                                  int k, const unsigned char* stb) {
-  gf32x4 w0[MB], w1[MB];
-  gu32x2 o0[MB], o1[MB];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
-    w0[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)(k * MB + j) * LPC * 16);
-    o0[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)(k * MB + j) * LPC * 8);
-    w1[j] = *reinterpret_cast<const gf32x4*>(wl + (size_t)((k + 1) * MB + j) * LPC * 16);
-    o1[j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)((k + 1) * MB + j) * LPC * 8);
-  }
-  _Float16 h0[MB][4], h1[MB][4];
 #pragma unroll
-  for (int j = 0; j < MB; ++j) {
-    h0[j][0] = *reinterpret_cast<const _Float16*>(stb + (o0[j][0] & 0xffffu));
-    h0[j][1] = *reinterpret_cast<const _Float16*>(stb + (o0[j][0] >> 16));
-    h0[j][2] = *reinterpret_cast<const _Float16*>(stb + (o0[j][1] & 0xffffu));
-    h0[j][3] = *reinterpret_cast<const _Float16*>(stb + (o0[j][1] >> 16));
-    h1[j][0] = *reinterpret_cast<const _Float16*>(stb + (o1[j][0] & 0xffffu));
-    h1[j][1] = *reinterpret_cast<const _Float16*>(stb + (o1[j][0] >> 16));
-    h1[j][2] = *reinterpret_cast<const _Float16*>(stb + (o1[j][1] & 0xffffu));
-    h1[j][3] = *reinterpret_cast<const _Float16*>(stb + (o1[j][1] >> 16));
+    for (int r = 0; r < NRUN; ++r) {
+      h[r][j][0] = *reinterpret_cast<const _Float16*>(stb + (o[r][j][0] & 0xffffu));
+      h[r][j][1] = *reinterpret_cast<const _Float16*>(stb + (o[r][j][0] >> 16));
+      h[r][j][2] = *reinterpret_cast<const _Float16*>(stb + (o[r][j][1] & 0xffffu));
+      h[r][j][3] = *reinterpret_cast<const _Float16*>(stb + (o[r][j][1] >> 16));
+    }
   }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j) o[r][j] = *reinterpret_cast<const gu32x2*>(ol_next + (size_t)(r * MB + j) * LPC * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < MB; ++j) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      f0 = gibbs_signed_add(h0[j][e], w0[j][e], f0);
-      f1 = gibbs_signed_add(h1[j][e], w1[j][e], f1);
+#pragma unroll
+      for (int r = 0; r < NRUN; ++r) f[r] = gibbs_signed_add(h[r][j][e], w[r][j][e], f[r]);
     }
   }
 }
@@ -353,12 +335,22 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   __syncthreads();  // the tables are staged
   if (!valid) return;
 
+  // the byte a lane stores its slot-k decision to: its spin's, or its own entry of the wave's sink when it has none
+  // (an unconditional store keeps a class step one straight line of code)
+  _Float16* sink = state + (size_t)WAVES * CPW * n_pad + (size_t)wave * 64 + lane;
   const unsigned char* wl = smem + (size_t)l * 16;
   const unsigned char* ol = smem + (size_t)n_slots * MB * LPC * 16 + (size_t)l * 8;
   const unsigned char* stb = reinterpret_cast<const unsigned char*>(st);
   u32x4 rr[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) rr[k] = u32x4{0u, 0u, 0u, 0u};
+  constexpr int NR = PAIRS ? 2 : 1;  // rows per step
+  gu32x2 o[NR][MB];                  // the coming step's state offsets
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+#pragma unroll
+    for (int j = 0; j < MB; ++j) o[r][j] = *reinterpret_cast<const gu32x2*>(ol + (size_t)(r * MB + j) * LPC * 8);
+  }
   for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
     const uint32_t tq = t >> 2, tw = t & 3u;
     if (t == sweep0 || tw == 0u) {
@@ -370,42 +362,32 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
     // four per slot and sweep)
     const uint32_t m1 = 0u - (tw & 1u), m2 = 0u - (tw >> 1);
 #define DVG_GIBBS_WORD(K) (((((rr[K].x & ~m1) | (rr[K].y & m1)) & ~m2)) | (((rr[K].z & ~m1) | (rr[K].w & m1)) & m2))
-    if constexpr (PAIRS) {
 #pragma unroll
-      for (int c = 0; c < MAXS / 2; ++c) {
-        if (2 * c >= n_slots) break;
-        {
-          const int k0 = 2 * c, k1 = 2 * c + 1;
-          if (__builtin_amdgcn_ballot_w64(sp[k1] >= 0) != 0) {
-            float f0 = hs[k0], f1 = hs[k1];
-            gibbs_lane_field2<MB, LPC>(f0, f1, wl, ol, k0, stb);
-            const _Float16 s0 = gibbs_decide(f0, a.two_beta, DVG_GIBBS_WORD(k0));
-            const _Float16 s1 = gibbs_decide(f1, a.two_beta, DVG_GIBBS_WORD(k1));
-            if (sp[k0] >= 0) st[sp[k0]] = s0;
-            if (sp[k1] >= 0) st[sp[k1]] = s1;
-          } else if (sp[k0] >= 0) {
-            const float f = gibbs_lane_field<MB, LPC>(hs[k0], wl, ol, k0, stb);
-            st[sp[k0]] = gibbs_decide(f, a.two_beta, DVG_GIBBS_WORD(k0));
-          }
-          // the next class reads what this one wrote (same wave): order LDS traffic
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    } else {
+    for (int c = 0; c < MAXS / NR; ++c) {
+      const int k0 = NR * c, k1 = k0 + NR - 1;
+      if (k0 >= n_slots) break;
+      const unsigned char* wlk = wl + (size_t)k0 * MB * LPC * 16;
+      const unsigned char* ol_next = ol + (size_t)(k0 + NR < n_slots ? k0 + NR : 0) * MB * LPC * 8;
+      float f[NR];
 #pragma unroll
-      for (int k = 0; k < MAXS; ++k) {
-        if (k >= n_slots) break;
-        {
-          if (sp[k] >= 0) {
-            const float f = gibbs_lane_field<MB, LPC>(hs[k], wl, ol, k, stb);
-            st[sp[k]] = gibbs_decide(f, a.two_beta, DVG_GIBBS_WORD(k));
-          }
-          // (passes of one class are independent of each other, so a fence between them is harmless)
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-        }
+      for (int r = 0; r < NR; ++r) f[r] = hs[k0 + r];
+      bool both = false;
+      if constexpr (PAIRS) both = __builtin_amdgcn_ballot_w64(sp[k1] >= 0) != 0;
+      if (both) {
+        gibbs_lane_class<MB, LPC, NR, NR>(f, o, wlk, ol_next, stb);
+        const _Float16 s0 = gibbs_decide(f[0], a.two_beta, DVG_GIBBS_WORD(k0));
+        const _Float16 s1 = gibbs_decide(f[NR - 1], a.two_beta, DVG_GIBBS_WORD(k1));
+        *(sp[k0] >= 0 ? st + sp[k0] : sink) = s0;
+        *(sp[k1] >= 0 ? st + sp[k1] : sink) = s1;
+      } else {  // one row (PAIRS: the class's second pass is empty for the whole wave)
+        gibbs_lane_class<MB, LPC, NR, 1>(f, o, wlk, ol_next, stb);
+        const _Float16 s0 = gibbs_decide(f[0], a.two_beta, DVG_GIBBS_WORD(k0));
+        *(sp[k0] >= 0 ? st + sp[k0] : sink) = s0;
       }
+      // the next class reads what this one wrote (same wave): order LDS traffic.  (Passes of one class are independent
+      // of each other, so a fence between them is harmless.)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #undef DVG_GIBBS_WORD
