@@ -19,7 +19,9 @@ namespace dvg {
 struct GibbsArgs {
   const int32_t *order, *class_ptr, *adj_idx, *adj_eid;
   const int32_t *adj_row, *adj_src4;  // padded-row image (graph.h)
-  const int32_t* lane_src;            // lane-major image (graph.h); null: none for this graph
+  const int32_t *lane_spin, *lane_eid;  // lane-major image (graph.h); null: none for this graph
+  const uint16_t* lane_off;
+  int n_rows;                           // fast kernel: rows of that image
   const float *linear, *quadratic;
   int n, n_batches, max_batches, n_colours;
   float prefactor, h_lo, h_hi, j_lo, j_hi, two_beta;
@@ -29,7 +31,6 @@ struct GibbsArgs {
   uint32_t chain_id0, k0, k1, sweep0;
   const uint32_t* sweep0_dev;  // non-null: read the first-sweep index from device memory (graph replay)
   int n_sweeps, init;
-  int passes;  // fast kernel: ceil(max_class / lanes per chain)
 };
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -209,25 +210,26 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
   }
 }
 
-// Fast path for graphs with at most GIBBS_MAXS (colour class, pass) slots per lane, a pass being LPC spins of a class,
-// and at most 4 MB <= 20 neighbours per spin -- every graph the shipped solvers produce up to 512 spins.  Same
-// arithmetic, same order, same random stream as gibbs_kernel (bit-exact); what changes is the schedule and the LDS image:
-//   * a lane owns the same spin of every slot in every sweep, so its spin index and clamped field offset are read once,
+// Fast path for graphs of at most 20 rows per lane -- a row being one pass of LPC spins of a colour class -- and
+// at most 4 MB <= 20 neighbours per spin: every graph the shipped solvers produce up to 1024 spins.  Same arithmetic,
+// same order, same random stream as gibbs_kernel (bit-exact); what changes is the schedule and the LDS image:
+//   * a lane owns the same spin of every row in every sweep, so its spin index and clamped field offset are read once,
 //     before the sweep loop, and live in registers;
-//   * the neighbour tables are stored LANE-MAJOR (graph.h, `lane_src`): batch j of slot k of lane l sits at
+//   * the neighbour tables are stored LANE-MAJOR (graph.h, `lane_eid` / `lane_off`): batch j of row k of lane l sits at
 //     ((k MB + j) LPC + l), so a batch read is one ds_read_b128 / ds_read_b64 at an IMMEDIATE offset from a per-lane base
 //     -- consecutive lanes read consecutive 16-byte words (no bank conflicts, where the per-row image scattered them) and
-//     the ~25 compare / select / address instructions per slot of the per-row walk are gone; a lane without a spin in a
-//     slot, or a row shorter than MB batches, finds J = 0 there;
-//   * the two passes of a colour class (PAIRS: classes of 65..128 spins on 64 lanes -- c3) are independent of each other
-//     and are computed side by side: at one wave per SIMD a single row leaves the wave waiting out two LDS round trips
-//     and a chain of 20 dependent adds with nothing else to issue;
+//     the ~25 compare / select / address instructions per row of the per-row walk are gone; a lane without a spin in a
+//     row, or a spin of fewer than MB batches, finds J = 0 there;
+//   * the passes of a colour class are independent of each other and are computed two at a time (NR = 2: classes of more
+//     than LPC spins -- c3, c5), side by side: at one wave per SIMD a single row leaves the wave waiting out its LDS
+//     round trips and a chain of 20 dependent adds with nothing else to issue;
+//   * the state offsets of a step are read one step AHEAD, the couplings first, the stores are unconditional (a sink
+//     for lanes without a spin): a step is one straight line of code with one LDS round trip waited out;
 //   * Philox words are drawn once per (spin, sweep >> 2) and serve four sweeps, as the counter layout intends.
-// (Rounds 3-5 history: the per-row image with register-resident row descriptors, 1.00 ms per c3 draw alone; its passes
-// side by side 0.88; a two-waves-per-chain form, faster alone, lost inside the step -- twice the workgroups beside the
-// encoder -- and so did 8 waves per workgroup.)
-constexpr int GIBBS_MAXS = 12;       // slots of the common instantiations (every shipped graph up to 512 spins)
-
+// (Rounds 3-5 history, c3 draw alone: the per-row image with register-resident row descriptors 1.00 ms; lane-major
+// 0.73; two passes side by side 0.68; offsets one step ahead + straight-line steps 0.54.  Forms that lost: two waves
+// per chain with 4-wave workgroups (faster alone, twice the workgroups beside the encoder: slower step); a wave PAIR per
+// chain in 8-wave workgroups meeting at a barrier per class (0.61 ms); 8 or 2 waves per workgroup (step +0.2 ms).)
 __host__ __device__ __forceinline__ size_t gibbs_lane_lds_bytes(int slots, int mb, int lpc, int n, int chains) {
   // tables | one state row per chain | a 64-entry sink per wave (where lanes without a spin in a slot store)
   return (size_t)slots * mb * lpc * 24 + sizeof(_Float16) * (size_t)chains * ((n + 15) & ~15) +
@@ -276,22 +278,34 @@ __device__ __forceinline__ void gibbs_lane_class(float (&f)[NR], gu32x2 (&o)[NR]
   }
 }
 
-template <int LPC, int WAVES, int MB, bool PAIRS, int MAXS = GIBBS_MAXS>
+template <int LPC, int WAVES, int MB, int NR, int MAXS>
 __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int n = a.n, n_pad = (n + 15) & ~15;
-  const int passes = a.passes, n_slots = a.n_colours * passes;
+  const int n_rows = a.n_rows;
   const int tid = threadIdx.x;
-  // LDS: couplings [n_slots MB][LPC] x 16 B | state offsets [n_slots MB][LPC] x 8 B | state [chains][n_pad] float16
-  float* wimg = reinterpret_cast<float*>(smem);
-  uint16_t* oimg = reinterpret_cast<uint16_t*>(smem + (size_t)n_slots * MB * LPC * 16);
-  _Float16* state = reinterpret_cast<_Float16*>(smem + (size_t)n_slots * MB * LPC * 24);
+  // LDS: couplings [n_rows MB][LPC] x 16 B | state offsets [n_rows MB][LPC] x 8 B | state [chains][n_pad] float16 | sinks
+  gf32x4* wimg = reinterpret_cast<gf32x4*>(smem);
+  gu32x2* oimg = reinterpret_cast<gu32x2*>(smem + (size_t)n_rows * MB * LPC * 16);
+  _Float16* state = reinterpret_cast<_Float16*>(smem + (size_t)n_rows * MB * LPC * 24);
   {
-    const int n_ent = n_slots * MB * LPC * 4;
-    for (int q = tid; q < n_ent; q += WAVES * 64) {
-      const int src = a.lane_src[q];
-      wimg[q] = src >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[src]]), a.j_lo, a.j_hi) : 0.0f;
-      oimg[q] = src >= 0 ? (uint16_t)(2 * a.adj_idx[src]) : (uint16_t)0;
+    // one (row, batch, lane) cell per thread and trip: four edge ids and four offsets in two coalesced loads, four
+    // gathered couplings; two cells in flight
+    const int n_cell = n_rows * MB * LPC;
+    const int4* eid4 = reinterpret_cast<const int4*>(a.lane_eid);
+    const gu32x2* off4 = reinterpret_cast<const gu32x2*>(a.lane_off);
+    auto coupling = [&](int e) {
+      return e >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[e]), a.j_lo, a.j_hi) : 0.0f;
+    };
+    for (int q = tid; q < n_cell; q += 2 * WAVES * 64) {
+      const int q1 = q + WAVES * 64;
+      const bool two = q1 < n_cell;
+      const int4 e0 = eid4[q], e1 = two ? eid4[q1] : int4{-1, -1, -1, -1};
+      const gu32x2 o0 = off4[q], o1 = two ? off4[q1] : gu32x2{0u, 0u};
+      const gf32x4 w0 = {coupling(e0.x), coupling(e0.y), coupling(e0.z), coupling(e0.w)};
+      const gf32x4 w1 = {coupling(e1.x), coupling(e1.y), coupling(e1.z), coupling(e1.w)};
+      wimg[q] = w0; oimg[q] = o0;
+      if (two) { wimg[q1] = w1; oimg[q1] = o1; }
     }
   }
 
@@ -317,20 +331,13 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
       for (int i = l; i < n; i += LPC) st[i] = (_Float16)(float)src[i];
     }
   }
-  // this lane's spin in each (colour, pass) slot (-1: none) and its clamped field offset
+  // this lane's spin in each row (-1: none) and its clamped field offset
   int sp[MAXS];
   float hs[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) {
-    sp[k] = -1; hs[k] = 0.f;
-    if (k < n_slots) {
-      const int col = k / passes, pass = k - col * passes;
-      const int p = a.class_ptr[col] + pass * LPC + l;
-      if (valid && p < a.class_ptr[col + 1]) {
-        sp[k] = a.order[p];
-        hs[k] = clampf(__fmul_rn(a.prefactor, a.linear[sp[k]]), a.h_lo, a.h_hi);
-      }
-    }
+    sp[k] = (valid && k < n_rows) ? a.lane_spin[k * LPC + l] : -1;
+    hs[k] = sp[k] >= 0 ? clampf(__fmul_rn(a.prefactor, a.linear[sp[k]]), a.h_lo, a.h_hi) : 0.f;
   }
   __syncthreads();  // the tables are staged
   if (!valid) return;
@@ -339,12 +346,11 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
   // (an unconditional store keeps a class step one straight line of code)
   _Float16* sink = state + (size_t)WAVES * CPW * n_pad + (size_t)wave * 64 + lane;
   const unsigned char* wl = smem + (size_t)l * 16;
-  const unsigned char* ol = smem + (size_t)n_slots * MB * LPC * 16 + (size_t)l * 8;
+  const unsigned char* ol = smem + (size_t)n_rows * MB * LPC * 16 + (size_t)l * 8;
   const unsigned char* stb = reinterpret_cast<const unsigned char*>(st);
   u32x4 rr[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) rr[k] = u32x4{0u, 0u, 0u, 0u};
-  constexpr int NR = PAIRS ? 2 : 1;  // rows per step
   gu32x2 o[NR][MB];                  // the coming step's state offsets
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -365,21 +371,21 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_fast_kernel(GibbsArgs a) {
 #pragma unroll
     for (int c = 0; c < MAXS / NR; ++c) {
       const int k0 = NR * c, k1 = k0 + NR - 1;
-      if (k0 >= n_slots) break;
+      if (k0 >= n_rows) break;
       const unsigned char* wlk = wl + (size_t)k0 * MB * LPC * 16;
-      const unsigned char* ol_next = ol + (size_t)(k0 + NR < n_slots ? k0 + NR : 0) * MB * LPC * 8;
+      const unsigned char* ol_next = ol + (size_t)(k0 + NR < n_rows ? k0 + NR : 0) * MB * LPC * 8;
       float f[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) f[r] = hs[k0 + r];
       bool both = false;
-      if constexpr (PAIRS) both = __builtin_amdgcn_ballot_w64(sp[k1] >= 0) != 0;
+      if constexpr (NR == 2) both = __builtin_amdgcn_ballot_w64(sp[k1] >= 0) != 0;
       if (both) {
         gibbs_lane_class<MB, LPC, NR, NR>(f, o, wlk, ol_next, stb);
         const _Float16 s0 = gibbs_decide(f[0], a.two_beta, DVG_GIBBS_WORD(k0));
         const _Float16 s1 = gibbs_decide(f[NR - 1], a.two_beta, DVG_GIBBS_WORD(k1));
         *(sp[k0] >= 0 ? st + sp[k0] : sink) = s0;
         *(sp[k1] >= 0 ? st + sp[k1] : sink) = s1;
-      } else {  // one row (PAIRS: the class's second pass is empty for the whole wave)
+      } else {  // one row (NR = 2: the step's second row is empty for the whole wave)
         gibbs_lane_class<MB, LPC, NR, 1>(f, o, wlk, ol_next, stb);
         const _Float16 s0 = gibbs_decide(f[0], a.two_beta, DVG_GIBBS_WORD(k0));
         *(sp[k0] >= 0 ? st + sp[k0] : sink) = s0;
@@ -426,13 +432,17 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s) {
   return DVG_OK;
 }
 
-template <int LPC, int WAVES, int MB>
-static int launch_gibbs_fast(GibbsArgs a, hipStream_t s, bool pairs) {
+template <int LPC, int WAVES, int MB, int NR, int MAXS>
+static int launch_gibbs_fast(GibbsArgs a, hipStream_t s) {
   constexpr int CPB = WAVES * (64 / LPC);
-  const size_t lds = gibbs_lane_lds_bytes(a.n_colours * a.passes, MB, LPC, a.n, CPB);
+  const size_t lds = gibbs_lane_lds_bytes(a.n_rows, MB, LPC, a.n, CPB);
+  if (lds > 160 * 1024) {
+    set_error("gibbs: graph (n=%d, %d rows per lane) needs %zu B of LDS > 160 KiB", a.n, a.n_rows, lds);
+    return DVG_E_UNSUPPORTED;
+  }
   const int grid = (int)ceil_div(a.n_chains, CPB);
   if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, WAVES * 64, lds}; return DVG_OK; }
-  auto kern = pairs ? gibbs_fast_kernel<LPC, WAVES, MB, true> : gibbs_fast_kernel<LPC, WAVES, MB, false>;
+  auto kern = gibbs_fast_kernel<LPC, WAVES, MB, NR, MAXS>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(WAVES * 64), lds, s, a);
@@ -464,7 +474,7 @@ extern "C" int dvg_gibbs_sample(const dvg_graph_t* g, const float* linear, const
   a.chain_id0 = chain_id0; a.k0 = (uint32_t)seed; a.k1 = (uint32_t)(seed >> 32);
   a.sweep0 = sweep0; a.n_sweeps = n_sweeps; a.init = init;
   a.sweep0_dev = dyn ? &dyn->sweep0 : nullptr;
-  a.lane_src = nullptr; a.passes = 0;
+  a.lane_spin = nullptr; a.lane_eid = nullptr; a.lane_off = nullptr; a.n_rows = 0;
   return gibbs_dispatch(g, a, n_chains, (hipStream_t)stream);
 }
 
@@ -490,36 +500,40 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // (option gibbs_generic = 1 forces the rolled reference schedule: A/B runs and the bit-exactness test of the fast one;
   // 2 = the fast schedule without its two-passes-side-by-side form)
   const int64_t form = opt(OPT_GIBBS_GENERIC);
-  if (g->lane_src && form != 1) {
-    // Lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass (graph.cpp chose it).
+  // Graphs of more than 12 rows per lane (1024 spins: ~140 KB of tables, one 4-chain workgroup per CU) take the fast
+  // schedule only for draws of at most 512 chains: it is the LATENCY form (c5-size graph, 2048 chains x 50 sweeps: 0.59 ms
+  // alone against the rolled 16-wave form's 1.20) and costs the same CU-time -- but it takes every CU's LDS while it
+  // runs, and the c5 step, whose encoder AND decoder forward hide behind a 1.2 ms draw on half the chip, got slower
+  // with it (2.88 -> 3.01 ms: `profiles/r05_gibbs_c5_forms.txt`).
+  const bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512);
+  if (lane_ok && form != 1) {
+    // Lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass, else 64 (graph.cpp).
     // Waves per workgroup.  Measured on the c2 step with the draw overlapped with the encoder forward: 4 -> 1.237 ms,
     // 8 -> 1.273, 16 -> 1.391: the sweep loop does contend for issue slots, fatter workgroups do not pay for the CUs they
-    // free (round 5, c3: 8 waves -- 32 workgroups instead of 64 -- 1.23 ms per draw against 1.00 and 8.41 ms per step
-    // against 8.26).  Small graphs with few chains (c2: 128 spins, 256 chains -> 32 four-wave workgroups on 256 CUs): one
-    // wave per workgroup spreads the draw over four times as many CUs at a few KB of tables each (c2 step 1.082 ->
-    // 1.060 ms).  Larger graphs keep four waves: every extra workgroup stages its own copy of the tables.
-    const int lpc = g->lane_lpc, mb = g->lane_mb;
-    a.lane_src = g->lane_src;
-    a.passes = g->lane_passes;
-    const bool pairs = a.passes == 2 && form != 2;
-    const bool small = gibbs_lane_lds_bytes(g->n_colours * a.passes, mb, lpc, g->n, 0) <= 16 * 1024 && n_chains <= 1024;
-#define DVG_GIBBS_FAST(LPC, MB)                                                       \
-  if (lpc == LPC && mb == MB)                                                         \
-    return small ? launch_gibbs_fast<LPC, 1, MB>(a, s, pairs) : launch_gibbs_fast<LPC, 4, MB>(a, s, pairs);
-    DVG_GIBBS_FAST(16, 4) DVG_GIBBS_FAST(16, 5) DVG_GIBBS_FAST(32, 4) DVG_GIBBS_FAST(32, 5)
-    DVG_GIBBS_FAST(64, 4) DVG_GIBBS_FAST(64, 5)
+    // free (round 5, c3: 8 or 2 waves instead of 4: step +0.2 ms).  Small graphs with few chains (c2: 128 spins, 256
+    // chains -> 32 four-wave workgroups on 256 CUs): one wave per workgroup spreads the draw over four times as many
+    // CUs at a few KB of tables each (c2 step 1.082 -> 1.060 ms).  Larger graphs keep four waves: every extra workgroup
+    // stages its own copy of the tables.
+    const int lpc = g->lane_lpc, mb = g->lane_mb, rows = g->lane_rows;
+    a.lane_spin = g->lane_spin; a.lane_eid = g->lane_eid; a.lane_off = g->lane_off; a.n_rows = rows;
+    const int nr = form == 2 ? 1 : g->lane_nr;  // (2: a two-row image walked one row at a time -- empty rows and all)
+    const bool small = gibbs_lane_lds_bytes(rows, mb, lpc, g->n, 0) <= 16 * 1024 && n_chains <= 1024 && rows <= 12;
+#define DVG_GIBBS_FAST(LPC, W, MB, NR, MAXS) \
+  if (lpc == LPC && mb == MB && nr == NR && rows <= MAXS && (W == 1) == small) return launch_gibbs_fast<LPC, W, MB, NR, MAXS>(a, s);
+    DVG_GIBBS_FAST(16, 1, 4, 1, 12) DVG_GIBBS_FAST(16, 4, 4, 1, 12) DVG_GIBBS_FAST(16, 1, 5, 1, 12) DVG_GIBBS_FAST(16, 4, 5, 1, 12)
+    DVG_GIBBS_FAST(32, 1, 4, 1, 12) DVG_GIBBS_FAST(32, 4, 4, 1, 12) DVG_GIBBS_FAST(32, 1, 5, 1, 12) DVG_GIBBS_FAST(32, 4, 5, 1, 12)
+    DVG_GIBBS_FAST(64, 1, 4, 1, 12) DVG_GIBBS_FAST(64, 4, 4, 1, 12) DVG_GIBBS_FAST(64, 1, 5, 1, 12) DVG_GIBBS_FAST(64, 4, 5, 1, 12)
+    DVG_GIBBS_FAST(64, 4, 4, 1, 20) DVG_GIBBS_FAST(64, 4, 5, 1, 20)
+    DVG_GIBBS_FAST(64, 4, 4, 2, 12) DVG_GIBBS_FAST(64, 4, 5, 2, 12) DVG_GIBBS_FAST(64, 4, 4, 2, 20) DVG_GIBBS_FAST(64, 4, 5, 2, 20)
 #undef DVG_GIBBS_FAST
-    set_error("gibbs: lane image with %d lanes per chain and %d batches has no kernel", lpc, mb);
+    set_error("gibbs: lane image (%d lanes per chain, %d batches, %d rows in steps of %d) has no kernel", lpc, mb, rows, nr);
     return DVG_E_UNSUPPORTED;
   }
-  // The rolled schedule: graphs without a lane image (more than GIBBS_MAXS slots per lane, more than 20 neighbours).
+  // The rolled schedule: graphs without a lane image (more than 20 rows per lane, more than 20 neighbours per spin).
   const int mc = g->max_class;
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
   // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw).
-  // (An 8-wave register-resident form for these graphs -- 24 slots, `gibbs_bigfast` -- existed in rounds 2-3: the
-  // faster draw alone, 1.49 against 2.20 ms at the c5 slice, but its ~110 KB LDS footprint on EVERY CU starved the
-  // convolutions beside it: c5 step 5.0 against 4.0 ms.  Retired in round 4.)
   if (gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024) return launch_gibbs<64, 16>(a, s);
   const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
 #define DVG_GIBBS_DISPATCH(LPC) return small ? launch_gibbs<LPC, 1>(a, s) : launch_gibbs<LPC, 4>(a, s);

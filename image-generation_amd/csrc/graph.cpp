@@ -81,25 +81,44 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
   delete[] row; delete[] src4;
   if (rc == DVG_OK) {  // the lane-major image of the sampler's fast schedule (graph.h)
     const int lpc = g->max_class <= 16 ? 16 : g->max_class <= 32 ? 32 : 64;
-    const int passes = (g->max_class + lpc - 1) / lpc, slots = n_colours * passes;
+    const int nr = g->max_class > lpc ? 2 : 1;
     const int mb = g->max_batches <= 4 ? 4 : 5;
-    if (slots <= 12 && g->max_batches <= 5) {
-      const size_t count = (size_t)slots * mb * lpc * 4;
-      int32_t* img = new (std::nothrow) int32_t[count];
-      if (!img) { dvg_graph_destroy(g); DVG_REQUIRE(false, "graph_create: out of host memory"); }
-      for (size_t q = 0; q < count; ++q) img[q] = -1;
-      for (int k = 0; k < slots; ++k) {
-        const int col = k / passes, pass = k - col * passes;
-        for (int l = 0; l < lpc; ++l) {
-          const int p = class_ptr[col] + pass * lpc + l;
-          if (p >= class_ptr[col + 1]) continue;
-          const int i = order[p], d = adj_ptr[i + 1] - adj_ptr[i];
-          for (int t = 0; t < d; ++t) img[(((size_t)k * mb + t / 4) * lpc + l) * 4 + t % 4] = adj_ptr[i] + t;
-        }
+    int rows = 0;
+    for (int c = 0; c < n_colours; ++c) {
+      const int passes = (class_ptr[c + 1] - class_ptr[c] + lpc - 1) / lpc;
+      rows += nr * ((passes + nr - 1) / nr);
+    }
+    if (rows <= (lpc == 64 ? 20 : 12) && g->max_batches <= 5 && n <= 32767) {
+      const size_t count = (size_t)rows * mb * lpc * 4;
+      int32_t* spin = new (std::nothrow) int32_t[(size_t)rows * lpc];
+      int32_t* eid = new (std::nothrow) int32_t[count];
+      uint16_t* off = new (std::nothrow) uint16_t[count];
+      if (!spin || !eid || !off) {
+        delete[] spin; delete[] eid; delete[] off; dvg_graph_destroy(g);
+        DVG_REQUIRE(false, "graph_create: out of host memory");
       }
-      rc = upload(&g->lane_src, img, count);
-      delete[] img;
-      g->lane_lpc = lpc; g->lane_mb = mb; g->lane_passes = passes;
+      for (size_t q = 0; q < (size_t)rows * lpc; ++q) spin[q] = -1;
+      for (size_t q = 0; q < count; ++q) { eid[q] = -1; off[q] = 0; }
+      int k = 0;
+      for (int c = 0; c < n_colours; ++c) {
+        const int size = class_ptr[c + 1] - class_ptr[c], passes = (size + lpc - 1) / lpc;
+        for (int pass = 0; pass < passes; ++pass)
+          for (int l = 0; l < lpc && pass * lpc + l < size; ++l) {
+            const int i = order[class_ptr[c] + pass * lpc + l], d = adj_ptr[i + 1] - adj_ptr[i];
+            spin[(size_t)(k + pass) * lpc + l] = i;
+            for (int t = 0; t < d; ++t) {
+              const size_t q = (((size_t)(k + pass) * mb + t / 4) * lpc + l) * 4 + t % 4;
+              eid[q] = adj_eid[adj_ptr[i] + t];
+              off[q] = (uint16_t)(2 * adj_idx[adj_ptr[i] + t]);
+            }
+          }
+        k += nr * ((passes + nr - 1) / nr);
+      }
+      rc = upload(&g->lane_spin, spin, (size_t)rows * lpc);
+      if (rc == DVG_OK) rc = upload(&g->lane_eid, eid, count);
+      if (rc == DVG_OK) rc = upload(&g->lane_off, off, count);
+      delete[] spin; delete[] eid; delete[] off;
+      g->lane_lpc = lpc; g->lane_mb = mb; g->lane_nr = nr; g->lane_rows = rows;
     }
   }
   if (rc != DVG_OK) {
@@ -121,7 +140,7 @@ extern "C" int dvg_graph_create(int n, int n_edges, const int32_t* edge_i, const
 extern "C" int dvg_graph_destroy(dvg_graph_t* g) {
   if (!g) return DVG_OK;
   hipFree(g->edge_i); hipFree(g->edge_j); hipFree(g->order); hipFree(g->class_ptr);
-  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid); hipFree(g->adj_row); hipFree(g->adj_src4); hipFree(g->lane_src);
+  hipFree(g->adj_ptr); hipFree(g->adj_idx); hipFree(g->adj_eid); hipFree(g->adj_row); hipFree(g->adj_src4); hipFree(g->lane_spin); hipFree(g->lane_eid); hipFree(g->lane_off);
   delete g;
   return DVG_OK;
 }
