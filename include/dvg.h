@@ -346,7 +346,8 @@ int dvg_stream_anchor(dvg_stream_t stream);
  * exact) and multiplied as the six piece products down to 2^-16 on the bf16 MFMA with float32 accumulation: what is
  * dropped is below 2^-23 of a product, i.e. float32-class results (same parity bars as DVG_PRECISION_F32) at 6/16 of
  * the f32 MFMA's matrix time.
- * Environment DVG_CONV_BF16=1 / DVG_CONV_MODE=0|1|2 select the mode at first use.
+ * (The library reads no environment variable: the host side -- `CONV_PRECISION` in the YAML, bench.py --precision --
+ * calls dvg_set_conv_precision.)
  */
 #define DVG_PRECISION_F32 0
 #define DVG_PRECISION_BF16_INPUTS 1
