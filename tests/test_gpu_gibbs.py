@@ -91,6 +91,38 @@ def test_gibbs_bit_exact_on_arbitrary_graphs(n, p_edge, C, sweeps):
                 assert int((got != want.astype(np.float32)).sum()) == 0, (generic, call)
 
 
+def test_gibbs_bit_exact_many_small_classes():
+    """50 disjoint 14-cliques: 14 colour classes of 50 spins -> one pass of 64 lanes each, 14 rows per lane -- the
+    lane-major schedule's one-row form at more than 12 rows (no shipped graph has that shape), against the C oracle."""
+    k, m = 14, 50
+    n = k * m
+    ei, ej = [], []
+    for c in range(m):
+        for a in range(k):
+            for b in range(a + 1, k):
+                ei.append(c * k + a); ej.append(c * k + b)
+    plan = graphs.build_plan(n, np.asarray(ei, np.int64), np.asarray(ej, np.int64))
+    sizes = np.diff(plan.class_ptr)
+    assert plan.n_colours == k and sizes.max() == m
+    rng = np.random.default_rng(7)
+    h = (0.5 * rng.uniform(-1, 1, n)).astype(np.float32)
+    J = (1.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)
+    hs, Js = gibbs.scaled_fields(h, J, 0.4, (-4, 4), (-1, 1))
+    C, sweeps = 21, 5
+    ids = np.arange(C, dtype=np.uint32) + 3
+    lin = torch.from_numpy(h).cuda(); quad = torch.from_numpy(J).cuda()
+    for generic in (0, 1):
+        with _lib.option_scope(gibbs_generic=generic):
+            s = smp.GibbsSampler(plan, list(range(n)), beta=1.2, sweeps=sweeps, seed=SEED, persistent=True, chain_offset=3,
+                                 h_range=(-4, 4), j_range=(-1, 1))
+            want = cref.init_state(ids, n, SEED)
+            for call in range(2):
+                got = s.sample_native(lin, quad, 0.4, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
+                want = cref.gibbs_sweeps(want, ids, hs, Js, 1.2, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
+                                         plan.adj_eid, SEED, call * sweeps, sweeps)
+                assert int((got != want.astype(np.float32)).sum()) == 0, (generic, call)
+
+
 def test_sample_ising_dict_path_and_sampleset():
     plan, nodes = _plan("pegasus", 64)
     rng = np.random.default_rng(1)
