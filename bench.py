@@ -233,8 +233,11 @@ def loss_parity(side_mode=None):
     r = entry.parity_check(steps=12)
     if side_mode:
         s = entry.parity_check_by_state(side_mode, steps=12)
-        return {"steps": s["steps"], "max_rel_dev": s["max_rel_dev"], "tolerance": 1e-5, "mode": side_mode,
+        # (the by-state losses are each step's FORWARD pass only -- named so -- and the side mode's backward
+        # pass is reported beside them: every parameter gradient against the float32 step from the same state)
+        return {"steps": s["steps"], "max_rel_dev_by_state_forward_only": s["max_rel_dev"], "tolerance": 1e-5, "mode": side_mode,
                 "how": "each step taken from the float32 trajectory's saved training state",
+                "grad_rel_l2_vs_f32_by_state": {k: s["grad_rel_l2_vs_f32_by_state"][k] for k in ("worst_tensor", "worst")},
                 "max_rel_dev_free_run": r["max_rel_dev"], "gibbs_spin_mismatches": r["gibbs_spin_mismatches"],
                 "gibbs_spins_checked": r["gibbs_spins_checked"],
                 "against": "tests/golden/step_n64.npz (reference step orchestration over the CPU oracle, B=8, n=64, R=2)"}

@@ -612,6 +612,13 @@ def test_step_losses_match_reference_orchestration_split3_mode(golden_dir):
         assert dev_ <= 1e-5, (name, dev_)
     for name, dev_ in r["max_rel_dev_leading_f32_run"].items():  # (the trajectory the float32 test pins)
         assert dev_ <= 1e-5, (name, dev_)
+    # ... and the side mode's BACKWARD pass at every one of those states (the losses above are each step's forward
+    # pass only): every parameter gradient of the split-mode step against the float32 step from the same state, batch and
+    # noise.  The bar is the full-size tests' gradient bar against float64 (tests/test_gpu_headline.py); the one pooling
+    # window of the docstring routes ONE of 16384 windows of one layer differently, which is inside it.
+    g = r["grad_rel_l2_vs_f32_by_state"]
+    print("split-mode gradients vs float32, state by state: worst", g["worst_tensor"], f"{g['worst']:.2e}")
+    assert g["per_tensor"] and g["worst"] <= 5e-3, (g["worst_tensor"], g["worst"])
 
     # the free run: first step at the exact bar (one forward pass separates it from the reference), every later step
     # tracking the reference (a wrong backward or update would not)
