@@ -80,6 +80,8 @@ enum KernelId : int {
   K_IGEMM_WSPACE,   // conv_igemm_kernel launches on weights only (the composed decoder layers' weight-space products)
   K_IGEMM_WINO,     // conv_wino8_kernel (profiler name "conv_wino_kernel"): Winograd F(2x2,3x3) form of the encoder's 3x3 layers (work = executed FLOPs: 4/9 of the direct form's)
   K_WGRAD_WINO,     // conv_wino_wgrad8_kernel (profiler name "conv_wino_wgrad_kernel"): Winograd form of the encoder's 3x3 weight gradients (work = executed FLOPs)
+  K_IGEMM_WINO4,    // conv_wino4_kernel: Winograd F(4x4,3x3) form of the encoder's 3x3 layers (work = executed FLOPs: 1/4 of the direct form's)
+  K_WGRAD_WINO4,    // conv_wino4_wgrad_kernel: F(4x4,3x3) form of the encoder's 3x3 weight gradients (work = executed FLOPs)
   K_COUNT
 };
 

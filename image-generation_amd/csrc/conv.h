@@ -120,6 +120,46 @@ __device__ __forceinline__ void wino_pack_entry(const float* __restrict__ w, con
   }
 }
 
+// One (a, b) entry of the F(4x4, 3x3) weight pack U = G g G^T (conv_wino4.hip), G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6;
+// 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]: 36 floats (position 6 xi + nu) at [a / 4][b / 32][a % 4][b % 32] -- the 18 KiB a
+// workgroup's chunk reads (4 reduction channels x 32 output channels) are one contiguous piece.
+__device__ __forceinline__ void wino4_pack_entry(const float* __restrict__ w, const WeightMap& map, uint32_t e,
+                                                 float* __restrict__ u) {
+  typedef float pack_f32x4 __attribute__((ext_vector_type(4)));
+  const uint32_t av = e / (uint32_t)map.Cb, b = e - av * (uint32_t)map.Cb;
+  float g[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t] = packed_weight(w, map, t, (int)av, (int)b);
+  float tg[6][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const float g0 = g[s], g1 = g[3 + s], g2 = g[6 + s];
+    tg[0][s] = 0.25f * g0;
+    tg[1][s] = (-1.f / 6.f) * ((g0 + g1) + g2);
+    tg[2][s] = (-1.f / 6.f) * ((g0 - g1) + g2);
+    tg[3][s] = (g0 * (1.f / 24.f) + g1 * (1.f / 12.f)) + g2 * (1.f / 6.f);
+    tg[4][s] = (g0 * (1.f / 24.f) - g1 * (1.f / 12.f)) + g2 * (1.f / 6.f);
+    tg[5][s] = g2;
+  }
+  float o[36];
+#pragma unroll
+  for (int x = 0; x < 6; ++x) {
+    const float g0 = tg[x][0], g1 = tg[x][1], g2 = tg[x][2];
+    o[6 * x + 0] = 0.25f * g0;
+    o[6 * x + 1] = (-1.f / 6.f) * ((g0 + g1) + g2);
+    o[6 * x + 2] = (-1.f / 6.f) * ((g0 - g1) + g2);
+    o[6 * x + 3] = (g0 * (1.f / 24.f) + g1 * (1.f / 12.f)) + g2 * (1.f / 6.f);
+    o[6 * x + 4] = (g0 * (1.f / 24.f) - g1 * (1.f / 12.f)) + g2 * (1.f / 6.f);
+    o[6 * x + 5] = g2;
+  }
+  float* dst = u + ((size_t)((av >> 2) * ((uint32_t)map.Cb >> 5) + (b >> 5)) * 128 + (size_t)((av & 3) * 32 + (b & 31))) * 36;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const pack_f32x4 v = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+    *reinterpret_cast<pack_f32x4*>(dst + 4 * q) = v;
+  }
+}
+
 // Implicit-GEMM 3x3 (or 1-tap) convolution:  out[m][co] = sum_{tap,ci} in[nbr(m,tap)][ci] Wp[tap][ci][co] (+ bias)
 struct ConvArgs {
   const float* in;    // [(images * HW_in), Cin]; HW_in = HW/4 when `ups` (nearest-upsampled on the fly)
@@ -193,6 +233,12 @@ bool conv_wino_ok(int64_t M, int Cin, int Cout, int L, int kind = 0);  // kind: 
 int conv_wino_stats_blocks(int64_t M, int Cout);
 int launch_conv_wino(const ConvArgs& a, hipStream_t s);
 int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
+// Winograd F(4x4,3x3) form of the same layers (conv_wino4.hip): `wp` = the pack of a PackJob with wino = 2 (36 Cin Cout
+// floats: wino4_pack_entry), stats rows = conv_wino4_stats_blocks (tile blocks of 1024 pixels)
+bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L);  // shape only
+int conv_wino4_stats_blocks(int64_t M);
+int launch_conv_wino4(const ConvArgs& a, hipStream_t s);
+int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
 // Winograd form of a stride-1 3x3 layer's WEIGHT gradient (conv_wino_wgrad.hip): slabs [nslabs][16][Cin][Cout] (at most
 // conv_wino_wgrad_slab_floats), reduced and transformed back (G^T dU G) into the checkpoint layout `map` by the same call
 bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);      // policy (options) + shape
@@ -248,7 +294,7 @@ int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStrea
 // bf16t: the operand form of the launch the pack feeds (conv_launch_mode): 0 -> [tap][a][b], 3 / 4 / 5 -> K-major [tap][b][a]
 // rows: GEMM rows of the launch this pack feeds (launch_conv_igemm's M over all classes): together with map.Cb it
 // decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
-// wino = 1: the job writes the Winograd pack [Ca][Cb][16] of a 9-tap map instead (wino_pack_entry)
+// wino = 1: the job writes the Winograd pack [Ca][Cb][16] of a 9-tap map instead (wino_pack_entry); 2: the F(4x4,3x3) pack (wino4_pack_entry)
 struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; int wino = 0; };
 // operand form of one forward / data-gradient launch (ConvArgs.bf16): the process-wide mode mapped onto the kernels
 int conv_launch_mode(int64_t gemm_rows, int Cout);

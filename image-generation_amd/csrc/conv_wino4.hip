@@ -1,0 +1,542 @@
+// Winograd F(4x4, 3x3) form of the stride-1 3x3 convolutions of the encoder (forward of layers 1-3 and their data
+// gradients: /root/reference/src/encoder.py:28-36), float32 on v_mfma_f32_16x16x4_f32.
+//
+// Why: F(2x2, 3x3) (conv_wino.hip) issues 16 multiplies per 2x2 output quad and channel pair -- 4.0 per output; the
+// 4x4 output tile needs 36 per 16 outputs -- 2.25 per output: 0.5625 of the matrix work for the same float32 convolution,
+// paid for with transform constants 1/24 .. 8 instead of +-1, 1/2 (the measured error) and 36 accumulator
+// tiles per (tile, channel) sub-tile where the 2x2 form has 16.
+//
+//   U[xi][nu][ci][co] = (G g G^T)            weights, once per step (wino4_pack_entry), G = 6x3
+//   V[xi][nu][tile][ci] = (B^T d B)          6x6 input patch d of the 4x4 output tile (zero padded), B^T = 6x6
+//   M[xi][nu][tile][co] = sum_ci V U         36 independent GEMMs: the MFMA work
+//   Y[tile][4x4][co]    = A^T M A (+bias)    A^T = 4x6
+//
+// Morton-ordered activations (conv.h): a 4x4 output tile IS sixteen consecutive rows, 64 tiles are whole images.
+//
+// One workgroup = 8 waves on one CU, two per SIMD, a tile block of 64 tiles (1024 pixels) x 32 output channels.  The 36
+// position GEMMs of a 16 tile x 16 channel sub-tile live in ONE wave (36 accumulator tiles of 4 registers on the 16x16x4
+// MFMA = 144 registers), so the output transform is lane-local: no exchange between waves, no barrier in the epilogue
+// but the one that hands the block on.  (The 32x32x2 MFMA would need 576 accumulator registers per sub-tile, i.e. the 36
+// positions split over four waves and a reduce-scatter of 10 accumulator tiles per wave through LDS per tile block.)
+// The price is operand traffic: a 16x16x4 MFMA takes one A and one B value per lane for 32 cycles of matrix work, twice
+// the LDS read rate per FLOP of the 32x32x2 form -- one ds_read_b128 per operand and FOUR MFMAs (a 144-byte entry holds
+// the 36 positions of one (k, row); entries 36 words apart are conflict-free for the 16 lanes of a read pass as they
+// are, no swizzle).
+//
+// Channels are walked in chunks of 4 (one MFMA k-step); per chunk three LDS images: the raw input pixels of the block's
+// images as zero-haloed row-major pictures [image][y][x][4] (LDS-DMA with a per-lane source: the Morton -> row-major
+// permutation and the halo -- an out-of-range offset loads zeros -- cost nothing, and every tap of a patch is then ONE
+// base register + an immediate), the transformed weights [k][co][36] (LDS-DMA of a contiguous 18 KiB piece of the
+// pack), the transformed input [k][tile][36], written by waves 0-3 (a patch per thread and chunk, under the MFMAs).
+// Two stages of each, one barrier per chunk, the chunk sequence runs on across the tile blocks a workgroup owns
+// (persistent grid, dynamic deal: conv_wino.hip).
+#include <atomic>
+
+#include "conv.h"
+#include "conv_tile.h"
+
+namespace dvg {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+
+struct Wino4Args {
+  const float* in;    // [16 tiles][Cin]  (Morton pixel order: tile t = rows 16t .. 16t+15)
+  const float* u;     // [Cin / 4][Cout / 32][4][32][36] transformed weights (wino4_pack_entry)
+  const float* bias;  // [Cout] or null
+  float* out;         // [16 tiles][Cout]
+  float* stats;       // [nblk][Cout][2] per tile block (sum, sum of squares) of the output, or null
+  int cus = 0;        // CUs the persistent grid is sized for (0 = 256)
+  int* dyn = nullptr; // tile counters of the dynamic deal (conv_wino.hip), or null: round-robin
+  int Cin, Cout;
+  int nblk;           // tile blocks (of 64 tiles)
+  int dbg = 0;        // (diagnostic builds: bit 0 no output stores, bit 1 staggered start)
+};
+
+template <int L>
+struct Wino4Cfg {
+  static constexpr int H = 1 << L, HW = H * H, TPI = HW / 16, IPB = 64 / TPI;  // tiles per image, images per tile block
+  // The raw pictures, in 16-byte cells (a pixel's 4 channels).  4x4 images: one tile per image, the halo is known at
+  // compile time -- 16 cells in Morton order + 1 (an ODD image stride: the 8 images of a 32-lane read pass start in 8
+  // different bank groups).  8x8: a zero-haloed 10 x 10 picture per image + 1.  16x16: rows of 23 cells -- left halo, a
+  // dead cell, then FIVE cells per 4 pixels (the fifth dead), right halo: a tile's x-step is 5 cells, so the 8 tiles a
+  // read pass spans (x bit 0, x bit 1, y bit 0) start in 8 different bank groups -- and 17 rows per image (the bottom
+  // halo row is the next image's top one).
+  static constexpr int ROWC = L == 3 ? 10 : 23, ROWS_IMG = L == 3 ? 10 : 17;
+  static constexpr int CELLS_IMG = L == 2 ? 17 : (L == 3 ? 101 : ROWS_IMG * ROWC);
+  static constexpr int NCELL = L == 4 ? (IPB * ROWS_IMG + 1) * ROWC : IPB * CELLS_IMG;
+  static constexpr int RAW_B = NCELL * 16;
+  static constexpr int NRAWP = (NCELL + 63) / 64;   // 1 KiB DMA pieces (the last one is moved back to end at NCELL)
+  // transformed input: [k][entry][36 floats], 32 bytes between the k planes (see the bank notes in the kernel)
+  static constexpr int VPL = 64 * 144 + 32, V_B = 4 * VPL;
+  static constexpr int U_B = 4 * 32 * 144, U_PIECES = U_B / 1024;
+  static constexpr int OFF_RAW = 0, OFF_V = 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B, OFF_NEXT = OFF_RED + 1024;
+  static constexpr int LDS_BYTES = OFF_NEXT + 16;
+  static_assert(L >= 2 && L <= 4 && NCELL >= 64 && U_PIECES == 18 && LDS_BYTES <= 160 * 1024, "unsupported shape");
+  // cell offset of patch element (i, j) from the thread's base cell
+  static constexpr int poff(int i, int j) {
+    if (L == 2) return (int)(((unsigned)(j - 1) & 1u) | (((unsigned)(i - 1) & 1u) << 1) | (((unsigned)(j - 1) & 2u) << 1) | (((unsigned)(i - 1) & 2u) << 2));
+    if (L == 3) return i * ROWC + j;
+    return i * ROWC + (j == 0 ? 0 : (j == 5 ? 7 : j + 1));  // (from the row's cell 5 tx: the left neighbour of the tile)
+  }
+};
+
+// Entry of MFMA row r (0..15) inside its group of sixteen: rows {0-3, 12-15} on the even entries, rows {4-11} on the odd
+// ones.  A ds_read_b128 is served in lane groups that pair the rows {0-3, 12-15} of one k plane with the rows {4-11} of
+// the next; with the planes 32 bytes apart (what makes the transform's ds_write_b128 conflict-free: its 8-lane groups
+// hold 4 planes x 2 entries) the two halves of a group then fall on the even and the odd 16-byte bank groups.
+__device__ __forceinline__ constexpr int wino4_entry(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
+
+// B^T x for one line of six (12 operations); ZE: x0 = x5 = 0 (the halo of a 4x4 image)
+template <bool ZE>
+__device__ __forceinline__ void wino4_in6(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5) {
+  const float p = __builtin_fmaf(-4.f, x2, x4), q = __builtin_fmaf(-4.f, x1, x3);
+  const float r = x4 - x2, s = x3 - x1;
+  float t0, t5;
+  if constexpr (ZE) {
+    t0 = __builtin_fmaf(-5.f, x2, x4);
+    t5 = __builtin_fmaf(-5.f, x3, 4.f * x1);
+  } else {
+    t0 = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
+    t5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
+  }
+  x0 = t0; x1 = p + q; x2 = p - q; x3 = __builtin_fmaf(2.f, s, r); x4 = __builtin_fmaf(-2.f, s, r); x5 = t5;
+}
+
+__device__ __forceinline__ f32x4 vfma(float k, const f32x4& a, const f32x4& b) {
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(k, a[i], b[i]);
+  return o;
+}
+
+// A^T m for one line of six accumulator tiles -> four (10 operations per component)
+__device__ __forceinline__ void wino4_out6(const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, const f32x4& m4,
+                                           const f32x4& m5, f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
+  const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y0 = (m0 + s1) + s2;
+  y1 = vfma(2.f, d2, d1);
+  y2 = vfma(4.f, s2, s1);
+  y3 = vfma(8.f, d2, d1) + m5;
+}
+
+template <int L>
+__device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned char* wsm) {
+  using C = Wino4Cfg<L>;
+  constexpr int H = C::H, HW = C::HW;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave & 3, wc = wave >> 2;  // the wave's 16 tiles and 16 channels of the block's 64 x 32
+  const int kq = lane >> 4, r16 = lane & 15;
+  const int n0 = blockIdx.y * 32;
+  const int nch = a.Cin / 4;
+
+  // ---- the patch a thread of waves 0-3 transforms per chunk: channel t_k of tile tl.  Lane bits: k (2), then three tile
+  // bits p, a, b, then c; wave bits w.  (1) The 32 lanes of a raw read pass (k, p, a, b) hold 4 channels x 8 cells that
+  // start in 8 different bank groups; (2) the 8 lanes of a ds_write_b128 group (k, p) hold 4 planes x 2 entries of
+  // different parity (p flips bit 2 of the tile's MFMA row: wino4_entry), 8 different bank groups.
+  const int t_k = lane & 3, bp = (lane >> 2) & 1, ba = (lane >> 3) & 1, bb = (lane >> 4) & 1, bc = lane >> 5;
+  int t_img, t_ty = 0, t_tx = 0, cell0;
+  if constexpr (L == 2) {
+    t_img = ba | (bb << 1) | (bp << 2) | (bc << 3) | (wt << 4);
+    cell0 = t_img * 17;
+  } else if constexpr (L == 3) {
+    t_img = bp | (ba << 1) | (bc << 2) | ((wt & 1) << 3); t_tx = bb; t_ty = wt >> 1;
+    cell0 = t_img * C::CELLS_IMG + 4 * t_ty * C::ROWC + 4 * t_tx;
+  } else {
+    t_img = wt; t_tx = ba | (bp << 1); t_ty = bb | (bc << 1);
+    cell0 = (t_img * C::ROWS_IMG + 4 * t_ty) * C::ROWC + 5 * t_tx;
+  }
+  const int tl = t_img * C::TPI + (int)morton((uint32_t)t_ty, (uint32_t)t_tx);
+  const int t_entry = (tl & ~15) + wino4_entry(tl & 15);
+  // (one base register per stage: the LDS image spans 160 KB and a DS instruction's immediate offset 64 KB -- with ONE
+  // base the compiler adds the stage's offset in front of every access)
+  uint32_t rbase[2], vst[2], aaddr[2], baddr[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    rbase[st] = lds0 + C::OFF_RAW + st * C::RAW_B + (uint32_t)((cell0 * 4 + t_k) * 4);
+    vst[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(t_k * C::VPL + t_entry * 144);
+    // MFMA operands: entry (k, row) of 144 bytes; lane (kq, r16) reads k = kq of its row / column
+    aaddr[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(kq * C::VPL + (16 * wt + wino4_entry(r16)) * 144);
+    baddr[st] = lds0 + C::OFF_U + st * C::U_B + (uint32_t)((kq * 32 + 16 * wc + r16) * 144);
+    asm volatile("" : "+v"(rbase[st]), "+v"(vst[st]), "+v"(aaddr[st]), "+v"(baddr[st]));  // (kept apart: not base + constant again)
+  }
+
+  // ---- DMA of one chunk's images: 1 KiB pieces; raw piece p by wave p % 8, weight piece q by wave 4 + q % 4
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * 1024 * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.u), 0, (int)((int64_t)a.Cin * a.Cout * 144), 0x00020000);
+  // Every wave of a role issues the SAME number of pieces, unconditionally (a piece index past the end repeats the last
+  // piece: same bytes, same place): with a conditional piece the compiler's wait-count pass loses the order of the
+  // vector-memory operations at the join and puts vmcnt(0) in front of every barrier -- which drains the output stores.
+  // Waves 0-3 (the transform role): RX raw pieces each; waves 4-7: RN raw pieces and the UPW weight pieces.
+  constexpr int RX = C::NRAWP / 8, RN = (C::NRAWP - 4 * RX + 3) / 4, RPW = RN, UPW = 5;
+  static_assert(RX >= 1 && RN >= RX && 4 * (RX + RN) >= C::NRAWP, "raw pieces");
+  int rvoff[RPW];
+  uint32_t rdst[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    int p = wave < 4 ? wave + 4 * q : 4 * RX + (wave - 4) + 4 * q;
+    if (p > C::NRAWP - 1) p = C::NRAWP - 1;
+    // (the last piece ends at the image's last cell: it rewrites a few cells of the piece before it with the same bytes
+    // instead of running past the stage)
+    const int c0 = p == C::NRAWP - 1 ? C::NCELL - 64 : p * 64;
+    const int cell = c0 + lane, img = cell / C::CELLS_IMG, rem = cell - img * C::CELLS_IMG;
+    bool inside;
+    int px;
+    if constexpr (L == 2) {
+      inside = rem < 16;
+      px = img * 16 + rem;
+    } else if constexpr (L == 3) {
+      const int yy = rem / C::ROWC, xx = rem - yy * C::ROWC;
+      inside = rem < C::ROWC * C::ROWC && yy >= 1 && yy <= H && xx >= 1 && xx <= H;
+      px = img * HW + (int)morton((uint32_t)(inside ? yy - 1 : 0), (uint32_t)(inside ? xx - 1 : 0));
+    } else {
+      const int row = cell / C::ROWC, xx = cell - row * C::ROWC, im = row / C::ROWS_IMG, yy = row - im * C::ROWS_IMG;
+      const int g = xx - 2, grp = g / 5, w5 = g - grp * 5;  // cells 0 / 22: the halo; 1 and every fifth: dead
+      inside = yy >= 1 && im < C::IPB && g >= 0 && xx < C::ROWC - 1 && w5 < 4;
+      px = im * HW + (int)morton((uint32_t)(inside ? yy - 1 : 0), (uint32_t)(inside ? 4 * grp + w5 : 0));
+    }
+    rvoff[q] = inside ? px * a.Cin * 4 : (int)0x80000000u;  // (past num_records: the hardware writes zeros -- the halo)
+    rdst[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + (uint32_t)c0 * 16));
+  }
+  // (one piece per call, so that a chunk can place them between its MFMA groups; q-th piece of this wave)
+  auto raw_soff = [&](int blk, int ch) { return __builtin_amdgcn_readfirstlane((blk * 1024 * a.Cin + ch * 4) * 4); };
+  auto issue_raw_piece = [&](int soff, int st, int q) {
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rdst[q] + (uint32_t)(st * C::RAW_B)));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
+  };
+  const int ustride = a.Cout / 32 * C::U_B;  // bytes between two chunks of the pack
+  auto u_sbase = [&](int ch) { return __builtin_amdgcn_readfirstlane(ch * ustride + (int)blockIdx.y * C::U_B); };
+  auto issue_u_piece = [&](int sbase, int st, int q) {  // (waves 4-7; pieces 18, 19 repeat pieces 0, 1)
+    int p = ((wave - 4) & 3) + 4 * q;
+    if (p >= C::U_PIECES) p -= C::U_PIECES;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_U + st * C::U_B + p * 1024));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_void_t*)(uintptr_t)dst, 16, lane * 16, sbase + p * 1024, 0, 0);
+  };
+  // all of a chunk's pieces at once (the prologue): XFW = the wave's role
+  auto issue_all = [&](auto xfc, int blk, int ch, int st, bool with_u) {
+    constexpr bool XFW = decltype(xfc)::value != 0;
+    const int soff = raw_soff(blk, ch);
+#pragma unroll
+    for (int q = 0; q < (XFW ? RX : RN); ++q) issue_raw_piece(soff, st, q);
+    if constexpr (!XFW) {
+      if (with_u) {
+        const int sbase = u_sbase(ch);
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) issue_u_piece(sbase, st, q);
+      }
+    }
+  };
+
+  // ---- input transform of the thread's patch: raw stage `rs` -> transformed stage `vs`, in place in d[36]
+  constexpr int I0 = L == 2 ? 1 : 0, I1 = L == 2 ? 5 : 6;  // (4x4 images: ring 0 / 5 of the patch is the zero padding)
+  auto load_patch = [&](int rs, float (&d)[36]) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+#pragma unroll
+      for (int j = I0; j < I1; ++j) {
+        d[i * 6 + j] = *reinterpret_cast<lds_cf32*>((uintptr_t)(rbase[rs] + (uint32_t)(C::poff(i, j) * 16)));
+      }
+    if constexpr (L == 2) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e)
+        if (e / 6 == 0 || e / 6 == 5 || e % 6 == 0 || e % 6 == 5) d[e] = 0.f;
+    }
+  };
+  auto xform_col = [&](int j, float (&d)[36]) {  // B^T d, column j
+    if (L == 2 && (j == 0 || j == 5)) return;    // (a zero column stays zero)
+    wino4_in6<L == 2>(d[j], d[6 + j], d[12 + j], d[18 + j], d[24 + j], d[30 + j]);
+  };
+  auto xform_row = [&](int i, float (&d)[36]) {  // (.) B, row i
+    wino4_in6<L == 2>(d[6 * i], d[6 * i + 1], d[6 * i + 2], d[6 * i + 3], d[6 * i + 4], d[6 * i + 5]);
+  };
+  auto store_quads = [&](int vs, int q0, const float (&d)[36]) {  // entries 4 q0 .. 4 q0 + 11 (two transformed rows)
+#pragma unroll
+    for (int q = q0; q < q0 + 3; ++q) {
+      const f32x4 o = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst[vs] + (uint32_t)(q * 16))) = o;
+    }
+  };
+
+  f32x4 acc[36];  // acc[6 xi + nu][v] = M[xi][nu] of tile 16 wt + r16, channel 16 wc + 4 kq + v (the weights are the MFMA's A operand)
+
+  const bool dynq = a.dyn != nullptr;
+  volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
+  auto finish = [&]() {
+    if (dynq && tid == 0 && atomicAdd(a.dyn + 16 + blockIdx.y, 1) == (int)gridDim.x - 1) {
+      atomicExch(a.dyn + blockIdx.y, 0);
+      atomicExch(a.dyn + 16 + blockIdx.y, 0);
+    }
+  };
+  int blk_cur = (int)blockIdx.x, blk_nxt = blk_cur + (int)gridDim.x;
+  if (dynq) {
+    if (tid == 0) { nslot[0] = atomicAdd(a.dyn + blockIdx.y, 1); nslot[1] = atomicAdd(a.dyn + blockIdx.y, 1); }
+    __syncthreads();
+    blk_cur = __builtin_amdgcn_readfirstlane(nslot[0]);
+    blk_nxt = __builtin_amdgcn_readfirstlane(nslot[1]);
+    __syncthreads();
+  }
+  bool has_next = blk_nxt < a.nblk;
+  if (blk_cur >= a.nblk) { finish(); return; }
+  if (a.dbg & 2) {  // workgroup phases a quarter of a tile block apart (~1100 cycles per chunk and quarter)
+    const int n = ((int)(blockIdx.x + blockIdx.y) & 3) * nch * 9;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2);
+  }
+  if (wave < 4) { issue_all(std::integral_constant<int, 1>{}, blk_cur, 0, 0, true); issue_all(std::integral_constant<int, 1>{}, blk_cur, 1, 1, false); }
+  else { issue_all(std::integral_constant<int, 0>{}, blk_cur, 0, 0, true); issue_all(std::integral_constant<int, 0>{}, blk_cur, 1, 1, false); }
+  __syncthreads();  // (the workgroup fence waits for the LDS-DMA pieces)
+  if (wave < 4) {
+    float d[36];
+    load_patch(0, d);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xform_col(j, d);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xform_row(i, d);
+    store_quads(0, 0, d); store_quads(0, 3, d); store_quads(0, 6, d);
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+      a.out, 0, (a.dbg & 1) ? 0 : (int)((int64_t)a.nblk * 1024 * a.Cout * 4), 0x00020000);  // (diagnostic: no records = every store dropped)
+  const int ch_out = n0 + 16 * wc + 4 * kq;               // the lane's four output channels
+  const int ovoff = (r16 * 16 * a.Cout + ch_out) * 4;     // tile r16 of the wave's sixteen, pixel 0
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + ch_out);
+
+  // outputs of the tile block just finished (16 pixels x 4 channels per lane), stored beside the MFMAs of the NEXT block's
+  // first chunk (or behind the last block): all workgroups reach their epilogues together and 128 KB per workgroup stored
+  // at once is a burst the memory system takes microseconds to drain -- and stores count on vmcnt like the LDS-DMA
+  // pieces, so a chunk barrier behind them would sit that out.  Issued behind the first chunk's pieces they stay in
+  // flight across its barrier; a store's registers are free again before the accumulator tiles come alive.
+  f32x4 yp[16];  // yp[b 4 + a]: pixel (a, b) of the lane's tile
+  int pblk = 0;
+  auto store_pending = [&](int idx) {
+    const int b = idx >> 2, aa = idx & 3;
+    // (the row index is kept opaque: its products with the 16 constant row offsets would each take a scalar register)
+    int row0 = __builtin_amdgcn_readfirstlane((pblk * 64 + 16 * wt) * 16);
+    asm volatile("" : "+s"(row0));
+    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, yp[idx]), rsrc_out, ovoff,
+                                           (row0 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, 0);
+  };
+  // the epilogue: Y = A^T M A per (tile, channel), lane-local; + bias, BatchNorm partials
+  auto epilogue = [&](int blk) {
+    f32x4 c[24];  // c[4 xi + b] = sum_nu M[xi][nu] A[nu][b]
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+      wino4_out6(acc[6 * xi], acc[6 * xi + 1], acc[6 * xi + 2], acc[6 * xi + 3], acc[6 * xi + 4], acc[6 * xi + 5],
+                 c[4 * xi], c[4 * xi + 1], c[4 * xi + 2], c[4 * xi + 3]);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x4 y[4];
+      wino4_out6(c[b], c[4 + b], c[8 + b], c[12 + b], c[16 + b], c[20 + b], y[0], y[1], y[2], y[3]);
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa) {
+        const f32x4 v = y[aa] + bias;
+        s1 += v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s2[i] = __builtin_fmaf(v[i], v[i], s2[i]);
+        yp[b * 4 + aa] = v;
+      }
+    }
+    pblk = blk;
+    if (a.stats) {  // per-wave column sums (over the wave's 16 tiles: lanes r16); summed over the block's four tile groups behind the caller's barrier
+      float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], m, 64); s2[i] += __shfl_xor(s2[i], m, 64); }
+      if (r16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { red[(wt * 32 + 16 * wc + 4 * kq + i) * 2] = s1[i]; red[(wt * 32 + 16 * wc + 4 * kq + i) * 2 + 1] = s2[i]; }
+      }
+    }
+  };
+  auto stats_finish = [&](int blk) {
+    if (a.stats && tid < 32) {
+      const float* red = reinterpret_cast<const float*>(wsm + C::OFF_RED);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 32 + tid) * 2]; t2 += red[(w * 32 + tid) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)blk * a.Cout + n0 + tid) * 2;
+      dst[0] = t1; dst[1] = t2;
+    }
+  };
+
+  // One chunk: 9 operand quads (a ds_read_b128 per operand, positions 4 q .. 4 q + 3) x 4 MFMAs as one pinned stream,
+  // operands two quads ahead; waves 0-3 (XF) read their patch of the NEXT chunk at the start and transform it in pieces
+  // beside the MFMAs: the six columns, then the six rows, the entries stored as they complete.
+  auto chunk = [&](int cix, auto stc, auto xfc, auto firstc, auto pendc) {
+    constexpr int st = decltype(stc)::value;
+    constexpr bool XF = decltype(xfc)::value != 0, FIRST = decltype(firstc)::value != 0, PEND = decltype(pendc)::value != 0;
+    const int u_ch = cix + 1 < nch ? cix + 1 : 0;
+    const bool over = cix + 2 >= nch;
+    const int r_ch = !over ? cix + 2 : (has_next ? cix + 2 - nch : nch - 1);
+    const int r_blk = over && has_next ? blk_nxt : blk_cur;
+    const int usb = u_sbase(u_ch), rso = raw_soff(r_blk, r_ch);
+    f32x4 qa[3], qb[3];
+    auto load_quad = [&](int q) {  // (qa: the weights -- the MFMA's A operand; qb: the tiles)
+      qa[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st] + (uint32_t)(q * 16)));
+      qb[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st] + (uint32_t)(q * 16)));
+    };
+    float d[36];
+    load_quad(0);
+    load_quad(1);
+    if constexpr (XF) load_patch(st ^ 1, d);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q + 2 < 9) load_quad(q + 2);
+      if constexpr (XF) {
+        // pieces: q = 1..3 two columns each, q = 4..6 two rows each and their three entry quads
+        if (q >= 1 && q <= 3) { xform_col(2 * q - 2, d); xform_col(2 * q - 1, d); }
+        if (q >= 4 && q <= 6) { xform_row(2 * q - 8, d); xform_row(2 * q - 7, d); store_quads(st ^ 1, 3 * (q - 4), d); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (FIRST) acc[4 * q + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q % 3][m], qb[q % 3][m], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else acc[4 * q + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q % 3][m], qb[q % 3][m], acc[4 * q + m], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the chunk's LDS-DMA pieces behind its first MFMA groups (the matrix pipe has work while they issue; they have the
+      // rest of the chunk to land): the next chunk's weights first (waves 4-7: five pieces), then the raw pixels of
+      // the chunk after next
+      if constexpr (!XF) { if (q < UPW) issue_u_piece(usb, st ^ 1, q); }
+      if (q < (XF ? RX : RN)) issue_raw_piece(rso, st, q);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PEND) {
+        // (behind the wave's last piece: the stores stay in flight across the chunk barrier; the transform role, whose
+        // patch registers are live beside the growing accumulator set, has few pieces and starts early)
+        constexpr int SQ = XF ? RX : UPW;
+        if (q >= SQ && q < SQ + 4) {
+#pragma unroll
+          for (int idx = 4 * (q - SQ); idx < 4 * (q - SQ) + 4; ++idx) store_pending(idx);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // The chunk barrier.  hipcc counts the LDS-DMA pieces on vmcnt and the workgroup fence waits for exactly them: the
+    // output stores issued behind this chunk's pieces stay in flight across it (conv_wino.hip).
+    __syncthreads();
+  };
+
+  auto run = [&](auto xfc) {
+    int par = 1;
+    bool go = true, pend = false;
+    using I0c = std::integral_constant<int, 0>;
+    using I1c = std::integral_constant<int, 1>;
+    while (go) {
+      int fetched = 0;
+      if (dynq && tid == 0 && has_next) fetched = atomicAdd(a.dyn + blockIdx.y, 1);
+      if (pend) chunk(0, I0c{}, xfc, I1c{}, I1c{});
+      else chunk(0, I0c{}, xfc, I1c{}, I0c{});
+      for (int ch = 2; ch < nch; ch += 2) {
+        chunk(ch - 1, I1c{}, xfc, I0c{}, I0c{});
+        chunk(ch, I0c{}, xfc, I0c{}, I0c{});
+      }
+      chunk(nch - 1, I1c{}, xfc, I0c{}, I0c{});
+      epilogue(blk_cur);
+      pend = true;
+      // ONE barrier per tile block behind the epilogue: the per-wave BatchNorm partials are in LDS, the next block's id is
+      // handed round (dynamic deal: two slots in turn)
+      if (dynq) {
+        par ^= 1;
+        if (tid == 0) nslot[par] = fetched;
+      }
+      __syncthreads();
+      stats_finish(blk_cur);
+      go = has_next;
+      blk_cur = blk_nxt;
+      if (dynq) blk_nxt = __builtin_amdgcn_readfirstlane(nslot[par]);
+      else blk_nxt = blk_cur + (int)gridDim.x;
+      has_next = blk_nxt < a.nblk;
+    }
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) store_pending(idx);  // (the last block's)
+  };
+  // (one instantiation per role: waves 0-3 carry the input transform)
+  if (wave < 4) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
+  finish();
+}
+
+template <int L>
+__global__ __launch_bounds__(512) void conv_wino4_kernel(Wino4Args a) {
+  extern __shared__ __align__(16) unsigned char wino4_smem[];
+  conv_wino4_body<L>(a, wino4_smem);
+}
+
+bool wino4_shape_ok(int64_t M, int Cin, int Cout, int L) {
+  if (L < 2 || L > 4 || Cout % 32 || Cin % 8 || M % 1024) return false;  // whole tile blocks (of whole images), an even chunk count
+  if (Cout / 32 > 16) return false;                                        // (the dynamic deal's counters: one per column block)
+  if (M * (int64_t)(Cin > Cout ? Cin : Cout) * 4 >= 2147483647LL || (int64_t)Cin * Cout * 144 >= 2147483647LL) return false;
+  return true;
+}
+
+template <int L>
+int launch_wino4_cfg(const Wino4Args& a, double flops, hipStream_t s) {
+  using C = Wino4Cfg<L>;
+  auto kern = conv_wino4_kernel<L>;
+  static std::atomic<uint64_t> attr_done{0};
+  DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
+  const int ny = a.Cout / 32;
+  int cus = a.cus > 0 ? a.cus : 256;
+  if (cus < ny) cus = ny;
+  if (cus > 256) cus = 256;
+  int gx = cus / ny;
+  if (gx < 1) gx = 1;
+  if (gx > a.nblk) gx = a.nblk;
+  Wino4Args ad = a;
+  ad.dyn = (opt(OPT_WINO_DYNAMIC) != 0 && a.nblk >= 3 * gx) ? dyn_tile_counters() : nullptr;
+  if (!ad.dyn) gx = (a.nblk + (a.nblk + gx - 1) / gx - 1) / ((a.nblk + gx - 1) / gx);
+  DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO4, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), C::LDS_BYTES, s, ad);
+  return DVG_OK;
+}
+
+}  // namespace
+
+bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L) { return wino4_shape_ok(M, Cin, Cout, L); }
+
+int conv_wino4_stats_blocks(int64_t M) { return (int)(M / 1024); }
+
+// a.wp must be the F(4x4, 3x3) pack of a PackJob with wino = 2 ([Cin / 4][Cout / 32][4][32][36] floats: wino4_pack_entry)
+int launch_conv_wino4(const ConvArgs& a, hipStream_t s) {
+  DVG_REQUIRE(wino4_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.wino_um == 0,
+              "conv_wino4: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
+  Wino4Args w;
+  w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
+  w.Cin = a.Cin; w.Cout = a.Cout; w.cus = a.wino_cus & 0xffff; w.dbg = a.wino_cus >> 16;
+  w.nblk = (int)(a.M / 1024);
+  // EXECUTED matrix FLOPs: 36 transform-domain GEMMs over the M / 16 tiles (1/4 of the direct form's 2 M Cin Cout 9)
+  const double flops = 2.0 * (double)(a.M / 16) * 36.0 * a.Cin * a.Cout;
+  switch (a.L) {
+    case 2: return launch_wino4_cfg<2>(w, flops, s);
+    case 3: return launch_wino4_cfg<3>(w, flops, s);
+    default: return launch_wino4_cfg<4>(w, flops, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u) {
+  const uint32_t total = (uint32_t)map.Ca * (uint32_t)map.Cb;
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) wino4_pack_entry(w, map, e, u);
+}
+
+int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s) {
+  int64_t gx = ceil_div((int64_t)map.Ca * map.Cb, 256);
+  if (gx > 1024) gx = 1024;
+  DVG_LAUNCH(K_WEIGHT_PACK, wino4_weight_pack_kernel, dim3((unsigned)gx), dim3(256), 0, s, w, map, u);
+  return DVG_OK;
+}
+
+}  // namespace dvg

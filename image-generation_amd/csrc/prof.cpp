@@ -24,7 +24,8 @@ static const char* kNames[K_COUNT] = {
     "enc_bn_pool_fwd", "enc_bn_pool_bwd_reduce", "enc_bn_pool_bwd_apply", "enc_proj_fwd",
     "enc_proj_bwd", "dec_bn_act_fwd", "dec_bn_act_bwd_reduce",
     "dec_bn_act_bwd_apply", "dec_conv3_fwd", "dec_conv3_bwd", "dec_final_fwd", "dec_final_bwd",
-    "mse", "adam", "misc", "conv_igemm_weight_space", "conv_wino_kernel", "conv_wino_wgrad_kernel"};
+    "mse", "adam", "misc", "conv_igemm_weight_space", "conv_wino_kernel", "conv_wino_wgrad_kernel",
+    "conv_wino4_kernel", "conv_wino4_wgrad_kernel"};
 
 struct EvPair { hipEvent_t a, b; float share = 1.0f; };
 static uint64_t g_mask = 0;

@@ -14,6 +14,9 @@ _SIGS = {
     "dvg_dev_conv_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
     "dvg_dev_conv_wino": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
                           [ctypes.c_int64] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "dvg_dev_conv_wino4": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
+                           [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "dvg_dev_conv_wino4_shape": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wino_ok": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wino_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
     "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -92,6 +95,22 @@ def conv_wino(x_m, w, mode, M, Cin, Cout, L, bias=None, stats=False):
     st = torch.empty((Lb.dvg_dev_conv_wino_stats_blocks(M, Cout), Cout, 2), device=dev) if stats else None
     _lib.check(Lb.dvg_dev_conv_wino(x_m.data_ptr(), w.data_ptr(), mode, u.data_ptr(), _lib.ptr(bias), out.data_ptr(),
                                     _lib.ptr(st), M, Cin, Cout, L, _lib.stream_ptr(dev)))
+    return (out, st) if stats else out
+
+
+def conv_wino4_shape(M, Cin, Cout, L):
+    return bool(lib().dvg_dev_conv_wino4_shape(M, Cin, Cout, L))
+
+
+def conv_wino4(x_m, w, mode, M, Cin, Cout, L, bias=None, stats=False, cus=0):
+    """The same layer in the Winograd F(4x4,3x3) form (csrc/conv_wino4.hip)."""
+    Lb = lib()
+    dev = x_m.device
+    u = torch.empty(36 * Cin * Cout, device=dev)
+    out = torch.empty((M, Cout), device=dev)
+    st = torch.empty((M // 1024, Cout, 2), device=dev) if stats else None
+    _lib.check(Lb.dvg_dev_conv_wino4(x_m.data_ptr(), w.data_ptr(), mode, u.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                     _lib.ptr(st), M, Cin, Cout, L, int(cus), _lib.stream_ptr(dev)))
     return (out, st) if stats else out
 
 

@@ -21,6 +21,12 @@ size_t dvg_dev_conv_splitk_floats(int64_t M, int Cin, int Cout, int ntaps, int p
 int dvg_dev_conv_wino(const float *in, const float *w, int mode, float *u, const float *bias, float *out, float *stats,
                       int64_t M, int Cin, int Cout, int L, dvg_stream_t stream);
 int dvg_dev_conv_wino_ok(int64_t M, int Cin, int Cout, int L);
+/* The same layer in the Winograd F(4x4,3x3) form (csrc/conv_wino4.hip: 36 position GEMMs per 4x4 output tile, 2.25 multiplies
+ * per output where F(2x2,3x3) issues 4.0): `u` = scratch of 36*Cin*Cout floats, `stats` rows = M / 1024 (tile blocks of 64
+ * tiles), cus = CUs the persistent grid is sized for (0 = 256).  Shapes: whole 1024-pixel blocks of 4x4 / 8x8 / 16x16 images. */
+int dvg_dev_conv_wino4(const float *in, const float *w, int mode, float *u, const float *bias, float *out, float *stats,
+                       int64_t M, int Cin, int Cout, int L, int cus, dvg_stream_t stream);
+int dvg_dev_conv_wino4_shape(int64_t M, int Cin, int Cout, int L);
 int dvg_dev_conv_wino_stats_blocks(int64_t M, int Cout);
 int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
 /* grad_w (checkpoint layout, `mode` = the layer's FORWARD mode) = sum_m in[nbr(m,tap)] (x) dy[m]; slabs: scratch of

@@ -78,6 +78,48 @@ def test_winograd_form_of_the_3x3_layers(N, Cin, Cout, side):
     assert _rel(s[:, 0], y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y64 ** 2).sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("N,Cin,Cout,side", [(64, 32, 64, 16), (256, 64, 128, 8), (512, 128, 512, 4), (512, 512, 128, 4),
+                                             (128, 128, 64, 8), (64, 64, 32, 16), (4, 32, 64, 16), (64, 32, 32, 4), (16, 32, 32, 8), (48, 96, 160, 8)])
+def test_winograd_f4x4_form_of_the_3x3_layers(N, Cin, Cout, side):
+    """The Winograd F(4x4,3x3) form (csrc/conv_wino4.hip: 36 position GEMMs per 4x4 output tile on the 16x16x4 MFMA,
+    lane-local output transform) against float64 convolutions -- forward with bias and BatchNorm partial sums, and the
+    data gradient -- for every image size it serves (4x4: one tile per image, the halo known at compile time; 8x8; 16x16),
+    with the F(2x2,3x3) kernel's and the direct kernel's own distances from float64 beside it.  Its transform constants are
+    1/24 .. 8 where F(2x2) has +-1, 1/2: the bar is float32 summation noise of the LARGER intermediate values (measured
+    on the CPU before the kernel existed, profiles/r05_wino_f43_accuracy_cpu.txt: rms 2e-6 of the output's rms)."""
+    from image_generation_amd import _lib
+    torch.manual_seed(N + Cin)
+    x = torch.randn(N, Cin, side, side); w = torch.randn(Cout, Cin, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    gy = torch.randn(N, Cout, side, side)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    dx64 = F.conv_transpose2d(gy.double(), w.double(), padding=1)
+    L, M = side.bit_length() - 1, N * side * side
+    assert dev.conv_wino4_shape(M, Cin, Cout, L) and dev.conv_wino4_shape(M, Cout, Cin, L)
+    xm, gym = dev.nchw_to_morton(x).cuda(), dev.nchw_to_morton(gy).cuda()
+    out, st = dev.conv_wino4(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda(), stats=True)
+    dx = dev.conv_wino4(gym, w.cuda(), 1, M, Cout, Cin, L)
+    rms = lambda a, ref: float((a.double() - ref).norm() / ref.norm())  # noqa: E731
+    o4, g4 = dev.morton_to_nchw(out.cpu(), N, Cout, side), dev.morton_to_nchw(dx.cpu(), N, Cin, side)
+    out_d = dev.conv_igemm(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda())
+    dx_d = dev.conv_igemm(gym, w.cuda(), 1, M, Cout, Cin, L)
+    od, gd = dev.morton_to_nchw(out_d.cpu(), N, Cout, side), dev.morton_to_nchw(dx_d.cpu(), N, Cin, side)
+    row = {"fwd max": (_rel(o4, y64), _rel(od, y64)), "fwd rms": (rms(o4, y64), rms(od, y64)),
+           "dgrad max": (_rel(g4, dx64), _rel(gd, dx64)), "dgrad rms": (rms(g4, dx64), rms(gd, dx64))}
+    with _lib.option_scope(enc_wino=1):
+        if dev.conv_wino_ok(M, Cin, Cout, L) and dev.conv_wino_ok(M, Cout, Cin, L):
+            o2 = dev.morton_to_nchw(dev.conv_wino(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda()).cpu(), N, Cout, side)
+            g2 = dev.morton_to_nchw(dev.conv_wino(gym, w.cuda(), 1, M, Cout, Cin, L).cpu(), N, Cin, side)
+            row["F(2x2) fwd max/rms, dgrad max/rms"] = (_rel(o2, y64), rms(o2, y64), _rel(g2, dx64), rms(g2, dx64))
+    print(f"F(4x4) vs float64 [N={N} {Cin}->{Cout} @{side}] (F(4x4), direct):", {k: tuple(f"{v:.2e}" for v in vs) for k, vs in row.items()})
+    assert row["fwd max"][0] < 3e-5 and row["fwd rms"][0] < 8e-6, row
+    assert row["dgrad max"][0] < 3e-5 and row["dgrad rms"][0] < 8e-6, row
+    s = st.sum(0).cpu().double()
+    assert _rel(s[:, 0], y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y64 ** 2).sum((0, 2, 3))) < 1e-5
+    # twice the same launch: same bits (dynamic tile deal, fixed arithmetic per tile)
+    out2 = dev.conv_wino4(xm, w.cuda(), 0, M, Cin, Cout, L, bias=b.cuda())
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side,ups", [(64, 32, 64, 16, 0), (256, 64, 128, 8, 0), (512, 128, 512, 4, 0),  # the encoder's layers 1-3
                                                  (37, 64, 64, 8, 0), (5, 32, 64, 4, 0),                             # ragged image counts
                                                  (256, 128, 64, 8, 1), (64, 64, 32, 16, 1), (24, 64, 64, 4, 1)])    # behind the x2 upsample
