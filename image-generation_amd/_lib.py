@@ -191,6 +191,16 @@ SIGNATURES = {
 }
 
 
+# include/dvg_dev.h: the A/B references and test knobs (not part of the drop-in boundary; SIGNATURES covers exactly dvg.h)
+DEV_OPTION_SIGNATURES = {
+    "dvg_dev_option_count": (c_int, []),
+    "dvg_dev_option_name": (c_char_p, [c_int]),
+    "dvg_dev_option_doc": (c_char_p, [c_int]),
+    "dvg_dev_set_option": (c_int, [c_char_p, c_int64]),
+    "dvg_dev_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
+}
+
+
 def build(verbose: bool = False) -> str:
     """Compile libdvg.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     cmd = ["make", "-C", _HERE, "-j8"]
@@ -214,7 +224,7 @@ def lib() -> ctypes.CDLL:
         import torch  # noqa: F401
 
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in SIGNATURES.items():
+        for name, (restype, argtypes) in list(SIGNATURES.items()) + list(DEV_OPTION_SIGNATURES.items()):
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
@@ -277,24 +287,46 @@ def set_conv_precision(mode: str) -> None:
     check(lib().dvg_set_conv_precision(modes[mode]), "dvg_set_conv_precision")
 
 
+def _dev_names() -> set:
+    L = lib()
+    return {L.dvg_dev_option_name(i).decode() for i in range(L.dvg_dev_option_count())}
+
+
 def set_option(name: str, value: int) -> None:
-    """A kernel-form option of the library (include/dvg.h, dvg_set_option; ``options()`` lists them)."""
-    check(lib().dvg_set_option(name.encode(), int(value)), f"dvg_set_option({name})")
+    """A kernel-form option of the library: one of the product's switches (include/dvg.h, dvg_set_option; ``options()``
+    lists them) or one of the A/B references / test knobs behind include/dvg_dev.h (``dev_options()``)."""
+    if name in _dev_names():
+        check(lib().dvg_dev_set_option(name.encode(), int(value)), f"dvg_dev_set_option({name})")
+    else:
+        check(lib().dvg_set_option(name.encode(), int(value)), f"dvg_set_option({name})")
 
 
 def get_option(name: str) -> int:
     v = c_int64()
-    check(lib().dvg_get_option(name.encode(), ctypes.byref(v)), f"dvg_get_option({name})")
+    if name in _dev_names():
+        check(lib().dvg_dev_get_option(name.encode(), ctypes.byref(v)), f"dvg_dev_get_option({name})")
+    else:
+        check(lib().dvg_get_option(name.encode(), ctypes.byref(v)), f"dvg_get_option({name})")
     return int(v.value)
 
 
 def options() -> dict:
-    """name -> (value, doc) of every kernel-form option."""
+    """name -> (value, doc) of every kernel-form option of the boundary (include/dvg.h)."""
     L = lib()
     out = {}
     for i in range(L.dvg_option_count()):
         name = L.dvg_option_name(i).decode()
         out[name] = (get_option(name), L.dvg_option_doc(i).decode())
+    return out
+
+
+def dev_options() -> dict:
+    """name -> (value, doc) of the A/B references and test knobs (include/dvg_dev.h)."""
+    L = lib()
+    out = {}
+    for i in range(L.dvg_dev_option_count()):
+        name = L.dvg_dev_option_name(i).decode()
+        out[name] = (get_option(name), L.dvg_dev_option_doc(i).decode())
     return out
 
 

@@ -236,6 +236,7 @@ int launch_wino_weight_pack(const float* w, const WeightMap& map, float* u, hipS
 // Winograd F(4x4,3x3) form of the same layers (conv_wino4.hip): `wp` = the pack of a PackJob with wino = 2 (36 Cin Cout
 // floats: wino4_pack_entry), stats rows = conv_wino4_stats_blocks (tile blocks of 1024 pixels)
 bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L);  // shape only
+bool conv_wino4_ok(int64_t M, int Cin, int Cout, int L);     // policy (option enc_wino4) + shape: asked for launches conv_wino_ok accepted
 int conv_wino4_stats_blocks(int64_t M);
 int launch_conv_wino4(const ConvArgs& a, hipStream_t s);
 int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);

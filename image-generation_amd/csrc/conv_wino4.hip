@@ -58,6 +58,10 @@ struct Wino4Args {
   int dbg = 0;        // (diagnostic builds: bit 0 no output stores, bit 1 staggered start)
 };
 
+#ifndef WINO4_RX
+#define WINO4_RX 0   // raw pieces per wave of the transform role (-1: an eighth of them)
+#endif
+
 template <int L>
 struct Wino4Cfg {
   static constexpr int H = 1 << L, HW = H * H, TPI = HW / 16, IPB = 64 / TPI;  // tiles per image, images per tile block
@@ -177,8 +181,8 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   // piece: same bytes, same place): with a conditional piece the compiler's wait-count pass loses the order of the
   // vector-memory operations at the join and puts vmcnt(0) in front of every barrier -- which drains the output stores.
   // Waves 0-3 (the transform role): RX raw pieces each; waves 4-7: RN raw pieces and the UPW weight pieces.
-  constexpr int RX = C::NRAWP / 8, RN = (C::NRAWP - 4 * RX + 3) / 4, RPW = RN, UPW = 5;
-  static_assert(RX >= 1 && RN >= RX && 4 * (RX + RN) >= C::NRAWP, "raw pieces");
+  constexpr int RX = WINO4_RX < 0 ? C::NRAWP / 8 : WINO4_RX, RN = (C::NRAWP - 4 * RX + 3) / 4, RPW = RN, UPW = 5;
+  static_assert(RN >= RX && 4 * (RX + RN) >= C::NRAWP, "raw pieces");
   int rvoff[RPW];
   uint32_t rdst[RPW];
 #pragma unroll
@@ -210,12 +214,14 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   // (one piece per call, so that a chunk can place them between its MFMA groups; q-th piece of this wave)
   auto raw_soff = [&](int blk, int ch) { return __builtin_amdgcn_readfirstlane((blk * 1024 * a.Cin + ch * 4) * 4); };
   auto issue_raw_piece = [&](int soff, int st, int q) {
+    if (a.dbg & 4) return;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rdst[q] + (uint32_t)(st * C::RAW_B)));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
   };
   const int ustride = a.Cout / 32 * C::U_B;  // bytes between two chunks of the pack
   auto u_sbase = [&](int ch) { return __builtin_amdgcn_readfirstlane(ch * ustride + (int)blockIdx.y * C::U_B); };
   auto issue_u_piece = [&](int sbase, int st, int q) {  // (waves 4-7; pieces 18, 19 repeat pieces 0, 1)
+    if (a.dbg & 8) return;
     int p = ((wave - 4) & 3) + 4 * q;
     if (p >= C::U_PIECES) p -= C::U_PIECES;
     p = __builtin_amdgcn_readfirstlane(p);
@@ -267,7 +273,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     }
   };
 
-  f32x4 acc[36];  // acc[6 xi + nu][v] = M[xi][nu] of tile 16 wt + r16, channel 16 wc + 4 kq + v (the weights are the MFMA's A operand)
+  f32x4 acc[36];  // acc[6 xi + nu][i] = M[xi][nu] of tile 16 wt + 4 kq + i, channel 16 wc + r16
 
   const bool dynq = a.dyn != nullptr;
   volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
@@ -307,26 +313,24 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
 
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (a.dbg & 1) ? 0 : (int)((int64_t)a.nblk * 1024 * a.Cout * 4), 0x00020000);  // (diagnostic: no records = every store dropped)
-  const int ch_out = n0 + 16 * wc + 4 * kq;               // the lane's four output channels
-  const int ovoff = (r16 * 16 * a.Cout + ch_out) * 4;     // tile r16 of the wave's sixteen, pixel 0
-  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + ch_out);
+  const int ch_out = n0 + 16 * wc + r16;
+  const int ovoff = (4 * kq * 16 * a.Cout + ch_out) * 4;  // tile 4 kq of the wave's sixteen, pixel 0, the lane's channel
+  const float bias = a.bias ? a.bias[ch_out] : 0.f;
 
-  // outputs of the tile block just finished (16 pixels x 4 channels per lane), stored beside the MFMAs of the NEXT block's
-  // first chunk (or behind the last block): all workgroups reach their epilogues together and 128 KB per workgroup stored
-  // at once is a burst the memory system takes microseconds to drain -- and stores count on vmcnt like the LDS-DMA
-  // pieces, so a chunk barrier behind them would sit that out.  Issued behind the first chunk's pieces they stay in
-  // flight across its barrier; a store's registers are free again before the accumulator tiles come alive.
-  f32x4 yp[16];  // yp[b 4 + a]: pixel (a, b) of the lane's tile
+  // outputs of the tile block just finished (64 per lane: 4 tiles x 16 pixels of one channel), stored beside the MFMAs of
+  // the NEXT block's first chunk (or behind the last block), BEHIND that chunk's LDS-DMA pieces: stores count on vmcnt like
+  // the pieces, in issue order, so they stay in flight across that chunk's barrier (the next one waits them out: all
+  // workgroups reach their epilogues together and 128 KB per workgroup stored at once is a burst the memory system
+  // takes microseconds to drain); a store's register is free again before the accumulator tiles come alive.
+  float yp[64];  // yp[(b 4 + a) 4 + i]: pixel (a, b) of tile 4 kq + i
   int pblk = 0;
   auto store_pending = [&](int idx) {
-    const int b = idx >> 2, aa = idx & 3;
-    // (the row index is kept opaque: its products with the 16 constant row offsets would each take a scalar register)
+    const int b = idx >> 4, aa = (idx >> 2) & 3, i = idx & 3;
+    // (the row index is kept opaque: its products with the 64 constant row offsets would each take a scalar register)
     int row0 = __builtin_amdgcn_readfirstlane((pblk * 64 + 16 * wt) * 16);
     asm volatile("" : "+s"(row0));
-    typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, yp[idx]), rsrc_out, ovoff,
-                                           (row0 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yp[idx]), rsrc_out, ovoff,
+                                          (row0 + i * 16 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, 0);
   };
   // the epilogue: Y = A^T M A per (tile, channel), lane-local; + bias, BatchNorm partials
   auto epilogue = [&](int blk) {
@@ -335,31 +339,26 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     for (int xi = 0; xi < 6; ++xi)
       wino4_out6(acc[6 * xi], acc[6 * xi + 1], acc[6 * xi + 2], acc[6 * xi + 3], acc[6 * xi + 4], acc[6 * xi + 5],
                  c[4 * xi], c[4 * xi + 1], c[4 * xi + 2], c[4 * xi + 3]);
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f32x4 y[4];
       wino4_out6(c[b], c[4 + b], c[8 + b], c[12 + b], c[16 + b], c[20 + b], y[0], y[1], y[2], y[3]);
 #pragma unroll
-      for (int aa = 0; aa < 4; ++aa) {
-        const f32x4 v = y[aa] + bias;
-        s1 += v;
+      for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s2[i] = __builtin_fmaf(v[i], v[i], s2[i]);
-        yp[b * 4 + aa] = v;
-      }
+        for (int i = 0; i < 4; ++i) {
+          const float v = y[aa][i] + bias;
+          s1 += v; s2 = __builtin_fmaf(v, v, s2);
+          yp[(b * 4 + aa) * 4 + i] = v;
+        }
     }
     pblk = blk;
-    if (a.stats) {  // per-wave column sums (over the wave's 16 tiles: lanes r16); summed over the block's four tile groups behind the caller's barrier
+    if (a.stats) {  // per-wave column sums; summed over the block's four tile groups behind the caller's barrier
       float* red = reinterpret_cast<float*>(wsm + C::OFF_RED);
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s1[i] += __shfl_xor(s1[i], m, 64); s2[i] += __shfl_xor(s2[i], m, 64); }
-      if (r16 == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { red[(wt * 32 + 16 * wc + 4 * kq + i) * 2] = s1[i]; red[(wt * 32 + 16 * wc + 4 * kq + i) * 2 + 1] = s2[i]; }
-      }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kq == 0) { red[(wt * 32 + 16 * wc + r16) * 2] = s1; red[(wt * 32 + 16 * wc + r16) * 2 + 1] = s2; }
     }
   };
   auto stats_finish = [&](int blk) {
@@ -383,21 +382,32 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     const bool over = cix + 2 >= nch;
     const int r_ch = !over ? cix + 2 : (has_next ? cix + 2 - nch : nch - 1);
     const int r_blk = over && has_next ? blk_nxt : blk_cur;
-    const int usb = u_sbase(u_ch), rso = raw_soff(r_blk, r_ch);
+    // the chunk's LDS-DMA pieces first (they have the whole chunk to land): the next chunk's weights (waves 4-7), then the
+    // raw pixels of the chunk after next
+    {
+      const int usb = u_sbase(u_ch), rso = raw_soff(r_blk, r_ch);
+      if constexpr (!XF) {
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) issue_u_piece(usb, st ^ 1, q);
+      }
+#pragma unroll
+      for (int q = 0; q < (XF ? RX : RN); ++q) issue_raw_piece(rso, st, q);
+    }
     f32x4 qa[3], qb[3];
-    auto load_quad = [&](int q) {  // (qa: the weights -- the MFMA's A operand; qb: the tiles)
-      qa[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st] + (uint32_t)(q * 16)));
-      qb[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st] + (uint32_t)(q * 16)));
+    auto load_quad = [&](int q) {
+      qa[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st] + (uint32_t)(q * 16)));
+      qb[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st] + (uint32_t)(q * 16)));
     };
     float d[36];
     load_quad(0);
     load_quad(1);
-    if constexpr (XF) load_patch(st ^ 1, d);
+    const bool xf_on = !(a.dbg & 16);
+    if constexpr (XF) { if (xf_on) load_patch(st ^ 1, d); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       if (q + 2 < 9) load_quad(q + 2);
-      if constexpr (XF) {
+      if (XF && xf_on) {
         // pieces: q = 1..3 two columns each, q = 4..6 two rows each and their three entry quads
         if (q >= 1 && q <= 3) { xform_col(2 * q - 2, d); xform_col(2 * q - 1, d); }
         if (q >= 4 && q <= 6) { xform_row(2 * q - 8, d); xform_row(2 * q - 7, d); store_quads(st ^ 1, 3 * (q - 4), d); }
@@ -409,19 +419,10 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
         else acc[4 * q + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q % 3][m], qb[q % 3][m], acc[4 * q + m], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // the chunk's LDS-DMA pieces behind its first MFMA groups (the matrix pipe has work while they issue; they have the
-      // rest of the chunk to land): the next chunk's weights first (waves 4-7: five pieces), then the raw pixels of
-      // the chunk after next
-      if constexpr (!XF) { if (q < UPW) issue_u_piece(usb, st ^ 1, q); }
-      if (q < (XF ? RX : RN)) issue_raw_piece(rso, st, q);
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (PEND) {
-        // (behind the wave's last piece: the stores stay in flight across the chunk barrier; the transform role, whose
-        // patch registers are live beside the growing accumulator set, has few pieces and starts early)
-        constexpr int SQ = XF ? RX : UPW;
-        if (q >= SQ && q < SQ + 4) {
+        if (q < 8) {
 #pragma unroll
-          for (int idx = 4 * (q - SQ); idx < 4 * (q - SQ) + 4; ++idx) store_pending(idx);
+          for (int idx = 8 * q; idx < 8 * q + 8; ++idx) store_pending(idx);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -463,7 +464,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
       has_next = blk_nxt < a.nblk;
     }
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) store_pending(idx);  // (the last block's)
+    for (int idx = 0; idx < 64; ++idx) store_pending(idx);  // (the last block's)
   };
   // (one instantiation per role: waves 0-3 carry the input transform)
   if (wave < 4) run(std::integral_constant<int, 1>{});
@@ -507,6 +508,14 @@ int launch_wino4_cfg(const Wino4Args& a, double flops, hipStream_t s) {
 }  // namespace
 
 bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L) { return wino4_shape_ok(M, Cin, Cout, L); }
+
+// option enc_wino4: 1 (default) every encoder launch that runs in the Winograd domain and whose shape qualifies, 0 never
+// (F(2x2,3x3) everywhere).  Measured at c3, alternating runs in one process: the step 7.46 ms with F(2x2) everywhere, 7.28
+// with the layers on 4x4 and 8x8 images in this form, 7.22 with the 16x16 layer too (alone on the chip that layer's two
+// launches are level with the F(2x2) kernel -- both wait for their output stores there -- inside the step they are not).
+bool conv_wino4_ok(int64_t M, int Cin, int Cout, int L) {
+  return opt(OPT_ENC_WINO4) != 0 && wino4_shape_ok(M, Cin, Cout, L);
+}
 
 int conv_wino4_stats_blocks(int64_t M) { return (int)(M / 1024); }
 

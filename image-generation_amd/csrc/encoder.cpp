@@ -21,6 +21,7 @@ struct EncPlan {
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
   bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
   bool wino_w[4];             // ... its weight gradient too (conv_wino_wgrad.hip)
+  bool wino4_f[4], wino4_d[4]; // ... in the F(4x4,3x3) form (conv_wino4.hip) instead of F(2x2,3x3)
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, mom_part, mom, pimg, splitk;
   int ksplit[4];
   size_t total_floats;
@@ -51,7 +52,10 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
     p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l], training ? 0 : 2);
     p.wino_d[l] = l > 0 && training && conv_wino_ok(p.M[l], C, ch[l], p.L[l], 1);
     p.wino_w[l] = l > 0 && training && conv_wino_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
-    p.nblk[l] = l == 0 ? enc_conv0_blocks(B) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C));
+    p.wino4_f[l] = p.wino_f[l] && conv_wino4_ok(p.M[l], ch[l], C, p.L[l]);
+    p.wino4_d[l] = p.wino_d[l] && conv_wino4_ok(p.M[l], C, ch[l], p.L[l]);
+    p.nblk[l] = l == 0 ? enc_conv0_blocks(B)
+                       : (p.wino4_f[l] ? conv_wino4_stats_blocks(p.M[l]) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C)));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
     p.Xp[l] = bump(o, (size_t)p.Q[l] * C);
     p.mean[l] = bump(o, C);
@@ -60,8 +64,8 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
     p.wp[l] = p.wpd[l] = 0;
     p.ksplit[l] = 0;
     if (l > 0) {
-      p.wp[l] = bump(o, conv_pack_floats((size_t)(p.wino_f[l] ? 16 : 9) * ch[l] * C));
-      p.wpd[l] = bump(o, conv_pack_floats((size_t)(p.wino_d[l] ? 16 : 9) * ch[l] * C));
+      p.wp[l] = bump(o, conv_pack_floats((size_t)(p.wino4_f[l] ? 36 : (p.wino_f[l] ? 16 : 9)) * ch[l] * C));
+      p.wpd[l] = bump(o, conv_pack_floats((size_t)(p.wino4_d[l] ? 36 : (p.wino_d[l] ? 16 : 9)) * ch[l] * C));
       p.ksplit[l] = wgrad_ksplit(p.M[l], ch[l], C, 9);
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
@@ -101,6 +105,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
 uint32_t enc_plan_signature(const EncPlan& pl, int training) {
   uint32_t sig = (uint32_t)conv_launch_mode(pl.B, 64) | (opt(OPT_ENC_L0_FUSED) != 0 ? 1u << 30 : 0u) | (training ? 1u << 31 : 0u);
   for (int l = 1; l < 4; ++l) sig |= (pl.wino_f[l] ? 1u : 0u) << (8 + 2 * l) | (pl.wino_d[l] ? 1u : 0u) << (9 + 2 * l);
+  for (int l = 1; l < 4; ++l) sig |= (pl.wino4_f[l] ? 1u : 0u) << (16 + 2 * l) | (pl.wino4_d[l] ? 1u : 0u) << (17 + 2 * l);
   return sig;
 }
 
@@ -150,8 +155,8 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
     int nj = 0;
     for (int l = 1; l < 4; ++l) {
       const WeightMap mf{WM_CONV_FWD, pl.ch[l], pl.ch[l + 1], 9}, md{WM_CONV_DGRAD, pl.ch[l + 1], pl.ch[l], 9};
-      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wp[l], mf, 0, pl.M[l], pl.wino_f[l] ? 1 : 0};  // (Winograd launches read U = G g G^T)
-      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wpd[l], md, 0, pl.M[l], pl.wino_d[l] ? 1 : 0};
+      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wp[l], mf, 0, pl.M[l], pl.wino4_f[l] ? 2 : (pl.wino_f[l] ? 1 : 0)};  // (Winograd launches read U = G g G^T)
+      jobs[nj++] = PackJob{p->conv_w[l], W + pl.wpd[l], md, 0, pl.M[l], pl.wino4_d[l] ? 2 : (pl.wino_d[l] ? 1 : 0)};
     }
     DVG_TRY(launch_weight_pack_multi(jobs, nj, s));
   }
@@ -187,7 +192,8 @@ extern "C" int dvg_encoder_fwd(const dvg_encoder_params_t* p, int n, const float
       // dynamically, so the grid is sized to the chip and the workgroups that get their CU late, when the draw ends,
       // take what is left; under option wino_dynamic = 0 -- the static deal, A/B -- a quarter of the chip is left out)
       a.wino_cus = (training && opt(OPT_WINO_DYNAMIC) == 0) ? 192 : 0;
-      if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
+      if (pl.wino4_f[l]) DVG_TRY(launch_conv_wino4(a, s));
+      else if (pl.wino_f[l]) DVG_TRY(launch_conv_wino(a, s));
       else DVG_TRY(launch_conv_igemm(a, s));
     }
     DVG_TRY(launch_bn_finalize(W + pl.stats[l], pl.nblk[l], C, pl.M[l], training, W + pl.mean[l], W + pl.invstd[l],
@@ -207,7 +213,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
   DVG_TRY(check_common(p, n, B, ws, ws_bytes, pl));
   DVG_REQUIRE(conv_precision_matches_forward(ws), "encoder_bwd: the GEMM operand mode (dvg_set_conv_precision) changed since the forward call on this workspace");
   DVG_REQUIRE(plan_forward_flag(ws, 1u << 31), "encoder_bwd: backward requires a training-mode forward on this workspace (the last forward call here ran in evaluation mode: running statistics, no saved batch statistics)");
-  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl, 1)), "encoder_bwd: a kernel-form option (dvg_set_option: igemm_dma / enc_wino / enc_l0_fused) changed since the forward call on this workspace");
+  DVG_REQUIRE(plan_matches_forward(ws, enc_plan_signature(pl, 1)), "encoder_bwd: a kernel-form option (dvg_set_option: igemm_dma / enc_wino / enc_wino4 / enc_l0_fused) changed since the forward call on this workspace");
   DVG_REQUIRE(images && grad_logits && g, "encoder_bwd: null argument");
   for (int l = 0; l < 4; ++l)
     DVG_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "encoder_bwd: null gradient buffer, layer %d", l);
@@ -265,7 +271,8 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
     a.wino_cus = WINO_CUS_ENC_DGRAD;  // (the layer's weight-gradient chain runs beside it on the side stream)
-    if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
+    if (pl.wino4_d[l]) DVG_TRY(launch_conv_wino4(a, s));
+    else if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
     else DVG_TRY(launch_conv_igemm(a, s));
     if (s2 != s) DVG_TRY(stream_wait_mark(s2, dy_ready));
     if (proj_pending) {

@@ -13,25 +13,26 @@
 
 namespace dvg {
 namespace {
-struct OptDef { const char* name; int64_t def; const char* doc; };
+struct OptDef { const char* name; int64_t def; const char* doc; bool dev = false; };  // dev: reached through include/dvg_dev.h only
 // (order = enum Opt in common.h)
 const OptDef kDefs[OPT_COUNT] = {
-    {"igemm_dma", 1, "float32 forward / data-gradient GEMM: 1 LDS-DMA staging (default), 0 register staging (tensors of 4 GiB and more always; A/B reference)"},
+    {"igemm_dma", 1, "float32 forward / data-gradient GEMM: 1 LDS-DMA staging (default), 0 register staging (tensors of 4 GiB and more always; A/B reference)", true},
     {"igemm_posmajor", 1, "position-major tiles (padding taps of small images never multiplied): 1 on, 0 pixel-major tiles"},
-    {"igemm_thr128", 512, "blocks a launch must have for the 128x128 tile (the tests lower it to send small fixtures through that tile)"},
-    {"wgrad_dma", 1, "weight-gradient GEMMs: 1 LDS-DMA staging (default), 0 register staging (tensors of 4 GiB and more always)"},
+    {"igemm_thr128", 512, "blocks a launch must have for the 128x128 tile (the tests lower it to send small fixtures through that tile)", true},
+    {"wgrad_dma", 1, "weight-gradient GEMMs: 1 LDS-DMA staging (default), 0 register staging (tensors of 4 GiB and more always)", true},
     {"dec_fold", 1, "decoder: Upsample(x2) + ConvTranspose as 4 class GEMMs with pre-summed taps (4/9 of the FLOPs)"},
     {"dec_d22", 1, "decoder: first ConvTranspose layer on 2x2 images as one dense map per image (16/36 of the FLOPs)"},
     {"dec_lc0", -1, "decoder: Linear composed with that map: -1 from 4096 rows up (default), 0 never, 1 always"},
-    {"mmd_w128", -1, "MMD: 128-row-block pair kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows"},
-    {"mmd_d256", -1, "MMD: 256-row distance-sum kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows"},
-    {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule, 2 the lane-major schedule one row at a time instead of two passes of a class side by side (both bit-identical; A/B references)"},
+    {"mmd_w128", -1, "MMD: 128-row-block pair kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
+    {"mmd_d256", -1, "MMD: 256-row distance-sum kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
+    {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule, 2 the lane-major schedule one row at a time instead of two passes of a class side by side (both bit-identical; A/B references)", true},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
     {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form, forward, data gradient and weight gradient: -1 by size (default: evaluation-mode forward launches of 256 workgroups' worth of tiles or more, training launches of 512 or more), 0 never, 1 every launch the shape allows; forward / data gradient never in the bf16-input mode"},
     {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions), forward, data gradient and weight gradient: -1 from 8192 decoder rows up (default), 0 never, 1 whenever the shape allows"},
-    {"enc_l0_fused", 1, "encoder layer 0: 1 = its output is recomputed by every pass that needs it (BatchNorm statistics, BN/pool/LeakyReLU, the backward sums, the weight gradient) and never stored (default), 0 = stored and re-read (rounds 1-2)"},
-    {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)"},
-    {"wino_dynamic", 1, "Winograd forward / data-gradient launches deal their tile blocks dynamically (an atomic counter per grid row) instead of round-robin: a workgroup that gets its CU late takes fewer blocks (1 default, 0 = the static deal of rounds 3-4)"},
+    {"enc_l0_fused", 1, "encoder layer 0: 1 = its output is recomputed by every pass that needs it (BatchNorm statistics, BN/pool/LeakyReLU, the backward sums, the weight gradient) and never stored (default), 0 = stored and re-read (rounds 1-2)", true},
+    {"dec_tail_fused", 1, "decoder: 1 = the 8x8x32 stage's BatchNorm / Dropout / LeakyReLU (forward and backward) run inside the 32 -> 1 layer's kernels, its activated map and that map's gradient are never stored (default), 0 = separate passes (rounds 1-2)", true},
+    {"wino_dynamic", 1, "Winograd forward / data-gradient launches deal their tile blocks dynamically (an atomic counter per grid row) instead of round-robin: a workgroup that gets its CU late takes fewer blocks (1 default, 0 = the static deal of rounds 3-4)", true},
+    {"enc_wino4", 1, "encoder 3x3 layers that run in the Winograd domain: 1 (default) forward and data gradient in the F(4x4,3x3) form wherever the shape qualifies (36 position GEMMs per 4x4 output tile: 2.25 multiplies per output instead of 4.0), 0 the F(2x2,3x3) form everywhere"},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;
@@ -50,31 +51,52 @@ int64_t opt(Opt id) {
 
 using namespace dvg;
 
-extern "C" int dvg_option_count(void) { return OPT_COUNT; }
-
-extern "C" const char* dvg_option_name(int index) { return index >= 0 && index < OPT_COUNT ? kDefs[index].name : nullptr; }
-
-extern "C" const char* dvg_option_doc(int index) { return index >= 0 && index < OPT_COUNT ? kDefs[index].doc : nullptr; }
-
-extern "C" int dvg_set_option(const char* name, int64_t value) {
-  DVG_REQUIRE(name, "dvg_set_option: null name");
+namespace {
+// index of the i-th option of one kind (public: include/dvg.h; dev: include/dvg_dev.h), or -1
+int nth(bool dev, int i) {
+  for (int k = 0; k < OPT_COUNT; ++k)
+    if (kDefs[k].dev == dev && i-- == 0) return k;
+  return -1;
+}
+int count(bool dev) {
+  int n = 0;
+  for (int k = 0; k < OPT_COUNT; ++k) n += kDefs[k].dev == dev;
+  return n;
+}
+int set_opt(bool dev, const char* what, const char* name, int64_t value) {
+  DVG_REQUIRE(name, "%s: null name", what);
   init_once();
   for (int i = 0; i < OPT_COUNT; ++i)
-    if (!strcmp(name, kDefs[i].name)) { g_val[i].store(value, std::memory_order_relaxed); return DVG_OK; }
-  set_error("dvg_set_option: unknown option '%s'", name);
+    if (kDefs[i].dev == dev && !strcmp(name, kDefs[i].name)) { g_val[i].store(value, std::memory_order_relaxed); return DVG_OK; }
+  set_error("%s: unknown option '%s'", what, name);
   return DVG_E_INVALID;
 }
-
-extern "C" int dvg_get_option(const char* name, int64_t* value) {
-  DVG_REQUIRE(name && value, "dvg_get_option: null argument");
+int get_opt(bool dev, const char* what, const char* name, int64_t* value) {
+  DVG_REQUIRE(name && value, "%s: null argument", what);
   init_once();
   for (int i = 0; i < OPT_COUNT; ++i)
-    if (!strcmp(name, kDefs[i].name)) { *value = g_val[i].load(std::memory_order_relaxed); return DVG_OK; }
-  set_error("dvg_get_option: unknown option '%s'", name);
+    if (kDefs[i].dev == dev && !strcmp(name, kDefs[i].name)) { *value = g_val[i].load(std::memory_order_relaxed); return DVG_OK; }
+  set_error("%s: unknown option '%s'", what, name);
   return DVG_E_INVALID;
 }
+}  // namespace
 
-extern "C" int dvg_reset_options(void) {
+// The product's switches (include/dvg.h): eight.
+extern "C" int dvg_option_count(void) { return count(false); }
+extern "C" const char* dvg_option_name(int index) { const int k = nth(false, index); return k >= 0 ? kDefs[k].name : nullptr; }
+extern "C" const char* dvg_option_doc(int index) { const int k = nth(false, index); return k >= 0 ? kDefs[k].doc : nullptr; }
+extern "C" int dvg_set_option(const char* name, int64_t value) { return set_opt(false, "dvg_set_option", name, value); }
+extern "C" int dvg_get_option(const char* name, int64_t* value) { return get_opt(false, "dvg_get_option", name, value); }
+
+// A/B references and test knobs (include/dvg_dev.h): the forms a default replaced, kept so that the tests can hold the
+// product's form to them bit for bit.  Not part of the drop-in boundary.
+extern "C" int dvg_dev_option_count(void) { return count(true); }
+extern "C" const char* dvg_dev_option_name(int index) { const int k = nth(true, index); return k >= 0 ? kDefs[k].name : nullptr; }
+extern "C" const char* dvg_dev_option_doc(int index) { const int k = nth(true, index); return k >= 0 ? kDefs[k].doc : nullptr; }
+extern "C" int dvg_dev_set_option(const char* name, int64_t value) { return set_opt(true, "dvg_dev_set_option", name, value); }
+extern "C" int dvg_dev_get_option(const char* name, int64_t* value) { return get_opt(true, "dvg_dev_get_option", name, value); }
+
+extern "C" int dvg_reset_options(void) {  // (both kinds)
   init_once();
   for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
   return DVG_OK;

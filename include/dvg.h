@@ -21,12 +21,14 @@
  *     (3) one library-owned side stream + event ring per device, created under
  *     a mutex by the first *_workspace_bytes query or backward call on that
  *     device and used for the fork/join inside dvg_encoder_bwd /
- *     dvg_decoder_bwd, (4) sixteen kernel-form switches (dvg_set_option: named
+ *     dvg_decoder_bwd, (4) eight kernel-form switches (dvg_set_option: named
  *     integers, relaxed atomics, read per call), each selecting between two
  *     TESTED forms of the same function; the product path is every switch's
  *     default and no caller in this repository sets one outside tests and A/B
  *     measurements (round 4 had 32, among them grid-sizing knobs that
- *     ModelWrapper set per model: those are compile-time constants now).  A
+ *     ModelWrapper set per model: those are compile-time constants now; round
+ *     5 had 16: the A/B references of forms a default replaced and the test
+ *     knobs live behind include/dvg_dev.h, dvg_dev_set_option, since round 6).  A
  *     switch is process-wide: flipping one between a forward call and its
  *     backward call is caught per workspace (the forward records the plan, a
  *     backward under another plan fails with DVG_E_INVALID instead of reading

@@ -44,6 +44,16 @@ int dvg_dev_conv_wino_wgrad(const float *in, const float *dy, float *slabs, floa
  * Xp[l], out[8..11] = batch means, out[12..15] = batch inverse standard deviations.  Diagnostics only.  (Y[0] is only
  * written under option enc_l0_fused = 0: the default recomputes layer 0 wherever its output is needed.) */
 int dvg_dev_encoder_layout(int64_t B, int n_latents, size_t out[16]);
+/* A/B references and test knobs: the kernel forms a default of the library replaced (register-staged GEMMs, the stored
+ * encoder layer 0, the unfused decoder tail, the static Winograd tile deal, the rolled sampler schedule, forced MMD
+ * kernels) and the tile threshold the small fixtures lower.  Same semantics as dvg_set_option / dvg_get_option
+ * (include/dvg.h), a separate name space: the product's boundary carries eight switches, these are not among them.
+ * dvg_reset_options restores both kinds. */
+int dvg_dev_option_count(void);
+const char *dvg_dev_option_name(int index);
+const char *dvg_dev_option_doc(int index);
+int dvg_dev_set_option(const char *name, int64_t value);
+int dvg_dev_get_option(const char *name, int64_t *value);
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ import image_generation_amd  # noqa: E402,F401
 from image_generation_amd import _lib, dev  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""   # e.g. "L1 fwd": that launch alone (PMC passes)
 n = 512
 shapes = [("L1 fwd", 32, 64, 16, 0), ("L2 fwd", 64, 128, 8, 0), ("L3 fwd", 128, n, 4, 0),
           ("L3 dgrad", n, 128, 4, 1), ("L2 dgrad", 128, 64, 8, 1), ("L1 dgrad", 64, 32, 16, 1)]
@@ -37,6 +38,8 @@ def timeit(fn, reps=10):
 _lib.set_option("enc_wino", 1)
 print(f"B = {B}; us per launch alone on the chip (minimum of two interleaved rounds of 10), pack launch included in every form")
 for name, Cin, Cout, side, mode in shapes:
+    if ONLY and name != ONLY:
+        continue
     L, M = side.bit_length() - 1, B * side * side
     x = torch.randn(M, Cin, device="cuda")
     w = torch.randn((Cout, Cin, 3, 3) if mode == 0 else (Cin, Cout, 3, 3), device="cuda") / 30
