@@ -240,6 +240,14 @@ bool conv_wino4_ok(int64_t M, int Cin, int Cout, int L);     // policy (option e
 int conv_wino4_stats_blocks(int64_t M);
 int launch_conv_wino4(const ConvArgs& a, hipStream_t s);
 int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
+// ... and of their weight gradients (conv_wino4_wgrad.hip): slabs [nsplit][36][Cin][Cout] (at most
+// conv_wino4_wgrad_slab_floats), summed and transformed back (G^T dU G) into the checkpoint layout `map` by the same call;
+// cus = CUs the launch is sized for (0: WINO_CUS_ENC_WGRAD)
+bool conv_wino4_wgrad_ok(int64_t M, int Cin, int Cout, int L);      // policy (option enc_wino4) + shape
+bool conv_wino4_wgrad_shape(int64_t M, int Cin, int Cout, int L);   // shape only
+size_t conv_wino4_wgrad_slab_floats(int64_t M, int Cin, int Cout);
+int launch_conv_wino4_wgrad(const float* in, const float* dy, int64_t M, int Cin, int Cout, int L, float* slabs,
+                            const WeightMap& map, float* grad_w, hipStream_t s, int cus = 0);
 // Winograd form of a stride-1 3x3 layer's WEIGHT gradient (conv_wino_wgrad.hip): slabs [nslabs][16][Cin][Cout] (at most
 // conv_wino_wgrad_slab_floats), reduced and transformed back (G^T dU G) into the checkpoint layout `map` by the same call
 bool conv_wino_wgrad_ok(int64_t M, int Cin, int Cout, int L);      // policy (options) + shape

@@ -34,6 +34,7 @@
 
 #include "conv.h"
 #include "conv_tile.h"
+#include "conv_wino4.h"
 
 namespace dvg {
 
@@ -95,39 +96,6 @@ struct Wino4Cfg {
 // the next; with the planes 32 bytes apart (what makes the transform's ds_write_b128 conflict-free: its 8-lane groups
 // hold 4 planes x 2 entries) the two halves of a group then fall on the even and the odd 16-byte bank groups.
 __device__ __forceinline__ constexpr int wino4_entry(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
-
-// B^T x for one line of six (12 operations); ZE: x0 = x5 = 0 (the halo of a 4x4 image)
-template <bool ZE>
-__device__ __forceinline__ void wino4_in6(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5) {
-  const float p = __builtin_fmaf(-4.f, x2, x4), q = __builtin_fmaf(-4.f, x1, x3);
-  const float r = x4 - x2, s = x3 - x1;
-  float t0, t5;
-  if constexpr (ZE) {
-    t0 = __builtin_fmaf(-5.f, x2, x4);
-    t5 = __builtin_fmaf(-5.f, x3, 4.f * x1);
-  } else {
-    t0 = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));
-    t5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));
-  }
-  x0 = t0; x1 = p + q; x2 = p - q; x3 = __builtin_fmaf(2.f, s, r); x4 = __builtin_fmaf(-2.f, s, r); x5 = t5;
-}
-
-__device__ __forceinline__ f32x4 vfma(float k, const f32x4& a, const f32x4& b) {
-  f32x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = __builtin_fmaf(k, a[i], b[i]);
-  return o;
-}
-
-// A^T m for one line of six accumulator tiles -> four (10 operations per component)
-__device__ __forceinline__ void wino4_out6(const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, const f32x4& m4,
-                                           const f32x4& m5, f32x4& y0, f32x4& y1, f32x4& y2, f32x4& y3) {
-  const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-  y0 = (m0 + s1) + s2;
-  y1 = vfma(2.f, d2, d1);
-  y2 = vfma(4.f, s2, s1);
-  y3 = vfma(8.f, d2, d1) + m5;
-}
 
 template <int L>
 __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned char* wsm) {

@@ -76,3 +76,15 @@ extern "C" int dvg_dev_conv_wino_wgrad(const float* in, const float* dy, float* 
   DVG_REQUIRE(in && dy && slabs && grad_w, "dev_conv_wino_wgrad: null argument");
   return launch_conv_wino_wgrad(in, dy, M, Cin, Cout, L, slabs, WeightMap{mode, Cin, Cout, 9}, grad_w, (hipStream_t)stream, ups, cus);
 }
+
+// The same weight gradient in the Winograd F(4x4,3x3) form (conv_wino4_wgrad.hip): slabs of dvg_dev_wino4_wgrad_slab_floats()
+// floats (0 = the shape does not qualify)
+extern "C" size_t dvg_dev_wino4_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L) {
+  return conv_wino4_wgrad_shape(M, Cin, Cout, L) ? conv_wino4_wgrad_slab_floats(M, Cin, Cout) : 0;
+}
+
+extern "C" int dvg_dev_conv_wino4_wgrad(const float* in, const float* dy, float* slabs, float* grad_w, int mode, int64_t M,
+                                        int Cin, int Cout, int L, int cus, dvg_stream_t stream) {
+  DVG_REQUIRE(in && dy && slabs && grad_w, "dev_conv_wino4_wgrad: null argument");
+  return launch_conv_wino4_wgrad(in, dy, M, Cin, Cout, L, slabs, WeightMap{mode, Cin, Cout, 9}, grad_w, (hipStream_t)stream, cus);
+}

@@ -21,7 +21,7 @@ struct EncPlan {
   size_t Y[4], Xp[4], mean[4], invstd[4], stats[4], wp[4], wpd[4];
   bool wino_f[4], wino_d[4];  // layer's forward / data-gradient GEMM runs in the Winograd form (conv_wino.hip)
   bool wino_w[4];             // ... its weight gradient too (conv_wino_wgrad.hip)
-  bool wino4_f[4], wino4_d[4]; // ... in the F(4x4,3x3) form (conv_wino4.hip) instead of F(2x2,3x3)
+  bool wino4_f[4], wino4_d[4], wino4_w[4]; // ... in the F(4x4,3x3) form (conv_wino4.hip, conv_wino4_wgrad.hip) instead of F(2x2,3x3)
   size_t dXbuf, dYl[4], slabs, partA, partB[4], partP, part320, mom_part, mom, pimg, splitk;
   int ksplit[4];
   size_t total_floats;
@@ -54,6 +54,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
     p.wino_w[l] = l > 0 && training && conv_wino_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
     p.wino4_f[l] = p.wino_f[l] && conv_wino4_ok(p.M[l], ch[l], C, p.L[l]);
     p.wino4_d[l] = p.wino_d[l] && conv_wino4_ok(p.M[l], C, ch[l], p.L[l]);
+    p.wino4_w[l] = p.wino_w[l] && conv_wino4_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
     p.nblk[l] = l == 0 ? enc_conv0_blocks(B)
                        : (p.wino4_f[l] ? conv_wino4_stats_blocks(p.M[l]) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C)));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
@@ -70,7 +71,7 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
       const size_t slab = (size_t)p.ksplit[l] * 9 * ch[l] * C;
       if (slab > max_slab) max_slab = slab;
       if (p.wino_w[l]) {
-        const size_t sw = conv_wino_wgrad_slab_floats(p.M[l], ch[l], C, p.L[l]);
+        const size_t sw = p.wino4_w[l] ? conv_wino4_wgrad_slab_floats(p.M[l], ch[l], C) : conv_wino_wgrad_slab_floats(p.M[l], ch[l], C, p.L[l]);
         if (sw > max_slab) max_slab = sw;
       }
       const size_t sk_f = conv_splitk_floats(p.M[l], ch[l], C, 9, 0), sk_d = conv_splitk_floats(p.M[l], C, ch[l], 9, 0);
@@ -284,7 +285,10 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     WgradArgs wa;
     wa.in = W + pl.Xp[l - 1]; wa.dy = dY; wa.slabs = W + pl.slabs;
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
-    if (pl.wino_w[l]) {
+    if (pl.wino4_w[l]) {
+      DVG_TRY(launch_conv_wino4_wgrad(W + pl.Xp[l - 1], dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONV_FWD, Cin, C, 9},
+                                      g->conv_w[l], s2));
+    } else if (pl.wino_w[l]) {
       DVG_TRY(launch_conv_wino_wgrad(W + pl.Xp[l - 1], dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONV_FWD, Cin, C, 9},
                                      g->conv_w[l], s2));
     } else {

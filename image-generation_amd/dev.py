@@ -17,6 +17,9 @@ _SIGS = {
     "dvg_dev_conv_wino4": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
                            [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "dvg_dev_conv_wino4_shape": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dvg_dev_wino4_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dvg_dev_conv_wino4_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 4 +
+                                 [ctypes.c_void_p]),
     "dvg_dev_conv_wino_ok": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wino_stats_blocks": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int]),
     "dvg_dev_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -155,3 +158,18 @@ def encoder_saved(ws: torch.Tensor, B: int, n: int):
         stored = l > 0 or _lib.get_option("enc_l0_fused") == 0
         out.append(dict(Y=morton_to_nchw(y, B, C, side) if stored else None, mean=f[off[8 + l]: off[8 + l] + C], invstd=f[off[12 + l]: off[12 + l] + C]))
     return out
+
+
+def conv_wino4_wgrad(x_m, dy, mode, w_shape, M, Cin, Cout, L, cus=0):
+    """The 3x3 weight gradient in the Winograd F(4x4,3x3) form (csrc/conv_wino4_wgrad.hip), or None when the shape does not
+    qualify.  ``cus``: CUs the grid is sized for (0: the budget the training step gives the launch)."""
+    Lb = lib()
+    dev = x_m.device
+    nf = Lb.dvg_dev_wino4_wgrad_slab_floats(M, Cin, Cout, L)
+    if nf == 0:
+        return None
+    slabs = torch.empty(nf, device=dev)
+    gw = torch.empty(w_shape, device=dev)
+    _lib.check(Lb.dvg_dev_conv_wino4_wgrad(x_m.data_ptr(), dy.data_ptr(), slabs.data_ptr(), gw.data_ptr(), mode, M, Cin, Cout, L,
+                                           int(cus), _lib.stream_ptr(dev)))
+    return gw

@@ -27,6 +27,11 @@ int dvg_dev_conv_wino_ok(int64_t M, int Cin, int Cout, int L);
 int dvg_dev_conv_wino4(const float *in, const float *w, int mode, float *u, const float *bias, float *out, float *stats,
                        int64_t M, int Cin, int Cout, int L, int cus, dvg_stream_t stream);
 int dvg_dev_conv_wino4_shape(int64_t M, int Cin, int Cout, int L);
+/* ... and the layer's weight gradient in that form (csrc/conv_wino4_wgrad.hip): slabs of dvg_dev_wino4_wgrad_slab_floats()
+ * floats (0 = the shape does not qualify); cus: CUs the grid is sized for (0 = the training step's budget). */
+size_t dvg_dev_wino4_wgrad_slab_floats(int64_t M, int Cin, int Cout, int L);
+int dvg_dev_conv_wino4_wgrad(const float *in, const float *dy, float *slabs, float *grad_w, int mode, int64_t M, int Cin,
+                             int Cout, int L, int cus, dvg_stream_t stream);
 int dvg_dev_conv_wino_stats_blocks(int64_t M, int Cout);
 int dvg_dev_conv_stats_blocks(int64_t M, int Cout);
 /* grad_w (checkpoint layout, `mode` = the layer's FORWARD mode) = sum_m in[nbr(m,tap)] (x) dy[m]; slabs: scratch of

@@ -156,6 +156,34 @@ def test_winograd_weight_gradient_kernel(N, Cin, Cout, side, ups):
     assert torch.equal(gw, gw2)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,side,cus", [(64, 32, 64, 16, 0), (256, 64, 128, 8, 0), (512, 128, 512, 4, 0),   # the encoder's layers 1-3
+                                                 (36, 64, 64, 8, 0), (4, 32, 64, 4, 0), (8, 64, 32, 16, 0),          # few images (no split), the 64 x 32 tile on 16x16
+                                                 (512, 128, 512, 4, 256), (64, 32, 64, 16, 256)])                   # the whole chip's split
+def test_winograd_f4x4_weight_gradient_kernel(N, Cin, Cout, side, cus):
+    """conv_wino4_wgrad_kernel (csrc/conv_wino4_wgrad.hip: 36 position GEMMs over the 4x4 output tiles on the 16x16x4 MFMA,
+    both operands transformed in the workgroup from coalesced global loads) against a float64 weight gradient of the same
+    layer, with the F(2x2,3x3) kernel's and the direct kernel's distances beside it; both channel tiles (64 x 32, 32 x 64),
+    every image size, split and unsplit launches; and twice the same launch for the bits."""
+    torch.manual_seed(N + Cin + side)
+    L, M = side.bit_length() - 1, N * side * side
+    x = torch.randn(N, Cin, side, side)
+    gy = torch.randn(N, Cout, side, side)
+    shape = (Cout, Cin, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(x.double(), shape, gy.double(), padding=1)
+    xm, gym = dev.nchw_to_morton(x).cuda(), dev.nchw_to_morton(gy).cuda()
+    gw = dev.conv_wino4_wgrad(xm, gym, 0, shape, M, Cin, Cout, L, cus=cus)
+    assert gw is not None
+    gd = dev.conv_wgrad(xm, gym, 0, shape, M, Cin, Cout, L)
+    rel = lambda a: float((a.cpu().double() - ref).norm() / ref.norm())  # noqa: E731
+    e_4, e_d = rel(gw), rel(gd)
+    g2 = dev.conv_wino_wgrad(xm, gym, 0, shape, M, Cin, Cout, L)
+    print(f"F(4x4) weight gradient vs float64 [N={N} {Cin}->{Cout} @{side} cus={cus}]: F(4x4) {e_4:.2e}  direct {e_d:.2e}  F(2x2) " +
+          (f"{rel(g2):.2e}" if g2 is not None else "n/a"))
+    assert e_4 < 8e-6, (e_4, e_d)
+    gw2 = dev.conv_wino4_wgrad(xm, gym, 0, shape, M, Cin, Cout, L, cus=cus)
+    assert torch.equal(gw, gw2)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side", [(1024, 32, 64, 4), (8192, 32, 64, 2), (1024, 128, 128, 8)])
 def test_position_major_tiles_are_bit_identical_to_pixel_major_tiles(N, Cin, Cout, side):
     """Position-major tiles (conv.h: ConvArgs.posmajor) skip the taps that fall outside the image -- multiplications by
