@@ -464,7 +464,7 @@ def main():
     L = _lib.lib()
     for item in args.option:
         name, value = item.split("=")
-        _lib.set_option(name, int(value))
+        _lib.set_option(name, int(value, 0))
     _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
     is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel", "conv_wino_kernel", "conv_wino_wgrad_kernel")  # noqa: E731

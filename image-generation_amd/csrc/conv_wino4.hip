@@ -56,7 +56,6 @@ struct Wino4Args {
   int* dyn = nullptr; // tile counters of the dynamic deal (conv_wino.hip), or null: round-robin
   int Cin, Cout;
   int nblk;           // tile blocks (of 64 tiles)
-  int dbg = 0;        // (diagnostic builds: bit 0 no output stores, bit 1 staggered start)
 };
 
 #ifndef WINO4_RX
@@ -182,14 +181,12 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   // (one piece per call, so that a chunk can place them between its MFMA groups; q-th piece of this wave)
   auto raw_soff = [&](int blk, int ch) { return __builtin_amdgcn_readfirstlane((blk * 1024 * a.Cin + ch * 4) * 4); };
   auto issue_raw_piece = [&](int soff, int st, int q) {
-    if (a.dbg & 4) return;
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rdst[q] + (uint32_t)(st * C::RAW_B)));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
   };
   const int ustride = a.Cout / 32 * C::U_B;  // bytes between two chunks of the pack
   auto u_sbase = [&](int ch) { return __builtin_amdgcn_readfirstlane(ch * ustride + (int)blockIdx.y * C::U_B); };
   auto issue_u_piece = [&](int sbase, int st, int q) {  // (waves 4-7; pieces 18, 19 repeat pieces 0, 1)
-    if (a.dbg & 8) return;
     int p = ((wave - 4) & 3) + 4 * q;
     if (p >= C::U_PIECES) p -= C::U_PIECES;
     p = __builtin_amdgcn_readfirstlane(p);
@@ -261,10 +258,6 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   }
   bool has_next = blk_nxt < a.nblk;
   if (blk_cur >= a.nblk) { finish(); return; }
-  if (a.dbg & 2) {  // workgroup phases a quarter of a tile block apart (~1100 cycles per chunk and quarter)
-    const int n = ((int)(blockIdx.x + blockIdx.y) & 3) * nch * 9;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2);
-  }
   if (wave < 4) { issue_all(std::integral_constant<int, 1>{}, blk_cur, 0, 0, true); issue_all(std::integral_constant<int, 1>{}, blk_cur, 1, 1, false); }
   else { issue_all(std::integral_constant<int, 0>{}, blk_cur, 0, 0, true); issue_all(std::integral_constant<int, 0>{}, blk_cur, 1, 1, false); }
   __syncthreads();  // (the workgroup fence waits for the LDS-DMA pieces)
@@ -280,7 +273,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (a.dbg & 1) ? 0 : (int)((int64_t)a.nblk * 1024 * a.Cout * 4), 0x00020000);  // (diagnostic: no records = every store dropped)
+      a.out, 0, (int)((int64_t)a.nblk * 1024 * a.Cout * 4), 0x00020000);
   const int ch_out = n0 + 16 * wc + r16;
   const int ovoff = (4 * kq * 16 * a.Cout + ch_out) * 4;  // tile 4 kq of the wave's sixteen, pixel 0, the lane's channel
   const float bias = a.bias ? a.bias[ch_out] : 0.f;
@@ -369,13 +362,12 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     float d[36];
     load_quad(0);
     load_quad(1);
-    const bool xf_on = !(a.dbg & 16);
-    if constexpr (XF) { if (xf_on) load_patch(st ^ 1, d); }
+    if constexpr (XF) load_patch(st ^ 1, d);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       if (q + 2 < 9) load_quad(q + 2);
-      if (XF && xf_on) {
+      if constexpr (XF) {
         // pieces: q = 1..3 two columns each, q = 4..6 two rows each and their three entry quads
         if (q >= 1 && q <= 3) { xform_col(2 * q - 2, d); xform_col(2 * q - 1, d); }
         if (q >= 4 && q <= 6) { xform_row(2 * q - 8, d); xform_row(2 * q - 7, d); store_quads(st ^ 1, 3 * (q - 4), d); }
@@ -493,7 +485,7 @@ int launch_conv_wino4(const ConvArgs& a, hipStream_t s) {
               "conv_wino4: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
   Wino4Args w;
   w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
-  w.Cin = a.Cin; w.Cout = a.Cout; w.cus = a.wino_cus & 0xffff; w.dbg = a.wino_cus >> 16;
+  w.Cin = a.Cin; w.Cout = a.Cout; w.cus = a.wino_cus;
   w.nblk = (int)(a.M / 1024);
   // EXECUTED matrix FLOPs: 36 transform-domain GEMMs over the M / 16 tiles (1/4 of the direct form's 2 M Cin Cout 9)
   const double flops = 2.0 * (double)(a.M / 16) * 36.0 * a.Cin * a.Cout;

@@ -385,7 +385,7 @@ bool conv_wino4_wgrad_shape(int64_t M, int Cin, int Cout, int L) { return wino4_
 // kernel's time; on 8x8 and 16x16 images the two forms are level), 2 every layer the shape allows, 0 never
 bool conv_wino4_wgrad_ok(int64_t M, int Cin, int Cout, int L) {
   const int64_t o = opt(OPT_ENC_WINO4);
-  return o != 0 && wino4_wgrad_shape_ok(M, Cin, Cout, L) && (o >= 2 || L == 2);
+  return o != 0 && wino4_wgrad_shape_ok(M, Cin, Cout, L);  // (which layers: option enc_wino4_mask, encoder.cpp)
 }
 
 size_t conv_wino4_wgrad_slab_floats(int64_t M, int Cin, int Cout) {

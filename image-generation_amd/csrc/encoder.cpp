@@ -52,9 +52,10 @@ EncPlan enc_plan(int64_t B, int n, int training = 1) {
     p.wino_f[l] = l > 0 && conv_wino_ok(p.M[l], ch[l], C, p.L[l], training ? 0 : 2);
     p.wino_d[l] = l > 0 && training && conv_wino_ok(p.M[l], C, ch[l], p.L[l], 1);
     p.wino_w[l] = l > 0 && training && conv_wino_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
-    p.wino4_f[l] = p.wino_f[l] && conv_wino4_ok(p.M[l], ch[l], C, p.L[l]);
-    p.wino4_d[l] = p.wino_d[l] && conv_wino4_ok(p.M[l], C, ch[l], p.L[l]);
-    p.wino4_w[l] = p.wino_w[l] && conv_wino4_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
+    const int64_t m4 = opt(OPT_ENC_WINO4_MASK);  // (which launches take the F(4x4,3x3) form: measured per launch inside the step)
+    p.wino4_f[l] = l > 0 && p.wino_f[l] && ((m4 >> (l - 1)) & 1) && conv_wino4_ok(p.M[l], ch[l], C, p.L[l]);
+    p.wino4_d[l] = l > 0 && p.wino_d[l] && ((m4 >> (2 + l)) & 1) && conv_wino4_ok(p.M[l], C, ch[l], p.L[l]);
+    p.wino4_w[l] = l > 0 && p.wino_w[l] && ((m4 >> (5 + l)) & 1) && conv_wino4_wgrad_ok(p.M[l], ch[l], C, p.L[l]);
     p.nblk[l] = l == 0 ? enc_conv0_blocks(B)
                        : (p.wino4_f[l] ? conv_wino4_stats_blocks(p.M[l]) : (p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : conv_stats_blocks(p.M[l], C)));
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
@@ -271,7 +272,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     a.in = dY; a.wp = W + pl.wpd[l]; a.bias = nullptr; a.out = dX; a.stats = nullptr;
     a.M = pl.M[l]; a.Cin = C; a.Cout = Cin; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
     a.splitk_ws = W + pl.splitk;
-    a.wino_cus = WINO_CUS_ENC_DGRAD;  // (the layer's weight-gradient chain runs beside it on the side stream)
+    a.wino_cus = opt(OPT_ENC_DGRAD_CUS) > 0 ? (int)opt(OPT_ENC_DGRAD_CUS) : WINO_CUS_ENC_DGRAD;  // (the layer's weight-gradient chain runs beside it on the side stream)
     if (pl.wino4_d[l]) DVG_TRY(launch_conv_wino4(a, s));
     else if (pl.wino_d[l]) DVG_TRY(launch_conv_wino(a, s));
     else DVG_TRY(launch_conv_igemm(a, s));
@@ -287,10 +288,10 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     wa.M = pl.M[l]; wa.Cin = Cin; wa.Cout = C; wa.L = pl.L[l]; wa.ntaps = 9; wa.ups = 0; wa.ksplit = pl.ksplit[l];
     if (pl.wino4_w[l]) {
       DVG_TRY(launch_conv_wino4_wgrad(W + pl.Xp[l - 1], dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONV_FWD, Cin, C, 9},
-                                      g->conv_w[l], s2));
+                                      g->conv_w[l], s2, (int)opt(OPT_ENC_WGRAD_CUS)));
     } else if (pl.wino_w[l]) {
       DVG_TRY(launch_conv_wino_wgrad(W + pl.Xp[l - 1], dY, pl.M[l], Cin, C, pl.L[l], W + pl.slabs, WeightMap{WM_CONV_FWD, Cin, C, 9},
-                                     g->conv_w[l], s2));
+                                     g->conv_w[l], s2, 0, (int)opt(OPT_ENC_WGRAD_CUS)));
     } else {
       DVG_TRY(launch_conv_wgrad(wa, s2));
       DVG_TRY(launch_wgrad_reduce(W + pl.slabs, pl.ksplit[l], WeightMap{WM_CONV_FWD, Cin, C, 9}, g->conv_w[l], s2));
