@@ -85,7 +85,7 @@ def _profile(kind, config, lib_hash):
     """A committed profiles/ JSON of this round, or None when it was measured on a different build of the kernels:
     every file carries `kernels_hash` = dvg_source_hash() of the library it was measured on (tools/make_profiles.sh),
     and a number from another build would survive a kernel regression unchanged."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{kind}_{config}.json")
         if os.path.exists(path):
             d = json.load(open(path))
@@ -123,6 +123,18 @@ def pmc_mfma_busy(kernel, config, lib_hash):
     d, _src = _profile("pmc_mfma_busy", config, lib_hash)
     rec = _find_kernel(d, kernel) if d else None
     return rec["mfma_busy_frac"] if rec else None
+
+
+def pmc_mfma_busy_all(kernel, config, lib_hash):
+    """... of EVERY instantiation the profiler id `kernel` covers (conv_wino4_kernel<2>, <3>, <4>: one per image size),
+    {rocprof name: (matrix-pipe busy fraction alone at the in-step grid, launches per profiled run)}."""
+    d, _src = _profile("pmc_mfma_busy", config, lib_hash)
+    if not d:
+        return None
+    want = _NORM(PROF_TO_ROCPROF.get(kernel, kernel))
+    out = {name.split("(")[0].replace("void dvg::", ""): {"mfma_busy_frac": rec["mfma_busy_frac"], "launches": rec["launches"]}
+           for name, rec in d.get("kernels", {}).items() if _NORM(name) == want or _NORM(name).startswith(want)}
+    return out or None
 
 
 def cpu_model():
@@ -467,7 +479,7 @@ def main():
         _lib.set_option(name, int(value, 0))
     _lib.check(L.dvg_set_conv_precision({"f32": 0, "bf16": 1, "f32x3": 2}[args.precision]), "dvg_set_conv_precision")
     names = [L.dvg_prof_kernel_name(i).decode() for i in range(L.dvg_prof_num_kernels())]
-    is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel", "conv_wino_kernel", "conv_wino_wgrad_kernel")  # noqa: E731
+    is_gemm = lambda nm: nm.startswith("conv_igemm") or nm.startswith("conv_wgrad_kernel") or nm in ("mmd_main", "mmd_pm1", "conv_wgrad_fold_kernel", "conv_wino_kernel", "conv_wino_wgrad_kernel", "conv_wino4_kernel", "conv_wino4_wgrad_kernel")  # noqa: E731
     mask = sum(1 << i for i, nm in enumerate(names) if is_gemm(nm) or nm == "gibbs_sweeps") if not args.breakdown else (1 << len(names)) - 1
     # The autoencoder half of every step is replayed from a captured hipGraph (one graph launch instead of ~120 kernel
     # launches); on every 10th step the GRBM quasi-NLL update runs eagerly behind it.  --eager disables the graph.
@@ -595,6 +607,8 @@ def main():
                 e["algorithmic_f32_tflops"] = v["algorithmic_work"] / (v["total_ms"] * 1e-3) / 1e12
             e["traffic"], e["traffic_source"] = pmc_traffic(k, args.config, lib_hash)
             e["mfma_busy_pmc"] = pmc_mfma_busy(k, args.config, lib_hash) if args.precision == "f32" else None
+            if args.precision == "f32":  # (one profiler id, several template instantiations: each one's PMC figure)
+                e["mfma_busy_pmc_instantiations"] = pmc_mfma_busy_all(k, args.config, lib_hash)
             if k == "mmd_pm1":
                 i8, b16, terms = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
                 _lib.check(L.dvg_mmd_spin_flops(cfg["B"] * cfg["R"], cfg["C"], cfg["n"], ctypes.byref(i8), ctypes.byref(b16),
@@ -624,7 +638,7 @@ def main():
             # position-major tiles and the Winograd forms execute 0.3-0.45 of it; a rate above the f32 MFMA peak here is
             # algebra, not a mislabelled launch (the executed rate `frac` is the utilisation figure)
             ref_gflop = net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9
-            roofline["conv_all"] = {"tflops": tw / (tt * 1e-3) / 1e12, "note": "EXECUTED float32 FLOPs of all convolution GEMM kernels (Winograd launches: their 16 / 9 position GEMMs) / their summed time; frac against the f32 MFMA peak (bf16 peak in --precision bf16)",
+            roofline["conv_all"] = {"tflops": tw / (tt * 1e-3) / 1e12, "note": "EXECUTED float32 FLOPs of all convolution GEMM kernels (Winograd launches: their 36 position GEMMs per 4x4 tile -- F(4x4,3x3) -- or 16 / 9 per 2x2 quad / their summed time; frac against the f32 MFMA peak (bf16 peak in --precision bf16)",
                                     "reference_equivalent": {"gflop_per_step": ref_gflop, "tflops": ref_gflop * prof_steps / (tt * 1e-3) / 1e3,
                                                              "executed_over_reference": tw / prof_steps / 1e9 / ref_gflop},
                                     "frac": tw / (tt * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),

@@ -38,8 +38,6 @@
 
 namespace dvg {
 
-namespace {
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
@@ -464,8 +462,6 @@ int launch_wino4_cfg(const Wino4Args& a, double flops, hipStream_t s) {
   DVG_LAUNCH_WORK_SHARE(K_IGEMM_WINO4, flops, (float)(gx * ny > 256 ? 256 : gx * ny) / 256.0f, kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), C::LDS_BYTES, s, ad);
   return DVG_OK;
 }
-
-}  // namespace
 
 bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L) { return wino4_shape_ok(M, Cin, Cout, L); }
 

@@ -25,8 +25,6 @@
 
 namespace dvg {
 
-namespace {
-
 typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
@@ -37,7 +35,7 @@ struct Wino4WgradArgs {
   float* slabs;      // [nsplit][36][Cin][Cout]
   int Cin, Cout;
   int tiles;         // 4x4 output tiles (M / 16)
-  int nsplit;        // slabs: the tiles in nsplit equal runs of whole chunks
+  int per;           // chunks (4 tiles) per slab: slab z covers chunks [z per, min((z + 1) per, tiles / 4))
 };
 
 // WA x WB waves = 16 WA input channels x 16 WB output channels
@@ -62,8 +60,8 @@ __global__ __launch_bounds__(512) void conv_wino4_wgrad_kernel(Wino4WgradArgs a)
   const int kq = lane >> 4, r16 = lane & 15;
   const int ci0 = blockIdx.x * C::CI, co0 = blockIdx.y * C::CO;
   // the slab's chunks (4 tiles each)
-  const int nchunks = a.tiles / 4 / a.nsplit;
-  const int chunk0 = (int)blockIdx.z * nchunks;
+  const int chunk0 = (int)blockIdx.z * a.per;
+  const int nchunks = a.tiles / 4 - chunk0 < a.per ? a.tiles / 4 - chunk0 : a.per;
 
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in), 0, (int)((int64_t)a.tiles * 16 * a.Cin * 4), 0x00020000);
@@ -351,18 +349,19 @@ bool wino4_wgrad_shape_ok(int64_t M, int Cin, int Cout, int L) {
   return true;
 }
 
-struct Wino4WgradGeom { int cfg, nx, ny, nsplit; };
+struct Wino4WgradGeom { int cfg, nx, ny, nsplit, per; };
 Wino4WgradGeom wino4_wgrad_geom(int64_t M, int Cin, int Cout, int cus) {
   Wino4WgradGeom g;
   g.cfg = Cin % 64 == 0 ? 0 : 1;  // 0: 64 x 32 channel tile, 1: 32 x 64
   g.nx = Cin / (g.cfg == 0 ? 64 : 32);
   g.ny = Cout / (g.cfg == 0 ? 32 : 64);
   const int chunks = (int)(M / 64);
-  // one workgroup per CU of the budget; the split divides the chunks, every workgroup at least 8 chunks deep
+  // one workgroup per CU of the budget, every workgroup at least 8 chunks deep; the last slab may be shorter
   int want = cus / (g.nx * g.ny);
   if (want < 1) want = 1;
-  while (want > 1 && (chunks % want || chunks / want < 8)) --want;
-  g.nsplit = want;
+  if (want > chunks / 8) want = chunks / 8 > 0 ? chunks / 8 : 1;
+  g.per = (chunks + want - 1) / want;
+  g.nsplit = (chunks + g.per - 1) / g.per;
   return g;
 }
 
@@ -376,8 +375,6 @@ int launch_wino4_wgrad_cfg(const Wino4WgradArgs& a, double flops, dim3 grid, hip
   DVG_LAUNCH_WORK_SHARE(K_WGRAD_WINO4, flops, (float)(wgs > 256u ? 256u : wgs) / 256.0f, kern, grid, dim3(512), C::LDS_BYTES, s, a);
   return DVG_OK;
 }
-
-}  // namespace
 
 bool conv_wino4_wgrad_shape(int64_t M, int Cin, int Cout, int L) { return wino4_wgrad_shape_ok(M, Cin, Cout, L); }
 
@@ -401,7 +398,7 @@ int launch_conv_wino4_wgrad(const float* in, const float* dy, int64_t M, int Cin
   if (cus > 256) cus = 256;
   const Wino4WgradGeom g = wino4_wgrad_geom(M, Cin, Cout, cus);
   Wino4WgradArgs a;
-  a.in = in; a.dy = dy; a.slabs = slabs; a.Cin = Cin; a.Cout = Cout; a.tiles = (int)(M / 16); a.nsplit = g.nsplit;
+  a.in = in; a.dy = dy; a.slabs = slabs; a.Cin = Cin; a.Cout = Cout; a.tiles = (int)(M / 16); a.per = g.per;
   const double flops = 2.0 * (double)(M / 16) * 36.0 * Cin * Cout;  // executed position GEMMs
   const dim3 grid((unsigned)g.nx, (unsigned)g.ny, (unsigned)g.nsplit);
   int rc;

@@ -5,7 +5,7 @@
 # Every JSON written by the aggregators carries kernels_hash = dvg_source_hash() of the library measured; bench.py drops
 # profiles whose hash differs from the library it runs.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_new
 mkdir -p $OUT
@@ -63,6 +63,10 @@ python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut 
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
 python tools/wino_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_alone_c3.txt
 python tools/wino_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_wgrad_alone_c3.txt
+# the F(4x4,3x3) kernels alone, beside the F(2x2,3x3) and direct kernels on the same launches
+python tools/wino4_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_alone_c3.txt
+python tools/wino4_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_wgrad_alone_c3.txt
+python tools/wino4_sweep.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_time_per_chunk.txt
 # determinism: two processes, 300 graph-replayed c3 steps each, losses printed to the last digit (dynamic tile deal, pair
 # exchange and fixed-order slab sums included)
 (python tools/soak.py c3 300 2>&1 | tail -3; python tools/soak.py c3 300 2>&1 | tail -3) | grep -v amdgpu > $OUT/${R}_soak_c3_300_steps_twice.txt

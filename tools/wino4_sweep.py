@@ -28,17 +28,15 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-DBG = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-print("diagnostic flags", DBG)
-for side, B, Cout in ((16, 4096, 64), (4, 65536, 64)):
+for side, B, Cout in ((16, 4096, 64), (8, 16384, 64), (4, 65536, 64), (16, 4096, 32)):
     L, M = side.bit_length() - 1, B * side * side
     nblk, ny = M // 1024, Cout // 32
     per_wg = nblk * ny / 256
     rows = []
-    for Cin in (32, 128, 256):
+    for Cin in (8, 32, 128, 256):
         x = torch.randn(M, Cin, device="cuda")
         w = torch.randn(Cout, Cin, 3, 3, device="cuda") / 30
-        t = min(timeit(lambda: dev.conv_wino4(x, w, 0, M, Cin, Cout, L, cus=DBG << 16)) for _ in range(2))
+        t = min(timeit(lambda: dev.conv_wino4(x, w, 0, M, Cin, Cout, L)) for _ in range(2))
         rows.append((Cin // 4, t))
         del x
     (c0, t0), (c1, t1) = rows[-3], rows[-1]
