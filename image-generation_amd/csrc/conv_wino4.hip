@@ -465,10 +465,11 @@ int launch_wino4_cfg(const Wino4Args& a, double flops, hipStream_t s) {
 
 bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L) { return wino4_shape_ok(M, Cin, Cout, L); }
 
-// option enc_wino4: 1 (default) every encoder launch that runs in the Winograd domain and whose shape qualifies, 0 never
-// (F(2x2,3x3) everywhere).  Measured at c3, alternating runs in one process: the step 7.46 ms with F(2x2) everywhere, 7.28
-// with the layers on 4x4 and 8x8 images in this form, 7.22 with the 16x16 layer too (alone on the chip that layer's two
-// launches are level with the F(2x2) kernel -- both wait for their output stores there -- inside the step they are not).
+// option enc_wino4: 1 (default) the encoder launches of dev option enc_wino4_mask that run in the Winograd domain and whose
+// shape qualifies, 0 never (F(2x2,3x3) everywhere).  Measured at c3, alternating runs in one process: the step 7.46-7.54 ms
+// with F(2x2) everywhere, 7.24-7.34 with layer 3's forward, every data gradient and layer 3's weight gradient in this form
+// (the default mask), the same with the forwards of layers 1-2 added (alone on the chip those are 0.85 / 1.0 of the F(2x2)
+// kernel's time -- both forms wait for their output stores there -- and they stay on F(2x2): encoder.cpp, options.cpp).
 bool conv_wino4_ok(int64_t M, int Cin, int Cout, int L) {
   return opt(OPT_ENC_WINO4) != 0 && wino4_shape_ok(M, Cin, Cout, L);
 }
