@@ -213,12 +213,11 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
     for t in points:
         d = leg(t, 1, 3, 0.0, False)
         thread_sweep[str(t)] = {"ms_per_step": d["times_ms"][len(d["times_ms"]) // 2], "images_per_s": d["batch"] / (d["times_ms"][len(d["times_ms"]) // 2] * 1e-3)}
-    # (3-step points are noisy: round 4's lines picked 8, 16 and 32 threads on three runs of the same box.  16 threads --
-    # what every earlier round ran -- stays unless another point is more than 20 % faster, so that the baseline is the
-    # same measurement from run to run)
+    # (the baseline runs on the FASTEST point of the sweep -- a preference for 16 threads within 20 % biased the
+    # denominator of the reported speed-up in the GPU's favour; `cores_fastest_in_sweep` is kept beside `cores` so that a
+    # reader sees when a noisy 3-step point decided)
     best = min(thread_sweep, key=lambda k: thread_sweep[k]["ms_per_step"])
-    pref = str(min(16, host))
-    cores = int(pref if pref in thread_sweep and thread_sweep[pref]["ms_per_step"] <= 1.2 * thread_sweep[best]["ms_per_step"] else best)
+    cores = int(best)
     d = leg(cores, 3, 10, seconds, True)
     times, Bc = d["times_ms"], d["batch"]
     med = times[len(times) // 2] * 1e-3
@@ -228,8 +227,8 @@ def cpu_baseline(config, seconds=20.0, sweep=(8, 16, 32, 64)):
             "thread_sweep": thread_sweep,
             "sample": f"{len(times)} train steps of the {cfg['B']}-image workload's model (n={cfg['n']}, R={cfg['R']}, "
                       f"{cfg['C']} chains x {cfg['sweeps']} sweeps) at B={Bc} images per step on the CPU oracle after 3 "
-                      f"warm-up steps, {cores} threads in a fresh process (16 unless another of {points}, each measured in its own "
-                      f"process, is > 20 % faster); median {med * 1e3:.0f} ms/step, min {times[0]:.0f} ms",
+                      f"warm-up steps, {cores} threads in a fresh process (the fastest of {points}, each measured in its own "
+                      f"process over 3 steps); median {med * 1e3:.0f} ms/step, min {times[0]:.0f} ms",
             "ms_per_step_median": med * 1e3, "ms_per_step_min": times[0]}
 
 

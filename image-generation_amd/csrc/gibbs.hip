@@ -505,7 +505,18 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // alone against the rolled 16-wave form's 1.20) and costs the same CU-time -- but it takes every CU's LDS while it
   // runs, and the c5 step, whose encoder AND decoder forward hide behind a 1.2 ms draw on half the chip, got slower
   // with it (2.88 -> 3.01 ms: `profiles/r05_gibbs_c5_forms.txt`).
-  const bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512);
+  bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512);
+  if (lane_ok) {
+    // (a lane image the fast form cannot serve -- more than 160 KiB of LDS: 20 rows x 5 batches at n_pad > 1216;
+    // or a shape without an instantiation: two rows per step with a single small class -- falls through to the rolled
+    // schedule, which serves every graph, instead of failing the draw)
+    const int lpc = g->lane_lpc, mb = g->lane_mb, rows = g->lane_rows, nr = form == 2 ? 1 : g->lane_nr;
+    const bool small = gibbs_lane_lds_bytes(rows, mb, lpc, g->n, 0) <= 16 * 1024 && n_chains <= 1024 && rows <= 12;
+    const int waves = small ? 1 : 4;
+    const bool has_kernel = (lpc == 16 || lpc == 32 || lpc == 64) && (mb == 4 || mb == 5) && rows <= 20 &&
+                            (nr == 1 ? (rows <= 12 || (lpc == 64 && !small)) : (nr == 2 && lpc == 64 && !small));
+    if (!has_kernel || gibbs_lane_lds_bytes(rows, mb, lpc, g->n, waves * (64 / lpc)) > 160 * 1024) lane_ok = false;
+  }
   if (lane_ok && form != 1) {
     // Lanes per chain: the smallest of 16/32/64 that covers the largest colour class in one pass, else 64 (graph.cpp).
     // Waves per workgroup.  Measured on the c2 step with the draw overlapped with the encoder forward: 4 -> 1.237 ms,

@@ -590,11 +590,16 @@ class ModelWrapper:
             rec["decision"] = bool(max(rec["lags"]) > self.DEFER_LAG_MS)
         return bool(rec["decision"])
 
-    def _defer_undecided(self) -> bool:
-        """True while the shape the last step ran on is still being measured (its graph must not be captured yet)."""
+    def _defer_undecided(self, rows=None) -> bool:
+        """True while the shape of the step about to run (``rows`` = B x replicas; None: the last step's shape) is still
+        being measured (its graph must not be captured yet).  Keyed on the step's OWN shape: a ragged last
+        batch, which appears once per epoch and never reaches a decision, no longer sends the next epoch's first
+        full-shape step down the eager path although that shape's decision and graph exist."""
         if getattr(self, "defer_mmd_join", None) is not None or not (self.overlap_sampler and self.overlap_mmd):
             return False
-        rec = getattr(self, "_defer_rec", None)
+        rec = self.__dict__.get("_defer_by_rows", {}).get(int(rows)) if rows is not None else getattr(self, "_defer_rec", None)
+        if rows is not None and rec is None:
+            return True  # (a shape never seen: it measures first)
         return rec is not None and rec["decision"] is None
 
     def _hold_device_while_measuring(self, rows: int) -> None:
@@ -633,7 +638,8 @@ class ModelWrapper:
         eagerly behind the replay, on the replay's static spins); noise-injected (parity) steps take the eager path.
         With several GPUs the step is two graphs with the (eager) all-reduce between them."""
         return (self.use_graph and self._device.type == "cuda" and self.noise_hook is None and not self._graph_failed
-                and self._eager_steps >= 3 and not self.sync_losses and not self._defer_undecided()
+                and self._eager_steps >= 3 and not self.sync_losses
+                and not self._defer_undecided(int(images.shape[0]) * int(self.N_REPLICAS))
                 and (self._static_images is None or images.shape == self._static_images.shape))
 
     def _host_counters(self):

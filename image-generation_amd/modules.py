@@ -285,6 +285,11 @@ class _DecoderMseFn(torch.autograd.Function):
         x, im, ws, *params = ctx.saved_tensors
         module = ctx.module
         B, R, n = ctx.shape
+        # (the seed gradient is fixed at forward time -- a loss that was scaled or combined before it was
+        # differentiated would get silently wrong gradients.  Checked on the device, without a host wait, on every eager
+        # call; a captured step has run eagerly three times before its capture.)
+        if grad_loss is not None and not torch.cuda.is_current_stream_capturing():
+            torch._assert_async((grad_loss == 1).all(), "Decoder.forward_mse: differentiate the returned loss directly (unit upstream gradient)")
         st = module._native_struct(params)
         grads, direct = _grad_targets(module, params)
         gs = _decoder_grad_struct(grads)

@@ -67,6 +67,8 @@ python tools/wino_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_wgrad_al
 python tools/wino4_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_alone_c3.txt
 python tools/wino4_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_wgrad_alone_c3.txt
 python tools/wino4_sweep.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_time_per_chunk.txt
+# every F(4x4) instantiation against float64, with the F(2x2) and direct kernels' distances beside it (the kernel tests' own table)
+python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "f4x4" -s 2>&1 | grep -E "^\.?F\(4x4\)|passed|failed" | sed 's/^\.//' > $OUT/${R}_wino4_accuracy_vs_float64.txt
 # determinism: two processes, 300 graph-replayed c3 steps each, losses printed to the last digit (dynamic tile deal, pair
 # exchange and fixed-order slab sums included)
 (python tools/soak.py c3 300 2>&1 | tail -3; python tools/soak.py c3 300 2>&1 | tail -3) | grep -v amdgpu > $OUT/${R}_soak_c3_300_steps_twice.txt
