@@ -56,6 +56,9 @@ struct Wino4Args {
   int nblk;           // tile blocks (of 64 tiles)
 };
 
+#ifndef WINO4_STORE_AUX
+#define WINO4_STORE_AUX 0   // cache policy of the output stores (2 = nt)
+#endif
 #ifndef WINO4_RX
 #define WINO4_RX 0   // raw pieces per wave of the transform role (-1: an eighth of them)
 #endif
@@ -289,7 +292,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     int row0 = __builtin_amdgcn_readfirstlane((pblk * 64 + 16 * wt) * 16);
     asm volatile("" : "+s"(row0));
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yp[idx]), rsrc_out, ovoff,
-                                          (row0 + i * 16 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, 0);
+                                          (row0 + i * 16 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, WINO4_STORE_AUX);
   };
   // the epilogue: Y = A^T M A per (tile, channel), lane-local; + bias, BatchNorm partials
   auto epilogue = [&](int blk) {
