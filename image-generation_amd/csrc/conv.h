@@ -124,7 +124,7 @@ __device__ __forceinline__ void wino_pack_entry(const float* __restrict__ w, con
 // 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]: 36 floats (position 6 xi + nu) at [a / 4][b / 32][a % 4][b % 32] -- the 18 KiB a
 // workgroup's chunk reads (4 reduction channels x 32 output channels) are one contiguous piece.
 __device__ __forceinline__ void wino4_pack_entry(const float* __restrict__ w, const WeightMap& map, uint32_t e,
-                                                 float* __restrict__ u) {
+                                                 float* __restrict__ u, bool ups = false) {
   typedef float pack_f32x4 __attribute__((ext_vector_type(4)));
   const uint32_t av = e / (uint32_t)map.Cb, b = e - av * (uint32_t)map.Cb;
   float g[9];
@@ -152,7 +152,24 @@ __device__ __forceinline__ void wino4_pack_entry(const float* __restrict__ w, co
     o[6 * x + 4] = (g0 * (1.f / 24.f) - g1 * (1.f / 12.f)) + g2 * (1.f / 6.f);
     o[6 * x + 5] = g2;
   }
-  float* dst = u + ((size_t)((av >> 2) * ((uint32_t)map.Cb >> 5) + (b >> 5)) * 128 + (size_t)((av & 3) * 32 + (b & 31))) * 36;
+  const size_t cell = (size_t)((av >> 2) * ((uint32_t)map.Cb >> 5) + (b >> 5)) * 128 + (size_t)((av & 3) * 32 + (b & 31));
+  if (ups) {
+    // behind the x2 upsample: the 25 positions whose transformed input does not vanish (xi, nu over {0, 1, 3, 4, 5}), 28 floats
+    float o5[28];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+      for (int n = 0; n < 5; ++n) o5[5 * x + n] = o[6 * (x < 2 ? x : x + 1) + (n < 2 ? n : n + 1)];
+    o5[25] = o5[26] = o5[27] = 0.f;
+    float* dst = u + cell * 28;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const pack_f32x4 v = {o5[4 * q], o5[4 * q + 1], o5[4 * q + 2], o5[4 * q + 3]};
+      *reinterpret_cast<pack_f32x4*>(dst + 4 * q) = v;
+    }
+    return;
+  }
+  float* dst = u + cell * 36;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const pack_f32x4 v = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
@@ -239,7 +256,7 @@ bool conv_wino4_shape(int64_t M, int Cin, int Cout, int L);  // shape only
 bool conv_wino4_ok(int64_t M, int Cin, int Cout, int L);     // policy (option enc_wino4) + shape: asked for launches conv_wino_ok accepted
 int conv_wino4_stats_blocks(int64_t M);
 int launch_conv_wino4(const ConvArgs& a, hipStream_t s);
-int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s);
+int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s, int ups = 0);  // ups: the 25-position pack
 // ... and of their weight gradients (conv_wino4_wgrad.hip): slabs [nsplit][36][Cin][Cout] (at most
 // conv_wino4_wgrad_slab_floats), summed and transformed back (G^T dU G) into the checkpoint layout `map` by the same call;
 // cus = CUs the launch is sized for (0: WINO_CUS_ENC_WGRAD)
@@ -303,7 +320,7 @@ int launch_weight_pack(const float* w, const WeightMap& map, float* wp, hipStrea
 // bf16t: the operand form of the launch the pack feeds (conv_launch_mode): 0 -> [tap][a][b], 3 / 4 / 5 -> K-major [tap][b][a]
 // rows: GEMM rows of the launch this pack feeds (launch_conv_igemm's M over all classes): together with map.Cb it
 // decides the operand format that launch will use (conv_launch_mode); 0 = unknown: the process-wide mode as it stands
-// wino = 1: the job writes the Winograd pack [Ca][Cb][16] of a 9-tap map instead (wino_pack_entry); 2: the F(4x4,3x3) pack (wino4_pack_entry)
+// wino = 1: the job writes the Winograd pack [Ca][Cb][16] of a 9-tap map instead (wino_pack_entry); 2: the F(4x4,3x3) pack (wino4_pack_entry); 3: its 25-position form behind the x2 upsample
 struct PackJob { const float* w; float* wp; WeightMap map; int bf16t = 0; int64_t rows = 0; int wino = 0; };
 // operand form of one forward / data-gradient launch (ConvArgs.bf16): the process-wide mode mapped onto the kernels
 int conv_launch_mode(int64_t gemm_rows, int Cout);

@@ -851,8 +851,8 @@ __global__ __launch_bounds__(256) void weight_pack_multi_kernel(PackJobs jobs) {
   const PackJob& j = jobs.job[blockIdx.y];
   const WeightMap map = j.map;
   const uint32_t Ca = (uint32_t)map.Ca, Cb = (uint32_t)map.Cb, total = (uint32_t)map.ntaps * Ca * Cb;
-  if (j.wino == 2) {
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < Ca * Cb; e += gridDim.x * 256u) wino4_pack_entry(j.w, map, e, j.wp);
+  if (j.wino >= 2) {
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < Ca * Cb; e += gridDim.x * 256u) wino4_pack_entry(j.w, map, e, j.wp, j.wino == 3);
     return;
   }
   if (j.wino) {

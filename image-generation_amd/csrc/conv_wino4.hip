@@ -63,28 +63,45 @@ struct Wino4Args {
 #define WINO4_RX 0   // raw pieces per wave of the transform role (-1: an eighth of them)
 #endif
 
-template <int L>
+// UM = 1: the decoder's Upsample(x2) + 3x3 forward (/root/reference/src/decoder.py:34-46): `in` is the SOURCE map (half the
+// output's side).  The 6x6 patch of the upsampled map repeats a 4x4 patch s of source pixels, d = P s P^T, so V = T s T^T
+// with T = B^T P = [4 -5 1 0; 0 -8 2 0; 0 0 0 0; 0 -3 3 0; 0 1 -1 0; 0 4 -5 1]: transform row / column 2 vanishes
+// identically and 25 of the 36 position GEMMs remain -- 1.56 multiplies per output where the F(2x2) form behind the
+// upsample (conv_wino.hip, UM = 1: 9 of 16 positions) has 2.25.  Entries hold the 25 positions (xi', nu' over {0,1,3,4,5})
+// in 28 floats.
+// UM = 2: its adjoint, the data gradient onto the source map: `in` is the fine-grid gradient (the plain form's patches and
+// pictures), the input transform keeps rows / columns {0,1,3,4,5}, and the output transform sums each 2x2 quad of the 4x4
+// tile, (Q A^T) M (Q A^T)^T with Q A^T = [1 2 0 3 -1 0; 0 2 0 12 -4 1] -- column 2 is zero there too: the same 25 positions;
+// `out` is the source map's gradient, four rows per tile.
+template <int L, int UM = 0>
 struct Wino4Cfg {
   static constexpr int H = 1 << L, HW = H * H, TPI = HW / 16, IPB = 64 / TPI;  // tiles per image, images per tile block
+  static constexpr int NPOS = UM ? 25 : 36, EF = UM ? 28 : 36, EB = 4 * EF, NQ = EF / 4;  // positions, floats / bytes / quads per entry
   // The raw pictures, in 16-byte cells (a pixel's 4 channels).  4x4 images: one tile per image, the halo is known at
   // compile time -- 16 cells in Morton order + 1 (an ODD image stride: the 8 images of a 32-lane read pass start in 8
   // different bank groups).  8x8: a zero-haloed 10 x 10 picture per image + 1.  16x16: rows of 23 cells -- left halo, a
   // dead cell, then FIVE cells per 4 pixels (the fifth dead), right halo: a tile's x-step is 5 cells, so the 8 tiles a
   // read pass spans (x bit 0, x bit 1, y bit 0) start in 8 different bank groups -- and 17 rows per image (the bottom
   // halo row is the next image's top one).
-  static constexpr int ROWC = L == 3 ? 10 : 23, ROWS_IMG = L == 3 ? 10 : 17;
-  static constexpr int CELLS_IMG = L == 2 ? 17 : (L == 3 ? 101 : ROWS_IMG * ROWC);
-  static constexpr int NCELL = L == 4 ? (IPB * ROWS_IMG + 1) * ROWC : IPB * CELLS_IMG;
+  // UM = 1 (source pictures): 4x4 outputs <- 2x2 sources: 4 cells + 1 (the halo is known); 8x8 <- 4x4: a zero-haloed 6 x 6
+  // picture + 1.
+  static constexpr bool SRC = UM == 1;  // the input is the half-resolution source map (UM = 2: the fine-grid gradient, as the plain form)
+  static constexpr int ROWC = SRC ? 6 : (L == 3 ? 10 : 23), ROWS_IMG = L == 3 ? 10 : 17;
+  static constexpr int CELLS_IMG = SRC ? (L == 2 ? 5 : 37) : (L == 2 ? 17 : (L == 3 ? 101 : ROWS_IMG * ROWC));
+  static constexpr int NCELL = (L == 4 && !SRC) ? (IPB * ROWS_IMG + 1) * ROWC : IPB * CELLS_IMG;
+  static constexpr int SRC_PIX = SRC ? 256 : 1024;  // input pixels of a tile block
+  static constexpr int OUT_PIX = UM == 2 ? 256 : 1024;  // output pixels of a tile block (UM = 2: the source map's gradient)
   static constexpr int RAW_B = NCELL * 16;
   static constexpr int NRAWP = (NCELL + 63) / 64;   // 1 KiB DMA pieces (the last one is moved back to end at NCELL)
   // transformed input: [k][entry][36 floats], 32 bytes between the k planes (see the bank notes in the kernel)
-  static constexpr int VPL = 64 * 144 + 32, V_B = 4 * VPL;
-  static constexpr int U_B = 4 * 32 * 144, U_PIECES = U_B / 1024;
+  static constexpr int VPL = 64 * EB + 32, V_B = 4 * VPL;
+  static constexpr int U_B = 4 * 32 * EB, U_PIECES = U_B / 1024;
   static constexpr int OFF_RAW = 0, OFF_V = 2 * RAW_B, OFF_U = OFF_V + 2 * V_B, OFF_RED = OFF_U + 2 * U_B, OFF_NEXT = OFF_RED + 1024;
   static constexpr int LDS_BYTES = OFF_NEXT + 16;
-  static_assert(L >= 2 && L <= 4 && NCELL >= 64 && U_PIECES == 18 && LDS_BYTES <= 160 * 1024, "unsupported shape");
+  static_assert(L >= 2 && L <= 4 && (!UM || L <= 3) && NCELL >= 64 && U_B % 1024 == 0 && LDS_BYTES <= 160 * 1024, "unsupported shape");
   // cell offset of patch element (i, j) from the thread's base cell
   static constexpr int poff(int i, int j) {
+    if (SRC) return L == 2 ? (int)(((unsigned)(j - 1) & 1u) | (((unsigned)(i - 1) & 1u) << 1)) : i * ROWC + j;  // (4x4 source patch)
     if (L == 2) return (int)(((unsigned)(j - 1) & 1u) | (((unsigned)(i - 1) & 1u) << 1) | (((unsigned)(j - 1) & 2u) << 1) | (((unsigned)(i - 1) & 2u) << 2));
     if (L == 3) return i * ROWC + j;
     return i * ROWC + (j == 0 ? 0 : (j == 5 ? 7 : j + 1));  // (from the row's cell 5 tx: the left neighbour of the tile)
@@ -97,9 +114,10 @@ struct Wino4Cfg {
 // hold 4 planes x 2 entries) the two halves of a group then fall on the even and the odd 16-byte bank groups.
 __device__ __forceinline__ constexpr int wino4_entry(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
 
-template <int L>
+template <int L, int UM>
 __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned char* wsm) {
-  using C = Wino4Cfg<L>;
+  using C = Wino4Cfg<L, UM>;
+  constexpr int EB = C::EB, NQ = C::NQ, NPOS = C::NPOS;
   constexpr int H = C::H, HW = C::HW;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_t*)wsm;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -115,9 +133,12 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   // different parity (p flips bit 2 of the tile's MFMA row: wino4_entry), 8 different bank groups.
   const int t_k = lane & 3, bp = (lane >> 2) & 1, ba = (lane >> 3) & 1, bb = (lane >> 4) & 1, bc = lane >> 5;
   int t_img, t_ty = 0, t_tx = 0, cell0;
-  if constexpr (L == 2) {
+  if constexpr (UM == 1 && L == 3) {  // (source cells: tile x-step 2, y-step 12, image stride 37: p, a = image bits, b = y)
+    t_img = bp | (ba << 1) | ((wt & 1) << 2) | ((wt >> 1) << 3); t_ty = bb; t_tx = bc;
+    cell0 = t_img * C::CELLS_IMG + 2 * t_ty * C::ROWC + 2 * t_tx;
+  } else if constexpr (L == 2) {
     t_img = ba | (bb << 1) | (bp << 2) | (bc << 3) | (wt << 4);
-    cell0 = t_img * 17;
+    cell0 = t_img * C::CELLS_IMG;
   } else if constexpr (L == 3) {
     t_img = bp | (ba << 1) | (bc << 2) | ((wt & 1) << 3); t_tx = bb; t_ty = wt >> 1;
     cell0 = t_img * C::CELLS_IMG + 4 * t_ty * C::ROWC + 4 * t_tx;
@@ -133,23 +154,23 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     rbase[st] = lds0 + C::OFF_RAW + st * C::RAW_B + (uint32_t)((cell0 * 4 + t_k) * 4);
-    vst[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(t_k * C::VPL + t_entry * 144);
+    vst[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(t_k * C::VPL + t_entry * EB);
     // MFMA operands: entry (k, row) of 144 bytes; lane (kq, r16) reads k = kq of its row / column
-    aaddr[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(kq * C::VPL + (16 * wt + wino4_entry(r16)) * 144);
-    baddr[st] = lds0 + C::OFF_U + st * C::U_B + (uint32_t)((kq * 32 + 16 * wc + r16) * 144);
+    aaddr[st] = lds0 + C::OFF_V + st * C::V_B + (uint32_t)(kq * C::VPL + (16 * wt + wino4_entry(r16)) * EB);
+    baddr[st] = lds0 + C::OFF_U + st * C::U_B + (uint32_t)((kq * 32 + 16 * wc + r16) * EB);
     asm volatile("" : "+v"(rbase[st]), "+v"(vst[st]), "+v"(aaddr[st]), "+v"(baddr[st]));  // (kept apart: not base + constant again)
   }
 
   // ---- DMA of one chunk's images: 1 KiB pieces; raw piece p by wave p % 8, weight piece q by wave 4 + q % 4
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * 1024 * a.Cin * 4), 0x00020000);
+      const_cast<float*>(a.in), 0, (int)((int64_t)a.nblk * C::SRC_PIX * a.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.u), 0, (int)((int64_t)a.Cin * a.Cout * 144), 0x00020000);
+      const_cast<float*>(a.u), 0, (int)((int64_t)a.Cin * a.Cout * EB), 0x00020000);
   // Every wave of a role issues the SAME number of pieces, unconditionally (a piece index past the end repeats the last
   // piece: same bytes, same place): with a conditional piece the compiler's wait-count pass loses the order of the
   // vector-memory operations at the join and puts vmcnt(0) in front of every barrier -- which drains the output stores.
   // Waves 0-3 (the transform role): RX raw pieces each; waves 4-7: RN raw pieces and the UPW weight pieces.
-  constexpr int RX = WINO4_RX < 0 ? C::NRAWP / 8 : WINO4_RX, RN = (C::NRAWP - 4 * RX + 3) / 4, RPW = RN, UPW = 5;
+  constexpr int RX = WINO4_RX < 0 ? C::NRAWP / 8 : WINO4_RX, RN = (C::NRAWP - 4 * RX + 3) / 4, RPW = RN, UPW = (C::U_PIECES + 3) / 4;
   static_assert(RN >= RX && 4 * (RX + RN) >= C::NRAWP, "raw pieces");
   int rvoff[RPW];
   uint32_t rdst[RPW];
@@ -163,7 +184,14 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     const int cell = c0 + lane, img = cell / C::CELLS_IMG, rem = cell - img * C::CELLS_IMG;
     bool inside;
     int px;
-    if constexpr (L == 2) {
+    if constexpr (UM == 1 && L == 2) {
+      inside = rem < 4;
+      px = img * 4 + rem;
+    } else if constexpr (UM == 1) {  // (L = 3: 4x4 source images in zero-haloed 6 x 6 pictures)
+      const int yy = rem / C::ROWC, xx = rem - yy * C::ROWC;
+      inside = rem < C::ROWC * C::ROWC && yy >= 1 && yy <= H / 2 && xx >= 1 && xx <= H / 2;
+      px = img * (HW / 4) + (int)morton((uint32_t)(inside ? yy - 1 : 0), (uint32_t)(inside ? xx - 1 : 0));
+    } else if constexpr (L == 2) {
       inside = rem < 16;
       px = img * 16 + rem;
     } else if constexpr (L == 3) {
@@ -180,7 +208,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     rdst[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + C::OFF_RAW + (uint32_t)c0 * 16));
   }
   // (one piece per call, so that a chunk can place them between its MFMA groups; q-th piece of this wave)
-  auto raw_soff = [&](int blk, int ch) { return __builtin_amdgcn_readfirstlane((blk * 1024 * a.Cin + ch * 4) * 4); };
+  auto raw_soff = [&](int blk, int ch) { return __builtin_amdgcn_readfirstlane((blk * C::SRC_PIX * a.Cin + ch * 4) * 4); };
   auto issue_raw_piece = [&](int soff, int st, int q) {
     const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rdst[q] + (uint32_t)(st * C::RAW_B)));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_void_t*)(uintptr_t)dst, 16, rvoff[q], soff, 0, 0);
@@ -239,7 +267,47 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
     }
   };
 
-  f32x4 acc[36];  // acc[6 xi + nu][i] = M[xi][nu] of tile 16 wt + 4 kq + i, channel 16 wc + r16
+  // UM = 1: the 4x4 source patch (4x4 outputs <- 2x2 sources: its ring is the zero padding) -> V = T s T^T, 25 values in
+  // 28 floats (positions xi' 5 + nu' over {0,1,3,4,5}; three zero floats complete the last quad)
+  auto load_patch_u = [&](int rs, float (&sv)[16]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ring = i == 0 || i == 3 || j == 0 || j == 3;
+        if (L == 2 && ring) sv[i * 4 + j] = 0.f;
+        else sv[i * 4 + j] = *reinterpret_cast<lds_cf32*>((uintptr_t)(rbase[rs] + (uint32_t)(C::poff(i, j) * 16)));
+      }
+  };
+  auto xform_u_cols = [&](const float (&sv)[16], float (&t)[30]) {  // T s: t[xi' 4 + j]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wino4_ups5<L == 2>(sv[j], sv[4 + j], sv[8 + j], sv[12 + j], t[j], t[4 + j], t[8 + j], t[12 + j], t[16 + j]);
+  };
+  auto xform_u_row = [&](int i, const float (&t)[30], float (&v)[28]) {  // (.) T^T, row xi' = i
+    wino4_ups5<L == 2>(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3], v[5 * i], v[5 * i + 1], v[5 * i + 2], v[5 * i + 3], v[5 * i + 4]);
+  };
+  auto store_quads_u = [&](int vs, int q0, int q1, const float (&v)[28]) {
+#pragma unroll
+    for (int q = q0; q < q1; ++q) {
+      const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)(vst[vs] + (uint32_t)(q * 16))) = o;
+    }
+  };
+
+  // UM = 2: the plain 6x6 patch, rows / columns {0,1,3,4,5} of B^T d B
+  auto xform_g_cols = [&](const float (&d)[36], float (&t)[30], int j0, int j1) {  // t[xi' 6 + j]
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+      if (L == 2 && (j == 0 || j == 5)) { t[j] = t[6 + j] = t[12 + j] = t[18 + j] = t[24 + j] = 0.f; continue; }
+      wino4_in5<L == 2>(d[j], d[6 + j], d[12 + j], d[18 + j], d[24 + j], d[30 + j], t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j]);
+    }
+  };
+  auto xform_g_row = [&](int i, const float (&t)[30], float (&v)[28]) {
+    wino4_in5<L == 2>(t[6 * i], t[6 * i + 1], t[6 * i + 2], t[6 * i + 3], t[6 * i + 4], t[6 * i + 5],
+                      v[5 * i], v[5 * i + 1], v[5 * i + 2], v[5 * i + 3], v[5 * i + 4]);
+  };
+
+  f32x4 acc[4 * NQ];  // acc[position][i] = M[xi][nu] of tile 16 wt + 4 kq + i, channel 16 wc + r16 (position 6 xi + nu, or 5 xi' + nu')
 
   const bool dynq = a.dyn != nullptr;
   volatile int* nslot = reinterpret_cast<volatile int*>(wsm + C::OFF_NEXT);
@@ -263,20 +331,37 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   else { issue_all(std::integral_constant<int, 0>{}, blk_cur, 0, 0, true); issue_all(std::integral_constant<int, 0>{}, blk_cur, 1, 1, false); }
   __syncthreads();  // (the workgroup fence waits for the LDS-DMA pieces)
   if (wave < 4) {
-    float d[36];
-    load_patch(0, d);
+    if constexpr (UM == 1) {
+      float sv[16], t[30], v[28] = {};
+      load_patch_u(0, sv);
+      xform_u_cols(sv, t);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) xform_col(j, d);
+      for (int i = 0; i < 5; ++i) xform_u_row(i, t, v);
+      store_quads_u(0, 0, NQ, v);
+    } else if constexpr (UM == 2) {
+      float d[36], t[30], v[28] = {};
+      load_patch(0, d);
+      xform_g_cols(d, t, 0, 6);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xform_row(i, d);
-    store_quads(0, 0, d); store_quads(0, 3, d); store_quads(0, 6, d);
+      for (int i = 0; i < 5; ++i) xform_g_row(i, t, v);
+      store_quads_u(0, 0, NQ, v);
+    } else {
+      float d[36];
+      load_patch(0, d);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xform_col(j, d);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xform_row(i, d);
+      store_quads(0, 0, d); store_quads(0, 3, d); store_quads(0, 6, d);
+    }
   }
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (int)((int64_t)a.nblk * 1024 * a.Cout * 4), 0x00020000);
+      a.out, 0, (int)((int64_t)a.nblk * C::OUT_PIX * a.Cout * 4), 0x00020000);
   const int ch_out = n0 + 16 * wc + r16;
-  const int ovoff = (4 * kq * 16 * a.Cout + ch_out) * 4;  // tile 4 kq of the wave's sixteen, pixel 0, the lane's channel
+  constexpr int PPT = UM == 2 ? 4 : 16;  // output pixels per tile
+  const int ovoff = (4 * kq * PPT * a.Cout + ch_out) * 4;  // tile 4 kq of the wave's sixteen, pixel 0, the lane's channel
   const float bias = a.bias ? a.bias[ch_out] : 0.f;
 
   // outputs of the tile block just finished (64 per lane: 4 tiles x 16 pixels of one channel), stored beside the MFMAs of
@@ -284,28 +369,57 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   // the pieces, in issue order, so they stay in flight across that chunk's barrier (the next one waits them out: all
   // workgroups reach their epilogues together and 128 KB per workgroup stored at once is a burst the memory system
   // takes microseconds to drain); a store's register is free again before the accumulator tiles come alive.
-  float yp[64];  // yp[(b 4 + a) 4 + i]: pixel (a, b) of tile 4 kq + i
+  constexpr int NSTORE = 4 * PPT;
+  float yp[NSTORE];  // yp[(b 4 + a) 4 + i]: pixel (a, b) of tile 4 kq + i  (UM = 2: (b 2 + a) 4 + i, source pixel (a, b))
   int pblk = 0;
   auto store_pending = [&](int idx) {
-    const int b = idx >> 4, aa = (idx >> 2) & 3, i = idx & 3;
+    const int i = idx & 3;
+    const int b = UM == 2 ? idx >> 3 : idx >> 4, aa = UM == 2 ? (idx >> 2) & 1 : (idx >> 2) & 3;
     // (the row index is kept opaque: its products with the 64 constant row offsets would each take a scalar register)
-    int row0 = __builtin_amdgcn_readfirstlane((pblk * 64 + 16 * wt) * 16);
+    int row0 = __builtin_amdgcn_readfirstlane((pblk * 64 + 16 * wt) * PPT);
     asm volatile("" : "+s"(row0));
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yp[idx]), rsrc_out, ovoff,
-                                          (row0 + i * 16 + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, WINO4_STORE_AUX);
+                                          (row0 + i * PPT + (int)morton((uint32_t)aa, (uint32_t)b)) * a.Cout * 4, WINO4_STORE_AUX);
   };
   // the epilogue: Y = A^T M A per (tile, channel), lane-local; + bias, BatchNorm partials
   auto epilogue = [&](int blk) {
-    f32x4 c[24];  // c[4 xi + b] = sum_nu M[xi][nu] A[nu][b]
+    f32x4 c[24];  // c[4 xi + b] = sum_nu M[xi][nu] A[nu][b]  (UM: rows xi' over {0,1,3,4,5}; row / column 2 of M is zero)
+    if constexpr (UM == 2) {
+    } else if constexpr (UM) {
 #pragma unroll
-    for (int xi = 0; xi < 6; ++xi)
-      wino4_out6(acc[6 * xi], acc[6 * xi + 1], acc[6 * xi + 2], acc[6 * xi + 3], acc[6 * xi + 4], acc[6 * xi + 5],
-                 c[4 * xi], c[4 * xi + 1], c[4 * xi + 2], c[4 * xi + 3]);
+      for (int xi = 0; xi < 5; ++xi)
+        wino4_out5(acc[5 * xi], acc[5 * xi + 1], acc[5 * xi + 2], acc[5 * xi + 3], acc[5 * xi + 4],
+                   c[4 * xi], c[4 * xi + 1], c[4 * xi + 2], c[4 * xi + 3]);
+    } else {
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi)
+        wino4_out6(acc[6 * xi], acc[6 * xi + 1], acc[6 * xi + 2], acc[6 * xi + 3], acc[6 * xi + 4], acc[6 * xi + 5],
+                   c[4 * xi], c[4 * xi + 1], c[4 * xi + 2], c[4 * xi + 3]);
+    }
+    if constexpr (UM == 2) {
+      // the source map's gradient: (Q A^T) M (Q A^T)^T, two source pixels per line
+      f32x4 cq[10];  // cq[2 xi' + b]
+#pragma unroll
+      for (int xi = 0; xi < 5; ++xi)
+        wino4_out5q(acc[5 * xi], acc[5 * xi + 1], acc[5 * xi + 2], acc[5 * xi + 3], acc[5 * xi + 4], cq[2 * xi], cq[2 * xi + 1]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x4 y[2];
+        wino4_out5q(cq[b], cq[2 + b], cq[4 + b], cq[6 + b], cq[8 + b], y[0], y[1]);
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) yp[(b * 2 + aa) * 4 + i] = y[aa][i] + bias;
+      }
+      pblk = blk;
+      return;
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f32x4 y[4];
-      wino4_out6(c[b], c[4 + b], c[8 + b], c[12 + b], c[16 + b], c[20 + b], y[0], y[1], y[2], y[3]);
+      if constexpr (UM) wino4_out5(c[b], c[4 + b], c[8 + b], c[12 + b], c[16 + b], y[0], y[1], y[2], y[3]);
+      else wino4_out6(c[b], c[4 + b], c[8 + b], c[12 + b], c[16 + b], c[20 + b], y[0], y[1], y[2], y[3]);
 #pragma unroll
       for (int aa = 0; aa < 4; ++aa)
 #pragma unroll
@@ -360,15 +474,33 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
       qa[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(aaddr[st] + (uint32_t)(q * 16)));
       qb[q % 3] = *reinterpret_cast<lds_cf32x4*>((uintptr_t)(baddr[st] + (uint32_t)(q * 16)));
     };
-    float d[36];
+    float d[36], su[16], tu[30], vu[28];  // (the plain form's patch; behind the upsample: source patch, T s / B^T d, V)
     load_quad(0);
     load_quad(1);
-    if constexpr (XF) load_patch(st ^ 1, d);
+    if constexpr (XF) {
+      if constexpr (UM == 1) load_patch_u(st ^ 1, su);
+      else load_patch(st ^ 1, d);
+      if constexpr (UM) {
+#pragma unroll
+        for (int e = 25; e < 28; ++e) vu[e] = 0.f;
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      if (q + 2 < 9) load_quad(q + 2);
-      if constexpr (XF) {
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 2 < NQ) load_quad(q + 2);
+      if constexpr (XF && UM == 2) {
+        // pieces: q = 1, 2 three columns each, q = 3 rows 0-2 and entry quads 0-2, q = 4 rows 3-4 and quads 3-6
+        if (q == 1) xform_g_cols(d, tu, 0, 3);
+        if (q == 2) xform_g_cols(d, tu, 3, 6);
+        if (q == 3) { xform_g_row(0, tu, vu); xform_g_row(1, tu, vu); xform_g_row(2, tu, vu); store_quads_u(st ^ 1, 0, 3, vu); }
+        if (q == 4) { xform_g_row(3, tu, vu); xform_g_row(4, tu, vu); store_quads_u(st ^ 1, 3, NQ, vu); }
+      } else if constexpr (XF && UM == 1) {
+        // pieces: q = 1 the four columns, q = 2 rows 0-2 and entry quads 0-2, q = 3 rows 3-4 and quads 3-6
+        if (q == 1) xform_u_cols(su, tu);
+        if (q == 2) { xform_u_row(0, tu, vu); xform_u_row(1, tu, vu); xform_u_row(2, tu, vu); store_quads_u(st ^ 1, 0, 3, vu); }
+        if (q == 3) { xform_u_row(3, tu, vu); xform_u_row(4, tu, vu); store_quads_u(st ^ 1, 3, NQ, vu); }
+      } else if constexpr (XF) {
         // pieces: q = 1..3 two columns each, q = 4..6 two rows each and their three entry quads
         if (q >= 1 && q <= 3) { xform_col(2 * q - 2, d); xform_col(2 * q - 1, d); }
         if (q >= 4 && q <= 6) { xform_row(2 * q - 8, d); xform_row(2 * q - 7, d); store_quads(st ^ 1, 3 * (q - 4), d); }
@@ -376,14 +508,16 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        if (4 * q + m >= NPOS) continue;
         if constexpr (FIRST) acc[4 * q + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q % 3][m], qb[q % 3][m], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         else acc[4 * q + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[q % 3][m], qb[q % 3][m], acc[4 * q + m], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (PEND) {
-        if (q < 8) {
+        constexpr int SPQ = (NSTORE + NQ - 2) / (NQ - 1);  // stores per quad: all of them beside the first NQ - 1 quads
+        if (q < NQ - 1) {
 #pragma unroll
-          for (int idx = 8 * q; idx < 8 * q + 8; ++idx) store_pending(idx);
+          for (int idx = SPQ * q; idx < SPQ * q + SPQ && idx < NSTORE; ++idx) store_pending(idx);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -425,7 +559,7 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
       has_next = blk_nxt < a.nblk;
     }
 #pragma unroll
-    for (int idx = 0; idx < 64; ++idx) store_pending(idx);  // (the last block's)
+    for (int idx = 0; idx < NSTORE; ++idx) store_pending(idx);  // (the last block's)
   };
   // (one instantiation per role: waves 0-3 carry the input transform)
   if (wave < 4) run(std::integral_constant<int, 1>{});
@@ -433,10 +567,10 @@ __device__ __forceinline__ void conv_wino4_body(const Wino4Args& a, unsigned cha
   finish();
 }
 
-template <int L>
+template <int L, int UM = 0>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(Wino4Args a) {
   extern __shared__ __align__(16) unsigned char wino4_smem[];
-  conv_wino4_body<L>(a, wino4_smem);
+  conv_wino4_body<L, UM>(a, wino4_smem);
 }
 
 bool wino4_shape_ok(int64_t M, int Cin, int Cout, int L) {
@@ -446,10 +580,10 @@ bool wino4_shape_ok(int64_t M, int Cin, int Cout, int L) {
   return true;
 }
 
-template <int L>
+template <int L, int UM = 0>
 int launch_wino4_cfg(const Wino4Args& a, double flops, hipStream_t s) {
-  using C = Wino4Cfg<L>;
-  auto kern = conv_wino4_kernel<L>;
+  using C = Wino4Cfg<L, UM>;
+  auto kern = conv_wino4_kernel<L, UM>;
   static std::atomic<uint64_t> attr_done{0};
   DVG_TRY(raise_dynamic_lds(attr_done, (const void*)kern, C::LDS_BYTES));
   const int ny = a.Cout / 32;
@@ -481,13 +615,22 @@ int conv_wino4_stats_blocks(int64_t M) { return (int)(M / 1024); }
 
 // a.wp must be the F(4x4, 3x3) pack of a PackJob with wino = 2 ([Cin / 4][Cout / 32][4][32][36] floats: wino4_pack_entry)
 int launch_conv_wino4(const ConvArgs& a, hipStream_t s) {
-  DVG_REQUIRE(wino4_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.wino_um == 0,
-              "conv_wino4: unsupported launch (M=%lld Cin=%d Cout=%d L=%d)", (long long)a.M, a.Cin, a.Cout, a.L);
+  DVG_REQUIRE(wino4_shape_ok(a.M, a.Cin, a.Cout, a.L) && a.ntaps == 9 && !a.ups && !a.poolsum && !a.fold && a.wino_um >= 0 &&
+                  a.wino_um <= 2 && (a.wino_um == 0 || a.L <= 3),
+              "conv_wino4: unsupported launch (M=%lld Cin=%d Cout=%d L=%d um=%d)", (long long)a.M, a.Cin, a.Cout, a.L, a.wino_um);
   Wino4Args w;
   w.in = a.in; w.u = a.wp; w.bias = a.bias; w.out = a.out; w.stats = a.stats;
   w.Cin = a.Cin; w.Cout = a.Cout; w.cus = a.wino_cus;
   w.nblk = (int)(a.M / 1024);
   // EXECUTED matrix FLOPs: 36 transform-domain GEMMs over the M / 16 tiles (1/4 of the direct form's 2 M Cin Cout 9)
+  // (wino_um = 1: Upsample(x2) + 3x3 forward, a.in = the SOURCE map, a.M / a.L of the output grid, a.wp = the pack of a
+  // PackJob with wino = 3: 25 of the 36 position GEMMs)
+  // (wino_um = 2: its data gradient: a.in = the fine-grid gradient, a.out = the source map's gradient, four rows per tile)
+  if (a.wino_um) {
+    const double flops_u = 2.0 * (double)(a.M / 16) * 25.0 * a.Cin * a.Cout;
+    if (a.wino_um == 1) return a.L == 2 ? launch_wino4_cfg<2, 1>(w, flops_u, s) : launch_wino4_cfg<3, 1>(w, flops_u, s);
+    return a.L == 2 ? launch_wino4_cfg<2, 2>(w, flops_u, s) : launch_wino4_cfg<3, 2>(w, flops_u, s);
+  }
   const double flops = 2.0 * (double)(a.M / 16) * 36.0 * a.Cin * a.Cout;
   switch (a.L) {
     case 2: return launch_wino4_cfg<2>(w, flops, s);
@@ -496,15 +639,15 @@ int launch_conv_wino4(const ConvArgs& a, hipStream_t s) {
   }
 }
 
-__global__ __launch_bounds__(256) void wino4_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u) {
+__global__ __launch_bounds__(256) void wino4_weight_pack_kernel(const float* __restrict__ w, WeightMap map, float* __restrict__ u, int ups) {
   const uint32_t total = (uint32_t)map.Ca * (uint32_t)map.Cb;
-  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) wino4_pack_entry(w, map, e, u);
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) wino4_pack_entry(w, map, e, u, ups != 0);
 }
 
-int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s) {
+int launch_wino4_weight_pack(const float* w, const WeightMap& map, float* u, hipStream_t s, int ups) {
   int64_t gx = ceil_div((int64_t)map.Ca * map.Cb, 256);
   if (gx > 1024) gx = 1024;
-  DVG_LAUNCH(K_WEIGHT_PACK, wino4_weight_pack_kernel, dim3((unsigned)gx), dim3(256), 0, s, w, map, u);
+  DVG_LAUNCH(K_WEIGHT_PACK, wino4_weight_pack_kernel, dim3((unsigned)gx), dim3(256), 0, s, w, map, u, ups);
   return DVG_OK;
 }
 

@@ -25,6 +25,7 @@ struct DecPlan {
   bool fold[4];  // layer runs in the folded-upsample form (conv.h: ConvArgs.fold)
   bool wino_w[4];  // layer's weight gradient runs in the Winograd form (conv_wino_wgrad.hip, 9 of 16 positions)
   bool wino_f[4], wino_d[4];  // ... its forward / data-gradient GEMM (conv_wino.hip, wino_um = 1 / 2)
+  bool wino4_f[4], wino4_d[4];  // ... the forward / data gradient in the F(4x4,3x3) form with 25 of 36 positions (conv_wino4.hip, wino_um = 1 / 2)
   bool d22;      // layer 0 (3x3 on 2x2 images) runs as the dense per-image map (conv.h: WM_CONVT_D22_FWD)
   // Large batches: Linear(n, 4n) and layer 0 have nothing but a reshape between them, so the pair is ONE linear map per
   // image, spins (n) -> the 4 x 128 pre-BatchNorm values, with the composed weight Wc = Wlin . Weff (a 2 n x 4n x 512
@@ -93,8 +94,12 @@ DecPlan dec_plan(int64_t N, int n) {
       const bool on = (l == 1 || l == 2) && o != 0 && conv_precision_mode() != 1 && (o > 0 || N >= 8192);
       p.wino_f[l] = on && conv_wino_shape(p.M[l], ch[l], C, p.L[l]);
       p.wino_d[l] = on && conv_wino_shape(p.M[l], C, ch[l], p.L[l]);
+      p.wino4_f[l] = p.wino_f[l] && opt(OPT_ENC_WINO4) != 0 && ((opt(OPT_DEC_WINO4_MASK) >> (l - 1)) & 1) && p.L[l] <= 3 &&
+                     conv_wino4_shape(p.M[l], ch[l], C, p.L[l]);
+      p.wino4_d[l] = p.wino_d[l] && opt(OPT_ENC_WINO4) != 0 && ((opt(OPT_DEC_WINO4_MASK) >> (l + 1)) & 1) && p.L[l] <= 3 &&
+                     conv_wino4_shape(p.M[l], C, ch[l], p.L[l]);
     }
-    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
+    p.nblk[l] = l == 3 ? dec_conv3_blocks(N) : p.wino4_f[l] ? conv_wino4_stats_blocks(p.M[l]) : p.wino_f[l] ? conv_wino_stats_blocks(p.M[l], C) : p.fold[l] ? conv_stats_blocks_fold(p.M[l] / 4, C) : conv_stats_blocks(p.M[l], C);
     // dense 2x2 form: the GEMM has N rows of 4 C columns; a row block's partials [4 C][2] read as 4 rows of [C][2]
     if (l == 0 && p.d22) p.nblk[l] = 4 * conv_stats_blocks(N, 4 * C);
     p.Y[l] = bump(o, (size_t)p.M[l] * C);
@@ -104,8 +109,8 @@ DecPlan dec_plan(int64_t N, int n) {
     p.stats[l] = bump(o, (size_t)(p.nblk[l] + BN_FOLD_ROWS) * C * 2);  // + scratch rows of launch_bn_finalize
     p.mask[l] = bump(o, (size_t)N * C);
     if (l < 3) {
-      p.wp[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));   // 9 taps, or 16 folded (class, tap) pairs
-      p.wpd[l] = bump(o, conv_pack_floats((size_t)16 * ch[l] * C));
+      p.wp[l] = bump(o, conv_pack_floats((size_t)28 * ch[l] * C));   // 9 taps, 16 folded (class, tap) pairs, or the 25-position F(4x4) pack
+      p.wpd[l] = bump(o, conv_pack_floats((size_t)28 * ch[l] * C));
       const bool d22 = l == 0 && p.d22;
       p.ksplit[l] = d22 ? wgrad_ksplit(N, 4 * ch[l], 4 * C, 1)
                         : p.fold[l] ? wgrad_fold_ksplit(p.M[l] / 4, ch[l], C) : wgrad_ksplit(p.M[l], ch[l], C, 9);
@@ -175,7 +180,8 @@ DecPlan dec_plan(int64_t N, int n) {
 uint32_t plan_signature(const DecPlan& pl) {
   return (uint32_t)pl.d22 | (uint32_t)pl.lc0 << 1 | (uint32_t)pl.fold[1] << 2 | (uint32_t)pl.fold[2] << 3 |
          (uint32_t)conv_launch_mode(pl.N, 128) << 4 | (uint32_t)pl.tail << 12 | (uint32_t)pl.wino_f[1] << 13 |
-         (uint32_t)pl.wino_f[2] << 14 | (uint32_t)pl.wino_d[1] << 15 | (uint32_t)pl.wino_d[2] << 16;
+         (uint32_t)pl.wino_f[2] << 14 | (uint32_t)pl.wino_d[1] << 15 | (uint32_t)pl.wino_d[2] << 16 |
+         (uint32_t)pl.wino4_f[1] << 17 | (uint32_t)pl.wino4_f[2] << 18 | (uint32_t)pl.wino4_d[1] << 19 | (uint32_t)pl.wino4_d[2] << 20;
 }
 
 int check_common(const dvg_decoder_params_t* p, int n, int64_t N, const void* ws, size_t ws_bytes, const DecPlan& pl) {
@@ -228,8 +234,8 @@ int dec_prologue(const dvg_decoder_params_t* p, int n, int64_t N, int training, 
     }
     // Winograd launches (conv_wino.hip, wino_um = 1 / 2) read the transformed pack U = G g G^T instead
     for (int l = 1; l < 3; ++l) {
-      if (pl.wino_f[l]) jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l], 1};
-      if (pl.wino_d[l]) jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l], 1};
+      if (pl.wino_f[l]) jobs[2 + 2 * l] = PackJob{p->conv_w[l], W + pl.wp[l], WeightMap{WM_CONVT_FWD, pl.ch[l], pl.ch[l + 1], 9}, 0, pl.M[l], pl.wino4_f[l] ? 3 : 1};
+      if (pl.wino_d[l]) jobs[3 + 2 * l] = PackJob{p->conv_w[l], W + pl.wpd[l], WeightMap{WM_CONVT_DGRAD, pl.ch[l + 1], pl.ch[l], 9}, 0, pl.M[l], pl.wino4_d[l] ? 3 : 1};
     }
     DVG_TRY(launch_weight_pack_multi(jobs, 8, s));
   }
@@ -345,7 +351,8 @@ int decoder_fwd_impl(const dvg_decoder_params_t* p, int n, const float* spins, i
       a.splitk_ws = W + pl.splitk;
       if (pl.wino_f[l]) {  // Winograd on the upsampled map: 9 of 16 transform positions (conv_wino.hip, UM = 1)
         a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.ups = 0; a.fold = 0; a.wino_um = 1; a.wino_cus = WINO_CUS_DEC;
-        DVG_TRY(launch_conv_wino(a, s));
+        if (pl.wino4_f[l]) DVG_TRY(launch_conv_wino4(a, s));  // (F(4x4,3x3): 25 of 36 positions)
+        else DVG_TRY(launch_conv_wino(a, s));
       } else {
         DVG_TRY(launch_conv_igemm(a, s));
       }
@@ -544,7 +551,8 @@ int decoder_bwd_impl(const dvg_decoder_params_t* p, int n, const float* spins, i
     a.splitk_ws = W + pl.splitk;
     if (pl.wino_d[l]) {  // fine-grid Winograd data gradient with the 2x2 sum folded into its output transform (UM = 2)
       a.M = pl.M[l]; a.L = pl.L[l]; a.ntaps = 9; a.poolsum = 0; a.fold = 0; a.wino_um = 2; a.wino_cus = WINO_CUS_DEC;
-      DVG_TRY(launch_conv_wino(a, s));
+      if (pl.wino4_d[l]) DVG_TRY(launch_conv_wino4(a, s));  // (F(4x4,3x3): 25 of 36 positions)
+      else DVG_TRY(launch_conv_wino(a, s));
     } else {
       DVG_TRY(launch_conv_igemm(a, s));
     }

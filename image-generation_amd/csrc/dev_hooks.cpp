@@ -32,14 +32,14 @@ extern "C" int dvg_dev_conv_wino(const float* in, const float* w, int mode, floa
 // The same layer in the Winograd F(4x4,3x3) form (conv_wino4.hip): `u` takes the 36 Cin Cout transformed weights; stats rows =
 // M / 1024.  DVG_E_INVALID when the shape does not qualify (dvg_dev_conv_wino4_shape).
 extern "C" int dvg_dev_conv_wino4(const float* in, const float* w, int mode, float* u, const float* bias, float* out,
-                                  float* stats, int64_t M, int Cin, int Cout, int L, int cus, dvg_stream_t stream) {
+                                  float* stats, int64_t M, int Cin, int Cout, int L, int cus, int um, dvg_stream_t stream) {
   DVG_REQUIRE(in && w && u && out, "dev_conv_wino4: null argument");
   hipStream_t s = (hipStream_t)stream;
-  DVG_TRY(launch_wino4_weight_pack(w, WeightMap{mode, Cin, Cout, 9}, u, s));
+  DVG_TRY(launch_wino4_weight_pack(w, WeightMap{mode, Cin, Cout, 9}, u, s, um != 0));
   ConvArgs a;
   a.in = in; a.wp = u; a.bias = bias; a.out = out; a.stats = stats;
   a.M = M; a.Cin = Cin; a.Cout = Cout; a.L = L; a.ntaps = 9; a.ups = 0; a.poolsum = 0;
-  a.splitk_ws = nullptr; a.wino_cus = cus;
+  a.splitk_ws = nullptr; a.wino_cus = cus; a.wino_um = um;
   return launch_conv_wino4(a, s);
 }
 extern "C" int dvg_dev_conv_wino4_shape(int64_t M, int Cin, int Cout, int L) { return conv_wino4_shape(M, Cin, Cout, L) ? 1 : 0; }

@@ -36,6 +36,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"enc_wino4_mask", 0x13c, "which encoder launches option enc_wino4 covers: bit l-1 the forward of layer l (1..3), bit 2+l its data gradient, bit 5+l its weight gradient (default 0x13c: layer 3's forward, every data gradient, layer 3's weight gradient -- the forwards of layers 1-2 gain nothing inside the step and their 7x float32 noise in front of two more max-pool stages moved the B = 1024 full-size gradient test from 4.6e-3 to 5.4e-3 of its 5e-3 bar; the weight gradients of layers 1-2 are level with the F(2x2,3x3) kernel)", true},
     {"enc_dgrad_cus", 0, "CUs the encoder's Winograd data-gradient launches are sized for (0: the measured constant of conv.h)", true},
     {"enc_wgrad_cus", 0, "CUs the encoder's Winograd weight-gradient launches are sized for (0: the measured constant of conv.h)", true},
+    {"dec_wino4_mask", 0x2, "which of the decoder's Winograd launches behind the upsample take the F(4x4,3x3) form with 25 of 36 positions (option enc_wino4 != 0): bit 0 / 1 the forward of the 128 -> 64 / 64 -> 32 layer (bit 0 off: with it the full-size decoder's reconstruction is 2.97e-6 from float64, the bar is 2e-6), bit 2 / 3 their data gradients", true},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;

@@ -15,7 +15,7 @@ _SIGS = {
     "dvg_dev_conv_wino": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
                           [ctypes.c_int64] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "dvg_dev_conv_wino4": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 +
-                           [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+                           [ctypes.c_int64] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "dvg_dev_conv_wino4_shape": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_wino4_wgrad_slab_floats": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dvg_dev_conv_wino4_wgrad": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64] + [ctypes.c_int] * 4 +
@@ -105,15 +105,17 @@ def conv_wino4_shape(M, Cin, Cout, L):
     return bool(lib().dvg_dev_conv_wino4_shape(M, Cin, Cout, L))
 
 
-def conv_wino4(x_m, w, mode, M, Cin, Cout, L, bias=None, stats=False, cus=0):
-    """The same layer in the Winograd F(4x4,3x3) form (csrc/conv_wino4.hip)."""
+def conv_wino4(x_m, w, mode, M, Cin, Cout, L, bias=None, stats=False, cus=0, um=0):
+    """The same layer in the Winograd F(4x4,3x3) form (csrc/conv_wino4.hip).  ``um`` = 1: the Upsample(x2) + 3x3 forward
+    (``x_m`` = the source map, M / L of the output grid; 25 of the 36 positions); ``um`` = 2: its data gradient (``x_m`` = the
+    fine-grid gradient, the result = the source map's gradient, M / 4 rows)."""
     Lb = lib()
     dev = x_m.device
     u = torch.empty(36 * Cin * Cout, device=dev)
-    out = torch.empty((M, Cout), device=dev)
+    out = torch.empty((M // 4 if um == 2 else M, Cout), device=dev)
     st = torch.empty((M // 1024, Cout, 2), device=dev) if stats else None
     _lib.check(Lb.dvg_dev_conv_wino4(x_m.data_ptr(), w.data_ptr(), mode, u.data_ptr(), _lib.ptr(bias), out.data_ptr(),
-                                     _lib.ptr(st), M, Cin, Cout, L, int(cus), _lib.stream_ptr(dev)))
+                                     _lib.ptr(st), M, Cin, Cout, L, int(cus), int(um), _lib.stream_ptr(dev)))
     return (out, st) if stats else out
 
 

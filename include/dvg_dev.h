@@ -25,7 +25,9 @@ int dvg_dev_conv_wino_ok(int64_t M, int Cin, int Cout, int L);
  * per output where F(2x2,3x3) issues 4.0): `u` = scratch of 36*Cin*Cout floats, `stats` rows = M / 1024 (tile blocks of 64
  * tiles), cus = CUs the persistent grid is sized for (0 = 256).  Shapes: whole 1024-pixel blocks of 4x4 / 8x8 / 16x16 images. */
 int dvg_dev_conv_wino4(const float *in, const float *w, int mode, float *u, const float *bias, float *out, float *stats,
-                       int64_t M, int Cin, int Cout, int L, int cus, dvg_stream_t stream);
+                       int64_t M, int Cin, int Cout, int L, int cus, int um, dvg_stream_t stream);
+/* (um = 1: Upsample(x2) + 3x3 forward, `in` = the source map ([M / 4][Cin]), 25 of 36 positions; um = 2: its data gradient,
+ * `in` = the fine-grid gradient, `out` = the source map's gradient ([M / 4][Cout])) */
 int dvg_dev_conv_wino4_shape(int64_t M, int Cin, int Cout, int L);
 /* ... and the layer's weight gradient in that form (csrc/conv_wino4_wgrad.hip): slabs of dvg_dev_wino4_wgrad_slab_floats()
  * floats (0 = the shape does not qualify); cus: CUs the grid is sized for (0 = the training step's budget). */

@@ -156,6 +156,55 @@ def test_winograd_weight_gradient_kernel(N, Cin, Cout, side, ups):
     assert torch.equal(gw, gw2)
 
 
+@pytest.mark.parametrize("N,Cin,Cout,side", [(256, 128, 64, 4), (64, 64, 32, 8), (64, 32, 32, 4), (16, 96, 64, 8), (128, 512, 128, 4)])
+def test_winograd_f4x4_behind_the_upsample(N, Cin, Cout, side):
+    """The decoder's Upsample(x2) + ConvTranspose2d 3x3 forward in the F(4x4,3x3) form with 25 of the 36 positions
+    (csrc/conv_wino4.hip, UM = 1: the input transform of the repeated source pixels has a vanishing row) against float64, with
+    the F(2x2)-behind-the-upsample kernel's distance beside it; side = OUTPUT resolution, the input lives at side / 2."""
+    from image_generation_amd import _lib
+    torch.manual_seed(N + Cin + side)
+    xs = torch.randn(N, Cin, side // 2, side // 2)
+    w = torch.randn(Cin, Cout, 3, 3) / (3 * Cin**0.5); b = torch.randn(Cout)
+    y64 = F.conv_transpose2d(F.interpolate(xs.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    L, M = side.bit_length() - 1, N * side * side
+    xm = dev.nchw_to_morton(xs).cuda()
+    out, st = dev.conv_wino4(xm, w.cuda(), 2, M, Cin, Cout, L, bias=b.cuda(), stats=True, um=1)
+    o4 = dev.morton_to_nchw(out.cpu(), N, Cout, side)
+    rms = lambda a, ref: float((a.double() - ref).norm() / ref.norm())  # noqa: E731
+    out_d = dev.conv_igemm(xm, w.cuda(), 2, M, Cin, Cout, L, ups=1, bias=b.cuda())
+    od = dev.morton_to_nchw(out_d.cpu(), N, Cout, side)
+    print(f"F(4x4) behind the upsample vs float64 [N={N} {Cin}->{Cout} @{side}]: max {_rel(o4, y64):.2e} rms {rms(o4, y64):.2e}; "
+          f"direct max {_rel(od, y64):.2e} rms {rms(od, y64):.2e}")
+    assert _rel(o4, y64) < 3e-5 and rms(o4, y64) < 8e-6
+    s = st.sum(0).cpu().double()
+    assert _rel(s[:, 0], y64.sum((0, 2, 3))) < 1e-4 and _rel(s[:, 1], (y64 ** 2).sum((0, 2, 3))) < 1e-5
+    out2 = dev.conv_wino4(xm, w.cuda(), 2, M, Cin, Cout, L, bias=b.cuda(), um=1)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,side", [(256, 128, 64, 4), (64, 64, 32, 8), (64, 32, 32, 4), (16, 96, 64, 8), (128, 512, 128, 4)])
+def test_winograd_f4x4_data_gradient_behind_the_upsample(N, Cin, Cout, side):
+    """The data gradient of the same layer onto the source map (csrc/conv_wino4.hip, UM = 2: the fine-grid gradient's patches,
+    rows / columns {0,1,3,4,5} of the input transform, and the 2x2 sum of the upsample's adjoint folded into the output
+    transform) against float64, with the direct kernel's distance beside it."""
+    torch.manual_seed(N + Cin + side + 1)
+    w = torch.randn(Cin, Cout, 3, 3) / (3 * Cout**0.5)
+    gy = torch.randn(N, Cout, side, side)
+    # d/d(source) = the 2x2 sums of the transposed convolution's adjoint (a plain convolution with the same weight)
+    dfine = F.conv2d(gy.double(), w.double(), padding=1)
+    ref = dfine.reshape(N, Cin, side // 2, 2, side // 2, 2).sum((3, 5))
+    L, M = side.bit_length() - 1, N * side * side
+    gym = dev.nchw_to_morton(gy).cuda()
+    dx = dev.conv_wino4(gym, w.cuda(), 3, M, Cout, Cin, L, um=2)
+    d4 = dev.morton_to_nchw(dx.cpu(), N, Cin, side // 2)
+    dd = dev.morton_to_nchw(dev.conv_igemm(gym, w.cuda(), 3, M, Cout, Cin, L, poolsum=1).cpu(), N, Cin, side // 2)
+    rms = lambda a: float((a.double() - ref).norm() / ref.norm())  # noqa: E731
+    print(f"F(4x4) data gradient behind the upsample vs float64 [N={N} {Cout}->{Cin} @{side}]: max {_rel(d4, ref):.2e} rms {rms(d4):.2e}; "
+          f"direct max {_rel(dd, ref):.2e} rms {rms(dd):.2e}")
+    assert _rel(d4, ref) < 3e-5 and rms(d4) < 8e-6
+    assert torch.equal(dx, dev.conv_wino4(gym, w.cuda(), 3, M, Cout, Cin, L, um=2))
+
+
 @pytest.mark.parametrize("N,Cin,Cout,side,cus", [(64, 32, 64, 16, 0), (256, 64, 128, 8, 0), (512, 128, 512, 4, 0),   # the encoder's layers 1-3
                                                  (36, 64, 64, 8, 0), (4, 32, 64, 4, 0), (8, 64, 32, 16, 0),          # few images (no split), the 64 x 32 tile on 16x16
                                                  (512, 128, 512, 4, 256), (64, 32, 64, 16, 256)])                   # the whole chip's split
