@@ -890,8 +890,56 @@ static unsigned ew_grid(int64_t n) {
   return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// The sum the 8-lanes-per-element kernels make of at most eight slabs, by one thread: there lane k holds slab k alone
+// (0.f + v_k) and the shuffle tree adds ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7)), absent slabs +0 -- the same bits.
+__device__ __forceinline__ float slab_tree8(const float (&v)[8]) {
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+// Few slabs of a LARGE weight (c5: the 1024-latent Linear layer, 4 M entries in 2 slabs; the 128 -> 1024 convolution): with
+// eight lanes per element most lanes idle, a wave reads 32-byte pieces of eight slabs and scatters single floats into the
+// checkpoint layout (207 us for the Linear layer's gradient at c5).  Here a block owns a 32 x 32 (a, b) tile with all its
+// taps: reads with lanes along b (the slabs' fastest index), one thread per element; writes through LDS with lanes along
+// whatever is fastest in the checkpoint layout (a for Conv2d / Linear weights, b for ConvTranspose2d: 128 / 1152 contiguous
+// bytes per row of the tile).
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ slabs, int ksplit, WeightMap map,
+                                                                float* __restrict__ grad_w) {
+  __shared__ float tile[NT][32][33];
+  const int tb = map.Cb / 32;
+  const int a0 = ((int)blockIdx.x / tb) * 32, b0 = ((int)blockIdx.x % tb) * 32;
+  const int64_t plane = (int64_t)map.Ca * map.Cb, total = NT * plane;
+  const int bl = threadIdx.x & 31, ar = threadIdx.x >> 5;
+  for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+    for (int al = ar; al < 32; al += 8) {
+      const int64_t e = tap * plane + (int64_t)(a0 + al) * map.Cb + b0 + bl;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = u < ksplit ? 0.f + slabs[(size_t)u * total + e] : 0.f;
+      tile[tap][al][bl] = slab_tree8(v);
+    }
+  __syncthreads();
+  const bool a_fast = map.mode == WM_CONV_FWD || map.mode == WM_CONVT_DGRAD || map.mode == WM_LIN_FWD;
+  for (int idx = threadIdx.x; idx < NT * 1024; idx += 256) {
+    const int tap = idx % NT, r = idx / NT, x = r & 31, y = r >> 5;
+    const int al = a_fast ? x : y, bb = a_fast ? y : x;
+    grad_w[torch_weight_offset(map, tap, a0 + al, b0 + bb)] = tile[tap][al][bb];
+  }
+}
+
+// dev option wgrad_reduce_tiled (1): the tiled form where it applies -- at most 8 slabs and at least 256 tiles
+static bool reduce_tiled(int ksplit, int64_t tiles) { return opt(OPT_WGRAD_REDUCE_TILED) != 0 && ksplit <= 8 && tiles >= 256; }
+
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
+  const int64_t tiles = (int64_t)(map.Ca / 32) * (map.Cb / 32);
+  if (map.Ca % 32 == 0 && map.Cb % 32 == 0 && (map.ntaps == 1 || map.ntaps == 9) && map.mode != WM_CONVT_D22_FWD &&
+      map.mode != WM_CONVT_D22_DGRAD && reduce_tiled(ksplit, tiles)) {
+    if (map.ntaps == 9) DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_tile_kernel<9>, dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+    else DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_tile_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_kernel, dim3(ew_grid(total * 8)), dim3(256), 0, s, slabs, ksplit, map, grad_w);
   return DVG_OK;
 }
@@ -996,7 +1044,46 @@ int launch_lc0_rows_to_linear(const float* t, int n, float* grad_lin_w, hipStrea
   return DVG_OK;
 }
 
+// The same for few slabs of a large weight (wgrad_reduce_tile_kernel's reasoning): one thread per (ci, co) pair makes all
+// nine taps -- the sixteen (p_in, p_out) blocks of each slab read once, lanes along co -- and a block writes its 256 pairs'
+// 2304 contiguous floats through LDS.  Same sums: per slab the blocks in p_out order, then slab_tree8.
+__global__ __launch_bounds__(256) void wgrad_d22_reduce_pair_kernel(const float* __restrict__ slabs, int ksplit, int Cin, int Cout,
+                                                                   float* __restrict__ grad_w) {
+  __shared__ float o[256 * 9];
+  const int64_t srow = 4 * (int64_t)Cout, slab = 4 * (int64_t)Cin * srow;
+  const int64_t ab = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (Cin Cout is a multiple of 256: the launcher checks)
+  const int ci = (int)(ab / Cout), co = (int)(ab - (int64_t)ci * Cout);
+  float v[9][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t][k] = 0.f;
+    if (k < ksplit) {
+      const float* sl = slabs + (size_t)k * slab;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+        for (int po = 0; po < 4; ++po) {
+          const int yi = (po >> 1) + dy, xi = (po & 1) + dx;
+          if (yi >= 0 && yi < 2 && xi >= 0 && xi < 2) v[t][k] += sl[((int64_t)((yi << 1 | xi) * Cin + ci)) * srow + po * Cout + co];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) o[threadIdx.x * 9 + (8 - t)] = slab_tree8(v[t]);
+  __syncthreads();
+  float* dst = grad_w + (int64_t)blockIdx.x * 256 * 9;
+  for (int i = threadIdx.x; i < 256 * 9; i += 256) dst[i] = o[i];
+}
+
 int launch_wgrad_d22_reduce(const float* slabs, int ksplit, int Cin, int Cout, float* grad_w, hipStream_t s) {
+  if (((int64_t)Cin * Cout) % 256 == 0 && reduce_tiled(ksplit, (int64_t)Cin * Cout / 256)) {
+    DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_d22_reduce_pair_kernel, dim3((unsigned)((int64_t)Cin * Cout / 256)), dim3(256), 0, s, slabs,
+               ksplit, Cin, Cout, grad_w);
+    return DVG_OK;
+  }
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_d22_reduce_kernel, dim3(ew_grid((int64_t)9 * Cin * Cout * 8)), dim3(256), 0, s, slabs, ksplit,
              Cin, Cout, grad_w);
   return DVG_OK;

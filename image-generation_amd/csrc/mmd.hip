@@ -1328,17 +1328,33 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // then scalar, no readfirstlane per piece)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5, c = lane & 31;
   const int64_t rbx = (a.nx + 127) / 128;
-  const int64_t rb = blockIdx.x;
+  // Block -> (row block, column split, feature slice).  One feature slice: the grid's own order (x fastest: the few y-row
+  // blocks are the last to start).  Sliced form: the gradient blocks take the lowest linear ids -- the chip's first round
+  // of workgroups is then gradient blocks only (the plan sizes them to the CU count) and the short loss-only blocks fill
+  // in behind; in grid order, 16 of c5's 256 gradient blocks started a whole block's time late (in-kernel timestamps).
+  int rb_i = blockIdx.x, sp_i = blockIdx.y, zc_i = blockIdx.z;
+  if (gridDim.z > 1) {
+    const int GX = gridDim.x, S = gridDim.y, nbx = (int)rbx, nby = GX - nbx;
+    int lin = blockIdx.x + GX * (blockIdx.y + S * blockIdx.z);
+    const int ngrad = nbx * S * gridDim.z;
+    const bool gx = lin < ngrad;
+    lin = gx ? lin : lin - ngrad;
+    const int nb = gx ? nbx : nby;
+    rb_i = (gx ? 0 : nbx) + lin % nb; sp_i = (lin / nb) % S; zc_i = lin / (nb * S);
+  }
+  const int64_t rb = rb_i;
   const bool rows_x = rb < rbx;
-  const int sp = blockIdx.y;
+  const int sp = sp_i;
   if (!rows_x && sp > 0) return;  // y-row blocks only feed the loss: one split walks all of their (few) chunks
   const int64_t cnt_i = rows_x ? a.nx : a.ny, base_i = (rows_x ? rb : rb - rbx) * 128, goff_i = rows_x ? 0 : a.nx;
   const int64_t gi = base_i + wave * 32 + c;  // this lane's row (column of the Gram / weight tiles)
   const bool vi = gi < cnt_i;
-  const int f0 = blockIdx.z * 32 * NFT;  // first feature of this block's slice of G^T
-  if (!rows_x && blockIdx.z > 0) return;
+  const int f0 = zc_i * 32 * NFT;  // first feature of this block's slice of G^T
   const bool want_grad = rows_x && a.grad_part != nullptr;
-  if (!want_grad && blockIdx.z > 0) return;  // feature slices beyond the first only add gradient columns
+  // Feature slices beyond the first only add gradient columns; the loss-only blocks (y rows; x rows when no gradient is
+  // asked for) exist once per slice too: they deal their chunks over those copies (d = 1024: 16 y-row blocks of 64 chunks
+  // beside 256 gradient blocks would be a second round of workgroups as long as the first; 128 blocks of 8 chunks are not)
+  const int zc = zc_i, nzc = gridDim.z;
   // chunk range of this block: x-row blocks see the x chunks then the y chunks, split evenly over gridDim.y
   const int64_t ncx = (a.nx + 31) / 32, ncy = (a.ny + 31) / 32;
   int64_t t0, t1;
@@ -1347,6 +1363,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     t0 = sp * per; t1 = t0 + per < nc ? t0 + per : nc;
   } else {
     t0 = ncx; t1 = ncx + ncy;
+  }
+  if (!want_grad && nzc > 1) {
+    const int64_t per = (t1 - t0 + nzc - 1) / nzc, u0 = t0 + zc * per;
+    t1 = u0 + per < t1 ? u0 + per : t1;
+    t0 = u0;
   }
   const int T = t1 > t0 ? (int)(t1 - t0) : 0;
   // (32-bit copies for the block-uniform per-chunk arithmetic of the loop: chunk and row counts are far below 2^31)
@@ -1637,7 +1658,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     auto iteration = [&](int k, auto parity, i32x16& Scur, i32x16& Snext) {
       (void)parity;  // (the two instantiations differ in which accumulator set is current: Scur / Snext)
       // ---- top: the one barrier (behind the wait for this wave's pieces of the previous iteration), the rare fixup
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (sliced form, d = 1024: an iteration is 48 MFMAs, 0.6 us -- less than the LDS-DMA round trip under 256 blocks' load,
+      // and the wait was the chunk's time, 3.5 us.  What iteration k fetches is first read in iteration k + 2: the wait
+      // leaves the newest iteration's pieces in flight; the barrier then still publishes everything iteration k + 1 reads.)
+      if constexpr (GPT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NZ8 + NZT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" : "+v"(Scur));
       if (cy.fix) {
@@ -1672,6 +1697,10 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
         // G^T tile out to vector registers and back around this tile every chunk.  The first k-step takes C = 0.
 #pragma unroll
         for (int u = 0; u < GPT; ++u) {
+          if constexpr (GPT > 1) {
+            if (ft == 0 && u == 0) Snext = (i32x16){0};
+            Snext = __builtin_amdgcn_mfma_i32_32x32x32_i8(zc[u], xb[ft * GPT + u], Snext, 0, 0, 0);
+          } else
           if (ft == 0 && u == 0)
             asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(Snext) : "v"(zc[u]), "v"(xb[ft * GPT + u]));
           else
@@ -1792,8 +1821,10 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   // ---- loss partial sums
   const double sxx = block_sum(l_xx, red), sxy = block_sum(l_xy, red), syy = block_sum(l_yy, red);
   if (tid == 0) {
-    double* lp = a.loss_part + ((size_t)sp * gridDim.x + blockIdx.x) * 3;
-    lp[0] = sxx; lp[1] = sxy; lp[2] = syy;
+    // (a gradient block's kernel sums are the same in every feature slice: slice 0's count)
+    const bool counts = !want_grad || zc == 0;
+    double* lp = a.loss_part + (((size_t)zc * gridDim.y + sp) * gridDim.x + rb) * 3;
+    lp[0] = counts ? sxx : 0.0; lp[1] = counts ? sxy : 0.0; lp[2] = counts ? syy : 0.0;
   }
   if (!want_grad) return;
 
@@ -1906,6 +1937,8 @@ static int mmd_w128_env() {  // (read per call: the tests flip it inside one pro
 
 // column splits of the pair kernel aim for this many blocks
 static int64_t mmd_target_blocks() { return 256; }
+// feature slices (grid z) of the 128-row-block pair kernel: NST / NFT of the instantiation dvg_mmd_fwd_bwd launches
+static int mmd_w128_slices(int d) { return d == 1024 ? 8 : 1; }
 
 static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   MmdPlan p;
@@ -1924,18 +1957,24 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.pm1_ok = d <= 1024;  // LDS: table + resident X rows + one Z panel
   // 128-row-block pair kernel: d = 128 .. 512 in steps of 128 (16 d / 32 accumulator registers per lane), and enough
   // rows of x that 128-row blocks fill the chip with at most 4 column splits of >= 16 chunks each
+  // (d = 1024, round 6: the rows still fit the registers -- 128 of them hold a lane's 1024 int8 features -- and the LDS
+  // image fits with 128-feature slices of G^T, W128<32, 4>: eight feature slices per row block, each redoing the int8
+  // Gram (32 of its 48 MFMAs per chunk).  c5's per-GPU slice, 2048 + 2048 rows: 16 row blocks x 8 slices x 2 splits;
+  // the 32-row kernel it replaces there staged 192 KB through LDS per 32 x 128 pairs and held every CU's register file
+  // with one workgroup at 0.05 of the matrix peak.)
   p.rb128x = ceil_div(nx, 128);
   p.rb128y = ceil_div(ny, 128);
   {
     const int64_t chunks = ceil_div(nx, 32) + ceil_div(ny, 32);
-    int64_t S2 = ceil_div(mmd_target_blocks(), p.rb128x);
+    const int64_t z128 = mmd_w128_slices(d);
+    int64_t S2 = ceil_div(mmd_target_blocks(), p.rb128x * z128);
     if (S2 > chunks / 16) S2 = chunks / 16;
     if (S2 < 1) S2 = 1;
     // (the 128-row-block kernel addresses both chunk images through 32-bit buffer offsets: the int8 rows and the bf16
     // transposed copy, 2 (nx + ny) d bytes, must stay below 2^31 -- larger problems keep the 32-row kernels' 64-bit pointers)
-    const bool shape_ok = d % 128 == 0 && d <= 512 && (int64_t)(nx + ny) * (int64_t)d * 2 < 2147483647LL;
+    const bool shape_ok = d % 128 == 0 && (d <= 512 || d == 1024) && (int64_t)(nx + ny) * (int64_t)d * 2 < 2147483647LL;
     const int env = mmd_w128_env();
-    p.w128 = shape_ok && (env == 1 || (env != 0 && S2 <= 4 && p.rb128x * S2 >= 128));
+    p.w128 = shape_ok && (env == 1 || (env != 0 && S2 <= 4 && p.rb128x * S2 * z128 >= 128));
     if (env == 1 && shape_ok) { S2 = S2 > 16 ? 16 : S2; }
     else if (S2 > 4) S2 = 4;
     p.S2 = (int)S2;
@@ -1971,7 +2010,7 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.off_dist = o; o = align_up(o + sizeof(double) * (size_t)(p.S1 * p.GX1), 256);
   {
     size_t nparts = (size_t)(p.S * (p.rbx + p.rby));
-    if (p.w128 && (size_t)(p.S2 * (p.rb128x + p.rb128y)) > nparts) nparts = (size_t)(p.S2 * (p.rb128x + p.rb128y));
+    if (p.w128 && (size_t)(p.S2 * mmd_w128_slices(d) * (p.rb128x + p.rb128y)) > nparts) nparts = (size_t)(p.S2 * mmd_w128_slices(d) * (p.rb128x + p.rb128y));
     if (p.w128 && (size_t)(p.S2 * (p.rbx + p.rby)) > nparts) nparts = (size_t)(p.S2 * (p.rbx + p.rby));
     p.off_loss = o; o = align_up(o + sizeof(double) * 3 * nparts, 256);
   }
@@ -2085,7 +2124,7 @@ extern "C" int dvg_mmd_spin_flops(int64_t nx, int64_t ny, int dim, double* int8_
   if (!p.pm1_ok) { *int8_flops = 0.0; *bf16_flops = 0.0; *bf16_terms = 0; return DVG_OK; }  // f32 kernels only
   // the form dvg_mmd_fwd_bwd launches: ONE feature slice per block (the Gram and the lookups computed once) unless the
   // two-slice form is asked for (mmd_two_slices(), d > 256 only)
-  const int passes = (p.w128 && dim > 256 && mmd_two_slices()) ? 2 : 1;
+  const int passes = p.w128 ? mmd_w128_slices(dim) * ((dim > 256 && dim <= 512 && mmd_two_slices()) ? 2 : 1) : 1;
   *bf16_terms = p.w128 ? 2 : 3;
   mmd_pm1_flops(nx, ny, dim, true, *bf16_terms, passes, int8_flops, bf16_flops);
   return DVG_OK;
@@ -2133,7 +2172,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   if (p.w128) {
     // (the 128-row-block pair kernel and the float32 kernel behind it number their loss partials by their own grids and
     // exactly one of them runs: the slots the other layout would have filled must read as zero in the final sum)
-    if ((int)(p.S2 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * (p.rb128x + p.rb128y));
+    if ((int)(p.S2 * mmd_w128_slices(dim) * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * mmd_w128_slices(dim) * (p.rb128x + p.rb128y));
     if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
   }
   if (p.pm1_ok) {  // row norms, int8 copy, +-1 flag and the transposed bf16 copy in one pass over the rows
@@ -2197,6 +2236,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
       // the compiler places the Gram tile and the operands in the other half without spills): the Gram and the lookups
       // are then computed once, 80 instead of 96 MFMAs per chunk: 2.70 -> 2.10 ms at c3 (the two-slice form is retired).
       case 3: rc = launch_pair_w128<12, 12>(a, p, s); break;
+      case 8: rc = launch_pair_w128<32, 4>(a, p, s); break;  // (eight 128-feature slices: mmd_plan)
       default: rc = launch_pair_w128<16, 16>(a, p, s); break;
     }
     DVG_TRY(rc);

@@ -273,6 +273,23 @@ def test_convtranspose_with_fused_upsample(N, Cin, Cout, side, staging):
     assert _rel(gw.cpu(), w.grad) < 3e-6
 
 
+@pytest.mark.parametrize("mode,M,Cin,Cout,side,ntaps", [(4, 1024, 512, 2048, 1, 1), (0, 64 * 16, 128, 1024, 4, 9), (2, 64 * 16, 512, 128, 4, 9)])
+def test_slab_sums_of_few_slabs_of_a_large_weight_are_the_same_bits(mode, M, Cin, Cout, side, ntaps):
+    """wgrad_reduce_tile_kernel (at most 8 slabs, at least 256 32 x 32 tiles: coalesced reads and writes) against the
+    8-lanes-per-element kernel on the same slabs: Linear, Conv2d and ConvTranspose2d checkpoint layouts."""
+    from image_generation_amd import _lib
+    torch.manual_seed(M + Cin)
+    L = side.bit_length() - 1
+    x = torch.randn(M, Cin, device="cuda"); dy = torch.randn(M, Cout, device="cuda")
+    shape = {4: (Cout, Cin), 0: (Cout, Cin, 3, 3), 2: (Cin, Cout, 3, 3)}[mode]
+    got = {}
+    for form in (0, 1):
+        with _lib.option_scope(wgrad_reduce_tiled=form):
+            got[form] = dev.conv_wgrad(x, dy, mode, shape, M, Cin, Cout, L, ntaps=ntaps)
+    assert torch.equal(got[0], got[1])
+    assert got[1].abs().max().item() > 0
+
+
 @pytest.mark.parametrize("N,n", [(37, 64), (700, 128), (16384, 128)])  # (n = 128: the 128 x 128-tile 1-tap weight-gradient kernel)
 def test_linear_as_one_tap_gemm(N, n, staging):
     torch.manual_seed(0)

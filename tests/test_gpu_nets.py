@@ -463,6 +463,27 @@ def test_decoder_gradients_do_not_depend_on_the_staging_form(n, B, R):
             assert torch.equal(grads["0"][k], grads["1"][k]), k
 
 
+@pytest.mark.parametrize("n,B,R", [(1024, 32, 8), (512, 64, 4)])
+def test_decoder_gradients_do_not_depend_on_the_slab_sum_form(n, B, R):
+    """c5's shapes (1024 latent spins): the slab sums of the Linear layer's and the dense 2x2 layer's weight gradients -- a few
+    slabs of a LARGE weight -- run as tiled one-thread-per-element kernels (csrc/conv_wgrad.hip: wgrad_reduce_tile_kernel,
+    wgrad_d22_reduce_pair_kernel); they add the slabs in the 8-lanes-per-element kernels' order: bit-identical gradients."""
+    params = gen.make_params(n, "decoder", 5 + n)
+    spins = torch.from_numpy(gen.make_spins(B, R, n, 11)).cuda()
+    masks = [torch.from_numpy(m).cuda() for m in gen.make_masks(B * R, 9)]
+    go = torch.randn(B, R, 1, 32, 32, generator=torch.Generator().manual_seed(5)).cuda()
+    grads = {}
+    for form in (0, 1):
+        with _lib.option_scope(wgrad_reduce_tiled=form):
+            dec = _load(Decoder(n), params).train()
+            dec.inject_dropout_masks(masks)
+            sg = spins.clone().requires_grad_(True)
+            (dec(sg) * go).sum().backward()
+            grads[form] = {k: v.grad.clone() for k, v in dec.named_parameters()}
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 @pytest.mark.parametrize("n,B,R,gtol", [(32, 7, 2, 2e-5), (64, 5, 3, 2e-5), (128, 16, 8, 2e-5), (256, 33, 4, 2e-5), (128, 64, 8, 2e-3)])
 def test_decoder_first_layers_dense_and_composed_forms_equal_the_9_tap_form(n, B, R, gtol):
     """ConvTranspose2d 3x3 on the 2x2 images behind the Linear layer runs as one dense map per image (only the 4 of 9
