@@ -928,8 +928,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __r
   }
 }
 
-// dev option wgrad_reduce_tiled (1): the tiled form where it applies -- at most 8 slabs and at least 256 tiles
-static bool reduce_tiled(int ksplit, int64_t tiles) { return opt(OPT_WGRAD_REDUCE_TILED) != 0 && ksplit <= 8 && tiles >= 256; }
+// dev option wgrad_reduce_tiled (1): the tiled form where it applies -- at most 8 slabs and at least 64 tiles
+static bool reduce_tiled(int ksplit, int64_t tiles) { return opt(OPT_WGRAD_REDUCE_TILED) != 0 && ksplit <= 8 && tiles >= 64; }
 
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;

@@ -46,7 +46,7 @@ bool fold_enabled() { return opt(OPT_DEC_FOLD) != 0; }
 bool d22_enabled() { return opt(OPT_DEC_D22) != 0; }
 
 // option dec_lc0 = 0: never compose the Linear layer with layer 0 (A/B runs, tests); 1: also for small batches (tests);
-// -1 (default): from 4096 rows up
+// -1 (default): from 4096 rows up, or N * n_latents >= 2^20 (dec_plan)
 int lc0_env() {
   const int64_t v = opt(OPT_DEC_LC0);
   return v < 0 ? -1 : (v ? 1 : 0);
@@ -134,7 +134,10 @@ DecPlan dec_plan(int64_t N, int n) {
     const int C = ch[1], env = lc0_env();
     // composed form: the LDS-DMA GEMMs only (their K-major float32 packs double as plain row-major matrices); every
     // operand mode has them (conv_launch_mode: 3 float32, 4 f32x3, 5 bf16 inputs), the register-staged A/B form does not
-    p.lc0 = p.d22 && env != 0 && (N >= 4096 || env == 1) && conv_pack_is_f32_kmajor(conv_launch_mode(N, 4 * C));
+    // (from 4096 rows up at c3's 256 latent spins -- measured there in round 4 -- and from N n >= 2^20 in general: the two
+    // layers cost 2 (4 n^2 + 16 n C) FLOPs per row and pass, the composed map 2 (4 n C), forming it ~128 C n^2 per step; at
+    // c5's n = 1024 the crossover measured between 512 and 1024 rows, and at its 2048 rows the step went 2.57 -> 2.18 ms)
+    p.lc0 = p.d22 && env != 0 && (N >= 4096 || N * (int64_t)n >= (1 << 20) || env == 1) && conv_pack_is_f32_kmajor(conv_launch_mode(N, 4 * C));
     p.tail = opt(OPT_DEC_TAIL_FUSED) != 0;
     if (p.lc0) {
       p.WcT = bump(o, (size_t)4 * C * n);

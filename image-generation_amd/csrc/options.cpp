@@ -22,7 +22,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"wgrad_dma", 1, "weight-gradient GEMMs: 1 LDS-DMA staging (default), 0 register staging (tensors of 4 GiB and more always)", true},
     {"dec_fold", 1, "decoder: Upsample(x2) + ConvTranspose as 4 class GEMMs with pre-summed taps (4/9 of the FLOPs)"},
     {"dec_d22", 1, "decoder: first ConvTranspose layer on 2x2 images as one dense map per image (16/36 of the FLOPs)"},
-    {"dec_lc0", -1, "decoder: Linear composed with that map: -1 from 4096 rows up (default), 0 never, 1 always"},
+    {"dec_lc0", -1, "decoder: Linear composed with that map: -1 from 4096 rows up or rows x n_latents >= 2^20 (default), 0 never, 1 always"},
     {"mmd_w128", -1, "MMD: 128-row-block pair kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
     {"mmd_d256", -1, "MMD: 256-row distance-sum kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
     {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule, 2 the lane-major schedule one row at a time instead of two passes of a class side by side (both bit-identical; A/B references)", true},
