@@ -667,6 +667,10 @@ def main():
                        "gibbs_sweeps": cfg["sweeps"], "parallelism": f"dp{args.gpus}",
                        "launch": ("hipGraph replay of the autoencoder half (GRBM update of every 10th step eager behind it)"
                                   if model.use_graph else "eager"),
+                       # (what the wrapper actually did over the whole process: replays of the captured step / eager steps /
+                       # whether a capture failed and the run fell back to eager launches)
+                       "launch_counts": {"graph_replays": int(model._replays), "eager_steps": int(model._eager_steps),
+                                         "capture_failed": bool(model._graph_failed)},
                        "net_gflop_per_step": net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9},
             "workload_losses": workload_losses,
             # what the process group looked like from inside (not what --gpus claimed): backend, world size RCCL reports,

@@ -898,46 +898,56 @@ __device__ __forceinline__ float slab_tree8(const float (&v)[8]) {
 
 // Few slabs of a LARGE weight (c5: the 1024-latent Linear layer, 4 M entries in 2 slabs; the 128 -> 1024 convolution): with
 // eight lanes per element most lanes idle, a wave reads 32-byte pieces of eight slabs and scatters single floats into the
-// checkpoint layout (207 us for the Linear layer's gradient at c5).  Here a block owns a 32 x 32 (a, b) tile with all its
+// checkpoint layout (207 us for the Linear layer's gradient at c5).  Here a block owns a TA x 32 (a, b) tile with all its
 // taps: reads with lanes along b (the slabs' fastest index), one thread per element; writes through LDS with lanes along
 // whatever is fastest in the checkpoint layout (a for Conv2d / Linear weights, b for ConvTranspose2d: 128 / 1152 contiguous
 // bytes per row of the tile).
-template <int NT>
+template <int NT, int TA>  // taps; a rows of a tile (32 b columns): 9 taps: 8 rows -- 72 independent loads per thread, 4 x the blocks
 __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ slabs, int ksplit, WeightMap map,
                                                                 float* __restrict__ grad_w) {
-  __shared__ float tile[NT][32][33];
+  __shared__ float tile[NT][TA][33];
   const int tb = map.Cb / 32;
-  const int a0 = ((int)blockIdx.x / tb) * 32, b0 = ((int)blockIdx.x % tb) * 32;
+  const int a0 = ((int)blockIdx.x / tb) * TA, b0 = ((int)blockIdx.x % tb) * 32;
   const int64_t plane = (int64_t)map.Ca * map.Cb, total = NT * plane;
   const int bl = threadIdx.x & 31, ar = threadIdx.x >> 5;
+  constexpr int NA = TA / 8;
+  float v[NT][NA][8];
+#pragma unroll
   for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
-    for (int al = ar; al < 32; al += 8) {
-      const int64_t e = tap * plane + (int64_t)(a0 + al) * map.Cb + b0 + bl;
-      float v[8];
+    for (int i = 0; i < NA; ++i) {
+      const int64_t e = tap * plane + (int64_t)(a0 + ar + 8 * i) * map.Cb + b0 + bl;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = u < ksplit ? 0.f + slabs[(size_t)u * total + e] : 0.f;
-      tile[tap][al][bl] = slab_tree8(v);
+      for (int u = 0; u < 8; ++u) v[tap][i][u] = u < ksplit ? slabs[(size_t)u * total + e] : 0.f;
+    }
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[tap][i][u] = 0.f + v[tap][i][u];
+      tile[tap][ar + 8 * i][bl] = slab_tree8(v[tap][i]);
     }
   __syncthreads();
   const bool a_fast = map.mode == WM_CONV_FWD || map.mode == WM_CONVT_DGRAD || map.mode == WM_LIN_FWD;
-  for (int idx = threadIdx.x; idx < NT * 1024; idx += 256) {
-    const int tap = idx % NT, r = idx / NT, x = r & 31, y = r >> 5;
-    const int al = a_fast ? x : y, bb = a_fast ? y : x;
+  for (int idx = threadIdx.x; idx < NT * TA * 32; idx += 256) {
+    const int tap = idx % NT, r = idx / NT;
+    const int al = a_fast ? r % TA : r / 32, bb = a_fast ? r / TA : r % 32;
     grad_w[torch_weight_offset(map, tap, a0 + al, b0 + bb)] = tile[tap][al][bb];
   }
 }
 
-// dev option wgrad_reduce_tiled (1): the tiled form where it applies -- at most 8 slabs and at least 64 tiles
-static bool reduce_tiled(int ksplit, int64_t tiles) { return opt(OPT_WGRAD_REDUCE_TILED) != 0 && ksplit <= 8 && tiles >= 64; }
+// dev option wgrad_reduce_tiled (1): the tiled form where it applies -- at most 8 slabs and at least 256 tiles
+static bool reduce_tiled(int ksplit, int64_t tiles) { return opt(OPT_WGRAD_REDUCE_TILED) != 0 && ksplit <= 8 && tiles >= 256; }
 
 int launch_wgrad_reduce(const float* slabs, int ksplit, const WeightMap& map, float* grad_w, hipStream_t s) {
   const int64_t total = (int64_t)map.ntaps * map.Ca * map.Cb;
-  const int64_t tiles = (int64_t)(map.Ca / 32) * (map.Cb / 32);
+  const int ta = map.ntaps == 9 ? 8 : 32;
+  const int64_t tiles = (int64_t)(map.Ca / ta) * (map.Cb / 32);
   if (map.Ca % 32 == 0 && map.Cb % 32 == 0 && (map.ntaps == 1 || map.ntaps == 9) && map.mode != WM_CONVT_D22_FWD &&
       map.mode != WM_CONVT_D22_DGRAD && reduce_tiled(ksplit, tiles)) {
-    if (map.ntaps == 9) DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_tile_kernel<9>, dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
-    else DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_tile_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+    if (map.ntaps == 9) DVG_LAUNCH(K_WGRAD_REDUCE, (wgrad_reduce_tile_kernel<9, 8>), dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
+    else DVG_LAUNCH(K_WGRAD_REDUCE, (wgrad_reduce_tile_kernel<1, 32>), dim3((unsigned)tiles), dim3(256), 0, s, slabs, ksplit, map, grad_w);
     return DVG_OK;
   }
   DVG_LAUNCH(K_WGRAD_REDUCE, wgrad_reduce_kernel, dim3(ew_grid(total * 8)), dim3(256), 0, s, slabs, ksplit, map, grad_w);

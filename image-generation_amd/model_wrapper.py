@@ -90,6 +90,8 @@ class ModelWrapper:
         # prepare_decoder: enqueue the decoder's weight-only prologue at the start of the step, beside the encoder
         # (None: from PREPARE_DECODER_ROWS decoder rows up; True / False force it)
         self.prepare_decoder = None
+        # defer_mmd_join: join the MMD stream behind the decoder's backward (None: measured per shape, _defer_mmd_join)
+        self.defer_mmd_join = None
         # fuse_decoder_mse: Decoder.forward_mse in the training step (the reconstruction is never written) -- None: from
         # FUSE_DECODER_MSE_ROWS decoder rows (B * R) up; True / False: always / never (A/B runs, tests)
         self.fuse_decoder_mse = None
@@ -673,6 +675,9 @@ class ModelWrapper:
         torch.cuda.synchronize(self._device)
         graph = torch.cuda.CUDAGraph()
         tail = None
+        dot = os.environ.get("DVG_GRAPH_DOT")  # diagnostics: write the captured graph (nodes and edges) to this path
+        if dot:
+            graph.enable_debug_mode()
         _lib.DYN = self._dyn.ptr
         try:
             # Data-parallel runs: graph 1 ends with the gradients packed into the optimizer's flat buffer; the ONE
@@ -691,6 +696,8 @@ class ModelWrapper:
             self._capturing_split = False
             _lib.DYN = None
             self._set_host_counters(saved)  # the capture pass launched nothing: roll the host counters back
+        if dot:
+            graph.debug_dump(dot)
         self._graphs.append((graph, static_images, (mse, dvae, mmd, spins.detach()), tail, self._graph_addresses()))
         self._graph = graph
 
