@@ -670,7 +670,8 @@ def main():
                        # (what the wrapper actually did over the whole process: replays of the captured step / eager steps /
                        # whether a capture failed and the run fell back to eager launches)
                        "launch_counts": {"graph_replays": int(model._replays), "eager_steps": int(model._eager_steps),
-                                         "capture_failed": bool(model._graph_failed)},
+                                         "capture_failed": bool(model._graph_failed),
+                                         "replay_call_host_us": round(1e6 * model._replay_host_s / max(1, int(model._replays)), 1)},
                        "net_gflop_per_step": net_flops_per_image(cfg["n"], cfg["R"]) * cfg["B"] / 1e9},
             "workload_losses": workload_losses,
             # what the process group looked like from inside (not what --gpus claimed): backend, world size RCCL reports,

@@ -10,6 +10,7 @@ checkpoint holds only the two ``state_dict``s (:148-162).
 from __future__ import annotations
 
 import os
+import time
 from pathlib import Path
 from typing import Callable, Optional
 
@@ -109,6 +110,7 @@ class ModelWrapper:
         self._pending_tail = None
         self._joint_grad = None   # [dvae gradients | GRBM gradients]: the buffer of that all-reduce
         self._replays = 0
+        self._replay_host_s = 0.0
         self._graph_failed = False
         self._static_images = None
         self._dyn = None
@@ -730,7 +732,9 @@ class ModelWrapper:
         self._replays += 1
         static_images.copy_(images)
         self._write_dyn()
+        t_host = time.perf_counter()
         graph.replay()
+        self._replay_host_s += time.perf_counter() - t_host  # (host time of the launch call alone: bench.py reports it)
         if tail is not None:  # data-parallel: the collective and the captured Adam launch follow in _flush_dist
             self._pending.append(self._dvae_optimizer)
             self._pending_tail = tail

@@ -50,6 +50,9 @@ python bench.py --config c3 --precision bf16 --no-cpu-baseline --steps 10 > $OUT
 python bench.py --config c3 --precision f32x3 --no-cpu-baseline --parity --steps 20 > $OUT/c3x.log 2>&1; last $OUT/c3x.log $OUT/${R}_bench_c3_f32x3.json
 python tools/mmd_accuracy.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_accuracy_c3.txt
 python tools/mmd_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_kernels_c3.txt
+# the c5 slice's MMD (2048 + 2048 rows, d = 1024): the 128-row-block kernel in eight feature slices, and the 32-row kernel it replaced
+(python tools/mmd_bench.py 2048 2048 1024; python tools/mmd_bench.py 2048 2048 1024 --w128 0) 2>&1 | grep -v amdgpu > $OUT/${R}_mmd_kernels_c5.txt
+python tools/wino4_dec_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino4_decoder_alone_c3.txt
 python tools/igemm_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_igemm_staging_ab.txt
 python tools/igemm_modes.py 2>&1 | grep -v amdgpu > $OUT/${R}_igemm_operand_modes.txt
 python tools/gibbs_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_gibbs_draw_alone_c3.txt
@@ -57,9 +60,10 @@ python tools/gibbs_bench.py 1024 2048 50 2>&1 | grep -v amdgpu > $OUT/${R}_gibbs
 # the driver's multi-GPU command shape, with the one rank this box has (a forced single-rank RCCL group): the line's `dist`
 # object shows what the process group looked like from inside
 HSA_ENABLE_IPC_MODE_LEGACY=0 DVG_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --child > $OUT/tr1.log 2>&1; last $OUT/tr1.log $OUT/${R}_bench_c3_torchrun_nproc1_forced_dist.json
-# kernel timeline of one c3 step
+# kernel timeline of one REPLAYED c3 step (index -35: behind the 10 timed steps bench.py runs 3 x 10 EAGER steps for its per-kernel
+# HIP-event timing; round 6 found the committed timelines of rounds 4-5 were of those -- for c3 the same picture, for c2 not)
 cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $ROOT/bench.py --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
-python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c3_step.txt; rm -rf $OUT/tr
+python tools/trace_step.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) -35 | cut -c1-120 > $OUT/${R}_timeline_c3_step.txt; rm -rf $OUT/tr
 python tools/wgrad_ab.py 2>&1 | grep -v amdgpu > $OUT/${R}_wgrad_staging_ab.txt
 python tools/wino_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_alone_c3.txt
 python tools/wino_wgrad_bench.py 2>&1 | grep -v amdgpu > $OUT/${R}_wino_wgrad_alone_c3.txt
@@ -72,8 +76,11 @@ python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "f4x4" -s 2>&1 | grep -E
 # determinism: two processes, 300 graph-replayed c3 steps each, losses printed to the last digit (dynamic tile deal, pair
 # exchange and fixed-order slab sums included)
 (python tools/soak.py c3 300 2>&1 | tail -3; python tools/soak.py c3 300 2>&1 | tail -3) | grep -v amdgpu > $OUT/${R}_soak_c3_300_steps_twice.txt
-# kernel timeline of one c2 step (eager: under rocprofv3 the captured graph's gaps are the profiler's)
-cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr2 -- python3 $ROOT/bench.py --config c2 --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
-python tools/trace_step.py $(ls $OUT/tr2/*/*kernel_trace.csv | head -1) -3 | cut -c1-120 > $OUT/${R}_timeline_c2_step.txt; rm -rf $OUT/tr2
+# kernel timelines of one REPLAYED c2 step and one of the c5 per-GPU slice (under rocprofv3 the replay's host side is slower: the
+# span is longer than the bench line's step)
+for C in c2 c5; do
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT/tr2 -- python3 $ROOT/bench.py --config $C --no-cpu-baseline --child --steps 10 --warmup 3 > /dev/null 2>&1; cd $ROOT
+python tools/trace_step.py $(ls $OUT/tr2/*/*kernel_trace.csv | head -1) -35 | cut -c1-120 > $OUT/${R}_timeline_${C}_step.txt; rm -rf $OUT/tr2
+done
 rm -rf $OUT/stats_* $OUT/pmc_f_* $OUT/pmc_w_* $OUT/pmc_m_* $OUT/pmc_g_*
 ls -la $OUT
