@@ -89,7 +89,7 @@ enum KernelId : int {
 enum Opt : int {
   OPT_IGEMM_DMA = 0, OPT_IGEMM_POSMAJOR, OPT_IGEMM_THR128, OPT_WGRAD_DMA, OPT_DEC_FOLD, OPT_DEC_D22, OPT_DEC_LC0, OPT_MMD_W128,
   OPT_MMD_D256, OPT_GIBBS_GENERIC, OPT_SIDE_STREAM, OPT_ENC_WINO, OPT_DEC_WINO, OPT_ENC_L0_FUSED, OPT_DEC_TAIL_FUSED,
-  OPT_WINO_DYNAMIC, OPT_ENC_WINO4, OPT_ENC_WINO4_MASK, OPT_ENC_DGRAD_CUS, OPT_ENC_WGRAD_CUS, OPT_DEC_WINO4_MASK, OPT_WGRAD_REDUCE_TILED, OPT_COUNT
+  OPT_WINO_DYNAMIC, OPT_ENC_WINO4, OPT_ENC_WINO4_MASK, OPT_ENC_DGRAD_CUS, OPT_ENC_WGRAD_CUS, OPT_DEC_WINO4_MASK, OPT_WGRAD_REDUCE_TILED, OPT_ENC_BN_REDUCE_POOLED, OPT_COUNT
 };
 int64_t opt(Opt id);
 

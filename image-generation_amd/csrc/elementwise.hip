@@ -506,9 +506,86 @@ __global__ __launch_bounds__(256) void enc_bn_pool_bwd_v4_kernel(const float* __
   }
 }
 
+// The reduce pass from the POOLED activations the forward call kept (the next layer's input): the pooled value is
+// lrelu(best) with best = gamma zhat_max + beta, both maps invertible, so (sum dz, sum dz zhat_max) need two values per pooled
+// pixel and channel -- the gradient and the activation -- instead of the gradient and the four pre-BatchNorm outputs of the
+// window (5 -> 2 floats read per element: 167 -> ~70 us over c3's three layers, on the data-gradient chain).  zhat_max =
+// (best - beta) / gamma carries the rounding of best (6e-8 max(|zhat|, |beta / gamma|)); a channel whose |gamma| is too small
+// for that to be harmless -- or zero: the window's maximum is then its first element, whatever zhat -- takes the window itself.
+__global__ __launch_bounds__(256) void enc_bn_pool_bwd_reduce_p_kernel(const float* __restrict__ Y, const float* __restrict__ P,
+                                                                       int64_t Q, int C, const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, int lrelu,
+                                                                       const float* __restrict__ dOut, float* __restrict__ part) {
+  __shared__ float red[2 * 4 * 256];
+  const Chan4 cm(C);
+  for (int c0 = 0; c0 < C; c0 += 4 * cm.CQ) {
+    const int c = c0 + 4 * cm.cq;
+    const f32x4v mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    bool inv_ok = true;
+    f32x4v ginv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      inv_ok = inv_ok && fabsf(g[j]) >= 1e-3f * (1.0f + fabsf(b[j]));
+      ginv[j] = 1.0f / g[j];
+    }
+    f32x4v acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (inv_ok) {
+      const int64_t stride = (int64_t)gridDim.x * cm.RL;
+      int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl;
+      auto one = [&](const f32x4v& pv, const f32x4v& go) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool neg = lrelu && !(pv[j] > 0.f);
+          const float best = neg ? pv[j] * (1.0f / LRELU_SLOPE) : pv[j];
+          const float dz = go[j] * (neg ? LRELU_SLOPE : 1.0f);
+          acc[0][j] += dz;
+          acc[1][j] = fmaf(dz, (best - b[j]) * ginv[j], acc[1][j]);
+        }
+      };
+      for (; q + stride < Q; q += 2 * stride) {  // (two rows in flight)
+        const f32x4v p0 = ld4(P + q * C + c), g0 = ld4(dOut + q * C + c);
+        const f32x4v p1 = ld4(P + (q + stride) * C + c), g1 = ld4(dOut + (q + stride) * C + c);
+        one(p0, g0);
+        one(p1, g1);
+      }
+      for (; q < Q; q += stride) one(ld4(P + q * C + c), ld4(dOut + q * C + c));
+    } else {
+      for (int64_t q = (int64_t)blockIdx.x * cm.RL + cm.rl; q < Q; q += (int64_t)gridDim.x * cm.RL) {
+        const float* y = Y + (q * 4) * C + c;
+        f32x4v w[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[s] = ld4(y + (size_t)s * C);
+        const f32x4v go = ld4(dOut + q * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float zh[4], best = 0.f;
+          int arg = 0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            zh[s] = (w[s][j] - mu[j]) * is[j];
+            const float z = fmaf(zh[s], g[j], b[j]);
+            if (s == 0 || z > best) { best = z; arg = s; }
+          }
+          const float dz = go[j] * ((lrelu && !(best > 0.f)) ? LRELU_SLOPE : 1.0f);
+          acc[0][j] += dz;
+          acc[1][j] = fmaf(dz, zh[arg], acc[1][j]);
+        }
+      }
+    }
+    block_reduce_store4<2>(acc, cm, red, part, C, c0);
+  }
+}
+
 int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
                                   const float* gamma, const float* beta, int lrelu, const float* dOut, float* part,
-                                  hipStream_t s) {
+                                  hipStream_t s, const float* pooled) {
+  if (C % 32 == 0 && pooled) {
+    DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_bn_pool_bwd_reduce_p_kernel, dim3(EW_BLOCKS), dim3(256), 0, s, Y, pooled, Q, C, mean,
+               invstd, gamma, beta, lrelu, dOut, part);
+    return DVG_OK;
+  }
   if (C % 32 == 0) {
     DVG_LAUNCH(K_ENC_BN_POOL_BWD_REDUCE, enc_bn_pool_bwd_v4_kernel<false>, dim3(EW_BLOCKS), dim3(256), 0, s, Y, Q, C, mean,
                invstd, gamma, beta, lrelu, dOut, nullptr, nullptr, 0.f, nullptr, part);

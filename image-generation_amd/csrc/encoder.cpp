@@ -254,7 +254,7 @@ extern "C" int dvg_encoder_bwd(const dvg_encoder_params_t* p, int n, const float
     }
     // BN + pool + lrelu backward: (sum dz -> d beta, sum dz*zhat -> d gamma), then dY
     DVG_TRY(launch_enc_bn_pool_bwd_reduce(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
-                                          dX, partA, s));
+                                          dX, partA, s, opt(OPT_ENC_BN_REDUCE_POOLED) != 0 ? W + pl.Xp[l] : nullptr));
     DVG_TRY(launch_colsum2(partA, EW_BLOCKS, 2 * C, C, g->bn_b[l], C, g->bn_g[l], s));
     DVG_TRY(launch_enc_bn_pool_bwd_apply(Y, pl.Q[l], C, W + pl.mean[l], W + pl.invstd[l], p->bn_g[l], p->bn_b[l], l < 3,
                                          dX, g->bn_b[l], g->bn_g[l], dY, W + pl.partB[l], s));

@@ -61,7 +61,7 @@ int launch_enc_bn_pool_fwd(const float* Y, int64_t Q, int C, const float* mean, 
 // part [EW_BLOCKS][2][C]: per-block (sum dz, sum dz*zhat)
 int launch_enc_bn_pool_bwd_reduce(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
                                   const float* gamma, const float* beta, int lrelu, const float* dOut, float* part,
-                                  hipStream_t s);
+                                  hipStream_t s, const float* pooled = nullptr);  // pooled: the forward's pooled activations [Q][C] (the sums from them: elementwise.hip)
 int launch_enc_bn_pool_bwd_apply(const float* Y, int64_t Q, int C, const float* mean, const float* invstd,
                                  const float* gamma, const float* beta, int lrelu, const float* dOut, const float* sum_dz,
                                  const float* sum_dzzh, float* dY, float* part_db, hipStream_t s);

@@ -38,6 +38,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"enc_wgrad_cus", 0, "CUs the encoder's Winograd weight-gradient launches are sized for (0: the measured constant of conv.h)", true},
     {"dec_wino4_mask", 0x2, "which of the decoder's Winograd launches behind the upsample take the F(4x4,3x3) form with 25 of 36 positions (option enc_wino4 != 0): bit 0 / 1 the forward of the 128 -> 64 / 64 -> 32 layer (bit 0 off: with it the full-size decoder's reconstruction is 2.97e-6 from float64, the bar is 2e-6), bit 2 / 3 their data gradients", true},
     {"wgrad_reduce_tiled", 1, "weight-gradient slab sums of at most 8 slabs and at least 256 tiles by the tiled one-thread-per-element kernels (same bits; 0: the 8-lanes-per-element kernels everywhere)", true},
+    {"enc_bn_reduce_pooled", 1, "encoder BatchNorm/pool backward: the (sum dz, sum dz zhat) pass reads the pooled activations the forward kept (2 floats per element) instead of the four pre-BatchNorm outputs of every window (5); 0: the window form", true},
 };
 std::atomic<int64_t> g_val[OPT_COUNT];
 std::once_flag g_once;

@@ -336,6 +336,44 @@ def test_encoder_matches_oracle_full_gradients(n, B):
         assert int(enc.state_dict()[f"conv.{4*l+1}.num_batches_tracked"]) == int(p[f"conv.{4*l+1}.num_batches_tracked"])
 
 
+@pytest.mark.parametrize("gamma_edge", [False, True])
+def test_encoder_bn_backward_sums_from_the_pooled_activations(gamma_edge):
+    """The BatchNorm/pool backward's (sum dz, sum dz zhat) pass reads the pooled activations the forward kept -- zhat of a
+    window's maximum is (lrelu^-1(pooled) - beta) / gamma -- instead of the window's four pre-BatchNorm outputs
+    (csrc/elementwise.hip, enc_bn_pool_bwd_reduce_p_kernel; dev option enc_bn_reduce_pooled): against the float64 oracle, and
+    against the window form on the same inputs.  gamma_edge: some BatchNorm weights zero, tiny and negative -- those channel
+    quads take the window form inside the kernel (a zero weight makes the window's first element the maximum, whatever zhat)."""
+    n, B = 64, 24
+    params = gen.make_params(n, "encoder", 31)
+    if gamma_edge:
+        for l, idx in ((1, 5), (2, 17), (3, 40)):
+            w = np.array(params[f"conv.{4*l+1}.weight"], dtype=np.float32)
+            w[idx] = 0.0; w[idx + 1] = 1e-6; w[idx + 8] = -0.7
+            params[f"conv.{4*l+1}.weight"] = w
+    p = {k: (torch.from_numpy(np.array(v)).double().requires_grad_("running" not in k) if np.array(v).dtype == np.float32
+             else torch.from_numpy(np.array(v))) for k, v in params.items()}
+    # (a zero weight ties a whole window: no tie-free images exist there, and near-ties may route differently in float64 --
+    # the edge case is held against the window form only)
+    x = ((torch.rand(B, 1, 32, 32, generator=torch.Generator().manual_seed(3)) < 0.3).float() if gamma_edge
+         else _tie_free_images(params, n, B, min_gap=3e-6))
+    gl = torch.randn(B, n, generator=torch.Generator().manual_seed(1))
+    if not gamma_edge:
+        want = nets.encoder_forward(p, x.double(), training=True)
+        (want * gl.double()).sum().backward()
+    grads = {}
+    for form in (1, 0):
+        with _lib.option_scope(enc_bn_reduce_pooled=form):
+            enc = _load(Encoder(n), params).train()
+            (enc(x.cuda()) * gl.cuda()).sum().backward()
+            grads[form] = {k: v.grad.clone().cpu() for k, v in enc.named_parameters()}
+    for name, g1 in grads[1].items():
+        if name.startswith("conv") and name.endswith("bias") and int(name.split(".")[1]) % 4 == 0:
+            continue  # (zero true gradient: a bias feeding a BatchNorm)
+        if not gamma_edge:
+            _close(g1, p[name].grad, 1e-4, name)
+        _close(g1, grads[0][name], 2e-5, name + " (pooled form against window form)")
+
+
 def test_encoder_layer0_moment_statistics_on_real_valued_images():
     """Layer 0's BatchNorm statistics come from the first / second moments of the 3x3 input patches (csrc/special.hip,
     enc_l0_moments_kernel) and its backward takes sum zhat (x) in_t from the same moments: nothing in that algebra needs
