@@ -9,6 +9,7 @@
 // them simultaneously; classes are separated by a wavefront-level fence only (no
 // workgroup barrier: chains never interact).
 #include <cstdlib>
+#include <utility>
 
 #include "common.h"
 #include "graph.h"
@@ -87,7 +88,7 @@ __device__ __forceinline__ GibbsLds gibbs_carve(unsigned char* smem, int n, int 
 }
 
 // stage the graph (coalesced reads of h, J and the padded-row image), all threads of the workgroup; ends with a barrier
-template <int NT>
+template <int NT, int OFF_SCALE = 2>  // OFF_SCALE: bytes between two spins of a chain's state (2: a row per chain; 32: [spin][16 chains])
 __device__ __forceinline__ void gibbs_stage(const GibbsArgs& a, const GibbsLds& L, int tid) {
   const int n = a.n;
   for (int i = tid; i < n; i += NT) {
@@ -99,7 +100,7 @@ __device__ __forceinline__ void gibbs_stage(const GibbsArgs& a, const GibbsLds& 
   for (int q = tid; q < n_ent + 4; q += NT) {
     const int src = q < n_ent ? a.adj_src4[q] : -1;
     L.w[q] = src >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[src]]), a.j_lo, a.j_hi) : 0.0f;
-    L.off[q] = src >= 0 ? (uint16_t)(2 * a.adj_idx[src]) : (uint16_t)0;
+    L.off[q] = src >= 0 ? (uint16_t)(OFF_SCALE * a.adj_idx[src]) : (uint16_t)0;
   }
   for (int i = tid; i <= a.n_colours; i += NT) L.cls[i] = a.class_ptr[i];
   __syncthreads();
@@ -204,6 +205,144 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
     int8_t* dst = a.state + (size_t)chain * n;
     for (int i = l; i < n; i += LPC) {
       const float v = (float)st[i];
+      dst[i] = (int8_t)v;
+      if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
+    }
+  }
+}
+
+// The rolled schedule with the 16 chains of a workgroup side by side in LDS (round 6), for the large graphs that keep it
+// (c5: 1024 spins, one 16-wave workgroup per CU, four waves per SIMD).  Same image, same arithmetic, same order, same random
+// stream as gibbs_kernel -- what changes is who does what.  gibbs_kernel gives a wave one chain, its 64 lanes 64 spins of a
+// colour class: every neighbour read is a gather of 64 random halfwords of the chain's state row -- ~11 cycles of the CU's
+// one LDS pipe per instruction (64 lanes over 64 banks at random: 4-5 deep), 20 per update, 16 waves: the draw is bound by
+// bank conflicts, which is why neither a quarter of the Philox calls nor two fewer dependent table reads per update moved
+// it (both built and measured this round: 1203 / 1193 against 1207 us), and why the lane-major form on twice the CUs takes
+// half the time.  Here a wave's lanes are 4 spins x 16 chains, and the state is stored [spin][chain]: a neighbour read is
+// four runs of sixteen consecutive halfwords (8 banks each), the table reads four addresses broadcast to sixteen lanes.
+// All 16 waves now work on the same 16 chains, so a colour class ends in a workgroup barrier instead of a wave fence
+// (5 per sweep).  A lane's (class, pass) slots are static (the host lists them: GibbsSlots), the slot loop unrolled.
+struct GibbsSlots { int n; uint32_t last_mask; int16_t lo[20], hi[20]; };
+
+// f + (the row's signed couplings, in row order) with the state stored [spin][16 chains]: `stc` = the lane's chain column
+__device__ __forceinline__ float gibbs_field_cm(float f, uint32_t rowinfo, const GibbsLds& L, const unsigned char* stc,
+                                                int zero_batch, int max_batches) {
+  const int first = (int)(rowinfo >> 8), nb = (int)(rowinfo & 255u);
+  for (int b0 = 0; b0 < max_batches; b0 += GIBBS_NB) {
+    gf32x4 w[GIBBS_NB];
+    gu32x2 o[GIBBS_NB];
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {
+      const int bi = b0 + j < nb ? first + b0 + j : zero_batch;
+      w[j] = *reinterpret_cast<const gf32x4*>(L.w + 4 * bi);
+      o[j] = *reinterpret_cast<const gu32x2*>(L.off + 4 * bi);
+    }
+    _Float16 h[GIBBS_NB][4];
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {  // (this kernel stages the offsets as 32 x spin: gibbs_stage<.., 32>)
+      h[j][0] = *reinterpret_cast<const _Float16*>(stc + (o[j][0] & 0xffffu));
+      h[j][1] = *reinterpret_cast<const _Float16*>(stc + (o[j][0] >> 16));
+      h[j][2] = *reinterpret_cast<const _Float16*>(stc + (o[j][1] & 0xffffu));
+      h[j][3] = *reinterpret_cast<const _Float16*>(stc + (o[j][1] >> 16));
+    }
+#pragma unroll
+    for (int j = 0; j < GIBBS_NB; ++j) {
+      f = gibbs_signed_add(h[j][0], w[j][0], f);
+      f = gibbs_signed_add(h[j][1], w[j][1], f);
+      f = gibbs_signed_add(h[j][2], w[j][2], f);
+      f = gibbs_signed_add(h[j][3], w[j][3], f);
+    }
+  }
+  return f;
+}
+
+template <int K, int MAXS>
+struct GibbsSlotLoop {
+  static __device__ __forceinline__ void run(const GibbsArgs& a, const GibbsSlots& sl, const GibbsLds& L, unsigned char* stc,
+                                             bool valid, uint32_t cid, uint32_t tq, uint32_t tw, bool fresh,
+                                             const uint32_t (&ir)[MAXS], uint32_t (&cy)[MAXS], uint32_t (&cz)[MAXS],
+                                             uint32_t (&cw)[MAXS]) {
+    if (K >= sl.n) return;
+    if (valid && ir[K] != 0xffffffffu) {
+      // (opaque copy: everything derived from the descriptor -- batch indices, table addresses, the state address -- is
+      // invariant over the sweeps, and hoisted out of the sweep loop it costs ~12 registers per slot: spills)
+      uint32_t irk = ir[K];
+      asm volatile("" : "+v"(irk));
+      const int i = (int)(irk >> 21);
+      const float f = gibbs_field_cm(L.hs[i], irk & 0x1fffffu, L, stc, a.n_batches, a.max_batches);
+      // the four words of a (spin, sweep >> 2) counter serve four sweeps: drawn once, three kept (with the LDS gathers out
+      // of the way the kernel is bound by its vector instructions, and a Philox call is 100 of an update's 190)
+      uint32_t word;
+      if (fresh) {
+        const u32x4 r = philox4x32_10((uint32_t)i, cid, tq, STREAM_GIBBS, a.k0, a.k1);
+        word = pick(r, tw);
+        cy[K] = r.y; cz[K] = r.z; cw[K] = r.w;
+      } else {
+        word = tw == 1u ? cy[K] : (tw == 2u ? cz[K] : cw[K]);
+      }
+      *reinterpret_cast<_Float16*>(stc + 32 * i) = gibbs_decide(f, a.two_beta, word);
+    }
+    if ((sl.last_mask >> K) & 1u) __syncthreads();  // the next class reads what this one wrote -- all 16 waves, the same chains
+    GibbsSlotLoop<K + 1, MAXS>::run(a, sl, L, stc, valid, cid, tq, tw, fresh, ir, cy, cz, cw);
+  }
+};
+template <int MAXS>
+struct GibbsSlotLoop<MAXS, MAXS> {
+  static __device__ __forceinline__ void run(const GibbsArgs&, const GibbsSlots&, const GibbsLds&, unsigned char*, bool, uint32_t,
+                                             uint32_t, uint32_t, bool, const uint32_t (&)[MAXS], uint32_t (&)[MAXS],
+                                             uint32_t (&)[MAXS], uint32_t (&)[MAXS]) {}
+};
+
+template <int MAXS>
+__global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlots sl) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int WAVES = 16, CH = 16;  // chains per workgroup
+  const int n = a.n;
+  const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
+  const int tid = threadIdx.x;
+  gibbs_stage<WAVES * 64, 32>(a, L, tid);
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;  // spin of the wave's four, chain of the workgroup's sixteen
+  const int chain = blockIdx.x * CH + c;
+  const bool valid = chain < a.n_chains;
+  unsigned char* stc = reinterpret_cast<unsigned char*>(L.state) + 2 * c;  // state[spin][chain]: spin i at stc + 32 i
+  const uint32_t cid = a.chain_id0 + (uint32_t)chain;
+  const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
+  if (valid) {
+    // (64 (wave, spin-of-four) pairs walk the chain's spins)
+    if (a.init) {
+      for (int i = wave * 4 + g; i < n; i += 64) {
+        u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
+        *reinterpret_cast<_Float16*>(stc + 32 * i) = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
+      }
+    } else {
+      const int8_t* src = a.state + (size_t)chain * n;
+      for (int i = wave * 4 + g; i < n; i += 64) *reinterpret_cast<_Float16*>(stc + 32 * i) = (_Float16)(float)src[i];
+    }
+  }
+  // this lane's spin of every slot and its row descriptor (spin << 21 | first batch << 8 | batches), read once (11 bits
+  // of spin, 13 of first batch: the launcher checks); words 1..3 of the slot's current Philox counter
+  uint32_t ir[MAXS], cy[MAXS], cz[MAXS], cw[MAXS];
+#pragma unroll
+  for (int k = 0; k < MAXS; ++k) {
+    const int p = k < sl.n ? sl.lo[k] + wave * 4 + g : 0;
+    const bool has = k < sl.n && p < sl.hi[k];
+    const int i = has ? L.order[p] : 0;
+    ir[k] = has ? ((uint32_t)i << 21) | L.row[i] : 0xffffffffu;
+    cy[k] = 0u; cz[k] = 0u; cw[k] = 0u;
+  }
+  __syncthreads();  // every chain's start state is in place
+  for (uint32_t t = sweep0; t < sweep0 + (uint32_t)a.n_sweeps; ++t) {
+    // (static slot indices: the slot registers must never be indexed at run time.  A plain unrolled loop with the `k >= n`
+    // exit was left rolled by the compiler, the arrays in scratch; a generic lambda per slot lost the LDS address space of
+    // the image -- flat loads -- and put the batch arrays in scratch: a recursive template it is.)
+    GibbsSlotLoop<0, MAXS>::run(a, sl, L, stc, valid, cid, t >> 2, t & 3u, t == sweep0 || (t & 3u) == 0u, ir, cy, cz, cw);
+  }
+  if (valid) {
+    int8_t* dst = a.state + (size_t)chain * n;
+    for (int i = wave * 4 + g; i < n; i += 64) {
+      const float v = (float)*reinterpret_cast<const _Float16*>(stc + 32 * i);
       dst[i] = (int8_t)v;
       if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
     }
@@ -432,6 +571,22 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s) {
   return DVG_OK;
 }
 
+static int launch_gibbs_slots(GibbsArgs a, const GibbsSlots& sl, hipStream_t s) {
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, 16);
+  if (lds > 160 * 1024) {
+    set_error("gibbs: graph (n=%d, %d neighbour batches) needs %zu B of LDS > 160 KiB", a.n, a.n_batches, lds);
+    return DVG_E_UNSUPPORTED;
+  }
+  const int grid = (int)ceil_div(a.n_chains, 16);
+  if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, 1024, lds}; return DVG_OK; }
+  // (18 slots: c5's graphs; the word registers of two more slots are what spills at 128 registers per wave)
+  auto kern = sl.n <= 18 ? gibbs_slot_kernel<18> : gibbs_slot_kernel<20>;
+  if (lds > 64 * 1024)
+    DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(1024), lds, s, a, sl);
+  return DVG_OK;
+}
+
 template <int LPC, int WAVES, int MB, int NR, int MAXS>
 static int launch_gibbs_fast(GibbsArgs a, hipStream_t s) {
   constexpr int CPB = WAVES * (64 / LPC);
@@ -505,7 +660,7 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // alone against the rolled 16-wave form's 1.20) and costs the same CU-time -- but it takes every CU's LDS while it
   // runs, and the c5 step, whose encoder AND decoder forward hide behind a 1.2 ms draw on half the chip, got slower
   // with it (2.88 -> 3.01 ms: `profiles/r05_gibbs_c5_forms.txt`).
-  bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512);
+  bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512 || form == 3);  // (3: the fast schedule whatever the size: A/B runs)
   if (lane_ok) {
     // (a lane image the fast form cannot serve -- more than 160 KiB of LDS: 20 rows x 5 batches at n_pad > 1216;
     // or a shape without an instantiation: two rows per step with a single small class -- falls through to the rolled
@@ -545,7 +700,23 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // Large graphs (c5: 1024 spins, 2|E| = 16 K -> ~105 KB of tables): one workgroup per CU fits, so the workgroup must
   // carry the CU's whole latency-hiding: 16 waves = 16 chains share one LDS copy of the graph (2 waves left 7/8 of
   // the issue slots empty: 7.3 ms per 2048-chain, 50-sweep draw).
-  if (gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024) return launch_gibbs<64, 16>(a, s);
+  if (gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024) {
+    // ... with static (class, pass) slots when the classes make at most 20 of them (gibbs_slot_kernel; option
+    // gibbs_generic = 1 keeps the plain rolled kernel: the reference of the bit-exactness tests)
+    GibbsSlots sl{};
+    bool slots_ok = form != 1 && g->n_colours <= 64 && g->n < 2048 && g->n_batches < 8192;  // (the slot registers' bit fields)
+    for (int k = 0; k < g->n_colours && slots_ok; ++k) {
+      const int lo = g->h_class_ptr[k], hi = g->h_class_ptr[k + 1];
+      for (int p = lo; p < hi; p += 64) {
+        if (sl.n >= 20) { slots_ok = false; break; }
+        sl.lo[sl.n] = (int16_t)p; sl.hi[sl.n] = (int16_t)hi;
+        if (p + 64 >= hi) sl.last_mask |= 1u << sl.n;
+        ++sl.n;
+      }
+    }
+    if (slots_ok && sl.n > 0) return launch_gibbs_slots(a, sl, s);
+    return launch_gibbs<64, 16>(a, s);
+  }
   const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
 #define DVG_GIBBS_DISPATCH(LPC) return small ? launch_gibbs<LPC, 1>(a, s) : launch_gibbs<LPC, 4>(a, s);
   if (mc <= 16) { DVG_GIBBS_DISPATCH(16) }

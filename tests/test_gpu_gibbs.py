@@ -31,6 +31,16 @@ def test_gibbs_bit_exact(fam, n, C, sweeps):
     _bit_exact(fam, n, C, sweeps)
 
 
+@pytest.mark.parametrize("fam,n,C,sweeps", [("zephyr", 1024, 530, 5), ("pegasus", 1024, 513, 7), ("zephyr", 1024, 2048, 4)])
+@pytest.mark.parametrize("generic", [0, 1])
+def test_gibbs_bit_exact_large_graph_many_chains(fam, n, C, sweeps, generic):
+    """More than 512 chains on a 1024-spin graph: the rolled schedule in 16-wave workgroups -- by default with static
+    (class, pass) slots and the Philox words of a counter kept for its four sweeps (gibbs_slot_kernel; draws of 5 and 7
+    sweeps start off the multiples of four), with gibbs_generic = 1 the plain rolled kernel -- against the C oracle."""
+    with _lib.option_scope(gibbs_generic=generic):
+        _bit_exact(fam, n, C, sweeps)
+
+
 @pytest.mark.parametrize("fam,n,C,sweeps", [("zephyr", 512, 70, 6), ("pegasus", 512, 256, 5)])
 def test_gibbs_bit_exact_one_row_at_a_time(fam, n, C, sweeps):
     """Graphs whose colour classes take two passes of 64 lanes run the passes side by side by default; option
