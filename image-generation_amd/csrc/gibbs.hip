@@ -256,7 +256,7 @@ __device__ __forceinline__ float gibbs_field_cm(float f, uint32_t rowinfo, const
   return f;
 }
 
-template <int K, int MAXS>
+template <int K, int MAXS, int SB>  // SB: bytes between two spins in the state image (2 x chains per workgroup)
 struct GibbsSlotLoop {
   static __device__ __forceinline__ void run(const GibbsArgs& a, const GibbsSlots& sl, const GibbsLds& L, unsigned char* stc,
                                              bool valid, uint32_t cid, uint32_t tq, uint32_t tw, bool fresh,
@@ -280,45 +280,45 @@ struct GibbsSlotLoop {
       } else {
         word = tw == 1u ? cy[K] : (tw == 2u ? cz[K] : cw[K]);
       }
-      *reinterpret_cast<_Float16*>(stc + 32 * i) = gibbs_decide(f, a.two_beta, word);
+      *reinterpret_cast<_Float16*>(stc + SB * i) = gibbs_decide(f, a.two_beta, word);
     }
     if ((sl.last_mask >> K) & 1u) __syncthreads();  // the next class reads what this one wrote -- all 16 waves, the same chains
-    GibbsSlotLoop<K + 1, MAXS>::run(a, sl, L, stc, valid, cid, tq, tw, fresh, ir, cy, cz, cw);
+    GibbsSlotLoop<K + 1, MAXS, SB>::run(a, sl, L, stc, valid, cid, tq, tw, fresh, ir, cy, cz, cw);
   }
 };
-template <int MAXS>
-struct GibbsSlotLoop<MAXS, MAXS> {
+template <int MAXS, int SB>
+struct GibbsSlotLoop<MAXS, MAXS, SB> {
   static __device__ __forceinline__ void run(const GibbsArgs&, const GibbsSlots&, const GibbsLds&, unsigned char*, bool, uint32_t,
                                              uint32_t, uint32_t, bool, const uint32_t (&)[MAXS], uint32_t (&)[MAXS],
                                              uint32_t (&)[MAXS], uint32_t (&)[MAXS]) {}
 };
 
-template <int MAXS>
+template <int MAXS, int CH>  // CH chains per workgroup (16; 8: the draws of few chains -- twice the workgroups, runs of 4 banks)
 __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlots sl) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int WAVES = 16, CH = 16;  // chains per workgroup
+  constexpr int WAVES = 16, SP = 64 / CH, SB = 2 * CH;  // spins per wave and pass; bytes between two spins of the state image
   const int n = a.n;
   const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
   const int tid = threadIdx.x;
-  gibbs_stage<WAVES * 64, 32>(a, L, tid);
+  gibbs_stage<WAVES * 64, SB>(a, L, tid);
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int g = lane >> 4, c = lane & 15;  // spin of the wave's four, chain of the workgroup's sixteen
+  const int g = lane / CH, c = lane % CH;  // spin of the wave's SP, chain of the workgroup's CH
   const int chain = blockIdx.x * CH + c;
   const bool valid = chain < a.n_chains;
-  unsigned char* stc = reinterpret_cast<unsigned char*>(L.state) + 2 * c;  // state[spin][chain]: spin i at stc + 32 i
+  unsigned char* stc = reinterpret_cast<unsigned char*>(L.state) + 2 * c;  // state[spin][chain]: spin i at stc + SB i
   const uint32_t cid = a.chain_id0 + (uint32_t)chain;
   const uint32_t sweep0 = a.sweep0_dev ? *a.sweep0_dev : a.sweep0;
   if (valid) {
     // (64 (wave, spin-of-four) pairs walk the chain's spins)
     if (a.init) {
-      for (int i = wave * 4 + g; i < n; i += 64) {
+      for (int i = wave * SP + g; i < n; i += 16 * SP) {
         u32x4 r = philox4x32_10((uint32_t)i, cid, sweep0, STREAM_INIT, a.k0, a.k1);
-        *reinterpret_cast<_Float16*>(stc + 32 * i) = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
+        *reinterpret_cast<_Float16*>(stc + SB * i) = (r.x >> 31) ? (_Float16)1.0f : (_Float16)-1.0f;
       }
     } else {
       const int8_t* src = a.state + (size_t)chain * n;
-      for (int i = wave * 4 + g; i < n; i += 64) *reinterpret_cast<_Float16*>(stc + 32 * i) = (_Float16)(float)src[i];
+      for (int i = wave * SP + g; i < n; i += 16 * SP) *reinterpret_cast<_Float16*>(stc + SB * i) = (_Float16)(float)src[i];
     }
   }
   // this lane's spin of every slot and its row descriptor (spin << 21 | first batch << 8 | batches), read once (11 bits
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlot
   uint32_t ir[MAXS], cy[MAXS], cz[MAXS], cw[MAXS];
 #pragma unroll
   for (int k = 0; k < MAXS; ++k) {
-    const int p = k < sl.n ? sl.lo[k] + wave * 4 + g : 0;
+    const int p = k < sl.n ? sl.lo[k] + wave * SP + g : 0;
     const bool has = k < sl.n && p < sl.hi[k];
     const int i = has ? L.order[p] : 0;
     ir[k] = has ? ((uint32_t)i << 21) | L.row[i] : 0xffffffffu;
@@ -337,12 +337,12 @@ __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlot
     // (static slot indices: the slot registers must never be indexed at run time.  A plain unrolled loop with the `k >= n`
     // exit was left rolled by the compiler, the arrays in scratch; a generic lambda per slot lost the LDS address space of
     // the image -- flat loads -- and put the batch arrays in scratch: a recursive template it is.)
-    GibbsSlotLoop<0, MAXS>::run(a, sl, L, stc, valid, cid, t >> 2, t & 3u, t == sweep0 || (t & 3u) == 0u, ir, cy, cz, cw);
+    GibbsSlotLoop<0, MAXS, SB>::run(a, sl, L, stc, valid, cid, t >> 2, t & 3u, t == sweep0 || (t & 3u) == 0u, ir, cy, cz, cw);
   }
   if (valid) {
     int8_t* dst = a.state + (size_t)chain * n;
-    for (int i = wave * 4 + g; i < n; i += 64) {
-      const float v = (float)*reinterpret_cast<const _Float16*>(stc + 32 * i);
+    for (int i = wave * SP + g; i < n; i += 16 * SP) {
+      const float v = (float)*reinterpret_cast<const _Float16*>(stc + SB * i);
       dst[i] = (int8_t)v;
       if (a.samples_out) a.samples_out[(size_t)chain * n + i] = v;
     }
@@ -571,16 +571,34 @@ static int launch_gibbs(GibbsArgs a, hipStream_t s) {
   return DVG_OK;
 }
 
+// pass = 16 waves x (64 / ch) spins; false: more than 20 (class, pass) slots, or a graph beyond the slot registers' bit fields
+static bool gibbs_make_slots(const dvg_graph_t* g, int ch, GibbsSlots* sl) {
+  *sl = GibbsSlots{};
+  if (g->n_colours > 64 || g->n >= 2048 || g->n_batches >= 8192) return false;
+  const int pass = 16 * (64 / ch);
+  for (int k = 0; k < g->n_colours; ++k) {
+    const int lo = g->h_class_ptr[k], hi = g->h_class_ptr[k + 1];
+    for (int p = lo; p < hi; p += pass) {
+      if (sl->n >= 20) return false;
+      sl->lo[sl->n] = (int16_t)p; sl->hi[sl->n] = (int16_t)hi;
+      if (p + pass >= hi) sl->last_mask |= 1u << sl->n;
+      ++sl->n;
+    }
+  }
+  return sl->n > 0;
+}
+
+template <int CH>
 static int launch_gibbs_slots(GibbsArgs a, const GibbsSlots& sl, hipStream_t s) {
-  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, 16);
+  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CH);
   if (lds > 160 * 1024) {
     set_error("gibbs: graph (n=%d, %d neighbour batches) needs %zu B of LDS > 160 KiB", a.n, a.n_batches, lds);
     return DVG_E_UNSUPPORTED;
   }
-  const int grid = (int)ceil_div(a.n_chains, 16);
+  const int grid = (int)ceil_div(a.n_chains, CH);
   if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, 1024, lds}; return DVG_OK; }
   // (18 slots: c5's graphs; the word registers of two more slots are what spills at 128 registers per wave)
-  auto kern = sl.n <= 18 ? gibbs_slot_kernel<18> : gibbs_slot_kernel<20>;
+  auto kern = sl.n <= 18 ? gibbs_slot_kernel<18, CH> : gibbs_slot_kernel<20, CH>;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(1024), lds, s, a, sl);
@@ -660,6 +678,10 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   // alone against the rolled 16-wave form's 1.20) and costs the same CU-time -- but it takes every CU's LDS while it
   // runs, and the c5 step, whose encoder AND decoder forward hide behind a 1.2 ms draw on half the chip, got slower
   // with it (2.88 -> 3.01 ms: `profiles/r05_gibbs_c5_forms.txt`).
+  if (form == 4) {  // (4: the chains-side-by-side schedule in 8-chain workgroups whatever the size: A/B runs)
+    GibbsSlots sl8;
+    if (gibbs_make_slots(g, 8, &sl8)) return launch_gibbs_slots<8>(a, sl8, s);
+  }
   bool lane_ok = g->lane_eid && (g->lane_rows <= 12 || n_chains <= 512 || form == 3);  // (3: the fast schedule whatever the size: A/B runs)
   if (lane_ok) {
     // (a lane image the fast form cannot serve -- more than 160 KiB of LDS: 20 rows x 5 batches at n_pad > 1216;
@@ -703,18 +725,8 @@ static int gibbs_dispatch(const dvg_graph_t* g, GibbsArgs& a, int n_chains, hipS
   if (gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 4) > 72 * 1024) {
     // ... with static (class, pass) slots when the classes make at most 20 of them (gibbs_slot_kernel; option
     // gibbs_generic = 1 keeps the plain rolled kernel: the reference of the bit-exactness tests)
-    GibbsSlots sl{};
-    bool slots_ok = form != 1 && g->n_colours <= 64 && g->n < 2048 && g->n_batches < 8192;  // (the slot registers' bit fields)
-    for (int k = 0; k < g->n_colours && slots_ok; ++k) {
-      const int lo = g->h_class_ptr[k], hi = g->h_class_ptr[k + 1];
-      for (int p = lo; p < hi; p += 64) {
-        if (sl.n >= 20) { slots_ok = false; break; }
-        sl.lo[sl.n] = (int16_t)p; sl.hi[sl.n] = (int16_t)hi;
-        if (p + 64 >= hi) sl.last_mask |= 1u << sl.n;
-        ++sl.n;
-      }
-    }
-    if (slots_ok && sl.n > 0) return launch_gibbs_slots(a, sl, s);
+    GibbsSlots sl;
+    if (form != 1 && gibbs_make_slots(g, 16, &sl)) return launch_gibbs_slots<16>(a, sl, s);
     return launch_gibbs<64, 16>(a, s);
   }
   const bool small = gibbs_lds_bytes(g->n, g->n_batches, g->n_colours, 0) <= 16 * 1024 && n_chains <= 1024;
