@@ -25,7 +25,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"dec_lc0", -1, "decoder: Linear composed with that map: -1 from 4096 rows up or rows x n_latents >= 2^20 (default), 0 never, 1 always"},
     {"mmd_w128", -1, "MMD: 128-row-block pair kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
     {"mmd_d256", -1, "MMD: 256-row distance-sum kernel: -1 by problem size (default), 0 never, 1 whenever the shape allows", true},
-    {"gibbs_generic", 0, "sampler: 1 forces the rolled reference schedule, 2 the lane-major schedule one row at a time instead of two passes of a class side by side (both bit-identical; A/B references)", true},
+    {"gibbs_generic", 0, "sampler: 1 forces the plain rolled reference schedule (no chains-side-by-side form for large graphs), 2 the lane-major schedule one row at a time instead of two passes of a class side by side, 3 the lane-major schedule whatever the size, 4 the chains-side-by-side schedule in 8-chain workgroups whatever the size (all bit-identical; A/B references)", true},
     {"side_stream", 1, "weight-gradient chains on the library's side stream (0 serialises everything on the caller's)"},
     {"enc_wino", -1, "encoder 3x3 layers in the Winograd F(2x2,3x3) form, forward, data gradient and weight gradient: -1 by size (default: evaluation-mode forward launches of 256 workgroups' worth of tiles or more, training launches of 512 or more), 0 never, 1 every launch the shape allows; forward / data gradient never in the bf16-input mode"},
     {"dec_wino", -1, "decoder Upsample(x2) + 3x3 layers in the Winograd form (9 of 16 transform positions), forward, data gradient and weight gradient: -1 from 8192 decoder rows up (default), 0 never, 1 whenever the shape allows"},

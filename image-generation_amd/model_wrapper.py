@@ -764,7 +764,7 @@ class ModelWrapper:
         N = int(images.shape[0]) * self.N_REPLICAS
         # (... or where the prologue is long whatever the rows: from 512 latent spins up the composed Linear o ConvTranspose
         # weights of csrc/decoder.cpp -- two n x 4n x 4C GEMMs and an 8 n^2-entry pack -- are 0.29 ms at c5's n = 1024)
-        n_lat = int(self.n_latents or 0)
+        n_lat = int(getattr(self, "n_latents", 0) or 0)
         big_prologue = n_lat >= 512 and N * n_lat >= (1 << 20)
         want = self.prepare_decoder if self.prepare_decoder is not None else (N >= self.PREPARE_DECODER_ROWS or big_prologue)
         if not want or self._device.type != "cuda":

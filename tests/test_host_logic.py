@@ -102,6 +102,9 @@ def test_schedule_decisions_of_the_wrapper_need_no_gpu():
     assert ModelWrapper.PREPARE_DECODER_ROWS == 32768
     m._prepare_decoder(torch.zeros(4096, 1, 32, 32), None)   # 32768 rows, but no GPU: nothing happens
     assert m._prep_stream is None
+    m.n_latents = 1024                                        # (round 6: ... and from 512 latent spins up, rows x spins >= 2^20)
+    m._prepare_decoder(torch.zeros(256, 1, 32, 32), None)
+    assert m._prep_stream is None
     m.overlap_sampler = m.overlap_mmd = True
     m.sampler = None
     m._hold_device_while_measuring(4096 * 8)                  # (returns before touching torch.cuda)
