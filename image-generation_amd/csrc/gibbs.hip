@@ -225,15 +225,17 @@ __global__ __launch_bounds__(WAVES * 64) void gibbs_kernel(GibbsArgs a) {
 struct GibbsSlots { int n; uint32_t last_mask; int16_t lo[20], hi[20]; };
 
 // f + (the row's signed couplings, in row order) with the state stored [spin][16 chains]: `stc` = the lane's chain column
+// (FIX: the image holds exactly GIBBS_NB batches per spin, spin i's at GIBBS_NB i -- rowinfo = that index; no per-batch select)
+template <bool FIX>
 __device__ __forceinline__ float gibbs_field_cm(float f, uint32_t rowinfo, const GibbsLds& L, const unsigned char* stc,
                                                 int zero_batch, int max_batches) {
-  const int first = (int)(rowinfo >> 8), nb = (int)(rowinfo & 255u);
-  for (int b0 = 0; b0 < max_batches; b0 += GIBBS_NB) {
+  const int first = FIX ? (int)rowinfo : (int)(rowinfo >> 8), nb = FIX ? GIBBS_NB : (int)(rowinfo & 255u);
+  for (int b0 = 0; b0 < (FIX ? GIBBS_NB : max_batches); b0 += GIBBS_NB) {
     gf32x4 w[GIBBS_NB];
     gu32x2 o[GIBBS_NB];
 #pragma unroll
     for (int j = 0; j < GIBBS_NB; ++j) {
-      const int bi = b0 + j < nb ? first + b0 + j : zero_batch;
+      const int bi = (FIX || b0 + j < nb) ? first + b0 + j : zero_batch;
       w[j] = *reinterpret_cast<const gf32x4*>(L.w + 4 * bi);
       o[j] = *reinterpret_cast<const gu32x2*>(L.off + 4 * bi);
     }
@@ -256,20 +258,22 @@ __device__ __forceinline__ float gibbs_field_cm(float f, uint32_t rowinfo, const
   return f;
 }
 
-template <int K, int MAXS, int SB>  // SB: bytes between two spins in the state image (2 x chains per workgroup)
+template <int K, int MAXS, int SB, bool FIX>  // SB: bytes between two spins in the state image (2 x chains per workgroup)
 struct GibbsSlotLoop {
   static __device__ __forceinline__ void run(const GibbsArgs& a, const GibbsSlots& sl, const GibbsLds& L, unsigned char* stc,
                                              bool valid, uint32_t cid, uint32_t tq, uint32_t tw, bool fresh,
                                              const uint32_t (&ir)[MAXS], uint32_t (&cy)[MAXS], uint32_t (&cz)[MAXS],
                                              uint32_t (&cw)[MAXS]) {
     if (K >= sl.n) return;
-    if (valid && ir[K] != 0xffffffffu) {
+    // (FIX: the descriptor is the spin alone, two slots per register -- the word cache leaves no room for one each)
+    const uint32_t desc = FIX ? (ir[K >> 1] >> (16 * (K & 1))) & 0xffffu : ir[K];
+    if (valid && desc != (FIX ? 0xffffu : 0xffffffffu)) {
       // (opaque copy: everything derived from the descriptor -- batch indices, table addresses, the state address -- is
       // invariant over the sweeps, and hoisted out of the sweep loop it costs ~12 registers per slot: spills)
-      uint32_t irk = ir[K];
+      uint32_t irk = desc;
       asm volatile("" : "+v"(irk));
-      const int i = (int)(irk >> 21);
-      const float f = gibbs_field_cm(L.hs[i], irk & 0x1fffffu, L, stc, a.n_batches, a.max_batches);
+      const int i = FIX ? (int)irk : (int)(irk >> 21);
+      const float f = gibbs_field_cm<FIX>(L.hs[i], FIX ? (uint32_t)(GIBBS_NB * i) : (irk & 0x1fffffu), L, stc, a.n_batches, a.max_batches);
       // the four words of a (spin, sweep >> 2) counter serve four sweeps: drawn once, three kept (with the LDS gathers out
       // of the way the kernel is bound by its vector instructions, and a Philox call is 100 of an update's 190)
       uint32_t word;
@@ -283,24 +287,62 @@ struct GibbsSlotLoop {
       *reinterpret_cast<_Float16*>(stc + SB * i) = gibbs_decide(f, a.two_beta, word);
     }
     if ((sl.last_mask >> K) & 1u) __syncthreads();  // the next class reads what this one wrote -- all 16 waves, the same chains
-    GibbsSlotLoop<K + 1, MAXS, SB>::run(a, sl, L, stc, valid, cid, tq, tw, fresh, ir, cy, cz, cw);
+    GibbsSlotLoop<K + 1, MAXS, SB, FIX>::run(a, sl, L, stc, valid, cid, tq, tw, fresh, ir, cy, cz, cw);
   }
 };
-template <int MAXS, int SB>
-struct GibbsSlotLoop<MAXS, MAXS, SB> {
+template <int MAXS, int SB, bool FIX>
+struct GibbsSlotLoop<MAXS, MAXS, SB, FIX> {
   static __device__ __forceinline__ void run(const GibbsArgs&, const GibbsSlots&, const GibbsLds&, unsigned char*, bool, uint32_t,
                                              uint32_t, uint32_t, bool, const uint32_t (&)[MAXS], uint32_t (&)[MAXS],
                                              uint32_t (&)[MAXS], uint32_t (&)[MAXS]) {}
 };
 
-template <int MAXS, int CH>  // CH chains per workgroup (16; 8: the draws of few chains -- twice the workgroups, runs of 4 banks)
+// LDS of the fixed-row image (FIX): h [n] | couplings [n][20] | state offsets [n][20] | order [n] | state [n_pad][CH]
+__host__ __device__ __forceinline__ size_t gibbs_fix_layout(int n, size_t off[5]) {
+  size_t b = 0;
+  off[0] = b; b += sizeof(float) * (size_t)((n + 3) & ~3);
+  off[1] = b; b += sizeof(float) * 20 * (size_t)n;
+  off[2] = b; b += sizeof(uint16_t) * 20 * (size_t)n;
+  off[3] = b; b += sizeof(uint16_t) * (size_t)((n + 7) & ~7);
+  off[4] = b;
+  return b;
+}
+
+// CH chains per workgroup (16; 8: the draws of few chains -- twice the workgroups, runs of 4 banks).  FIX: graphs of at most
+// 20 neighbours per spin whose image fits with every spin's row padded to five batches (c5's do, with 2 KB to spare): the
+// batch tables are then addressed by the spin alone -- 5 compares, 5 selects and 10 address computations less per update.
+template <int MAXS, int CH, bool FIX>
 __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlots sl) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int WAVES = 16, SP = 64 / CH, SB = 2 * CH;  // spins per wave and pass; bytes between two spins of the state image
   const int n = a.n;
-  const GibbsLds L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
   const int tid = threadIdx.x;
-  gibbs_stage<WAVES * 64, SB>(a, L, tid);
+  GibbsLds L;
+  if constexpr (FIX) {
+    size_t o[5];
+    gibbs_fix_layout(n, o);
+    L.hs = reinterpret_cast<float*>(smem + o[0]);
+    L.w = reinterpret_cast<float*>(smem + o[1]);
+    L.off = reinterpret_cast<uint16_t*>(smem + o[2]);
+    L.order = reinterpret_cast<uint16_t*>(smem + o[3]);
+    L.state = reinterpret_cast<_Float16*>(smem + o[4]);
+    L.row = nullptr; L.cls = nullptr;
+    for (int i = tid; i < n; i += WAVES * 64) {
+      L.hs[i] = clampf(__fmul_rn(a.prefactor, a.linear[i]), a.h_lo, a.h_hi);
+      L.order[i] = (uint16_t)a.order[i];
+    }
+    for (int q = tid; q < 20 * n; q += WAVES * 64) {
+      const int i = q / 20, e = q - 20 * i;
+      const uint32_t ri = (uint32_t)a.adj_row[i];
+      const int src = (e >> 2) < (int)(ri & 255u) ? a.adj_src4[4 * (int)(ri >> 8) + e] : -1;
+      L.w[q] = src >= 0 ? clampf(__fmul_rn(a.prefactor, a.quadratic[a.adj_eid[src]]), a.j_lo, a.j_hi) : 0.0f;
+      L.off[q] = src >= 0 ? (uint16_t)(SB * a.adj_idx[src]) : (uint16_t)0;
+    }
+    __syncthreads();
+  } else {
+    L = gibbs_carve(smem, n, a.n_batches, a.n_colours);
+    gibbs_stage<WAVES * 64, SB>(a, L, tid);
+  }
 
   const int wave = tid >> 6, lane = tid & 63;
   const int g = lane / CH, c = lane % CH;  // spin of the wave's SP, chain of the workgroup's CH
@@ -329,7 +371,8 @@ __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlot
     const int p = k < sl.n ? sl.lo[k] + wave * SP + g : 0;
     const bool has = k < sl.n && p < sl.hi[k];
     const int i = has ? L.order[p] : 0;
-    ir[k] = has ? ((uint32_t)i << 21) | L.row[i] : 0xffffffffu;
+    if (FIX) { if (!(k & 1)) ir[k >> 1] = 0u; ir[k >> 1] |= (has ? (uint32_t)i : 0xffffu) << (16 * (k & 1)); }
+    else ir[k] = has ? ((uint32_t)i << 21) | L.row[i] : 0xffffffffu;
     cy[k] = 0u; cz[k] = 0u; cw[k] = 0u;
   }
   __syncthreads();  // every chain's start state is in place
@@ -337,7 +380,7 @@ __global__ __launch_bounds__(1024) void gibbs_slot_kernel(GibbsArgs a, GibbsSlot
     // (static slot indices: the slot registers must never be indexed at run time.  A plain unrolled loop with the `k >= n`
     // exit was left rolled by the compiler, the arrays in scratch; a generic lambda per slot lost the LDS address space of
     // the image -- flat loads -- and put the batch arrays in scratch: a recursive template it is.)
-    GibbsSlotLoop<0, MAXS, SB>::run(a, sl, L, stc, valid, cid, t >> 2, t & 3u, t == sweep0 || (t & 3u) == 0u, ir, cy, cz, cw);
+    GibbsSlotLoop<0, MAXS, SB, FIX>::run(a, sl, L, stc, valid, cid, t >> 2, t & 3u, t == sweep0 || (t & 3u) == 0u, ir, cy, cz, cw);
   }
   if (valid) {
     int8_t* dst = a.state + (size_t)chain * n;
@@ -590,7 +633,10 @@ static bool gibbs_make_slots(const dvg_graph_t* g, int ch, GibbsSlots* sl) {
 
 template <int CH>
 static int launch_gibbs_slots(GibbsArgs a, const GibbsSlots& sl, hipStream_t s) {
-  const size_t lds = gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CH);
+  size_t fo[5];
+  const size_t lds_fix = gibbs_fix_layout(a.n, fo) + sizeof(_Float16) * (size_t)CH * ((a.n + 15) & ~15);
+  const bool fix = a.max_batches <= GIBBS_NB && lds_fix <= 160 * 1024;
+  const size_t lds = fix ? lds_fix : gibbs_lds_bytes(a.n, a.n_batches, a.n_colours, CH);
   if (lds > 160 * 1024) {
     set_error("gibbs: graph (n=%d, %d neighbour batches) needs %zu B of LDS > 160 KiB", a.n, a.n_batches, lds);
     return DVG_E_UNSUPPORTED;
@@ -598,7 +644,8 @@ static int launch_gibbs_slots(GibbsArgs a, const GibbsSlots& sl, hipStream_t s) 
   const int grid = (int)ceil_div(a.n_chains, CH);
   if (g_gibbs_probe) { *g_gibbs_probe = GibbsProbe{grid, 1024, lds}; return DVG_OK; }
   // (18 slots: c5's graphs; the word registers of two more slots are what spills at 128 registers per wave)
-  auto kern = sl.n <= 18 ? gibbs_slot_kernel<18, CH> : gibbs_slot_kernel<20, CH>;
+  auto kern = fix ? (sl.n <= 18 ? gibbs_slot_kernel<18, CH, true> : gibbs_slot_kernel<20, CH, true>)
+                  : (sl.n <= 18 ? gibbs_slot_kernel<18, CH, false> : gibbs_slot_kernel<20, CH, false>);
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DVG_LAUNCH_WORK(K_GIBBS, (double)a.n_chains * a.n * a.n_sweeps, kern, dim3(grid), dim3(1024), lds, s, a, sl);
