@@ -41,6 +41,14 @@ def test_gibbs_bit_exact_large_graph_many_chains(fam, n, C, sweeps, generic):
         _bit_exact(fam, n, C, sweeps)
 
 
+@pytest.mark.parametrize("fam,n,C,sweeps", [("zephyr", 512, 70, 6), ("pegasus", 512, 256, 5), ("zephyr", 128, 37, 9), ("zephyr", 1024, 100, 3)])
+def test_gibbs_bit_exact_chains_side_by_side_in_8_chain_workgroups(fam, n, C, sweeps):
+    """gibbs_generic = 4 (an A/B form: the chains-side-by-side schedule of the large graphs, gibbs_slot_kernel, in 8-chain
+    workgroups on any graph whose classes make at most 20 slots) -- same bits as the oracle; ragged last workgroups."""
+    with _lib.option_scope(gibbs_generic=4):
+        _bit_exact(fam, n, C, sweeps)
+
+
 @pytest.mark.parametrize("fam,n,C,sweeps", [("zephyr", 512, 70, 6), ("pegasus", 512, 256, 5)])
 def test_gibbs_bit_exact_one_row_at_a_time(fam, n, C, sweeps):
     """Graphs whose colour classes take two passes of 64 lanes run the passes side by side by default; option
