@@ -1292,13 +1292,15 @@ __device__ __forceinline__ void mmd_pm1_fq_body(const MmdArgs& a, unsigned char*
 // lane-linear).  The wave software-pipelines across chunks: the Gram of chunk t+1 is issued ahead of the gradient GEMM
 // of chunk t, and the table lookups of chunk t+1 are interleaved with that GEMM's MFMAs, so the matrix pipe has
 // independent work while the lookups' LDS latencies elapse.
-template <int NST, int NFT>  // d = 32 NST features; a block accumulates 32 NFT of them (grid z covers the rest)
+// ONE: only the pair table of the block's own column kind is resident (x columns or y columns: the plan guarantees that no
+// block's chunk range spans both) -- the 8 KB that lets d = 1024 run with 256-feature slices of G^T (NFT = 8)
+template <int NST, int NFT, bool ONE = false>  // d = 32 NST features; a block accumulates 32 NFT of them (grid z covers the rest)
 struct W128 {
   static constexpr int D = 32 * NST;
   static constexpr int TABN = D + 3;  // entries per table: h = 0 .. D, the all-zero entry D+1, the diagonal entry D+2
   // 8-byte entries {kernel sum (f32), weight as two bf16 terms hi | lo}: one ds_read_b64 per pair (round 3: 16 bytes with
   // the float32 weight beside its two terms; the row sums now add the two terms themselves, which is also what G^T holds)
-  static constexpr int TAB_BYTES = (2 * TABN * 8 + 1023) / 1024 * 1024;
+  static constexpr int TAB_BYTES = ((ONE ? 1 : 2) * TABN * 8 + 1023) / 1024 * 1024;
   static constexpr int RED_BYTES = 2048;
   static constexpr int Z8_BYTES = 32 * D;        // one chunk of int8 rows [32][D]
   static constexpr int ZT_BYTES = 64 * 32 * NFT; // one chunk of this block's slice of the transposed bf16 copy [32 NFT][32]
@@ -1313,9 +1315,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
                                    (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int NST, int NFT>
+template <int NST, int NFT, bool ONE = false>
 __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned char* smem) {
-  using L = W128<NST, NFT>;
+  using L = W128<NST, NFT, ONE>;
   constexpr int D = L::D;
   typedef __attribute__((address_space(3))) void lds_void;
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -1375,8 +1377,9 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
 
   // ---- one-time staging: pair table (+ the two masking entries per table) -> LDS, this wave's 32 rows -> B fragments
   constexpr int TABN = L::TABN;
-  for (int e = tid; e < 2 * TABN; e += 256) {
-    const int which = e / TABN, h = e - which * TABN;
+  const int one_which = (rows_x && t0 < (int64_t)((a.nx + 31) / 32)) ? 0 : 1;  // (ONE: the block's columns are x chunks / y chunks)
+  for (int e = tid; e < (ONE ? 1 : 2) * TABN; e += 256) {
+    const int which = ONE ? one_which : e / TABN, h = ONE ? e : e - which * TABN;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (h <= D) v = a.tab[which * (D + 1) + h];
     else if (h == D + 2) { v = a.tab[which * (D + 1)]; v.x = 0u; }
@@ -1548,7 +1551,7 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
     }
   };
   // (tb = table base + 4 D: the byte offset of Gram value S is then -4 S)
-  auto table_base = [&](bool cols_x) -> const unsigned char* { return smem + (cols_x ? 0 : TABN * 8) + 4 * D; };
+  auto table_base = [&](bool cols_x) -> const unsigned char* { return smem + ((ONE || cols_x) ? 0 : TABN * 8) + 4 * D; };
   double l_cx = 0.0, l_cy = 0.0;  // kernel sums against x columns / y columns
   // Per chunk the float32 running sums of a lane (16 pairs each) move into double accumulators.  For the row sums
   // this is an accuracy matter, not a nicety: a lane adds ~N/2 table values -- a few dozen DISTINCT values, so the
@@ -1852,11 +1855,11 @@ __device__ __forceinline__ void mmd_pm1_w128_body(const MmdArgs& a, unsigned cha
   }
 }
 
-template <int NST, int NFT>
+template <int NST, int NFT, bool ONE = false>
 __global__ __launch_bounds__(256, 1) void mmd_pair_w128_kernel(MmdArgs a) {
   extern __shared__ __align__(16) unsigned char w128_smem[];
   if (*a.not_pm1 != 0) return;  // general rows: the f32 kernel launched behind this one serves them
-  mmd_pm1_w128_body<NST, NFT>(a, w128_smem);
+  mmd_pm1_w128_body<NST, NFT, ONE>(a, w128_smem);
 }
 
 template <int NFB>
@@ -1926,6 +1929,7 @@ struct MmdPlan {
   int pm1_ok;
   int64_t ztb_x, ztb_y;  // 32-row blocks of the transposed copy (whole 128-row tiles)
   int w128, S2;          // 128-row-block pair kernel (large spin problems) and its column splits
+  int z128;              // ... its feature slices (grid z): 1; d = 1024: 4 (one resident table, W128<32, 8, true>) or 8 (W128<32, 4>)
   int64_t rb128x, rb128y;
 };
 
@@ -1966,14 +1970,29 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.rb128y = ceil_div(ny, 128);
   {
     const int64_t chunks = ceil_div(nx, 32) + ceil_div(ny, 32);
-    const int64_t z128 = mmd_w128_slices(d);
+    const int env = mmd_w128_env();
+    auto splits_for = [&](int64_t z) {
+      int64_t S = ceil_div(mmd_target_blocks(), p.rb128x * z);
+      if (S > chunks / 16) S = chunks / 16;
+      if (S < 1) S = 1;
+      if (env == 1) { if (S > 16) S = 16; } else if (S > 4) S = 4;
+      return S;
+    };
+    // d = 1024: 256-feature slices (four of them: the int8 Gram redone 4 instead of 8 times, 48 instead of 40 KB staged for
+    // 64 instead of 48 MFMAs per chunk) need the LDS of one pair table: possible when no block's chunk range spans the x / y
+    // boundary, i.e. when the x chunks are a whole number of column splits (c5: 64 + 64 chunks in 4 splits of 32)
+    int64_t z128 = mmd_w128_slices(d);
+    if (d == 1024) {
+      const int64_t S4 = splits_for(4), per4 = ceil_div(chunks, S4);
+      if (ceil_div(nx, 32) % per4 == 0) z128 = 4;
+    }
+    p.z128 = (int)z128;
     int64_t S2 = ceil_div(mmd_target_blocks(), p.rb128x * z128);
     if (S2 > chunks / 16) S2 = chunks / 16;
     if (S2 < 1) S2 = 1;
     // (the 128-row-block kernel addresses both chunk images through 32-bit buffer offsets: the int8 rows and the bf16
     // transposed copy, 2 (nx + ny) d bytes, must stay below 2^31 -- larger problems keep the 32-row kernels' 64-bit pointers)
     const bool shape_ok = d % 128 == 0 && (d <= 512 || d == 1024) && (int64_t)(nx + ny) * (int64_t)d * 2 < 2147483647LL;
-    const int env = mmd_w128_env();
     p.w128 = shape_ok && (env == 1 || (env != 0 && S2 <= 4 && p.rb128x * S2 * z128 >= 128));
     if (env == 1 && shape_ok) { S2 = S2 > 16 ? 16 : S2; }
     else if (S2 > 4) S2 = 4;
@@ -2010,7 +2029,7 @@ static MmdPlan mmd_plan(int64_t nx, int64_t ny, int d) {
   p.off_dist = o; o = align_up(o + sizeof(double) * (size_t)(p.S1 * p.GX1), 256);
   {
     size_t nparts = (size_t)(p.S * (p.rbx + p.rby));
-    if (p.w128 && (size_t)(p.S2 * mmd_w128_slices(d) * (p.rb128x + p.rb128y)) > nparts) nparts = (size_t)(p.S2 * mmd_w128_slices(d) * (p.rb128x + p.rb128y));
+    if (p.w128 && (size_t)(p.S2 * p.z128 * (p.rb128x + p.rb128y)) > nparts) nparts = (size_t)(p.S2 * p.z128 * (p.rb128x + p.rb128y));
     if (p.w128 && (size_t)(p.S2 * (p.rbx + p.rby)) > nparts) nparts = (size_t)(p.S2 * (p.rbx + p.rby));
     p.off_loss = o; o = align_up(o + sizeof(double) * 3 * nparts, 256);
   }
@@ -2082,10 +2101,10 @@ static int launch_pair_fq(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
   return DVG_OK;
 }
 
-template <int NST, int NFT>
+template <int NST, int NFT, bool ONE = false>
 static int launch_pair_w128(const MmdArgs& a, const MmdPlan& p, hipStream_t s) {
-  auto kern = mmd_pair_w128_kernel<NST, NFT>;
-  constexpr int lds = W128<NST, NFT>::LDS_BYTES;
+  auto kern = mmd_pair_w128_kernel<NST, NFT, ONE>;
+  constexpr int lds = W128<NST, NFT, ONE>::LDS_BYTES;
   if (lds > 64 * 1024)
     DVG_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   DVG_LAUNCH_WORK(K_MMD_PM1, mmd_pm1_work(a, 2, NST / NFT), kern, dim3((unsigned)(p.rb128x + p.rb128y), (unsigned)p.S2, NST / NFT),
@@ -2124,7 +2143,7 @@ extern "C" int dvg_mmd_spin_flops(int64_t nx, int64_t ny, int dim, double* int8_
   if (!p.pm1_ok) { *int8_flops = 0.0; *bf16_flops = 0.0; *bf16_terms = 0; return DVG_OK; }  // f32 kernels only
   // the form dvg_mmd_fwd_bwd launches: ONE feature slice per block (the Gram and the lookups computed once) unless the
   // two-slice form is asked for (mmd_two_slices(), d > 256 only)
-  const int passes = p.w128 ? mmd_w128_slices(dim) * ((dim > 256 && dim <= 512 && mmd_two_slices()) ? 2 : 1) : 1;
+  const int passes = p.w128 ? p.z128 * ((dim > 256 && dim <= 512 && mmd_two_slices()) ? 2 : 1) : 1;
   *bf16_terms = p.w128 ? 2 : 3;
   mmd_pm1_flops(nx, ny, dim, true, *bf16_terms, passes, int8_flops, bf16_flops);
   return DVG_OK;
@@ -2172,7 +2191,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
   if (p.w128) {
     // (the 128-row-block pair kernel and the float32 kernel behind it number their loss partials by their own grids and
     // exactly one of them runs: the slots the other layout would have filled must read as zero in the final sum)
-    if ((int)(p.S2 * mmd_w128_slices(dim) * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * mmd_w128_slices(dim) * (p.rb128x + p.rb128y));
+    if ((int)(p.S2 * p.z128 * (p.rb128x + p.rb128y)) > loss_parts) loss_parts = (int)(p.S2 * p.z128 * (p.rb128x + p.rb128y));
     if ((int)(p.S2 * (p.rbx + p.rby)) > loss_parts) loss_parts = (int)(p.S2 * (p.rbx + p.rby));
   }
   if (p.pm1_ok) {  // row norms, int8 copy, +-1 flag and the transposed bf16 copy in one pass over the rows
@@ -2236,7 +2255,7 @@ extern "C" int dvg_mmd_fwd_bwd(const float* x, int64_t nx, const float* y, int64
       // the compiler places the Gram tile and the operands in the other half without spills): the Gram and the lookups
       // are then computed once, 80 instead of 96 MFMAs per chunk: 2.70 -> 2.10 ms at c3 (the two-slice form is retired).
       case 3: rc = launch_pair_w128<12, 12>(a, p, s); break;
-      case 8: rc = launch_pair_w128<32, 4>(a, p, s); break;  // (eight 128-feature slices: mmd_plan)
+      case 8: rc = p.z128 == 4 ? launch_pair_w128<32, 8, true>(a, p, s) : launch_pair_w128<32, 4>(a, p, s); break;  // (four / eight feature slices: mmd_plan)
       default: rc = launch_pair_w128<16, 16>(a, p, s); break;
     }
     DVG_TRY(rc);

@@ -41,7 +41,7 @@ def test_mmd_default_matches_oracle(nx, ny, d):
 
 
 @pytest.mark.parametrize("nx,ny,d", [(300, 77, 128), (1000, 256, 256), (513, 33, 384), (2053, 256, 512), (128, 130, 512),
-                                      (97, 5, 256), (300, 77, 1024), (2048, 2048, 1024), (1031, 130, 1024)])  # (d = 1024: eight feature slices; c5's slice)
+                                      (97, 5, 256), (300, 77, 1024), (2048, 2048, 1024), (1031, 130, 1024), (1000, 1000, 1024)])  # (d = 1024: eight feature slices, or four with one resident pair table where the x chunks are whole column splits -- c5's slice, and 1000 + 1000 ragged rows)
 @pytest.mark.parametrize("kw", [dict(), dict(biased=True), dict(squared=True)])
 def test_mmd_128_row_block_kernel_matches_oracle(monkeypatch, nx, ny, d, kw):
     """The 128-row-block spin pair kernel (large problems: c3) forced on small, ragged shapes -- partial row blocks,
