@@ -18,7 +18,8 @@ quad = torch.from_numpy((5.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float
 print(f"n={n} chains={C} sweeps={sweeps} colours={plan.n_colours} max class={max(np.diff(plan.class_ptr))} "
       f"max degree={int(np.diff(plan.adj_ptr).max())}")
 only_default = "default" in sys.argv  # (PMC passes: the product's form only)
-forms = (("default (1 wave / chain)", dict()), ("one row at a time", dict(gibbs_generic=2)), ("rolled reference", dict(gibbs_generic=1)))
+forms = (("default", dict()), ("one row at a time", dict(gibbs_generic=2)), ("rolled reference", dict(gibbs_generic=1)),
+         ("chains side by side, 8-chain workgroups", dict(gibbs_generic=4)))
 for name, opts in forms[:1] if only_default else forms:
     with _lib.option_scope(**opts):
         s = smp.GibbsSampler(plan, nodes, beta=20.0, sweeps=sweeps, seed=seed, persistent=True)
