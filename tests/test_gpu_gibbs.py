@@ -109,6 +109,35 @@ def test_gibbs_bit_exact_on_arbitrary_graphs(n, p_edge, C, sweeps):
                 assert int((got != want.astype(np.float32)).sum()) == 0, (generic, call)
 
 
+@pytest.mark.parametrize("generic", [0, 1])
+def test_gibbs_bit_exact_large_arbitrary_graph(generic):
+    """A 700-spin random graph (average degree 14, some spins beyond 20 neighbours: no lane-major image, rows of up to seven
+    batches, a spin count that is no multiple of 16, a dozen colour classes of uneven size): large enough for the 16-wave
+    workgroups of the rolled schedule -- by default its chains-side-by-side form with the general (not five-batch) image,
+    where the classes make at most 20 slots -- against the C oracle; gibbs_generic = 1: the plain rolled kernel."""
+    n, C, sweeps = 700, 45, 3
+    rng = np.random.default_rng(n)
+    iu, ju = np.triu_indices(n, 1)
+    keep = rng.uniform(size=iu.size) < 0.02
+    ei, ej = iu[keep].astype(np.int64), ju[keep].astype(np.int64)
+    plan = graphs.build_plan(n, ei, ej)
+    assert np.diff(plan.adj_ptr).max() > 20
+    h = (0.5 * rng.uniform(-1, 1, n)).astype(np.float32)
+    J = (2.0 * rng.uniform(-1, 1, plan.n_edges)).astype(np.float32)
+    hs, Js = gibbs.scaled_fields(h, J, 0.3, (-4, 4), (-1, 1))
+    ids = np.arange(C, dtype=np.uint32) + 7
+    lin = torch.from_numpy(h).cuda(); quad = torch.from_numpy(J).cuda()
+    with _lib.option_scope(gibbs_generic=generic):
+        s = smp.GibbsSampler(plan, list(range(n)), beta=1.5, sweeps=sweeps, seed=SEED, persistent=True, chain_offset=7,
+                             h_range=(-4, 4), j_range=(-1, 1))
+        want = cref.init_state(ids, n, SEED)
+        for call in range(3):
+            got = s.sample_native(lin, quad, 0.3, (-4, 4), (-1, 1), num_reads=C).cpu().numpy()
+            want = cref.gibbs_sweeps(want, ids, hs, Js, 1.5, plan.order, plan.class_ptr, plan.adj_ptr, plan.adj_idx,
+                                     plan.adj_eid, SEED, call * sweeps, sweeps)
+            assert int((got != want.astype(np.float32)).sum()) == 0, (generic, call)
+
+
 def test_gibbs_bit_exact_many_small_classes():
     """50 disjoint 14-cliques: 14 colour classes of 50 spins -> one pass of 64 lanes each, 14 rows per lane -- the
     lane-major schedule's one-row form at more than 12 rows (no shipped graph has that shape), against the C oracle."""
